@@ -1,0 +1,412 @@
+#!/usr/bin/env python
+"""Golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the reference's own modules (never copied, never shipped), loads closed-form
+weights (oracle.make_state_dict -- a seed-free index hash) into them, runs the reference
+code and stores inputs + expected outputs as small .npz fixtures next to this script.
+While doing so it also asserts that the oracle restatement agrees with the reference.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import vqvae_model as ref_vqvae  # noqa: E402
+import vector_quantization as ref_vq  # noqa: E402
+import lrschedule as ref_lr  # noqa: E402
+from wavenet_vocoder import WaveNet as RefWaveNet  # noqa: E402
+from wavenet_vocoder import mixture as ref_mix  # noqa: E402
+from wavenet_vocoder import upsample as ref_up  # noqa: E402
+from wavenet_vocoder.modules import ResidualConv1dGLU as RefGLU  # noqa: E402
+
+from oracle import wae_oracle as O  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(4)
+
+
+# out-of-place residual add: the reference's in-place `out += x` on a ReLU output breaks autograd
+# under torch >= 1.x.  Mathematically identical; reference files untouched.
+def _crr_forward(self, x):
+    out = self.relu(self.conv(x))
+    if self.stride == 1 and self.dim_in == self.dim_out:
+        out = out + x
+    return out
+
+
+ref_vqvae.ConvReLURes.forward = _crr_forward
+
+CFG_A = dict(name="A", layers=4, stacks=2, R=32, G=48, S=32, O=64, Cc=16, Cg=8, k=3, n_speakers=5,
+             upsample_scales=[4, 4, 8, 5], encoder_hid=32, c_in=39, K=32, cin_pad=0)
+CFG_B = dict(name="B", layers=6, stacks=2, R=32, G=80, S=64, O=64, Cc=16, Cg=16, k=3, n_speakers=4,
+             upsample_scales=[4, 4, 4, 5], encoder_hid=32, c_in=39, K=32, cin_pad=0)
+CFG_S = dict(name="S", layers=4, stacks=2, R=32, G=64, S=32, O=30, Cc=16, Cg=8, k=3, n_speakers=5,
+             upsample_scales=[4, 4, 8, 5], encoder_hid=32, c_in=39, K=32, cin_pad=0, scalar_input=True)
+
+
+def build_ref_wavenet(cfg):
+    return RefWaveNet(out_channels=cfg["O"], layers=cfg["layers"], stacks=cfg["stacks"],
+                      residual_channels=cfg["R"], gate_channels=cfg["G"], skip_out_channels=cfg["S"],
+                      kernel_size=cfg["k"], dropout=0.0, cin_channels=cfg["Cc"], gin_channels=cfg["Cg"],
+                      n_speakers=cfg["n_speakers"], upsample_conditional_features=True,
+                      upsample_net="ConvInUpsampleNetwork",
+                      upsample_params=dict(upsample_scales=cfg["upsample_scales"], cin_channels=cfg["Cc"], cin_pad=0),
+                      scalar_input=bool(cfg.get("scalar_input")), use_speaker_embedding=True,
+                      output_distribution="Logistic", cin_pad=0)
+
+
+def build_ref_vqvae(cfg, sd):
+    wn = build_ref_wavenet(cfg)
+    m = ref_vqvae.VQVAE(c_in=cfg["c_in"], hid=cfg["Cc"], K=cfg["K"], wavenet=wn, encoder_hid=cfg["encoder_hid"])
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+def close(a, b, tol=2e-5, what=""):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= tol * max(1.0, ref), f"oracle != reference for {what}: {err} (ref max {ref})"
+    return err
+
+
+def inputs_for(cfg, B, F, salt):
+    """c (B, c_in, F) MFCC-like, x indices (B, T), g (B,), with T = F/4 * prod(scales)."""
+    hop = int(np.prod(cfg["upsample_scales"]))
+    Tq = ((F - 1) // 2 + 1 - 1) // 2 + 1
+    T = Tq * hop
+    c = O.hash_fill((B, cfg["c_in"], F), salt + 1, 1.7)
+    if cfg.get("scalar_input"):
+        x = O.hash_fill((B, 1, T), salt + 2, 0.98)
+        xin = x
+    else:
+        x = ((O.hash_fill((B, T), salt + 2) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+        xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    g = ((O.hash_fill((B,), salt + 3) * 0.5 + 0.5) * cfg["n_speakers"]).long().clamp(0, cfg["n_speakers"] - 1)
+    return c, x, xin, g, T
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def gen_model(cfg, salt):
+    sd = O.make_state_dict(cfg, salt)
+    B, F = 2, 8
+    c, x, xin, g, T = inputs_for(cfg, B, F, salt * 10)
+    model = build_ref_vqvae(cfg, sd).eval()
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    with torch.no_grad():
+        lat = model.encoder(c)
+        quant, vq_loss, perp = model.vq(lat)
+        c_up = model.wavenet.upsample_net(quant)
+        y_hat, vq2, perp2 = model(xin, c, g, False)
+        y_sm = model.wavenet(xin, quant, g, True)
+    # oracle agreement
+    o_lat = O.encoder_forward(sd, c)
+    close(o_lat, lat, what="latents")
+    o_q, o_vq, o_perp, o_idx = O.vq_forward(sd["vq.embedding.weight"], lat)
+    close(o_q, quant, what="quant")
+    close(o_vq, vq_loss, what="vq_loss")
+    close(o_perp, perp, what="perp")
+    dist = O.vq_distances(sd["vq.embedding.weight"], lat)
+    top2 = dist.topk(2, dim=1, largest=False)[0]
+    margin = (top2[:, 1] - top2[:, 0])
+    qf = quant.permute(0, 2, 1).reshape(-1, cfg["Cc"])
+    ref_idx = ((qf[:, None, :] - sd["vq.embedding.weight"][None]) ** 2).sum(-1).argmin(1)   # x+(q-x) rounds, so nearest row
+    assert torch.equal(ref_idx, o_idx)
+    close(O.upsample_forward(sd, quant, cfg["upsample_scales"]), c_up, what="c_up")
+    o_y, o_vq2, o_perp2, _ = O.vqvae_forward(sd, ocfg, xin, c, g)
+    e = close(o_y, y_hat, what="logits")
+    print(f"  cfg {cfg['name']}: T={T} logits max|oracle-ref| = {e:.2e}, min VQ margin = {margin.min().item():.3e}")
+    close(O.wavenet_forward(sd, ocfg, xin, quant, g, softmax=True), y_sm, what="softmax")
+    save(f"model_{cfg['name']}", cfg=json.dumps(cfg), salt=salt, c=c, x=x.numpy() if not cfg.get("scalar_input") else x,
+         g=g, latents=lat, quant=quant, vq_idx=o_idx, vq_margin=margin, vq_loss=vq_loss, perp=perp, c_up=c_up,
+         y_hat=y_hat, y_softmax_probe=y_sm[:, :, ::37])
+    return sd, model, (c, x, xin, g, T), ocfg
+
+
+def gen_layers(cfg, sd, model, ins):
+    """(4) single GLU layers at several dilations, with and without conditioning."""
+    c, x, xin, g, T = ins
+    B = 2
+    R, Cc, Cg = cfg["R"], cfg["Cc"], cfg["Cg"]
+    xr = O.hash_fill((B, R, T), 901, 1.2)
+    cr = O.hash_fill((B, Cc, T), 902, 1.0)
+    gr = O.hash_fill((B, Cg, 1), 903, 0.5)
+    probe_t = torch.cat([torch.arange(0, 48), torch.arange(48, T, 11)])
+    out = dict(x_salt=901, c_salt=902, g_salt=903, x_scale=1.2, c_scale=1.0, g_scale=0.5, T=T, probe_t=probe_t)
+    for d in (1, 2, 512):
+        lay = RefGLU(R, cfg["G"], kernel_size=3, skip_out_channels=cfg["S"], cin_channels=Cc, gin_channels=Cg,
+                     dropout=0.0, dilation=d, bias=True).eval()
+        p = "wavenet.conv_layers.1."
+        lsd = {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+        lay.load_state_dict(lsd, strict=True)
+        with torch.no_grad():
+            for tag, (cc, gg) in dict(cg=(cr, gr), none=(None, None)).items():
+                xo, so = lay(xr, cc, None if gg is None else gg.expand(B, Cg, T).contiguous())
+                oxo, oso = O.glu_layer_forward(sd, p, xr, cc, gg, d)
+                close(oxo, xo, what=f"glu x d={d}")
+                close(oso, so, what=f"glu s d={d}")
+                out[f"xo_d{d}_{tag}"] = xo[:, :, probe_t]
+                out[f"so_d{d}_{tag}"] = so[:, :, probe_t]
+    save(f"glu_{cfg['name']}", **out)
+
+
+def gen_losses(cfg, sd, model, ins, ocfg):
+    """(6) CE (masked, shifted) value + logits-gradient."""
+    c, x, xin, g, T = ins
+    lengths = torch.tensor([T, T - 137])
+    y = x.unsqueeze(-1)
+    y_hat = model(xin, c, g, False)[0].detach().requires_grad_(True)
+    mask = O.sequence_mask(lengths, T).unsqueeze(-1)[:, 1:, :]
+    crit = torch.nn.CrossEntropyLoss(reduction="none")
+    losses = crit(y_hat[:, :, :-1].unsqueeze(-1), y[:, 1:, :])
+    loss = (losses * mask).sum() / mask.sum()
+    loss.backward()
+    yo = y_hat.detach().clone().requires_grad_(True)
+    lo = O.masked_ce_loss(yo, y, lengths)
+    lo.backward()
+    close(lo, loss, what="ce")
+    close(yo.grad, y_hat.grad, what="ce grad", tol=1e-6)
+    save(f"ce_{cfg['name']}", lengths=lengths, loss=loss.detach(), dlogits_probe=y_hat.grad[:, :, ::29])
+
+
+def gen_dmol():
+    """(6b) DMoL loss incl. edge cases and the sampler."""
+    B, T, M = 2, 96, 10
+    y_hat = O.hash_fill((B, 3 * M, T), 777, 3.0)
+    y_hat[:, 2 * M:, :] = O.hash_fill((B, M, T), 778, 6.0) - 5.0      # log-scales in [-11, 1]
+    y = O.hash_fill((B, T, 1), 779, 1.0)
+    y[0, :6, 0] = torch.tensor([-1.0, -0.9995, 1.0, 0.9995, 0.999, -0.999])
+    # force cdf_delta <= 1e-5: tiny scale and target far from every mean
+    y_hat[1, 2 * M:, 5] = -12.0
+    y_hat[1, M:2 * M, 5] = 0.9
+    y[1, 5, 0] = -0.5
+    yh = y_hat.clone().requires_grad_(True)
+    out = {}
+    for lsm in (-7.0, -9.0):
+        if yh.grad is not None:
+            yh.grad = None
+        l_el = ref_mix.discretized_mix_logistic_loss(yh, y, num_classes=256, log_scale_min=lsm, reduce=False)
+        l_sum = ref_mix.discretized_mix_logistic_loss(yh, y, num_classes=256, log_scale_min=lsm, reduce=True)
+        l_sum.backward()
+        yo = y_hat.clone().requires_grad_(True)
+        o_el = O.dmol_loss(yo, y, 256, lsm, reduce=False)
+        O.dmol_loss(yo, y, 256, lsm, reduce=True).backward()
+        close(o_el, l_el, what="dmol")
+        close(yo.grad, yh.grad, what="dmol grad", tol=1e-5)
+        out[f"loss_el_{int(-lsm)}"] = l_el.detach()
+        out[f"loss_sum_{int(-lsm)}"] = l_sum.detach()
+        out[f"grad_{int(-lsm)}"] = yh.grad.clone()
+    # 65536-class variant (raw 16-bit input default, hparams.py:21)
+    l16 = ref_mix.discretized_mix_logistic_loss(y_hat, y, num_classes=65536, log_scale_min=-16.0, reduce=False)
+    close(O.dmol_loss(y_hat, y, 65536, -16.0, reduce=False), l16, what="dmol16")
+    out["loss_el_65536"] = l16
+    # sampler: reproduce the reference's uniform_ draws from the global RNG
+    torch.manual_seed(4242)
+    s_ref = ref_mix.sample_from_discretized_mix_logistic(y_hat, log_scale_min=-7.0)
+    torch.manual_seed(4242)
+    u_mix = torch.empty(B, T, M).uniform_(1e-5, 1.0 - 1e-5)
+    u_log = torch.empty(B, T).uniform_(1e-5, 1.0 - 1e-5)
+    s_or = O.dmol_sample(y_hat, u_mix, u_log, -7.0)
+    close(s_or, s_ref, what="dmol sample")
+    save("dmol", y_hat=y_hat, y=y, u_mix=u_mix, u_log=u_log, sample=s_ref, **out)
+
+
+def gen_train_step(cfg, sd, ins, ocfg):
+    """(7) parameter gradients of one step, post-Adam weights, EMA shadow (vqwae_train.py:709-798)."""
+    c, x, xin, g, T = ins
+    model = build_ref_vqvae(cfg, {k: v.clone() for k, v in sd.items()}).train()
+    lengths = torch.tensor([T, T])
+    y = x.unsqueeze(-1)
+    opt = torch.optim.Adam(model.parameters(), lr=4e-4, eps=1e-8, weight_decay=0.0)
+    shadow = {n: p.data.clone() for n, p in model.named_parameters() if p.requires_grad}
+    mask = O.sequence_mask(lengths, T).unsqueeze(-1)[:, 1:, :]
+    opt.zero_grad()
+    y_hat, vq_loss, perp = model(xin, c, g, False)
+    crit = torch.nn.CrossEntropyLoss(reduction="none")
+    ce = ((crit(y_hat[:, :, :-1].unsqueeze(-1), y[:, 1:, :]) * mask).sum()) / mask.sum()
+    loss = ce + vq_loss.mean()
+    loss.backward()
+    none = [n for n, p in model.named_parameters() if p.grad is None]
+    print("  params without grad in the reference step:", none)
+    grads = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 100.0)
+    opt.step()
+    for n, p in model.named_parameters():
+        d = shadow[n] - p.data
+        shadow[n] -= (1.0 - 0.9999) * d
+    # oracle: autograd through the functional restatement + own Adam/EMA
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oy, ovq, operp, _ = O.vqvae_forward(psd, ocfg, xin, c, g)
+    oloss = O.masked_ce_loss(oy, y, lengths) + ovq
+    oloss.backward()
+    close(oloss, loss, what="train loss")
+    ograds = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in psd.items()}
+    for k in grads:
+        close(ograds[k], grads[k], what=f"grad {k}", tol=2e-4)
+    params = {k: v.detach().clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    vv = {k: torch.zeros_like(v) for k, v in params.items()}
+    osh = {k: v.clone() for k, v in params.items()}
+    ogn = O.clip_adam_ema_step(params, {k: v.detach() for k, v in ograds.items()}, m, vv, osh, 1, 4e-4)
+    close(ogn, gn, what="grad norm", tol=1e-4)
+    new = dict(model.named_parameters())
+    for k in params:
+        close(params[k], new[k].data, what=f"adam {k}", tol=1e-5)
+        close(osh[k], shadow[k], what=f"ema {k}", tol=1e-6)
+    keys = ["wavenet.conv_layers.0.conv.weight_v", "wavenet.conv_layers.0.conv.weight_g",
+            "wavenet.conv_layers.2.conv1x1c.weight_v", "wavenet.conv_layers.3.conv1x1_skip.bias",
+            "wavenet.first_conv.weight_v", "wavenet.last_conv_layers.3.weight_v", "wavenet.embed_speakers.weight",
+            "wavenet.upsample_net.conv_in.weight", "wavenet.upsample_net.upsample.up_layers.5.weight_v",
+            "encoder.net.0.conv.weight", "encoder.net.3.conv.weight", "encoder.lin.weight", "vq.embedding.weight"]
+    out = dict(loss=loss.detach(), ce=ce.detach(), vq_loss=vq_loss.detach(), perp=perp.detach(), grad_norm=gn)
+    for k in keys:
+        out["grad:" + k] = grads[k]
+        out["new:" + k] = new[k].data
+        out["ema:" + k] = shadow[k]
+    out["grad_sq_by_key"] = json.dumps({k: float((v.double() ** 2).sum()) for k, v in grads.items()})
+    save(f"train_{cfg['name']}", **out)
+
+
+def gen_ar(cfg, sd, model, ins, ocfg):
+    """(8) incremental_forward: teacher-forced (== forward) and a greedy roll-out."""
+    c, x, xin, g, T = ins
+    Tar = 96
+    with torch.no_grad():
+        lat = model.encoder(c)
+        quant = model.vq(lat)[0]
+        c_up = model.wavenet.upsample_net(quant)[:, :, :Tar].contiguous()
+        # feed pre-upsampled c by disabling the upsample net on a fresh reference decoder
+        wn = build_ref_wavenet(cfg).eval()
+        wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items() if k.startswith("wavenet.")})
+        wn.upsample_net = None
+        init0 = torch.zeros(2, cfg["O"], 1)
+        init0[:, cfg["O"] // 2 - 1, 0] = 1
+        tf = wn.incremental_forward(init0, c=c_up, g=g, T=Tar, test_inputs=xin[:, :, :Tar].contiguous(),
+                                    softmax=False, quantize=False)
+        fwd = wn(xin[:, :, :Tar].contiguous(), c_up, g, False)
+        close(tf, fwd, what="incremental == forward", tol=1e-5)
+        wn.make_generation_fast_()
+        fwd_fast = wn(xin[:, :, :Tar].contiguous(), c_up, g, False)
+        assert (fwd_fast - fwd).abs().max().item() < 1e-5
+    o_tf = O.incremental_forward(sd, ocfg, c_up, g, Tar, test_inputs=xin[:, :, :Tar], mode="logits")
+    close(o_tf, tf, what="oracle AR teacher-forced", tol=1e-5)
+    # greedy roll-out: reference has no argmax mode; drive its one-step API by feeding back argmax ourselves
+    with torch.no_grad():
+        wn2 = build_ref_wavenet(cfg).eval()
+        wn2.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items() if k.startswith("wavenet.")})
+        wn2.upsample_net = None
+        cur = torch.zeros(2, cfg["O"], 1)
+        cur[:, cfg["O"] // 2 - 1, 0] = 1
+        init = cur.clone()
+        seq = []
+        hist = []
+        for t in range(24):
+            hist.append(cur)
+            full = torch.cat(hist, dim=-1)
+            out = wn2.incremental_forward(init, c=c_up[:, :, :t + 1].contiguous(), g=g, T=t + 1, test_inputs=full,
+                                          softmax=False, quantize=False)
+            idx = out[:, :, -1].argmax(1)
+            seq.append(idx)
+            cur = torch.nn.functional.one_hot(idx, cfg["O"]).float().unsqueeze(-1)
+        greedy = torch.stack(seq, dim=1)
+    o_g = O.incremental_forward(sd, ocfg, c_up[:, :, :24].contiguous(), g, 24, initial_input=init, mode="argmax")
+    assert torch.equal(o_g.argmax(1), greedy), "greedy roll-out differs"
+    save(f"ar_{cfg['name']}", c_up=c_up, tf_logits=tf, greedy=greedy, init=init)
+
+
+def gen_misc():
+    steps = [0, 1, 399999, 400000, 400001, 800000, 1200000]
+    lr = [ref_lr.step_learning_rate_decay(4e-4, s, anneal_rate=0.5, anneal_interval=400000) for s in steps]
+    assert lr == [O.step_learning_rate_decay(4e-4, s, 0.5, 400000) for s in steps]
+    noam = [float(ref_lr.noam_learning_rate_decay(1e-3, s)) for s in steps]
+    cyc = [float(ref_lr.cyclic_cosine_annealing(1e-3, s, 1000, 5)) for s in steps]
+    from hparams import hparams as ref_hp
+    defaults = dict(ref_hp.values())
+    status = {}
+    vq = None
+    for f in sorted(os.listdir(os.path.join(REF, "hps"))):
+        from hparams import hparams as hp
+        import copy
+        h = copy.deepcopy(hp)
+        try:
+            with open(os.path.join(REF, "hps", f)) as fh:
+                h.parse_json(fh.read())
+            status[f] = "ok"
+            if f == "vqwae.json":
+                h.parse("layers=24,batch_size=8,ema_decay=0.99")
+                vq = dict(h.values())
+        except Exception as e:  # noqa: BLE001
+            status[f] = type(e).__name__
+    rf = {f"{L}_{s}_{k}": RefWaveNetRF(L, s, k) for (L, s, k) in [(20, 2, 3), (24, 2, 3), (24, 4, 3), (48, 4, 3), (4, 2, 3)]}
+    with open(os.path.join(HERE, "misc.json"), "w") as fh:
+        json.dump(dict(lr_steps=steps, step_lr=lr, noam=noam, cyclic=cyc, hparams_defaults=defaults,
+                       preset_status=status, vqwae_parsed_with_overrides=vq, receptive_field=rf), fh, indent=1, sort_keys=True)
+    print("wrote misc.json", status)
+
+
+def RefWaveNetRF(L, s, k):
+    from wavenet_vocoder import receptive_field_size
+    r = receptive_field_size(L, s, k)
+    assert r == O.receptive_field_size(L, s, k)
+    return r
+
+
+def gen_vqwae_probe():
+    """Full-size hps/vqwae.json model: sparse logits probe + sums (closed-form weights, short clip)."""
+    cfg = dict(name="vqwae", layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153,
+               upsample_scales=[4, 4, 8, 5], encoder_hid=256, c_in=39, K=256, cin_pad=0)
+    sd = O.make_state_dict(cfg, 7)
+    assert len(sd) == 302 and sum(v.numel() for v in sd.values()) == 7555218, (len(sd), sum(v.numel() for v in sd.values()))
+    c, x, xin, g, T = inputs_for(cfg, 1, 16, 70)
+    model = build_ref_vqvae(cfg, sd).eval()
+    with torch.no_grad():
+        y_hat, vq_loss, perp = model(xin, c, g, False)
+    ocfg = dict(layers=20, stacks=2, upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    oy, ovq, operp, aux = O.vqvae_forward(sd, ocfg, xin, c, g)
+    e = close(oy, y_hat, what="vqwae logits", tol=5e-5)
+    print(f"  vqwae.json full-size: T={T}, max|oracle-ref| = {e:.2e}; keys={len(sd)}")
+    ti = torch.arange(0, T, 41)
+    save("model_vqwae_probe", cfg=json.dumps(cfg), salt=7, probe_t=ti, y_probe=y_hat[0][:, ti], vq_idx=aux["idx"],
+         y_sum=y_hat.double().sum(), y_abs_sum=y_hat.double().abs().sum(), vq_loss=vq_loss, perp=perp,
+         keys=json.dumps({k: list(v.shape) for k, v in sd.items()}))
+
+
+def main():
+    gen_misc()
+    gen_dmol()
+    for cfg, salt in ((CFG_A, 1), (CFG_B, 2)):
+        sd, model, ins, ocfg = gen_model(cfg, salt)
+        gen_layers(cfg, sd, model, ins)
+        gen_losses(cfg, sd, model, ins, ocfg)
+        gen_ar(cfg, sd, model, ins, ocfg)
+        if cfg is CFG_A:
+            gen_train_step(cfg, sd, ins, ocfg)
+    # scalar-input (DMoL) decoder
+    sd, model, ins, ocfg = gen_model(CFG_S, 3)
+    gen_vqwae_probe()
+
+
+if __name__ == "__main__":
+    main()

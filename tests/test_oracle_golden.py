@@ -1,0 +1,169 @@
+"""Pins the CPU oracle against vectors produced by the reference itself
+(tests/golden/make_golden.py imported /root/reference to make them)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wae_oracle as O
+from helpers import GOLDEN, golden_model, load_npz, rel_err
+
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("name", ["A", "B", "S"])
+def test_model_forward_matches_reference(name):
+    cfg, sd, ins, z, ocfg = golden_model(name)
+    lat = O.encoder_forward(sd, ins["c"])
+    assert rel_err(lat, z["latents"]) < TOL
+    q, vq_loss, perp, idx = O.vq_forward(sd["vq.embedding.weight"], lat)
+    assert np.array_equal(idx.numpy(), z["vq_idx"])                      # bit-exact
+    assert rel_err(q, z["quant"]) < TOL
+    assert abs(float(vq_loss) - float(z["vq_loss"])) < 1e-6 * max(1, abs(float(z["vq_loss"])))
+    assert abs(float(perp) - float(z["perp"])) < 1e-4
+    assert rel_err(O.upsample_forward(sd, q, cfg["upsample_scales"]), z["c_up"]) < TOL
+    y, _, _, _ = O.vqvae_forward(sd, ocfg, ins["xin"], ins["c"], ins["g"])
+    assert rel_err(y, z["y_hat"]) < TOL
+    ys = O.wavenet_forward(sd, ocfg, ins["xin"], q, ins["g"], softmax=True)
+    assert rel_err(ys[:, :, ::37], z["y_softmax_probe"]) < TOL
+
+
+def test_wrong_cond_length_raises():
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    q = torch.from_numpy(z["quant"])
+    with pytest.raises(Exception):
+        O.wavenet_forward(sd, ocfg, ins["xin"][:, :, :-3], q, ins["g"])
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_glu_layer(name):
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    z = load_npz("glu_" + name)
+    T, B = int(z["T"]), 2
+    x = O.hash_fill((B, cfg["R"], T), int(z["x_salt"]), float(z["x_scale"]))
+    c = O.hash_fill((B, cfg["Cc"], T), int(z["c_salt"]), float(z["c_scale"]))
+    g = O.hash_fill((B, cfg["Cg"], 1), int(z["g_salt"]), float(z["g_scale"]))
+    pt = torch.from_numpy(z["probe_t"])
+    for d in (1, 2, 512):
+        for tag, (cc, gg) in dict(cg=(c, g), none=(None, None)).items():
+            xo, so = O.glu_layer_forward(sd, "wavenet.conv_layers.1.", x, cc, gg, d)
+            assert rel_err(xo[:, :, pt], z[f"xo_d{d}_{tag}"]) < TOL
+            assert rel_err(so[:, :, pt], z[f"so_d{d}_{tag}"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_masked_ce(name):
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    z = load_npz("ce_" + name)
+    y_hat = torch.from_numpy(zm["y_hat"]).requires_grad_(True)
+    loss = O.masked_ce_loss(y_hat, ins["x"].unsqueeze(-1), torch.from_numpy(z["lengths"]))
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-6
+    assert rel_err(y_hat.grad[:, :, ::29], z["dlogits_probe"]) < 1e-5
+
+
+def test_dmol_loss_and_sampler():
+    z = load_npz("dmol")
+    y_hat, y = torch.from_numpy(z["y_hat"]), torch.from_numpy(z["y"])
+    for lsm in (7, 9):
+        yh = y_hat.clone().requires_grad_(True)
+        el = O.dmol_loss(yh, y, 256, -float(lsm), reduce=False)
+        assert rel_err(el, z[f"loss_el_{lsm}"]) < TOL
+        s = O.dmol_loss(yh, y, 256, -float(lsm), reduce=True)
+        s.backward()
+        assert abs(float(s) - float(z[f"loss_sum_{lsm}"])) < 1e-3
+        assert rel_err(yh.grad, z[f"grad_{lsm}"]) < 1e-4
+    assert rel_err(O.dmol_loss(y_hat, y, 65536, -16.0, reduce=False), z["loss_el_65536"]) < TOL
+    smp = O.dmol_sample(y_hat, torch.from_numpy(z["u_mix"]), torch.from_numpy(z["u_log"]), -7.0)
+    assert rel_err(smp, z["sample"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_incremental_forward(name):
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    z = load_npz("ar_" + name)
+    c_up = torch.from_numpy(z["c_up"])
+    Tar = c_up.shape[-1]
+    tf = O.incremental_forward(sd, ocfg, c_up, ins["g"], Tar, test_inputs=ins["xin"][:, :, :Tar], mode="logits")
+    assert rel_err(tf, z["tf_logits"]) < TOL
+    # known-answer property from SURVEY section 4: incremental == batch forward
+    sd2 = {k: v for k, v in sd.items() if "upsample_net" not in k}
+    fwd = O.wavenet_forward(sd2, dict(ocfg, upsample_scales=None), ins["xin"][:, :, :Tar], c_up, ins["g"])
+    assert rel_err(tf, fwd) < TOL
+    gr = O.incremental_forward(sd, ocfg, c_up[:, :, :24].contiguous(), ins["g"], 24,
+                               initial_input=torch.from_numpy(z["init"]), mode="argmax")
+    assert np.array_equal(gr.argmax(1).numpy(), z["greedy"])
+
+
+def test_train_step_grads_adam_ema():
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    z = load_npz("train_A")
+    T = ins["x"].shape[-1]
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y, vq, perp, _ = O.vqvae_forward(psd, ocfg, ins["xin"], ins["c"], ins["g"])
+    ce = O.masked_ce_loss(y, ins["x"].unsqueeze(-1), torch.tensor([T, T]))
+    loss = ce + vq
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    assert abs(float(perp) - float(z["perp"])) < 1e-4
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in psd.items()}
+    gsq = json.loads(str(z["grad_sq_by_key"]))
+    for k, v in gsq.items():
+        assert abs(float((grads[k].double() ** 2).sum()) - v) <= 1e-3 * max(v, 1e-9) + 1e-12, k
+    params = {k: v.detach().clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    vv = {k: torch.zeros_like(v) for k, v in params.items()}
+    sh = {k: v.clone() for k, v in params.items()}
+    gn = O.clip_adam_ema_step(params, grads, m, vv, sh, 1, 4e-4)
+    assert abs(float(gn) - float(z["grad_norm"])) < 1e-4 * float(z["grad_norm"])
+    for key in [k[5:] for k in z if k.startswith("grad:")]:
+        assert rel_err(grads[key], z["grad:" + key]) < 2e-4, key
+        assert rel_err(params[key], z["new:" + key]) < 1e-5, key
+        assert rel_err(sh[key], z["ema:" + key]) < 1e-6, key
+
+
+def test_vqwae_fullsize_probe():
+    z = load_npz("model_vqwae_probe")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(cfg, int(z["salt"]))
+    shapes = json.loads(str(z["keys"]))
+    assert {k: list(v.shape) for k, v in sd.items()} == shapes and len(sd) == 302
+    import sys
+    sys.path.insert(0, os.path.join(GOLDEN))
+    hop = 640
+    c = O.hash_fill((1, 39, 16), 71, 1.7)
+    T = 4 * hop
+    x = ((O.hash_fill((1, T), 72) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    g = ((O.hash_fill((1,), 73) * 0.5 + 0.5) * 153).long().clamp(0, 152)
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    ocfg = dict(layers=20, stacks=2, upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    with torch.no_grad():
+        y, vq, perp, aux = O.vqvae_forward(sd, ocfg, xin, c, g)
+    assert np.array_equal(aux["idx"].numpy(), z["vq_idx"])
+    assert rel_err(y[0][:, torch.from_numpy(z["probe_t"])], z["y_probe"]) < 5e-5
+    assert abs(float(y.double().sum()) - float(z["y_sum"])) < 1e-3 * float(z["y_abs_sum"])
+
+
+def test_misc_schedules_and_receptive_field():
+    with open(os.path.join(GOLDEN, "misc.json")) as fh:
+        m = json.load(fh)
+    for s, lr in zip(m["lr_steps"], m["step_lr"]):
+        assert O.step_learning_rate_decay(4e-4, s, 0.5, 400000) == lr
+    for key, rf in m["receptive_field"].items():
+        L, s, k = map(int, key.split("_"))
+        assert O.receptive_field_size(L, s, k) == rf
+    assert m["receptive_field"]["20_2_3"] == 4093
+
+
+def test_mulaw_hand_values():
+    # hand-computed from the mu-law formula (nnmnkwii absent: "unpinned by import")
+    assert int(O.mulaw_quantize(0.0, 255)) == 127
+    assert int(O.mulaw_quantize(1.0, 255)) == 255
+    assert int(O.mulaw_quantize(-1.0, 255)) == 0
+    x = np.array([-0.5, -0.01, 0.01, 0.5])
+    q = O.mulaw_quantize(x, 255)
+    assert q.tolist() == [15, 98, 156, 239]   # e.g. (1-ln(128.5)/ln(256))/2*255 = 15.84 -> 15
+    back = O.inv_mulaw_quantize(q, 255)
+    assert np.all(np.abs(back - x) < 0.03)
