@@ -1,0 +1,144 @@
+/*
+ * wae.h -- C ABI of libwae_hip.so: the MI355X (gfx950) kernels behind the WaveNet-autoencoder hot path.
+ *
+ * The reference (MingjieChen/wavenet_autoencoders) has no FFI: its hot path is plain PyTorch modules.
+ * Each entry point below replaces the ATen op sequence of the cited reference lines; the Python host
+ * (wavenet_autoencoders_amd/) mirrors the reference's module API and binds these with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless the name ends in _host
+ *   - nothing here allocates, frees, synchronises or owns memory; kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream)
+ *   - returns WAE_OK (0) or a negative error code; wae_last_error() gives a thread-local message
+ *   - dtype: WAE_F32 (fp32 storage, exact-fp32 MFMA 32x32x2) or WAE_BF16 (bf16 storage, MFMA 32x32x16,
+ *     fp32 accumulate).  Skip accumulators, biases, losses and the encoder/VQ are always fp32.
+ *   - activation layout inside the decoder stack is time-major rows, channels innermost:
+ *     x[b][t][Cp] with Cp = channels padded to a multiple of 128 (64 for c; pad channels are zero).  The
+ *     reference's (B,C,T) tensors enter/leave through wae_to_btc / wae_from_btc, the first-conv gather
+ *     and the head (which writes (B,O,T) logits).
+ *   - packed weights are in MFMA A-fragment order produced by wae_pack_gather from index maps the host
+ *     builds once (wavenet_autoencoders_amd/packing.py documents the order).
+ */
+#ifndef WAE_H
+#define WAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAE_OK 0
+#define WAE_EINVAL (-1)
+#define WAE_EUNSUPPORTED (-2)
+#define WAE_EHIP (-3)
+
+#define WAE_F32 0
+#define WAE_BF16 1
+
+/* flags of wae_glu_desc.flags */
+#define WAE_GLU_SKIP_INIT 1 /* skip = s   instead of skip += s (first layer; replaces `skips = 0`, wavenet.py:204) */
+#define WAE_GLU_SAVE_Z 2    /* also store the pre-activation z (B,T,2Hp) for backward */
+#define WAE_GLU_NO_OUT 4    /* do not compute/store x' (last layer: the reference's x' is dead, wavenet.py:205-207) */
+
+const char* wae_version(void);
+const char* wae_last_error(void);
+
+/* ---- K14 weight norm (modules.py:18, upsample.py:44): w = g * v / ||v|| per output row --------------
+ * Parameters live in one flat fp32 arena.  eff <- copy of params, then for every weight-normed row r:
+ * eff[v_off[r] .. +cols[r]) = params[g_off[r]] * v / ||v||.  Tables are int64 device arrays of nrows. */
+int wae_weight_norm_fwd(const float* params, float* eff, int64_t n_params, const int64_t* v_off,
+                        const int64_t* g_off, const int32_t* cols, int32_t nrows, void* stream);
+/* backward: given d_eff (grad wrt effective weights, same layout) accumulate into grads:
+ * grads[v] = g/||v|| * (dw - v * (dw.v)/||v||^2), grads[g] = (dw.v)/||v||; every other slot: grads = d_eff. */
+int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, int64_t n_params,
+                        const int64_t* v_off, const int64_t* g_off, const int32_t* cols, int32_t nrows,
+                        void* stream);
+
+/* dst[i + b*dst_stride] = (dtype) (map[i] < 0 ? 0 : src[map[i] + b*src_stride]),  i < n, b < nbatch */
+int wae_pack_gather(const float* src, const int32_t* map, void* dst, int64_t n, int32_t nbatch,
+                    int64_t src_stride, int64_t dst_stride, int32_t dtype, void* stream);
+/* inverse (gradients): dst[map[i] + b*dst_stride] += src[i + b*src_stride] (fp32, map[i] >= 0 unique) */
+int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int64_t n, int32_t nbatch,
+                           int64_t src_stride, int64_t dst_stride, void* stream);
+
+/* ---- a1 encoder block (vqvae_model.py:17-23): y = relu(conv1d(x,w,b,stride,pad=k/2)) (+x) ; fp32 (B,C,T)
+ * relu/residual/pad selectable so the same entry serves Encoder.lin (vqvae_model.py:50, k=1) and the
+ * upsample net's conv_in (upsample.py:77-78: k = 2*cin_pad+1, pad 0, no bias).  Tout = (Tin+2*pad-k)/stride+1 */
+int wae_enc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
+                     int32_t Tin, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t relu,
+                     int32_t residual, void* stream);
+
+/* ---- a2 VectorQuantize.forward (vector_quantization.py:21-49) -----------------------------------------
+ * lat (B,D,Tq) fp32, emb (K,D).  idx int64 (B*Tq) first-minimum of ||e||^2+||x||^2-2x.e; quant (B,D,Tq);
+ * stats[0] = vq_loss = (beta+1)*mean((q-x)^2) forward value, stats[1] = perplexity; hist: (K+1) int32 scratch. */
+int wae_vq_nearest(const float* lat, const float* emb, int64_t* idx, float* quant, float* stats, int32_t* hist,
+                   int32_t B, int32_t D, int32_t Tq, int32_t K, float beta, void* stream);
+
+/* ---- a3 one upsample stage (upsample.py:19-21 stretch + :39-46 FIR) ------------------------------------
+ * in (B,C,Tin) fp32 -> nearest-stretch by s, FIR w[2s+1] zero-padded.  If out_btc != 0 the result is written
+ * time-major (B,Tin*s,Cp) in `dtype` (pad channels zeroed), else (B,C,Tin*s) fp32. */
+int wae_upsample_stage_fwd(const float* in, const float* w, void* out, int32_t B, int32_t C, int32_t Tin,
+                           int32_t s, int32_t out_btc, int32_t Cp, int32_t dtype, void* stream);
+
+/* ---- a4/K5 hoisted global conditioning: zb[b][l][2Hp] = bias_l + Wg_l . g_b  (modules.py:148-152) ------
+ * g_b = eff[emb_off + gid[b]*Cg ..] (Embedding lookup, wavenet.py:185-190) when gid != NULL, else gvec[b*Cg ..]
+ * (external features); both NULL or wg_off < 0 = no global conditioning.  Layer l reads its conv bias at
+ * eff[bias_off + l*layer_stride] and its conv1x1g weight (G,Cg) at eff[wg_off + l*layer_stride]. */
+int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride, const int32_t* gid,
+                  int64_t emb_off, const float* gvec, float* zb, int32_t B, int32_t L, int32_t G, int32_t Hp,
+                  int32_t Cg, void* stream);
+
+/* ---- a5 first_conv on one-hot input = column gather + bias (wavenet.py:119-122,203) --------------------
+ * idx (B*T) int32 class ids; table (O,Rp) fp32 = W^T ; x0 (B,T,Rp) dtype.  scalar mode: xs (B*T) fp32,
+ * table (1,Rp). */
+int wae_first_conv_fwd(const int32_t* idx, const float* xs, const float* table, const float* bias, void* x0,
+                       int64_t BT, int32_t Rp, int32_t O, int32_t dtype, void* stream);
+
+/* ---- a6+a7 ResidualConv1dGLU._forward + skip accumulate (modules.py:115-163, wavenet.py:204-207) -------- */
+typedef struct wae_glu_desc {
+  int32_t dtype;
+  int32_t B, T;
+  int32_t Rp, Sp, Ccp, Hp; /* padded: Rp,Sp % 128 == 0, Ccp % 64 == 0 (may be 0), Hp % 32 == 0, Hp <= 256 */
+  int32_t ktaps;           /* kernel_size */
+  int32_t dilation;
+  int32_t flags;
+} wae_glu_desc;
+/* x_in,x_out (B,T,Rp) dtype; c_up (B,T,Ccp) dtype; skip (B,T,Sp) fp32; zb (B,2Hp) fp32 for THIS layer
+ * (row stride zb_stride floats); z_save (B,T,2Hp) dtype or NULL; w_packed = [W1 chunks | W2 chunks];
+ * bias2 (Rp+Sp) fp32 = [out bias | skip bias]. */
+int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* x_out, const void* c_up, float* skip,
+                      const float* zb, int64_t zb_stride, void* z_save, const void* w_packed,
+                      const float* bias2, void* stream);
+int64_t wae_glu_packed_bytes(const wae_glu_desc* d);
+
+/* ---- a8+a9 head (wavenet.py:136-141,208-214) + MaskedCrossEntropyLoss (vqwae_train.py:363-379,:764) ----
+ * h = relu(skip*scale); h = relu(W1 h + b1); logits = W3 h + b3.  logits (B,O,T) fp32 or NULL.
+ * If target != NULL: nll[b*T+t] = logsumexp(logits[:,t]) - logits[target[b*T+t+1], t] for t < T-1
+ * (the reference's one-step shift), 0 at t = T-1. */
+typedef struct wae_head_desc {
+  int32_t dtype;
+  int32_t B, T;
+  int32_t Sp, Op; /* padded to multiples of 64 */
+  int32_t O;      /* true class count */
+  float scale;    /* sqrt(1/L) */
+} wae_head_desc;
+int wae_head_fwd(const wae_head_desc* d, const float* skip, const void* w_packed, const float* bias,
+                 float* logits, const int32_t* target, float* nll, void* h1_save, void* stream);
+int64_t wae_head_packed_bytes(const wae_head_desc* d);
+
+/* masked mean of per-sample losses: out[0] = sum_{b,t<len[b]-1} nll / sum mask  (vqwae_train.py:379) */
+int wae_masked_mean(const float* nll, const int32_t* lengths, float* out, int32_t B, int32_t T, void* stream);
+
+/* ---- a10 discretized mixture of logistics (mixture.py:26-106) on (B,3M,T) fp32 logits ------------------ */
+int wae_dmol_loss_fwd(const float* y_hat, const float* y, float* nll, float* dy_hat, int32_t B, int32_t M,
+                      int32_t T, int32_t num_classes, float log_scale_min, int32_t shift, void* stream);
+
+/* layout helpers: (B,C,T) fp32 <-> (B,T,Cp) dtype */
+int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);
+int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAE_H */

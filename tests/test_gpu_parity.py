@@ -1,0 +1,154 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (north star): fp32 mode <= 1e-3 relative on encoder latents and decoder logits, VQ indices
+bit-exact.  bf16 mode (bf16 storage of activations/weights, fp32 accumulate) is checked against the same
+oracle with a looser, explicitly stated tolerance: 5e-2 of the logit range.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_model, load_npz, rel_err
+from oracle import wae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-3
+BF16_TOL = 5e-2
+
+
+def _engine(cfg, sd, dtype):
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+    eng.load_state_dict(sd)
+    return eng
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_full_model_against_golden(name, dtype, tol):
+    cfg, sd, ins, z, ocfg = golden_model(name)
+    eng = _engine(cfg, sd, dtype)
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    T = x.shape[1]
+    lengths = torch.tensor([T, T - 137])
+    out = eng.forward(x, c, g, targets=x, lengths=lengths.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(out["latents"].cpu(), z["latents"]) < FP32_TOL          # encoder + VQ are always fp32
+    assert np.array_equal(out["idx"].cpu().numpy(), z["vq_idx"])            # bit-exact
+    assert rel_err(out["quant"].cpu(), z["quant"]) < 1e-6
+    assert abs(float(out["vq_loss"]) - float(z["vq_loss"])) < 1e-4 * max(1.0, float(z["vq_loss"]))
+    assert abs(float(out["perp"]) - float(z["perp"])) < 1e-3
+    assert rel_err(out["logits"].cpu(), z["y_hat"]) < tol
+    ce = O.masked_ce_loss(torch.from_numpy(z["y_hat"]), ins["x"].unsqueeze(-1), lengths)
+    assert abs(float(out["loss"]) - float(ce)) < (1e-4 if dtype == "fp32" else 2e-2)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+def test_upsample_against_golden(dtype, tol):
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    eng = _engine(cfg, sd, dtype)
+    eng.prepare_weights()
+    q = torch.from_numpy(z["quant"]).cuda()
+    B, Cc, Tq = q.shape
+    T = Tq * 640
+    out = torch.zeros(B, T, eng.g.Ccp, dtype=eng.tdtype, device="cuda")
+    eng.upsample_forward(q, out)
+    got = out[:, :, :Cc].float().transpose(1, 2).cpu()
+    assert rel_err(got, z["c_up"]) < (1e-5 if dtype == "fp32" else 1e-2)
+    assert float(out[:, :, Cc:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("name", ["A", "B"])
+@pytest.mark.parametrize("d", [1, 2, 512])
+def test_single_glu_layer(name, d, dtype, tol):
+    """wae_glu_layer_fwd alone against the golden single-layer vectors (modules.py:115-163)."""
+    import ctypes
+    from wavenet_autoencoders_amd import _lib as L
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    z = load_npz("glu_" + name)
+    eng = _engine(cfg, sd, dtype)
+    eng.prepare_weights()
+    g = eng.g
+    T, B = int(z["T"]), 2
+    x = O.hash_fill((B, cfg["R"], T), int(z["x_salt"]), float(z["x_scale"]))
+    c = O.hash_fill((B, cfg["Cc"], T), int(z["c_salt"]), float(z["c_scale"]))
+    gv = O.hash_fill((B, cfg["Cg"], 1), int(z["g_salt"]), float(z["g_scale"]))
+    st = eng.stream()
+    xin = torch.zeros(B, T, g.Rp, dtype=eng.tdtype, device="cuda")
+    cin = torch.zeros(B, T, g.Ccp, dtype=eng.tdtype, device="cuda")
+    L.check(eng.lib.wae_to_btc(L.ptr(x.cuda()), L.ptr(xin), B, g.R, T, g.Rp, eng.dt, st))
+    L.check(eng.lib.wae_to_btc(L.ptr(c.cuda()), L.ptr(cin), B, g.Cc, T, g.Ccp, eng.dt, st))
+    zb = torch.zeros(B, g.layers, 2 * g.Hp, device="cuda")
+    gvec = gv.view(B, -1).contiguous().cuda()
+    L.check(eng.lib.wae_gproj_fwd(L.ptr(eng.eff), eng.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v"),
+                                  eng.lay.off("wavenet.conv_layers.0.conv.bias"), eng.lay.layer_stride, None, 0,
+                                  L.ptr(gvec), L.ptr(zb), B, g.layers, g.G, g.Hp, g.Cg, st))
+    xout = torch.zeros_like(xin)
+    skip = torch.full((B, T, g.Sp), 7.0, device="cuda")
+    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, d, L.GLU_SKIP_INIT)
+    i = 1  # golden uses the weights of conv_layers.1
+    es = eng.w_glu.element_size()
+    L.check(eng.lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(xin), L.ptr(xout), L.ptr(cin), L.ptr(skip),
+                                      ctypes.c_void_p(zb.data_ptr() + i * 2 * g.Hp * 4), g.layers * 2 * g.Hp, None,
+                                      ctypes.c_void_p(eng.w_glu.data_ptr() + i * eng.glu_elems * es),
+                                      ctypes.c_void_p(eng.b_glu.data_ptr() + i * (g.Rp + g.Sp) * 4), st))
+    torch.cuda.synchronize()
+    pt = torch.from_numpy(z["probe_t"])
+    xo = xout[:, :, :g.R].float().transpose(1, 2).cpu()[:, :, pt]
+    so = skip[:, :, :g.S].transpose(1, 2).cpu()[:, :, pt]
+    assert rel_err(xo, z[f"xo_d{d}_cg"]) < tol
+    assert rel_err(so, z[f"so_d{d}_cg"]) < tol
+    # pad channels must stay exactly zero and the accumulate form must add
+    assert float(xout[:, :, g.R:].abs().max()) == 0.0
+    desc.flags = 0
+    L.check(eng.lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(xin), L.ptr(xout), L.ptr(cin), L.ptr(skip),
+                                      ctypes.c_void_p(zb.data_ptr() + i * 2 * g.Hp * 4), g.layers * 2 * g.Hp, None,
+                                      ctypes.c_void_p(eng.w_glu.data_ptr() + i * eng.glu_elems * es),
+                                      ctypes.c_void_p(eng.b_glu.data_ptr() + i * (g.Rp + g.Sp) * 4), st))
+    torch.cuda.synchronize()
+    so2 = skip[:, :, :g.S].transpose(1, 2).cpu()[:, :, pt]
+    assert rel_err(so2, 2 * torch.from_numpy(z[f"so_d{d}_cg"])) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+def test_ragged_T_and_wrong_cond_length(dtype, tol):
+    """T not a multiple of the 128-step tile; seeded inputs against the oracle; wavenet.py:198-200 error."""
+    cfg, sd, ins, z, ocfg = golden_model("B")
+    eng = _engine(cfg, sd, dtype)
+    B, T = 3, 1000
+    x = ((O.hash_fill((B, T), 5) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+    c = O.hash_fill((B, cfg["Cc"], T), 6, 1.0)
+    g = torch.tensor([0, 3, 1])
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    sd2 = {k: v for k, v in sd.items() if "upsample_net" not in k}
+    with torch.no_grad():
+        ref = O.wavenet_forward(sd2, dict(ocfg, upsample_scales=None), xin, c, g)
+    out = eng.decoder_forward(x.cuda(), c.cuda(), g.cuda(), c_is_upsampled=True)
+    torch.cuda.synchronize()
+    assert rel_err(out["logits"].cpu(), ref) < tol
+    with pytest.raises(Exception):
+        eng.decoder_forward(x.cuda(), c[:, :, :-5].cuda(), g.cuda(), c_is_upsampled=True)
+
+
+def test_vqwae_fullsize_probe_fp32():
+    """hps/vqwae.json geometry (R=G=S=256, L=20), sparse golden probe from the reference."""
+    import json
+    z = load_npz("model_vqwae_probe")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(cfg, int(z["salt"]))
+    eng = _engine(cfg, sd, "fp32")
+    c = O.hash_fill((1, 39, 16), 71, 1.7)
+    T = 4 * 640
+    x = ((O.hash_fill((1, T), 72) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    g = ((O.hash_fill((1,), 73) * 0.5 + 0.5) * 153).long().clamp(0, 152)
+    out = eng.forward(x.cuda(), c.cuda(), g.cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(out["idx"].cpu().numpy(), z["vq_idx"])
+    y = out["logits"].cpu()
+    assert rel_err(y[0][:, torch.from_numpy(z["probe_t"])], z["y_probe"]) < FP32_TOL
+    assert abs(float(y.double().sum()) - float(z["y_sum"])) < 1e-3 * float(z["y_abs_sum"])

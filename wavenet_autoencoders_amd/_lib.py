@@ -1,0 +1,86 @@
+"""ctypes binding of libwae_hip.so (the C ABI declared in include/wae.h).
+
+There is no CPU fallback: if the shared object is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwae_hip.so")
+
+WAE_F32, WAE_BF16 = 0, 1
+GLU_SKIP_INIT, GLU_SAVE_Z, GLU_NO_OUT = 1, 2, 4
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class GluDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Rp", "Sp", "Ccp", "Hp", "ktaps", "dilation", "flags")]
+
+
+class HeadDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Sp", "Op", "O")] + [("scale", c_f32)]
+
+
+# name -> (restype, argtypes); mirrors include/wae.h one to one
+SIGNATURES = {
+    "wae_version": (ctypes.c_char_p, []),
+    "wae_last_error": (ctypes.c_char_p, []),
+    "wae_weight_norm_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "wae_weight_norm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "wae_pack_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_vp]),
+    "wae_unpack_scatter_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp]),
+    "wae_enc_conv_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp]),
+    "wae_vq_nearest": (c_i32, [c_vp] * 6 + [c_i32] * 4 + [c_f32, c_vp]),
+    "wae_upsample_stage_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
+    "wae_gproj_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
+    "wae_first_conv_fwd": (c_i32, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "wae_glu_layer_fwd": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "wae_glu_packed_bytes": (c_i64, [ctypes.POINTER(GluDesc)]),
+    "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 8),
+    "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
+    "wae_masked_mean": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
+    "wae_from_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
+}
+
+_lib = None
+
+
+class WaeError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libwae_hip.so (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean"])
+    subprocess.check_call(["make", "-C", src, "-j4"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WaeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise WaeError(f"{what} failed (rc={rc}): {lib().wae_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

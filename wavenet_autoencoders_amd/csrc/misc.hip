@@ -1,0 +1,518 @@
+// Small HBM-bound kernels of the hot path: weight norm, fragment packing, encoder conv, VQ, upsample stages,
+// hoisted global conditioning, first-conv gather, layout converters, masked mean.  All fp32 arithmetic.
+#include <stdarg.h>
+#include "wae_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void wae_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int wae_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    wae_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return WAE_EHIP;
+  }
+  return WAE_OK;
+}
+extern "C" const char* wae_version(void) { return "wae-hip 0.1 (gfx950)"; }
+extern "C" const char* wae_last_error(void) { return g_err; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename E>
+__device__ __forceinline__ void store_e(void* p, int64_t i, float v);
+template <>
+__device__ __forceinline__ void store_e<float>(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+template <>
+__device__ __forceinline__ void store_e<__bf16>(void* p, int64_t i, float v) { ((__bf16*)p)[i] = (__bf16)v; }
+template <typename E>
+__device__ __forceinline__ float load_e(const void* p, int64_t i);
+template <>
+__device__ __forceinline__ float load_e<float>(const void* p, int64_t i) { return ((const float*)p)[i]; }
+template <>
+__device__ __forceinline__ float load_e<__bf16>(const void* p, int64_t i) { return (float)((const __bf16*)p)[i]; }
+
+// ---------------------------------------------------------------------------------------------------
+// weight norm: one wave per weight row (modules.py:18: w = g * v / ||v||, norm over all dims but 0)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) weight_norm_fwd_kernel(const float* __restrict__ params, float* __restrict__ eff,
+                                                              const int64_t* __restrict__ v_off,
+                                                              const int64_t* __restrict__ g_off,
+                                                              const int32_t* __restrict__ cols, int nrows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  const float* v = params + v_off[row];
+  const int n = cols[row];
+  float ss = 0.f;
+  for (int i = lane; i < n; i += 64) ss += v[i] * v[i];
+  ss = wave_sum(ss);
+  const float sc = params[g_off[row]] / sqrtf(ss);
+  float* w = eff + v_off[row];
+  for (int i = lane; i < n; i += 64) w[i] = v[i] * sc;
+}
+
+extern "C" int wae_weight_norm_fwd(const float* params, float* eff, int64_t n_params, const int64_t* v_off,
+                                   const int64_t* g_off, const int32_t* cols, int32_t nrows, void* stream) {
+  WAE_REQUIRE(params && eff && n_params > 0, "weight_norm_fwd: null arena");
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(eff, params, n_params * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    wae_set_error("weight_norm_fwd: arena copy failed");
+    return WAE_EHIP;
+  }
+  if (nrows > 0) {
+    WAE_REQUIRE(v_off && g_off && cols, "weight_norm_fwd: null tables");
+    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, params, eff, v_off, g_off,
+                       cols, nrows);
+  }
+  return wae_check_launch("weight_norm_fwd");
+}
+
+__global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __restrict__ params,
+                                                              const float* __restrict__ d_eff, float* __restrict__ grads,
+                                                              const int64_t* __restrict__ v_off,
+                                                              const int64_t* __restrict__ g_off,
+                                                              const int32_t* __restrict__ cols, int nrows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  const float* v = params + v_off[row];
+  const float* dw = d_eff + v_off[row];
+  const int n = cols[row];
+  float ss = 0.f, dv = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    ss += v[i] * v[i];
+    dv += v[i] * dw[i];
+  }
+  ss = wave_sum(ss);
+  dv = wave_sum(dv);
+  const float g = params[g_off[row]];
+  const float inv = 1.0f / sqrtf(ss);
+  float* gv = grads + v_off[row];
+  for (int i = lane; i < n; i += 64) gv[i] = g * inv * (dw[i] - v[i] * dv * inv * inv);
+  if (lane == 0) grads[g_off[row]] = dv * inv;
+}
+
+extern "C" int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, int64_t n_params,
+                                   const int64_t* v_off, const int64_t* g_off, const int32_t* cols, int32_t nrows,
+                                   void* stream) {
+  WAE_REQUIRE(params && d_eff && grads && n_params > 0, "weight_norm_bwd: null arena");
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(grads, d_eff, n_params * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    wae_set_error("weight_norm_bwd: arena copy failed");
+    return WAE_EHIP;
+  }
+  if (nrows > 0)
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, params, d_eff, grads, v_off,
+                       g_off, cols, nrows);
+  return wae_check_launch("weight_norm_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fragment packing: gather through a host-built index map
+// ---------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) pack_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ map,
+                                                          void* __restrict__ dst, int64_t n, int64_t src_stride,
+                                                          int64_t dst_stride) {
+  const int b = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int32_t m = map[i];
+    store_e<E>(dst, i + b * dst_stride, m < 0 ? 0.f : src[m + b * src_stride]);
+  }
+}
+
+extern "C" int wae_pack_gather(const float* src, const int32_t* map, void* dst, int64_t n, int32_t nbatch,
+                               int64_t src_stride, int64_t dst_stride, int32_t dtype, void* stream) {
+  WAE_REQUIRE(src && map && dst && n > 0 && nbatch > 0, "pack_gather: bad arguments");
+  WAE_REQUIRE(dtype == WAE_F32 || dtype == WAE_BF16, "pack_gather: bad dtype");
+  const int gx = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (dtype == WAE_BF16)
+    hipLaunchKernelGGL(pack_gather_kernel<__bf16>, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
+                       src_stride, dst_stride);
+  else
+    hipLaunchKernelGGL(pack_gather_kernel<float>, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
+                       src_stride, dst_stride);
+  return wae_check_launch("pack_gather");
+}
+
+__global__ void __launch_bounds__(256) unpack_scatter_add_kernel(const float* __restrict__ src,
+                                                                 const int32_t* __restrict__ map, float* __restrict__ dst,
+                                                                 int64_t n, int64_t src_stride, int64_t dst_stride) {
+  const int b = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int32_t m = map[i];
+    if (m >= 0) dst[m + b * dst_stride] += src[i + b * src_stride];
+  }
+}
+
+extern "C" int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int64_t n, int32_t nbatch,
+                                      int64_t src_stride, int64_t dst_stride, void* stream) {
+  WAE_REQUIRE(src && map && dst && n > 0 && nbatch > 0, "unpack_scatter_add: bad arguments");
+  const int gx = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(unpack_scatter_add_kernel, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
+                     src_stride, dst_stride);
+  return wae_check_launch("unpack_scatter_add");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// encoder block (vqvae_model.py:17-23).  (B,C,T) fp32; one wave per (b, cout, 64 output frames): lanes
+// run along time so x reads coalesce; the (cin,k) reduction is sequential per lane.  The encoder runs at
+// 1/160 .. 1/640 of the audio rate (<1 % of a step), so this stays a plain VALU kernel.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) enc_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                           int Cin, int Tin, int Cout, int Tout, int k, int stride, int pad,
+                                                           int relu, int residual) {
+  const int to = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int co = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (co >= Cout || to >= Tout) return;
+  float acc = bias ? bias[co] : 0.f;
+  const float* xb = x + (int64_t)b * Cin * Tin;
+  const float* wr = w + (int64_t)co * Cin * k;
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xr = xb + (int64_t)ci * Tin;
+    for (int j = 0; j < k; ++j) {
+      const int ti = to * stride + j - pad;
+      if (ti >= 0 && ti < Tin) acc = fmaf(wr[ci * k + j], xr[ti], acc);
+    }
+  }
+  if (relu) acc = fmaxf(acc, 0.f);
+  if (residual) acc += xb[(int64_t)co * Tin + to];
+  y[((int64_t)b * Cout + co) * Tout + to] = acc;
+}
+
+extern "C" int wae_enc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
+                                int32_t Tin, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t relu,
+                                int32_t residual, void* stream) {
+  WAE_REQUIRE(x && w && y && B > 0 && Cin > 0 && Tin > 0 && Cout > 0 && k > 0 && stride > 0 && pad >= 0,
+              "enc_conv: bad arguments");
+  WAE_REQUIRE(!residual || (stride == 1 && Cin == Cout && 2 * pad == k - 1), "enc_conv: residual needs a same-shape conv");
+  const int Tout = (Tin + 2 * pad - k) / stride + 1;
+  WAE_REQUIRE(Tout > 0, "enc_conv: empty output");
+  hipLaunchKernelGGL(enc_conv_fwd_kernel, dim3((Tout + 63) / 64, (Cout + 3) / 4, B), dim3(256), 0, as_stream(stream), x,
+                     w, bias, y, B, Cin, Tin, Cout, Tout, k, stride, pad, relu, residual);
+  return wae_check_launch("enc_conv_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// VQ nearest (vector_quantization.py:21-49).  One workgroup per latent vector; thread k scores code k with the
+// reference's formulation ||e||^2 + ||x||^2 - 2 x.e, all fp32; first minimum wins (torch.argmin tie-break).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vq_nearest_kernel(const float* __restrict__ lat, const float* __restrict__ emb,
+                                                         int64_t* __restrict__ idx, float* __restrict__ quant,
+                                                         float* __restrict__ sqerr, int32_t* __restrict__ hist, int D,
+                                                         int Tq, int K) {
+  extern __shared__ float sh[];
+  float* xs = sh;                      // D
+  float* best_d = sh + D;              // 256
+  int* best_i = (int*)(best_d + 256);  // 256
+  const int row = blockIdx.x;          // b*Tq + t
+  const int b = row / Tq, t = row % Tq;
+  for (int i = threadIdx.x; i < D; i += 256) xs[i] = lat[((int64_t)b * D + i) * Tq + t];
+  __syncthreads();
+  float in_sqr = 0.f;
+  for (int i = 0; i < D; ++i) in_sqr += xs[i] * xs[i];
+  float bd = INFINITY;
+  int bi = 0x7fffffff;
+  for (int kk = threadIdx.x; kk < K; kk += 256) {
+    const float* e = emb + (int64_t)kk * D;
+    float es = 0.f, dot = 0.f;
+    for (int i = 0; i < D; ++i) {
+      es += e[i] * e[i];
+      dot += xs[i] * e[i];
+    }
+    const float d = (es + in_sqr) - 2.0f * dot;
+    if (d < bd) { bd = d; bi = kk; }
+  }
+  best_d[threadIdx.x] = bd;
+  best_i[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float od = best_d[threadIdx.x + s];
+      const int oi = best_i[threadIdx.x + s];
+      if (od < best_d[threadIdx.x] || (od == best_d[threadIdx.x] && oi < best_i[threadIdx.x])) {
+        best_d[threadIdx.x] = od;
+        best_i[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  const int win = best_i[0];
+  float se = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float q = emb[(int64_t)win * D + i];
+    quant[((int64_t)b * D + i) * Tq + t] = q;
+    const float df = q - xs[i];
+    se += df * df;
+  }
+  se = wave_sum(se);
+  if ((threadIdx.x & 63) == 0 && se != 0.f) atomicAdd(sqerr, se);
+  if (threadIdx.x == 0) {
+    idx[row] = win;
+    atomicAdd(hist + win, 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) vq_stats_kernel(const float* __restrict__ sqerr, const int32_t* __restrict__ hist,
+                                                       float* __restrict__ stats, int K, int N, int D, float beta) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float pk = (float)hist[k] / (float)N;
+    s += pk * logf(pk + 1e-10f);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = part[0] + part[1] + part[2] + part[3];
+    const float mse = sqerr[0] / ((float)N * (float)D);
+    stats[0] = beta * mse + mse;  // vector_quantization.py:41-43 (forward values of both terms are equal)
+    stats[1] = expf(-tot);
+  }
+}
+
+extern "C" int wae_vq_nearest(const float* lat, const float* emb, int64_t* idx, float* quant, float* stats, int32_t* hist,
+                              int32_t B, int32_t D, int32_t Tq, int32_t K, float beta, void* stream) {
+  WAE_REQUIRE(lat && emb && idx && quant && stats && hist, "vq_nearest: null pointer");
+  WAE_REQUIRE(B > 0 && D > 0 && Tq > 0 && K > 0, "vq_nearest: bad sizes");
+  hipStream_t st = as_stream(stream);
+  // scratch: hist[K] counts, then one float (sum of squared errors) stored after it
+  if (hipMemsetAsync(hist, 0, (size_t)(K + 1) * sizeof(int32_t), st) != hipSuccess) {
+    wae_set_error("vq_nearest: memset failed");
+    return WAE_EHIP;
+  }
+  float* sqerr = (float*)(hist + K);
+  const size_t lds = (size_t)(D + 512) * sizeof(float);
+  hipLaunchKernelGGL(vq_nearest_kernel, dim3(B * Tq), dim3(256), lds, st, lat, emb, idx, quant, sqerr, hist, D, Tq, K);
+  hipLaunchKernelGGL(vq_stats_kernel, dim3(1), dim3(256), 0, st, sqerr, hist, stats, K, B * Tq, D, beta);
+  return wae_check_launch("vq_nearest");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one upsample stage (upsample.py:19-21 nearest stretch + :39-46 shared FIR, zero padded at both ends)
+// ---------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) upsample_stage_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                             void* __restrict__ out, int C, int Tin, int s, int out_btc,
+                                                             int Cp) {
+  const int Tout = Tin * s;
+  const int b = blockIdx.z;
+  if (!out_btc) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (t >= Tout) return;
+    const float* r = in + ((int64_t)b * C + c) * Tin;
+    float acc = 0.f;
+    for (int j = 0; j <= 2 * s; ++j) {
+      const int u = t + j - s;
+      if (u >= 0 && u < Tout) acc = fmaf(w[j], r[u / s], acc);
+    }
+    ((float*)out)[((int64_t)b * C + c) * Tout + t] = acc;
+  } else {
+    // time-major output: thread -> (t, c) with c fastest so the stores coalesce
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int t = (int)(e / Cp), c = (int)(e % Cp);
+    if (t >= Tout) return;
+    float acc = 0.f;
+    if (c < C) {
+      const float* r = in + ((int64_t)b * C + c) * Tin;
+      for (int j = 0; j <= 2 * s; ++j) {
+        const int u = t + j - s;
+        if (u >= 0 && u < Tout) acc = fmaf(w[j], r[u / s], acc);
+      }
+    }
+    store_e<E>(out, ((int64_t)b * Tout + t) * Cp + c, acc);
+  }
+}
+
+extern "C" int wae_upsample_stage_fwd(const float* in, const float* w, void* out, int32_t B, int32_t C, int32_t Tin,
+                                      int32_t s, int32_t out_btc, int32_t Cp, int32_t dtype, void* stream) {
+  WAE_REQUIRE(in && w && out && B > 0 && C > 0 && Tin > 0 && s > 0, "upsample_stage: bad arguments");
+  const int Tout = Tin * s;
+  hipStream_t st = as_stream(stream);
+  if (!out_btc) {
+    hipLaunchKernelGGL(upsample_stage_kernel<float>, dim3((Tout + 255) / 256, C, B), dim3(256), 0, st, in, w, out, C, Tin,
+                       s, 0, C);
+  } else {
+    WAE_REQUIRE(Cp >= C, "upsample_stage: Cp < C");
+    const int64_t n = (int64_t)Tout * Cp;
+    dim3 grid((unsigned)((n + 255) / 256), 1, B);
+    if (dtype == WAE_BF16)
+      hipLaunchKernelGGL(upsample_stage_kernel<__bf16>, grid, dim3(256), 0, st, in, w, out, C, Tin, s, 1, Cp);
+    else
+      hipLaunchKernelGGL(upsample_stage_kernel<float>, grid, dim3(256), 0, st, in, w, out, C, Tin, s, 1, Cp);
+  }
+  return wae_check_launch("upsample_stage_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hoisted global conditioning (modules.py:148-152 re-convolves the same g at every t; exact hoist)
+// zb[b][l][row] , rows 0..Hp-1 = gate-a channels, Hp..2Hp-1 = gate-b channels (zero in the padding)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gproj_fwd_kernel(const float* __restrict__ eff, int64_t wg_off, int64_t bias_off,
+                                                        int64_t layer_stride, const int32_t* __restrict__ gid,
+                                                        int64_t emb_off, const float* __restrict__ gvec,
+                                                        float* __restrict__ zb, int L, int G, int Hp, int Cg) {
+  const int l = blockIdx.x, b = blockIdx.y;
+  const int H = G / 2;
+  const float* wg = wg_off >= 0 ? eff + wg_off + (int64_t)l * layer_stride : nullptr;
+  const float* bs = eff + bias_off + (int64_t)l * layer_stride;
+  const float* gv = gid ? eff + emb_off + (int64_t)gid[b] * Cg : (gvec ? gvec + (int64_t)b * Cg : nullptr);
+  float* o = zb + ((int64_t)b * L + l) * 2 * Hp;
+  for (int r = threadIdx.x; r < 2 * Hp; r += 256) {
+    const int half = r >= Hp, i = r - half * Hp;
+    float acc = 0.f;
+    if (i < H) {
+      const int ch = half * H + i;
+      acc = bs[ch];
+      if (wg && gv)
+        for (int c = 0; c < Cg; ++c) acc = fmaf(wg[(int64_t)ch * Cg + c], gv[c], acc);
+    }
+    o[r] = acc;
+  }
+}
+
+extern "C" int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride, const int32_t* gid,
+                             int64_t emb_off, const float* gvec, float* zb, int32_t B, int32_t L, int32_t G, int32_t Hp,
+                             int32_t Cg, void* stream) {
+  WAE_REQUIRE(eff && zb && B > 0 && L > 0 && G > 0 && G % 2 == 0 && Hp >= G / 2, "gproj: bad arguments");
+  hipLaunchKernelGGL(gproj_fwd_kernel, dim3(L, B), dim3(256), 0, as_stream(stream), eff, wg_off, bias_off, layer_stride,
+                     gid, emb_off, gvec, zb, L, G, Hp, Cg);
+  return wae_check_launch("gproj_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// first_conv on a one-hot input == column gather + bias (wavenet.py:203); scalar input: w*x + b
+// ---------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) first_conv_kernel(const int32_t* __restrict__ idx, const float* __restrict__ xs,
+                                                         const float* __restrict__ table, const float* __restrict__ bias,
+                                                         void* __restrict__ x0, int64_t BT, int Rp) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t bt = e / Rp;
+  const int r = (int)(e % Rp);
+  if (bt >= BT) return;
+  float v;
+  if (idx)
+    v = table[(int64_t)idx[bt] * Rp + r] + bias[r];
+  else
+    v = fmaf(table[r], xs[bt], bias[r]);
+  store_e<E>(x0, e, v);
+}
+
+extern "C" int wae_first_conv_fwd(const int32_t* idx, const float* xs, const float* table, const float* bias, void* x0,
+                                  int64_t BT, int32_t Rp, int32_t O, int32_t dtype, void* stream) {
+  WAE_REQUIRE((idx || xs) && table && bias && x0 && BT > 0 && Rp > 0, "first_conv: bad arguments");
+  (void)O;
+  dim3 grid((unsigned)((BT * Rp + 255) / 256));
+  if (dtype == WAE_BF16)
+    hipLaunchKernelGGL(first_conv_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp);
+  else
+    hipLaunchKernelGGL(first_conv_kernel<float>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp);
+  return wae_check_launch("first_conv_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// layout converters (B,C,T) fp32 <-> (B,T,Cp) dtype through a 64x64 LDS tile (coalesced on both sides)
+// ---------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) to_btc_kernel(const float* __restrict__ in, void* __restrict__ out, int C, int T,
+                                                     int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  for (int i = ly; i < 64; i += 4) {
+    const int c = c0 + i, t = t0 + lx;
+    tile[i][lx] = (c < C && t < T) ? in[((int64_t)b * C + c) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ly; i < 64; i += 4) {
+    const int t = t0 + i, c = c0 + lx;
+    if (t < T && c < Cp) store_e<E>(out, ((int64_t)b * T + t) * Cp + c, tile[lx][i]);
+  }
+}
+template <typename E>
+__global__ void __launch_bounds__(256) from_btc_kernel(const void* __restrict__ in, float* __restrict__ out, int C, int T,
+                                                       int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  for (int i = ly; i < 64; i += 4) {
+    const int t = t0 + i, c = c0 + lx;
+    tile[i][lx] = (t < T && c < Cp) ? load_e<E>(in, ((int64_t)b * T + t) * Cp + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ly; i < 64; i += 4) {
+    const int c = c0 + i, t = t0 + lx;
+    if (c < C && t < T) out[((int64_t)b * C + c) * T + t] = tile[lx][i];
+  }
+}
+
+extern "C" int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
+                          void* stream) {
+  WAE_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && Cp >= C, "to_btc: bad arguments");
+  dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
+  if (dtype == WAE_BF16)
+    hipLaunchKernelGGL(to_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+  else
+    hipLaunchKernelGGL(to_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+  return wae_check_launch("to_btc");
+}
+extern "C" int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
+                            void* stream) {
+  WAE_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && Cp >= C, "from_btc: bad arguments");
+  dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
+  if (dtype == WAE_BF16)
+    hipLaunchKernelGGL(from_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+  else
+    hipLaunchKernelGGL(from_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+  return wae_check_launch("from_btc");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked mean (vqwae_train.py:379): sum_{b, t < len[b]-1} nll[b,t] / sum_b max(len[b]-1, 0)
+// the mask is sequence_mask(lengths)[:,1:] applied to positions 0..T-2 (loss position t predicts y[t+1]).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) masked_mean_kernel(const float* __restrict__ nll, const int32_t* __restrict__ lengths,
+                                                           float* __restrict__ out, int B, int T) {
+  __shared__ double part[16];
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const int len = lengths ? min(lengths[b], T) : T;
+    const float* r = nll + (int64_t)b * T;
+    for (int t = threadIdx.x; t < len - 1; t += 1024) s += (double)r[t];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0, cnt = 0.0;
+    for (int i = 0; i < 16; ++i) tot += part[i];
+    for (int b = 0; b < B; ++b) {
+      const int len = lengths ? min(lengths[b], T) : T;
+      cnt += (double)max(len - 1, 0);
+    }
+    out[0] = (float)(tot / cnt);
+    out[1] = (float)cnt;
+  }
+}
+
+extern "C" int wae_masked_mean(const float* nll, const int32_t* lengths, float* out, int32_t B, int32_t T, void* stream) {
+  WAE_REQUIRE(nll && out && B > 0 && T > 0, "masked_mean: bad arguments");
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, as_stream(stream), nll, lengths, out, B, T);
+  return wae_check_launch("masked_mean");
+}

@@ -1,0 +1,110 @@
+// Shared device/host helpers for libwae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/wae.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+void wae_set_error(const char* fmt, ...);
+int wae_check_launch(const char* what);
+
+#define WAE_REQUIRE(cond, ...)      \
+  do {                              \
+    if (!(cond)) {                  \
+      wae_set_error(__VA_ARGS__);   \
+      return WAE_EINVAL;            \
+    }                               \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// Element traits: one 16-byte MFMA operand fragment per lane = 8 bf16 (one 32x32x16 MFMA) or 4 f32
+// (four exact-fp32 32x32x2 MFMAs).  A fragment block is 64 lanes x 16 B = 1 KiB in both cases, so the
+// LDS images, chunk sizes and byte addressing of the two precisions are identical.
+// ---------------------------------------------------------------------------------------------------
+template <typename E>
+struct ET;
+template <>
+struct ET<float> {
+  using frag = f32x4;
+  using vec4 = f32x4;  // 4 consecutive channels
+  static constexpr int EPL = 4;   // elements per 16-B fragment
+  static constexpr int CK = 32;   // channels per 128-B chunk row
+  static constexpr int KBU = 4;   // 16-B k-blocks per 32-row accumulator tile used as next operand
+  static constexpr int MT2 = 2;   // second-GEMM M-tiles per weight chunk (MT2*KBU == 8)
+  static constexpr int DT = WAE_F32;
+};
+template <>
+struct ET<__bf16> {
+  using frag = bf16x8;
+  using vec4 = bf16x4;
+  static constexpr int EPL = 8;
+  static constexpr int CK = 64;
+  static constexpr int KBU = 2;
+  static constexpr int MT2 = 4;
+  static constexpr int DT = WAE_BF16;
+};
+
+__device__ __forceinline__ void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 to_f32x4(const f32x4& v) { return v; }
+__device__ __forceinline__ f32x4 to_f32x4(const bf16x4& v) {
+  f32x4 r;
+  r.x = (float)v.x; r.y = (float)v.y; r.z = (float)v.z; r.w = (float)v.w;
+  return r;
+}
+template <typename E>
+__device__ __forceinline__ typename ET<E>::vec4 from_f32x4(const f32x4& v);
+template <>
+__device__ __forceinline__ f32x4 from_f32x4<float>(const f32x4& v) { return v; }
+template <>
+__device__ __forceinline__ bf16x4 from_f32x4<__bf16>(const f32x4& v) {
+  bf16x4 r;
+  r.x = (__bf16)v.x; r.y = (__bf16)v.y; r.z = (__bf16)v.z; r.w = (__bf16)v.w;
+  return r;
+}
+
+// 16 accumulator registers of a 32x32 tile -> the KBU operand fragments of the NEXT MFMA that sums over
+// the tile's row index.  bf16: k-step s takes registers 8s..8s+7 (row 16s+8(j>>2)+4h+(j&3)); f32: k-block
+// g takes registers 4g..4g+3 (row 8g+4h+j).  The host packs the A operand in the matching k order.
+__device__ __forceinline__ void acc_to_frags(const f32x16& u, bf16x8 (&f)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[s][j] = (__bf16)u[8 * s + j];
+}
+__device__ __forceinline__ void acc_to_frags(const f32x16& u, f32x4 (&f)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f[g].x = u[4 * g]; f[g].y = u[4 * g + 1]; f[g].z = u[4 * g + 2]; f[g].w = u[4 * g + 3];
+  }
+}
+
+// Linear global -> LDS copy of `bytes` (multiple of 256 threads * 16 B) by LDS-DMA: every wave instruction
+// moves 1 KiB to a wave-uniform LDS base + lane*16 (cdna_hip_programming.md section 5, Caveat).
+__device__ __forceinline__ void dma_chunk(const char* __restrict__ gsrc, char* lds_dst, int bytes, int wave, int lane) {
+  const int per_pass = 256 * 16;
+  for (int off = 0; off < bytes; off += per_pass) {
+    const char* g = gsrc + off + wave * 1024 + lane * 16;
+    char* l = lds_dst + off + wave * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

@@ -1,0 +1,286 @@
+"""WaeEngine: host-side driver of the HIP hot path (encoder -> VQ -> upsample -> gated stack -> head -> loss).
+
+PyTorch is used for device memory, streams and (elsewhere) torch.distributed only; every arithmetic step below
+is a call into libwae_hip.so through the C ABI of include/wae.h.  There is no CPU fallback.
+
+Reference call stack being replaced: VQVAE.forward (vqvae_model.py:66-72) -> Encoder.forward (:48-51),
+VectorQuantize.forward (vector_quantization.py:21-49), WaveNet.forward (wavenet.py:164-216).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import packing as P
+
+
+def _dt(dtype) -> int:
+    if dtype in ("bf16", torch.bfloat16, L.WAE_BF16):
+        return L.WAE_BF16
+    if dtype in ("fp32", "f32", torch.float32, L.WAE_F32):
+        return L.WAE_F32
+    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32' or 'bf16')")
+
+
+class WaeEngine:
+    def __init__(self, geom: P.Geometry, dtype="bf16", device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise L.WaeError("WaeEngine needs a ROCm GPU: the hot path has no CPU implementation")
+        self.lib = L.lib()
+        self.g = geom
+        self.dt = _dt(dtype)
+        self.tdtype = torch.bfloat16 if self.dt == L.WAE_BF16 else torch.float32
+        self.device = torch.device(device)
+        self.lay = P.ParamLayout(geom)
+        dev = self.device
+        self.params = torch.zeros(self.lay.total, dtype=torch.float32, device=dev)
+        self.eff = torch.zeros_like(self.params)
+        self.wn_v = torch.from_numpy(self.lay.wn_v_off).to(dev)
+        self.wn_g = torch.from_numpy(self.lay.wn_g_off).to(dev)
+        self.wn_c = torch.from_numpy(self.lay.wn_cols).to(dev)
+        g = geom
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.m_w1 = up(P.glu_w1_map(g, self.lay, self.dt))
+        self.m_w2 = up(P.glu_w2_map(g, self.lay, self.dt))
+        self.m_b2 = up(P.glu_bias2_map(g, self.lay))
+        tab, fb = P.first_conv_maps(g, self.lay)
+        self.m_tab, self.m_fb = up(tab), up(fb)
+        self.m_hw = up(P.head_w_map(g, self.lay, self.dt))
+        self.m_hb = up(P.head_bias_map(g, self.lay))
+        self.n_w1 = self.m_w1.numel()
+        self.n_w2 = self.m_w2.numel()
+        self.glu_elems = self.n_w1 + self.n_w2
+        assert self.glu_elems == P.glu_packed_elems(g, self.dt)
+        self.w_glu = torch.zeros(g.layers * self.glu_elems, dtype=self.tdtype, device=dev)
+        self.b_glu = torch.zeros(g.layers * (g.Rp + g.Sp), dtype=torch.float32, device=dev)
+        self.first_tab = torch.zeros(self.m_tab.numel(), dtype=torch.float32, device=dev)
+        self.first_bias = torch.zeros(g.Rp, dtype=torch.float32, device=dev)
+        self.w_head = torch.zeros(self.m_hw.numel(), dtype=self.tdtype, device=dev)
+        self.b_head = torch.zeros(g.Sp + g.Op, dtype=torch.float32, device=dev)
+        self._ws: Dict[tuple, dict] = {}
+        self.weights_dirty = True
+
+    # ------------------------------------------------------------------ parameters
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def view(self, name: str) -> torch.Tensor:
+        off = self.lay.off(name)
+        return self.params[off:off + self.lay.numel(name)].view(self.lay.shapes[name])
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        missing = [k for k in self.lay.offsets if k not in sd]
+        extra = [k for k in sd if k not in self.lay.offsets]
+        if strict and (missing or extra):
+            raise KeyError(f"state_dict mismatch: missing {missing[:5]}, unexpected {extra[:5]}")
+        host = torch.zeros(self.lay.total, dtype=torch.float32)
+        for k in self.lay.offsets:
+            if k in sd:
+                t = sd[k].detach().to(torch.float32).cpu().reshape(-1)
+                if t.numel() != self.lay.numel(k):
+                    raise ValueError(f"{k}: expected {self.lay.shapes[k]}, got {tuple(sd[k].shape)}")
+                host[self.lay.off(k):self.lay.off(k) + t.numel()] = t
+        self.params.copy_(host.to(self.device))
+        self.weights_dirty = True
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: self.view(k).detach().clone() for k in self.lay.offsets}
+
+    def prepare_weights(self):
+        """K14 weight norm + fragment packing; call after every parameter update."""
+        lib, st, g, lay = self.lib, self.stream(), self.g, self.lay
+        L.check(lib.wae_weight_norm_fwd(L.ptr(self.params), L.ptr(self.eff), lay.total, L.ptr(self.wn_v), L.ptr(self.wn_g),
+                                        L.ptr(self.wn_c), len(lay.wn_cols), st), "weight_norm_fwd")
+        es = self.w_glu.element_size()
+        w2 = ctypes.c_void_p(self.w_glu.data_ptr() + self.n_w1 * es)
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_w1), L.ptr(self.w_glu), self.n_w1, g.layers,
+                                    lay.layer_stride, self.glu_elems, self.dt, st), "pack W1")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_w2), w2, self.n_w2, g.layers, lay.layer_stride,
+                                    self.glu_elems, self.dt, st), "pack W2")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_b2), L.ptr(self.b_glu), g.Rp + g.Sp, g.layers,
+                                    lay.layer_stride, g.Rp + g.Sp, L.WAE_F32, st), "pack bias2")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_tab), L.ptr(self.first_tab), self.m_tab.numel(), 1, 0, 0,
+                                    L.WAE_F32, st), "pack first table")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_fb), L.ptr(self.first_bias), g.Rp, 1, 0, 0, L.WAE_F32, st),
+                "pack first bias")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hw), L.ptr(self.w_head), self.m_hw.numel(), 1, 0, 0,
+                                    self.dt, st), "pack head W")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hb), L.ptr(self.b_head), g.Sp + g.Op, 1, 0, 0, L.WAE_F32,
+                                    st), "pack head bias")
+        self.weights_dirty = False
+
+    # ------------------------------------------------------------------ workspaces
+    def workspace(self, B: int, T: int, train: bool = False) -> dict:
+        key = (B, T, train)
+        ws = self._ws.get(key)
+        if ws is None:
+            g, dev, td = self.g, self.device, self.tdtype
+            ws = dict(
+                x=[torch.empty(B, T, g.Rp, dtype=td, device=dev) for _ in range((g.layers + 1) if train else 2)],
+                skip=torch.empty(B, T, g.Sp, dtype=torch.float32, device=dev),
+                zb=torch.empty(B, g.layers, 2 * g.Hp, dtype=torch.float32, device=dev),
+                c_up=torch.zeros(B, T, g.Ccp, dtype=td, device=dev) if g.Ccp else None,
+                nll=torch.zeros(B, T, dtype=torch.float32, device=dev),
+                loss=torch.zeros(2, dtype=torch.float32, device=dev),
+            )
+            if train:
+                ws["z"] = [torch.empty(B, T, 2 * g.Hp, dtype=td, device=dev) for _ in range(g.layers)]
+                ws["h1"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ front end
+    def encoder_forward(self, c: torch.Tensor) -> torch.Tensor:
+        """a1: c (B, c_in, F) fp32 -> latents (B, Cc, F')  (vqvae_model.py:48-51)."""
+        g, lib, st = self.g, self.lib, self.stream()
+        x = c.contiguous().float()
+        B = x.shape[0]
+        for i, (k, s) in enumerate(P.ENCODER_BLOCKS):
+            wname = f"encoder.net.{i}.conv.weight"
+            co, ci, _ = self.lay.shapes[wname]
+            Tin = x.shape[-1]
+            Tout = (Tin + 2 * (k // 2) - k) // s + 1
+            y = torch.empty(B, co, Tout, dtype=torch.float32, device=self.device)
+            w = self.eff[self.lay.off(wname):]
+            bb = self.eff[self.lay.off(f"encoder.net.{i}.conv.bias"):]
+            L.check(lib.wae_enc_conv_fwd(L.ptr(x), L.ptr(w), L.ptr(bb), L.ptr(y), B, ci, Tin, co, k, s, k // 2, 1,
+                                         int(s == 1 and ci == co), st), "enc_conv")
+            x = y
+        Tq = x.shape[-1]
+        lat = torch.empty(B, g.Cc, Tq, dtype=torch.float32, device=self.device)
+        L.check(lib.wae_enc_conv_fwd(L.ptr(x), L.ptr(self.eff[self.lay.off("encoder.lin.weight"):]),
+                                     L.ptr(self.eff[self.lay.off("encoder.lin.bias"):]), L.ptr(lat), B, g.encoder_hid, Tq,
+                                     g.Cc, 1, 1, 0, 0, 0, st), "enc_lin")
+        return lat
+
+    def vq_forward(self, lat: torch.Tensor, beta: float = 0.25):
+        """a2: -> (quant (B,Cc,Tq), idx int64 (B*Tq), stats[2] = (vq_loss, perplexity))."""
+        g = self.g
+        B, D, Tq = lat.shape
+        idx = torch.empty(B * Tq, dtype=torch.int64, device=self.device)
+        quant = torch.empty_like(lat)
+        stats = torch.empty(2, dtype=torch.float32, device=self.device)
+        hist = torch.empty(g.K + 1, dtype=torch.int32, device=self.device)
+        L.check(self.lib.wae_vq_nearest(L.ptr(lat), L.ptr(self.eff[self.lay.off("vq.embedding.weight"):]), L.ptr(idx),
+                                        L.ptr(quant), L.ptr(stats), L.ptr(hist), B, D, Tq, g.K, beta, self.stream()),
+                "vq_nearest")
+        return quant, idx, stats
+
+    def upsample_forward(self, c: torch.Tensor, out: torch.Tensor):
+        """a3: c (B,Cc,Tc) fp32 -> out (B, Tc*prod(scales), Ccp) time-major compute dtype (upsample.py:83-85)."""
+        g, lib, st = self.g, self.lib, self.stream()
+        B, Cc, Tc = c.shape
+        kin = 2 * g.cin_pad + 1
+        Tin = Tc - 2 * g.cin_pad
+        x = torch.empty(B, Cc, Tin, dtype=torch.float32, device=self.device)
+        L.check(lib.wae_enc_conv_fwd(L.ptr(c.contiguous()), L.ptr(self.eff[self.lay.off("wavenet.upsample_net.conv_in.weight"):]),
+                                     None, L.ptr(x), B, Cc, Tc, Cc, kin, 1, 0, 0, 0, st), "conv_in")
+        n = len(g.upsample_scales)
+        for i, s in enumerate(g.upsample_scales):
+            w = self.eff[self.lay.off(f"wavenet.upsample_net.upsample.up_layers.{2 * i + 1}.weight_v"):]
+            last = i == n - 1
+            if last:
+                assert out.shape[1] == Tin * s, (out.shape, Tin * s)
+                y = out
+            else:
+                y = torch.empty(B, Cc, Tin * s, dtype=torch.float32, device=self.device)
+            L.check(lib.wae_upsample_stage_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, Cc, Tin, s, int(last), g.Ccp, self.dt, st),
+                    "upsample_stage")
+            x, Tin = y, Tin * s
+        return out
+
+    # ------------------------------------------------------------------ decoder
+    def decoder_forward(self, x: torch.Tensor, c: Optional[torch.Tensor], gid: Optional[torch.Tensor],
+                        targets: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
+                        want_logits: bool = True, train: bool = False, c_is_upsampled: bool = False,
+                        gvec: Optional[torch.Tensor] = None):
+        """WaveNet.forward (wavenet.py:164-216) on class ids.
+
+        x: (B,T) int32 class ids (mulaw-quantize) or (B,T) fp32 scalars (scalar_input).
+        c: (B,Cc,Tc) fp32 local conditioning (upsampled here) or, if c_is_upsampled, (B,Cc,T).
+        gid: (B,) int32 speaker ids.  targets: (B,T) int32 -> fused shifted CE.
+        Returns dict(logits (B,O,T) | None, nll (B,T) | None, loss | None).
+        """
+        if self.weights_dirty:
+            self.prepare_weights()
+        g, lib, st = self.g, self.lib, self.stream()
+        B, T = x.shape
+        ws = self.workspace(B, T, train)
+        # local conditioning
+        if g.Ccp:
+            if c is None:
+                raise ValueError("model has local conditioning but c is None")
+            if c_is_upsampled or not g.upsample_scales:
+                if c.shape[-1] != T:
+                    raise Exception(f"c {tuple(c.shape)} x T={T}")           # wavenet.py:198-200
+                L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(ws["c_up"]), B, g.Cc, T, g.Ccp, self.dt, st), "to_btc")
+            else:
+                Tup = (c.shape[-1] - 2 * g.cin_pad) * int(np.prod(g.upsample_scales))
+                if Tup != T:
+                    raise Exception(f"c {tuple(c.shape)} upsamples to {Tup} != T={T}")  # wavenet.py:198-200
+                self.upsample_forward(c.float(), ws["c_up"])
+        # global conditioning folded with the conv bias
+        wg_off = self.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
+        emb_off = self.lay.offsets.get("wavenet.embed_speakers.weight", 0)
+        use_gid = gid is not None and "wavenet.embed_speakers.weight" in self.lay.offsets
+        if gid is not None:
+            gid = gid.to(torch.int32).contiguous()
+        L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
+                                  self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
+                                  L.ptr(gid) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
+                                  L.ptr(ws["zb"]), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
+        # first conv
+        if g.scalar_input:
+            xs = x.contiguous().float()
+            L.check(lib.wae_first_conv_fwd(None, L.ptr(xs), L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(ws["x"][0]),
+                                           B * T, g.Rp, 1, self.dt, st), "first_conv")
+        else:
+            xi = x.to(torch.int32).contiguous()
+            L.check(lib.wae_first_conv_fwd(L.ptr(xi), None, L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(ws["x"][0]),
+                                           B * T, g.Rp, g.O, self.dt, st), "first_conv")
+        # gated residual stack
+        es = self.w_glu.element_size()
+        d = L.GluDesc(self.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, 1, 0)
+        nbuf = len(ws["x"])
+        for i, dil in enumerate(g.dilations):
+            d.dilation = dil
+            last = i == g.layers - 1
+            d.flags = (L.GLU_SKIP_INIT if i == 0 else 0) | (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0)
+            xin = ws["x"][i if train else i % 2]
+            xout = ws["x"][(i + 1) if train else (i + 1) % 2]
+            L.check(lib.wae_glu_layer_fwd(ctypes.byref(d), L.ptr(xin), None if last else L.ptr(xout), L.ptr(ws["c_up"]),
+                                          L.ptr(ws["skip"]), ctypes.c_void_p(ws["zb"].data_ptr() + i * 2 * g.Hp * 4),
+                                          g.layers * 2 * g.Hp, L.ptr(ws["z"][i]) if train else None,
+                                          ctypes.c_void_p(self.w_glu.data_ptr() + i * self.glu_elems * es),
+                                          ctypes.c_void_p(self.b_glu.data_ptr() + i * (g.Rp + g.Sp) * 4), st), f"glu layer {i}")
+        # head (+ fused CE)
+        hd = L.HeadDesc(self.dt, B, T, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
+        logits = torch.empty(B, g.O, T, dtype=torch.float32, device=self.device) if want_logits else None
+        tg = targets.to(torch.int32).contiguous() if targets is not None else None
+        L.check(lib.wae_head_fwd(ctypes.byref(hd), L.ptr(ws["skip"]), L.ptr(self.w_head), L.ptr(self.b_head), L.ptr(logits),
+                                 L.ptr(tg), L.ptr(ws["nll"]) if tg is not None else None,
+                                 L.ptr(ws["h1"]) if train else None, st), "head")
+        out = dict(logits=logits, nll=None, loss=None)
+        if tg is not None:
+            ln = lengths.to(torch.int32).contiguous() if lengths is not None else None
+            L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, st), "masked_mean")
+            out["nll"] = ws["nll"]
+            out["loss"] = ws["loss"][0]
+        return out
+
+    # ------------------------------------------------------------------ full autoencoder
+    def forward(self, x: torch.Tensor, c: torch.Tensor, gid: Optional[torch.Tensor], targets=None, lengths=None,
+                want_logits=True, train=False, beta: float = 0.25):
+        """VQVAE.forward (vqvae_model.py:66-72) -> dict(logits, vq_loss, perp, latents, idx, quant, loss)."""
+        if self.weights_dirty:
+            self.prepare_weights()
+        lat = self.encoder_forward(c)
+        quant, idx, stats = self.vq_forward(lat, beta)
+        out = self.decoder_forward(x, quant, gid, targets, lengths, want_logits, train)
+        out.update(latents=lat, quant=quant, idx=idx, vq_loss=stats[0], perp=stats[1])
+        return out

@@ -1,0 +1,291 @@
+"""Host logic: parameter arena layout and the index maps that put weights into MFMA A-fragment order.
+
+Everything here is numpy on the host and runs once per model geometry; the maps are uploaded and applied on
+the device by ``wae_pack_gather`` (csrc/misc.hip) every time the weights change.
+
+Fragment order (must match csrc/glu_fwd.hip and csrc/head_fwd.hip)
+------------------------------------------------------------------
+A *fragment block* is 64 lanes x 16 bytes = one A operand of a 32x32 MFMA tile: lane l = (i = l & 31, h = l >> 5)
+holds, for output row ``32*m + i`` of M-tile m, EPL consecutive-in-k elements (EPL = 8 bf16 / 4 f32).
+
+GEMM 1 stream ``[q][blk][m][lane][j]`` (chunk q = one 128-byte slice of an activation row):
+    q <  k*(Rp/CK): tap = q // (Rp/CK), cblk = q % (Rp/CK)   -> conv weight (G, R, k)
+    q >=          : c chunk                                   -> conv1x1c weight (G, Cc)
+    channel = cblk*CK + blk*2*EPL + h*EPL + j          (CK = 64 bf16 / 32 f32 channels per chunk)
+    M-tile m < NP is gate-a rows 32m.., m >= NP gate-b rows (reference row = half*H + i)
+GEMM 2 stream ``[q2][mt][kb][lane][j]``: M-tile gm = q2*MT2 + mt over [out rows (Rp) | skip rows (Sp)],
+    k index = row of u inside accumulator tile ut = kb // KBU, sub-block s = kb % KBU:
+      bf16: u_row = 32*ut + 16*s + 8*(j >> 2) + 4*h + (j & 3)
+      f32 : u_row = 32*ut +  8*s + 4*h + j
+    (the register order in which a 32x32 accumulator tile is reused as the next MFMA's B operand).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+F32, BF16 = 0, 1
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Geometry:
+    """Decoder/encoder sizes (reference ctor args: wavenet.py:98-111, vqvae_model.py:54) + padded sizes."""
+    layers: int
+    stacks: int
+    R: int
+    G: int
+    S: int
+    O: int
+    Cc: int = -1
+    Cg: int = -1
+    k: int = 3
+    n_speakers: Optional[int] = None
+    upsample_scales: Optional[List[int]] = None
+    cin_pad: int = 0
+    scalar_input: bool = False
+    use_speaker_embedding: bool = True
+    # autoencoder front end (None = decoder only)
+    c_in: Optional[int] = None
+    encoder_hid: Optional[int] = None
+    K: int = 256
+
+    def __post_init__(self):
+        assert self.layers % self.stacks == 0                       # wavenet.py:117
+        assert self.G % 2 == 0
+        self.H = self.G // 2
+        self.Rp = _ru(self.R, 128)
+        self.Sp = _ru(self.S, 128)
+        self.Op = _ru(self.O, 128)
+        self.Ccp = _ru(self.Cc, 64) if self.Cc > 0 else 0
+        self.Hp = _ru(self.H, 32)
+        self.NP = self.Hp // 32
+        per = self.layers // self.stacks
+        self.dilations = [2 ** (i % per) for i in range(self.layers)]   # wavenet.py:126
+        self.receptive_field = (self.k - 1) * sum(self.dilations) + 1   # wavenet.py:42-60
+        self.has_encoder = self.c_in is not None
+
+    @staticmethod
+    def from_cfg(cfg: dict) -> "Geometry":
+        return Geometry(layers=cfg["layers"], stacks=cfg["stacks"], R=cfg["R"], G=cfg["G"], S=cfg["S"], O=cfg["O"],
+                        Cc=cfg.get("Cc", -1), Cg=cfg.get("Cg", -1), k=cfg.get("k", 3), n_speakers=cfg.get("n_speakers"),
+                        upsample_scales=cfg.get("upsample_scales"), cin_pad=cfg.get("cin_pad", 0),
+                        scalar_input=bool(cfg.get("scalar_input")), c_in=cfg.get("c_in"),
+                        encoder_hid=cfg.get("encoder_hid"), K=cfg.get("K", 256))
+
+
+ENCODER_BLOCKS = [(3, 1), (3, 1), (5, 2), (5, 2), (3, 1), (3, 1), (1, 1), (1, 1), (1, 1), (1, 1)]  # vqvae_model.py:32-40
+
+
+def param_specs(g: Geometry) -> List[Tuple[str, Tuple[int, ...], bool]]:
+    """(name, shape, is_weight_norm_v) in the reference's registration order (state_dict keys)."""
+    out: List[Tuple[str, Tuple[int, ...], bool]] = []
+
+    def wn(prefix, cout, cin, k, bias=True, conv2d=False):
+        if bias:
+            out.append((prefix + ".bias", (cout,), False))
+        gs = (cout, 1, 1, 1) if conv2d else (cout, 1, 1)
+        vs = (cout, cin, 1, k) if conv2d else (cout, cin, k)
+        out.append((prefix + ".weight_g", gs, False))
+        out.append((prefix + ".weight_v", vs, True))
+
+    wn("wavenet.first_conv", g.R, 1 if g.scalar_input else g.O, 1)
+    for i in range(g.layers):
+        p = f"wavenet.conv_layers.{i}."
+        wn(p + "conv", g.G, g.R, g.k)
+        if g.Cc > 0:
+            wn(p + "conv1x1c", g.G, g.Cc, 1, bias=False)
+        if g.Cg > 0:
+            wn(p + "conv1x1g", g.G, g.Cg, 1, bias=False)
+        wn(p + "conv1x1_out", g.R, g.H, 1)
+        wn(p + "conv1x1_skip", g.S, g.H, 1)
+    wn("wavenet.last_conv_layers.1", g.S, g.S, 1)
+    wn("wavenet.last_conv_layers.3", g.O, g.S, 1)
+    if g.Cg > 0 and g.use_speaker_embedding and g.n_speakers:
+        out.append(("wavenet.embed_speakers.weight", (g.n_speakers, g.Cg), False))
+    if g.upsample_scales:
+        out.append(("wavenet.upsample_net.conv_in.weight", (g.Cc, g.Cc, 2 * g.cin_pad + 1), False))
+        for i, s in enumerate(g.upsample_scales):
+            wn(f"wavenet.upsample_net.upsample.up_layers.{2 * i + 1}", 1, 1, 2 * s + 1, bias=False, conv2d=True)
+    if g.has_encoder:
+        dims = [(g.c_in, g.encoder_hid)] + [(g.encoder_hid, g.encoder_hid)] * 9
+        for i, ((ci, co), (kk, _)) in enumerate(zip(dims, ENCODER_BLOCKS)):
+            out.append((f"encoder.net.{i}.conv.weight", (co, ci, kk), False))
+            out.append((f"encoder.net.{i}.conv.bias", (co,), False))
+        out.append(("encoder.lin.weight", (g.Cc, g.encoder_hid), False))
+        out.append(("encoder.lin.bias", (g.Cc,), False))
+        out.append(("vq.embedding.weight", (g.K, g.Cc), False))
+    return out
+
+
+class ParamLayout:
+    """Flat fp32 arena: name -> (offset, shape).  One contiguous buffer for parameters, one for gradients,
+    one for the effective (weight-normed) weights: a single all-reduce / optimizer launch covers everything."""
+
+    def __init__(self, g: Geometry):
+        self.geom = g
+        self.offsets: "OrderedDict[str, int]" = OrderedDict()
+        self.shapes: Dict[str, Tuple[int, ...]] = {}
+        off = 0
+        v_off, g_off, cols = [], [], []
+        for name, shape, is_v in param_specs(g):
+            n = int(np.prod(shape))
+            self.offsets[name] = off
+            self.shapes[name] = shape
+            off += _ru(n, 4)            # keep every tensor 16-byte aligned
+        self.total = off
+        for name, shape, is_v in param_specs(g):
+            if is_v:
+                rows = shape[0]
+                c = int(np.prod(shape[1:]))
+                gname = name[:-1] + "g"
+                for r in range(rows):
+                    v_off.append(self.offsets[name] + r * c)
+                    g_off.append(self.offsets[gname] + r)
+                    cols.append(c)
+        self.wn_v_off = np.asarray(v_off, dtype=np.int64)
+        self.wn_g_off = np.asarray(g_off, dtype=np.int64)
+        self.wn_cols = np.asarray(cols, dtype=np.int32)
+        if g.layers > 1:
+            self.layer_stride = self.offsets["wavenet.conv_layers.1.conv.bias"] - self.offsets["wavenet.conv_layers.0.conv.bias"]
+        else:
+            self.layer_stride = 0
+
+    def off(self, name: str) -> int:
+        return self.offsets[name]
+
+    def numel(self, name: str) -> int:
+        return int(np.prod(self.shapes[name]))
+
+
+def _traits(dtype: int):
+    if dtype == BF16:
+        return dict(EPL=8, CK=64, KBU=2, MT2=4, ES=2)
+    return dict(EPL=4, CK=32, KBU=4, MT2=2, ES=4)
+
+
+def u_row_index(dtype: int, kb: np.ndarray, h: np.ndarray, j: np.ndarray) -> np.ndarray:
+    """k index (row of the previous accumulator tile stack) held by element j of lane-half h in k-block kb."""
+    t = _traits(dtype)
+    ut, s = kb // t["KBU"], kb % t["KBU"]
+    if dtype == BF16:
+        return 32 * ut + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
+    return 32 * ut + 8 * s + 4 * h + j
+
+
+def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    """int32 map (relative to arena start, layer 0) for the GEMM-1 stream of one GLU layer."""
+    t = _traits(dtype)
+    EPL, CK = t["EPL"], t["CK"]
+    NM = 2 * g.NP
+    cpr = g.Rp // CK
+    nq_conv = g.k * cpr
+    nq1 = nq_conv + g.Ccp // CK
+    q, blk, m, lane, j = np.meshgrid(np.arange(nq1), np.arange(4), np.arange(NM), np.arange(64), np.arange(EPL),
+                                     indexing="ij")
+    i, h = lane & 31, lane >> 5
+    half = (m >= g.NP).astype(np.int64)
+    ig = 32 * (m - half * g.NP) + i
+    row = half * g.H + ig
+    is_conv = q < nq_conv
+    tap = np.where(is_conv, q // cpr, 0)
+    cblk = np.where(is_conv, q % cpr, q - nq_conv)
+    ch = cblk * CK + blk * 2 * EPL + h * EPL + j
+    conv_off = lay.off("wavenet.conv_layers.0.conv.weight_v")
+    src_conv = conv_off + (row * g.R + ch) * g.k + tap
+    valid_conv = (ig < g.H) & (ch < g.R)
+    if g.Cc > 0:
+        c_off = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
+        src_c = c_off + row * g.Cc + ch
+        valid_c = (ig < g.H) & (ch < g.Cc)
+    else:
+        src_c = np.zeros_like(src_conv)
+        valid_c = np.zeros_like(valid_conv)
+    out = np.where(is_conv, np.where(valid_conv, src_conv, -1), np.where(valid_c, src_c, -1))
+    return out.astype(np.int32).reshape(-1)
+
+
+def glu_w2_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    t = _traits(dtype)
+    EPL, KBU, MT2 = t["EPL"], t["KBU"], t["MT2"]
+    NKB = g.NP * KBU
+    n_mt = (g.Rp + g.Sp) // 32
+    assert n_mt % MT2 == 0 and (g.Rp // 32) % MT2 == 0
+    gm, kb, lane, j = np.meshgrid(np.arange(n_mt), np.arange(NKB), np.arange(64), np.arange(EPL), indexing="ij")
+    i, h = lane & 31, lane >> 5
+    ur = u_row_index(dtype, kb, h, j)
+    is_out = gm < g.Rp // 32
+    r_out = 32 * gm + i
+    r_skip = 32 * gm + i - g.Rp
+    src_out = lay.off("wavenet.conv_layers.0.conv1x1_out.weight_v") + r_out * g.H + ur
+    src_skip = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v") + r_skip * g.H + ur
+    out = np.where(is_out, np.where((r_out < g.R) & (ur < g.H), src_out, -1),
+                   np.where((r_skip < g.S) & (ur < g.H), src_skip, -1))
+    return out.astype(np.int32).reshape(-1)
+
+
+def glu_bias2_map(g: Geometry, lay: ParamLayout) -> np.ndarray:
+    r = np.arange(g.Rp + g.Sp)
+    o = lay.off("wavenet.conv_layers.0.conv1x1_out.bias")
+    s = lay.off("wavenet.conv_layers.0.conv1x1_skip.bias")
+    return np.where(r < g.Rp, np.where(r < g.R, o + r, -1), np.where(r - g.Rp < g.S, s + r - g.Rp, -1)).astype(np.int32)
+
+
+def first_conv_maps(g: Geometry, lay: ParamLayout):
+    """table (O or 1, Rp) with table[o][r] = W[r][o]; bias (Rp)."""
+    nin = 1 if g.scalar_input else g.O
+    o, r = np.meshgrid(np.arange(nin), np.arange(g.Rp), indexing="ij")
+    tab = np.where(r < g.R, lay.off("wavenet.first_conv.weight_v") + r * nin + o, -1).astype(np.int32).reshape(-1)
+    rr = np.arange(g.Rp)
+    bias = np.where(rr < g.R, lay.off("wavenet.first_conv.bias") + rr, -1).astype(np.int32)
+    return tab, bias
+
+
+def head_w_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    t = _traits(dtype)
+    EPL, CK, KBU = t["EPL"], t["CK"], t["KBU"]
+    NT = g.Sp // 32
+    nq1 = g.Sp // CK
+    q, blk, m, lane, j = np.meshgrid(np.arange(nq1), np.arange(4), np.arange(NT), np.arange(64), np.arange(EPL),
+                                     indexing="ij")
+    i, h = lane & 31, lane >> 5
+    row = 32 * m + i
+    ch = q * CK + blk * 2 * EPL + h * EPL + j
+    w1 = np.where((row < g.S) & (ch < g.S), lay.off("wavenet.last_conv_layers.1.weight_v") + row * g.S + ch, -1)
+    NKB = NT * KBU
+    n_mt = g.Op // 32
+    gm, kb, lane, j = np.meshgrid(np.arange(n_mt), np.arange(NKB), np.arange(64), np.arange(EPL), indexing="ij")
+    i, h = lane & 31, lane >> 5
+    ur = u_row_index(dtype, kb, h, j)
+    row = 32 * gm + i
+    w3 = np.where((row < g.O) & (ur < g.S), lay.off("wavenet.last_conv_layers.3.weight_v") + row * g.S + ur, -1)
+    return np.concatenate([w1.reshape(-1), w3.reshape(-1)]).astype(np.int32)
+
+
+def head_bias_map(g: Geometry, lay: ParamLayout) -> np.ndarray:
+    r = np.arange(g.Sp + g.Op)
+    b1 = lay.off("wavenet.last_conv_layers.1.bias")
+    b3 = lay.off("wavenet.last_conv_layers.3.bias")
+    return np.where(r < g.Sp, np.where(r < g.S, b1 + r, -1), np.where(r - g.Sp < g.O, b3 + r - g.Sp, -1)).astype(np.int32)
+
+
+def glu_packed_elems(g: Geometry, dtype: int) -> int:
+    t = _traits(dtype)
+    chb = 2 * g.NP * 4 * 1024
+    nq1 = g.k * (g.Rp // t["CK"]) + g.Ccp // t["CK"]
+    nq2 = ((g.Rp + g.Sp) // 32) // t["MT2"]
+    return (nq1 + nq2) * chb // t["ES"]
+
+
+def head_packed_elems(g: Geometry, dtype: int) -> int:
+    t = _traits(dtype)
+    chb = (g.Sp // 32) * 4 * 1024
+    mt2 = 4 // t["KBU"]
+    return (g.Sp // t["CK"] + (g.Op // 32) // mt2) * chb // t["ES"]
