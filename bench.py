@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- teacher-forced throughput of the decoder hot path on synthetic 16 kHz clips.
+
+Workload (BASELINE.json configs[1], "C2"): IN-WAE decoder dimensions (hps/inae_hp.json: R=256, G=368, S=256,
+Cc=64, Cg=64, k=3, upsample x320) with 24 layers / 2 stacks, batch 8 x 8000 samples per GPU, bf16 storage with
+fp32 accumulate.  A step = one teacher-forced pass over one batch: weight-norm + fragment packing of all
+parameters, conditioning upsample, speaker projection, first-conv gather, 24 fused gated layers, head and the
+fused shifted cross-entropy (mean loss on device).  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, each rank runs its own shard of the global
+batch (weak scaling; the forward path has no data-path collective), barrier + synchronize on both sides, MAX
+over ranks.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C2 = dict(layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153,
+          upsample_scales=[4, 4, 4, 5], cin_pad=0)
+B_PER_GPU, T = 8, 8000
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TF = 2500.0      # dense bf16
+FP32_MFMA_PEAK_TF = 157.3
+
+
+def synth_inputs(rank, device):
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(1234 + rank)
+    x = torch.from_numpy(rng.integers(0, 256, size=(B_PER_GPU, T), dtype=np.int64))
+    lat = torch.from_numpy(rng.standard_normal((B_PER_GPU, C2["Cc"], T // 320)).astype(np.float32))
+    g = torch.from_numpy(rng.integers(0, C2["n_speakers"], size=(B_PER_GPU,), dtype=np.int64))
+    return x.to(device), lat.to(device), g.to(device)
+
+
+def cpu_baseline(sd, nclips=1):
+    """Oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from oracle import wae_oracle as O
+    nthreads = min(os.cpu_count() or 1, 16)       # more threads than this only slows torch's CPU conv1d down
+    torch.set_num_threads(nthreads)
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy(rng.integers(0, 256, size=(nclips, T), dtype=np.int64))
+    lat = torch.from_numpy(rng.standard_normal((nclips, C2["Cc"], T // 320)).astype(np.float32))
+    g = torch.from_numpy(rng.integers(0, C2["n_speakers"], size=(nclips,), dtype=np.int64))
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    ocfg = dict(layers=C2["layers"], stacks=C2["stacks"], upsample_scales=C2["upsample_scales"], cin_pad=0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        y = O.wavenet_forward(sd, ocfg, xin, lat, g)
+        loss = O.masked_ce_loss(y, x.unsqueeze(-1), torch.full((nclips,), T))
+        dt = time.perf_counter() - t0
+    return dict(value=nclips * T / dt, unit="samples/s", cores=nthreads, kind="port",
+                sample=f"{nclips} of the {B_PER_GPU} clips x {T} samples, 1 forward+CE pass, oracle/wae_oracle.py on "
+                       f"torch CPU fp32, {nthreads} threads of {os.cpu_count()} cores ({dt:.1f} s)"), float(loss)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    from oracle import wae_oracle as O          # closed-form weights + the cpu_baseline leg only
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+
+    geom = Geometry.from_cfg(C2)
+    sd = O.make_state_dict(dict(C2), salt=5, with_encoder=False)
+    eng = WaeEngine(geom, dtype=args.dtype, device=str(device))
+    eng.load_state_dict(sd)
+    x, lat, g = synth_inputs(rank, device)
+    lengths = torch.full((B_PER_GPU,), T, dtype=torch.int32, device=device)
+    xi = x.to(torch.int32)
+
+    ev = []
+
+    def step(record=False):
+        eng.prepare_weights()
+        out = eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False,
+                                  layer_events=ev if record else None)
+        return out["loss"]
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(record=True)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_v = float(loss)
+
+    # dominant kernel: glu_fwd_kernel -- HIP events recorded on the launch stream around the 24-layer stack of
+    # every timed step; average per launch (includes the inter-kernel gaps, so it is conservative)
+    stack_ms = [a.elapsed_time(b) for a, b in ev]
+    glu_ms = sum(stack_ms) / len(stack_ms) / geom.layers
+    es = 2 if args.dtype == "bf16" else 4
+    samples = B_PER_GPU * T
+    bytes_per_launch = (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es * samples        # SURVEY 8(d) per layer
+    H = C2["G"] // 2
+    flops_per_launch = 2 * (C2["G"] * C2["R"] * C2["k"] + C2["G"] * C2["Cc"] + H * C2["R"] + H * C2["S"]) * samples
+    achieved_gbs = bytes_per_launch / (glu_ms * 1e-3) / 1e9
+    achieved_tf = flops_per_launch / (glu_ms * 1e-3) / 1e12
+    fwd_bytes_per_sample = geom.layers * (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es + (C2["S"] + 0) * es + 4 + 1
+    value = world * samples * args.steps / dt
+
+    if rank == 0:
+        res = {
+            "metric": "teacher-forced audio samples/sec (24-layer decoder, forward + CE)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "C2: IN-WAE decoder dims (R256 G368 S256 Cc64 Cg64 k3), 24 layers/2 stacks, "
+                                   f"batch {B_PER_GPU}x{T} per GPU, teacher-forced forward incl. weight-norm+pack, upsample, "
+                                   "head and fused CE; closed-form random weights",
+                       "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
+            "samples_per_sec_per_gpu": value / world,
+            "loss": loss_v,
+            "roofline": {"bound": "hbm", "kernel": "glu_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": glu_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "mfma_achieved_tflops": achieved_tf,
+                         "mfma_frac": achieved_tf / (MFMA_PEAK_TF if args.dtype == "bf16" else FP32_MFMA_PEAK_TF)},
+            "whole_forward_hbm_frac": fwd_bytes_per_sample * samples * args.steps / dt / 1e9 / HBM_PEAK_GBS * world / world,
+        }
+        if not args.no_cpu and world == 1:
+            cb, cpu_loss = cpu_baseline(sd)
+            res["cpu_baseline"] = cb
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

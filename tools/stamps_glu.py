@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Diagnostic: where one glu_fwd workgroup spends its cycles (s_memtime stamps; never quote run times from this)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wavenet_autoencoders_amd import Geometry, _lib as L  # noqa: E402
+from wavenet_autoencoders_amd.engine import WaeEngine  # noqa: E402
+
+C2 = dict(layers=2, stacks=1, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=4, upsample_scales=None)
+B, T = 8, 8000
+dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+flags = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
+eng = WaeEngine(Geometry.from_cfg(C2), dtype=dtype)
+torch.manual_seed(0)
+eng.params.normal_(0, 0.05)
+eng.prepare_weights()
+g = eng.g
+x = (torch.randn(B, T, g.Rp, device="cuda") * 0.5).to(eng.tdtype)
+c = (torch.randn(B, T, g.Ccp, device="cuda") * 0.5).to(eng.tdtype)
+xo = torch.empty_like(x)
+skip = torch.zeros(B, T, g.Sp, device="cuda")
+zb = torch.zeros(B, 2 * g.Hp, device="cuda")
+st = eng.stream()
+nwg = B * ((T + 127) // 128)
+stamps = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
+lib = eng.lib
+lib.wae_debug_set_stamps.argtypes = [ctypes.c_void_p]
+
+
+def run(fl, d=4):
+    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, d, fl)
+    L.check(lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(x), L.ptr(xo), L.ptr(c), L.ptr(skip), L.ptr(zb), 0, None,
+                                  L.ptr(eng.w_glu), L.ptr(eng.b_glu), st))
+
+
+for _ in range(5):
+    run(flags)
+lib.wae_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+for _ in range(3):
+    run(flags)
+torch.cuda.synchronize()
+lib.wae_debug_set_stamps(None)
+s = stamps.cpu().numpy().reshape(nwg, 16)
+names = ["init(zb, first dma/B issue)", "GEMM1", "gate", "GEMM2+epilogue"]
+d = np.diff(s[:, :5].astype(np.int64), axis=1)
+print(f"flags={flags:#x} workgroups={nwg}; cycles per phase (median / p10 / p90) over workgroups:")
+for i, nme in enumerate(names):
+    v = np.sort(d[:, i])
+    print(f"  {nme:30s} {int(np.median(v)):8d} {int(v[len(v)//10]):8d} {int(v[len(v)*9//10]):8d}")
+for i, nme in zip(range(8, 12), ["  g2: wait+barrier", "  g2: dma/old-load issue+bias", "  g2: mfma chunk", "  g2: stage_finish"]):
+    v = np.sort(s[:, i].astype(np.int64))
+    print(f"  {nme:30s} {int(np.median(v)):8d} {int(v[len(v)//10]):8d} {int(v[len(v)*9//10]):8d}")
+tot = np.sort(s[:, 4] - s[:, 0])
+print(f"  {'total':30s} {int(np.median(tot)):8d}")
+rt = s[:, 5].astype(np.int64)
+start = s[:, 0].astype(np.int64)
+print("  wall span of launch by s_memrealtime (100 MHz ticks):", int(rt.max() - rt.min()), "-> us", (rt.max() - rt.min()) / 100.0)
+order = np.argsort(rt)
+print("  end times (us, sorted) first/median/last:", (rt[order[0]] - rt.min()) / 100., (rt[order[nwg // 2]] - rt.min()) / 100., (rt[order[-1]] - rt.min()) / 100.)

@@ -15,6 +15,12 @@
 // from HBM/L2 as 16-byte fragments (time-major rows, channels innermost), zero-filled before t=0 (causal pad).
 #include "wae_common.hpp"
 
+// timing-only ablation bits (tools/ablate_glu.py); outputs are wrong when any is set
+#define DBG_NO_DMA 0x100
+#define DBG_NO_BLOAD 0x200
+#define DBG_NO_EPI 0x400
+#define DBG_NO_GATE 0x800
+
 struct GluArgs {
   const char* x_in;
   char* x_out;
@@ -26,7 +32,85 @@ struct GluArgs {
   const float* bias2;
   int64_t zb_stride;
   int B, T, Rp, Sp, Ccp, Hp, ktaps, dilation, flags;
+  unsigned long long* stamps;  // diagnostic only (wae_debug_set_stamps): 16 x u64 per workgroup, else null
 };
+
+static unsigned long long* g_stamps = nullptr;
+extern "C" void wae_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = dev_buf; }
+#define STAMP(i)                                                              \
+  do {                                                                        \
+    if (p.stamps) {                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                      \
+      st_[i] = __builtin_amdgcn_s_memtime();                                  \
+      __builtin_amdgcn_sched_barrier(0);                                      \
+    }                                                                         \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// staged_rows: one wave moves a [32 time rows x 256 B] tile between the MFMA accumulator layout (lane = time
+// column n, 4 consecutive channels per register group) and global-memory rows, through a wave-private 8 KiB
+// LDS tile whose 16-byte chunks are XOR-swizzled by the row (conflict-free row reads, 2-way column accesses).
+//   A. (LOAD_OLD) coalesced 16-B loads of the old rows  -> LDS
+//   B. every lane reads its accumulator-layout pieces, applies op(y, old), writes the result back in place
+//   C. coalesced 16-B row reads from LDS -> global stores
+// EO = element type in memory (bf16: NTP = 4 tiles per 256-B row segment, f32: NTP = 2).
+// ---------------------------------------------------------------------------------------------------
+#define STG_BYTES 8192
+// A: issue the coalesced loads of the old rows (call early; the data is consumed in stage_finish)
+__device__ __forceinline__ void stage_load(f32x4 (&old)[8], const char* gin, int64_t row_stride, int rows_valid, int lane) {
+  const int rr = lane >> 4, ck = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = min(4 * i + rr, rows_valid - 1);   // rows past T re-read the last valid row; never stored
+    old[i] = *(const f32x4*)(gin + row * row_stride + ck * 16);
+  }
+}
+// B + C
+template <typename EO, int NTP, bool LOAD_OLD, typename F>
+__device__ __forceinline__ void stage_finish(char* stg, f32x16* y, const f32x4 (&old)[8], char* gout, int64_t row_stride,
+                                             int rows_valid, int lane, F op) {
+  static_assert(NTP * 32 * sizeof(EO) == 256, "a staging pass covers 256 bytes per row");
+  using vec4 = typename ET<EO>::vec4;
+  const int n = lane & 31, h = lane >> 5;
+  const int rr = lane >> 4, ck = lane & 15;
+  if constexpr (LOAD_OLD) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + rr;
+      *(f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4)) = old[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#pragma unroll
+  for (int mt = 0; mt < NTP; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int c16, sub;
+      if constexpr (sizeof(EO) == 2) { c16 = 4 * mt + g; sub = 8 * h; } else { c16 = 8 * mt + 2 * g + h; sub = 0; }
+      char* a = stg + n * 256 + ((c16 ^ (n & 15)) << 4) + sub;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (LOAD_OLD) o = to_f32x4(*(const vec4*)a);
+      const f32x4 v = {y[mt][4 * g], y[mt][4 * g + 1], y[mt][4 * g + 2], y[mt][4 * g + 3]};
+      *(vec4*)a = from_f32x4<EO>(op(v, o));
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 4 * i + rr;
+    const f32x4 v = *(const f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4));
+    if (row < rows_valid) *(f32x4*)(gout + row * row_stride + ck * 16) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// 16 accumulator registers of a tile start from a per-row constant table: rows 8g + 4h + j, j < 4
+__device__ __forceinline__ void init_rows(f32x16& acc, const float* tab /* 32 floats, 16-B aligned */, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v = *(const f32x4*)(tab + 8 * g + 4 * h);
+    acc[4 * g + 0] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+  }
+}
 
 template <typename E, int NP, bool EXACT>
 __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
@@ -42,6 +126,8 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
   static_assert(MT2 * NKB * 1024 == CHB, "GEMM-2 chunk must equal GEMM-1 chunk");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long st_[16] = {};
+  STAMP(0);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,10 +157,11 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
     return p.w + (int64_t)q * CHB;
   };
 
+  const bool dbg_dma = !(p.flags & DBG_NO_DMA);
   frag Bn[4], Bc[4];
   auto load_B = [&](int q, frag (&Bf)[4]) {
     const char* src;
-    bool ok = tvalid;
+    bool ok = tvalid && !(p.flags & DBG_NO_BLOAD);
     if (q < nq_conv) {
       const int tap = q / cpr, cblk = q - tap * cpr;
       const int ts = t - (p.ktaps - 1 - tap) * p.dilation;
@@ -99,18 +186,16 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
   {
     const float* zbb = p.zb + (int64_t)b * p.zb_stride;
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const int row0 = (m < NP ? 32 * m : p.Hp + 32 * (m - NP)) + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *(const f32x4*)(zbb + row0 + 8 * g);
-        acc[m][4 * g + 0] = v.x; acc[m][4 * g + 1] = v.y; acc[m][4 * g + 2] = v.z; acc[m][4 * g + 3] = v.w;
-      }
-    }
+    for (int m = 0; m < NM; ++m) init_rows(acc[m], zbb + (m < NP ? 32 * m : p.Hp + 32 * (m - NP)), h);
   }
 
-  dma_chunk(chunk_src(0), smem, CHB, wave, lane);
+  // bias2 -> LDS once (read back per chunk with ds_read: keeps the second GEMM's accumulator init off vmcnt,
+  // where it would drain the LDS-DMA and row-prefetch queues)
+  float* bias_lds = (float*)(smem + 2 * CHB + 4 * STG_BYTES);
+  for (int i = threadIdx.x * 4; i < p.Rp + p.Sp; i += 1024) *(f32x4*)(bias_lds + i) = *(const f32x4*)(p.bias2 + i);
+  if (dbg_dma) dma_chunk(chunk_src(0), smem, CHB, wave, lane);
   load_B(0, Bn);
+  STAMP(1);
 
   // ---- GEMM 1 ----------------------------------------------------------------------------------------
   for (int q = 0; q < nq1; ++q) {
@@ -118,19 +203,13 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
-    if (q + 1 < nq_total) dma_chunk(chunk_src(q + 1), smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
+    if (q + 1 < nq_total && dbg_dma) dma_chunk(chunk_src(q + 1), smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
     if (q + 1 < nq1) load_B(q + 1, Bn);
     const char* buf = smem + (q & 1) * CHB + lane * 16;
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        const frag a = *(const frag*)(buf + (blk * NM + m) * 1024);
-        mma32(acc[m], a, Bc[blk]);
-      }
-    }
+    gemm_chunk<4 * NM, NM, 4>(buf, Bc, acc);
   }
 
+  STAMP(2);
   // ---- optional z save (training) ----------------------------------------------------------------------
   if ((p.flags & WAE_GLU_SAVE_Z) && tvalid) {
     char* zr = p.z_save + ((int64_t)b * p.T + t) * (2 * p.Hp) * ES;
@@ -153,12 +232,15 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float a = acc[pr][r], g = acc[NP + pr][r];
-      if constexpr (EXACT) {
+      if (p.flags & DBG_NO_GATE) {
+        u[r] = a * g;
+      } else if constexpr (EXACT) {
         u[r] = tanhf(a) * (1.0f / (1.0f + expf(-g)));
       } else {
-        const float ac = fminf(fmaxf(a, -15.0f), 15.0f);
-        const float ea = __expf(-2.0f * ac);
-        const float eg = __expf(-g);
+        // tanh(a)*sigmoid(g) = (1-ea) / ((1+ea)(1+eg)), ea = e^-2a, eg = e^-g; exponents clamped so that the
+        // product of the two denominators stays finite (|a| <= 15 is exact in fp32: tanh(15) == 1 - 2e-13)
+        const float ea = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(a, -15.0f, 15.0f) * -2.885390081777927f);
+        const float eg = __builtin_amdgcn_exp2f(fminf(g * -1.4426950408889634f, 60.0f));
         u[r] = (1.0f - ea) * fast_rcp((1.0f + ea) * (1.0f + eg));
       }
     }
@@ -168,69 +250,103 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
     for (int s = 0; s < KBU; ++s) uf[pr * KBU + s] = tmp[s];
   }
 
+  STAMP(3);
   // ---- GEMM 2 + epilogues ------------------------------------------------------------------------------
-  const float rs = 0.70710678118654752440f;
+  // Each chunk = MT2 M-tiles (out or skip rows) against all of u.  The accumulator layout (lane = time column,
+  // registers = channels) is turned into full 256-byte row segments through a wave-private swizzled LDS tile so
+  // that every global access of the residual read, the x' store and the skip read-modify-write is coalesced.
+  char* stg = smem + 2 * CHB + wave * STG_BYTES;
+  const int t0w = (blockIdx.x % tiles_per_b) * 128 + wave * 32;
+  const int rows_valid = min(max(p.T - t0w, 0), 32);
   const bool skip_init = p.flags & WAE_GLU_SKIP_INIT;
+  const float* bias2 = bias_lds;
+  constexpr int NPASS_SKIP = MT2 / 2;   // fp32 skip rows: 2 tiles (64 channels) per 256-byte pass
   for (int q2 = nq2_first; q2 < nq2; ++q2) {
     const int qi = nq1 + (q2 - nq2_first);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (qi + 1 < nq_total) dma_chunk(chunk_src(qi + 1), smem + ((qi + 1) & 1) * CHB, CHB, wave, lane);
+    unsigned long long sa = 0, sb = 0, sc = 0, sd = 0;
+    if (p.stamps) { __builtin_amdgcn_sched_barrier(0); sa = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    // the only VMEM ops younger than DMA(qi) are the previous chunk's row stores (<= 8 per pass): a counted
+    // wait retires the DMA without waiting for those stores to be acknowledged
+    if (q2 == nq2_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NPASS_SKIP == 2 && (q2 - 1) * MT2 >= (p.Rp >> 5)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (p.stamps) { __builtin_amdgcn_sched_barrier(0); sb = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    if (qi + 1 < nq_total && dbg_dma) dma_chunk(chunk_src(qi + 1), smem + ((qi + 1) & 1) * CHB, CHB, wave, lane);
     const char* buf = smem + (qi & 1) * CHB + lane * 16;
+    const int gm0 = q2 * MT2;
+    const bool is_out = gm0 < (p.Rp >> 5);
+    const bool no_epi = p.flags & DBG_NO_EPI;
+    // old rows of this chunk: issued now, consumed after the MFMAs
+    f32x4 old[NPASS_SKIP][8];
+    const int64_t roff = ((int64_t)b * p.T + t0w) * row_x + (int64_t)gm0 * 32 * ES;
+    char* srow0 = (char*)(p.skip + ((int64_t)b * p.T + t0w) * p.Sp + 32 * (gm0 - (p.Rp >> 5)));
+    const int64_t srs = (int64_t)p.Sp * 4;
+    if (!no_epi && rows_valid > 0) {   // wave-uniform: a wave wholly past T touches no row
+      if (is_out) {
+        stage_load(old[0], p.x_in + roff, row_x, rows_valid, lane);
+      } else if (!skip_init) {
 #pragma unroll
-    for (int mt = 0; mt < MT2; ++mt) {
-      const int gm = q2 * MT2 + mt;
-      f32x16 y;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *(const f32x4*)(p.bias2 + 32 * gm + 8 * g + 4 * h);
-        y[4 * g + 0] = v.x; y[4 * g + 1] = v.y; y[4 * g + 2] = v.z; y[4 * g + 3] = v.w;
-      }
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const frag a = *(const frag*)(buf + (mt * NKB + kb) * 1024);
-        mma32(y, a, uf[kb]);
-      }
-      if (tvalid) {
-        if (gm < (p.Rp >> 5)) {
-          const int64_t off = ((int64_t)b * p.T + t) * row_x + (32 * gm + 4 * h) * ES;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 res = to_f32x4(*(const vec4*)(p.x_in + off + 8 * g * ES));
-            f32x4 o;
-            o.x = (y[4 * g + 0] + res.x) * rs; o.y = (y[4 * g + 1] + res.y) * rs;
-            o.z = (y[4 * g + 2] + res.z) * rs; o.w = (y[4 * g + 3] + res.w) * rs;
-            *(vec4*)(p.x_out + off + 8 * g * ES) = from_f32x4<E>(o);
-          }
-        } else {
-          float* sp = p.skip + ((int64_t)b * p.T + t) * p.Sp + 32 * (gm - (p.Rp >> 5)) + 4 * h;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 o = {y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
-            if (!skip_init) {
-              const f32x4 old = *(const f32x4*)(sp + 8 * g);
-              o += old;
-            }
-            *(f32x4*)(sp + 8 * g) = o;
-          }
-        }
+        for (int hf = 0; hf < NPASS_SKIP; ++hf) stage_load(old[hf], srow0 + 256 * hf, srs, rows_valid, lane);
       }
     }
+    f32x16 y[MT2];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], bias2 + 32 * (gm0 + mt), h);
+    if (p.stamps) { __builtin_amdgcn_sched_barrier(0); sc = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    gemm_chunk<MT2 * NKB, MT2, NKB, true>(buf, uf, y);
+    if (p.stamps) { __builtin_amdgcn_sched_barrier(0); sd = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+      st_[8] += sb - sa; st_[9] += sc - sb; st_[10] += sd - sc; }
+    if (no_epi) {
+      if (y[0][0] == 12345.678f && tvalid) p.skip[t] = y[MT2 - 1][3];  // keep the MFMAs alive
+      continue;
+    }
+    if (is_out) {
+      // x' = (y + x) * sqrt(.5): rows of MT2*32 channels = 256 bytes in E
+      stage_finish<E, MT2, true>(stg, y, old[0], p.x_out + roff, row_x, rows_valid, lane,
+                                 [](const f32x4& v, const f32x4& o) {
+                                   const float rs = 0.70710678118654752440f;
+                                   f32x4 r = {(v.x + o.x) * rs, (v.y + o.y) * rs, (v.z + o.z) * rs, (v.w + o.w) * rs};
+                                   return r;
+                                 });
+    } else {
+#pragma unroll
+      for (int hf = 0; hf < NPASS_SKIP; ++hf) {
+        if (skip_init)
+          stage_finish<float, 2, false>(stg, &y[2 * hf], old[hf], srow0 + 256 * hf, srs, rows_valid, lane,
+                                        [](const f32x4& v, const f32x4&) { return v; });
+        else
+          stage_finish<float, 2, true>(stg, &y[2 * hf], old[hf], srow0 + 256 * hf, srs, rows_valid, lane,
+                                       [](const f32x4& v, const f32x4& o) { f32x4 r = v + o; return r; });
+      }
+    }
+    if (p.stamps) { __builtin_amdgcn_sched_barrier(0); st_[11] += __builtin_amdgcn_s_memtime() - sd; __builtin_amdgcn_sched_barrier(0); }
+  }
+  STAMP(4);
+  if (p.stamps && threadIdx.x == 0) {
+    st_[5] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 16 + i] = st_[i];
   }
 }
 
 template <typename E, int NP, bool EXACT>
 static int launch_glu(const GluArgs& a, hipStream_t st) {
   constexpr int CHB = 2 * NP * 4 * 1024;
-  const size_t lds = 2 * CHB;
-  static bool attr_done = false;
-  if (!attr_done) {
+  const size_t lds = 2 * CHB + 4 * STG_BYTES + (size_t)(a.Rp + a.Sp) * 4;
+  if (lds > 160 * 1024) {
+    wae_set_error("glu_fwd: needs %zu bytes of LDS (> 160 KiB): Hp=%d with Rp+Sp=%d is not supported yet", lds, NP * 32,
+                  a.Rp + a.Sp);
+    return WAE_EUNSUPPORTED;
+  }
+  static size_t attr_done = 0;
+  if (attr_done < lds) {
     if (hipFuncSetAttribute((const void*)glu_fwd_kernel<E, NP, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       wae_set_error("glu_fwd: cannot raise dynamic LDS to %zu", lds);
       return WAE_EHIP;
     }
-    attr_done = true;
+    attr_done = lds;
   }
   const int tiles = (a.T + 127) / 128;
   hipLaunchKernelGGL((glu_fwd_kernel<E, NP, EXACT>), dim3(a.B * tiles), dim3(256), lds, st, a);
@@ -286,7 +402,7 @@ extern "C" int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* 
   a.x_in = (const char*)x_in; a.x_out = (char*)x_out; a.c_up = (const char*)c_up; a.skip = skip; a.zb = zb;
   a.z_save = (char*)z_save; a.w = (const char*)w_packed; a.bias2 = bias2; a.zb_stride = zb_stride;
   a.B = d->B; a.T = d->T; a.Rp = d->Rp; a.Sp = d->Sp; a.Ccp = d->Ccp; a.Hp = d->Hp; a.ktaps = d->ktaps;
-  a.dilation = d->dilation; a.flags = d->flags;
+  a.dilation = d->dilation; a.flags = d->flags; a.stamps = g_stamps;
   hipStream_t st = as_stream(stream);
   if (d->dtype == WAE_BF16) return dispatch_np<__bf16, false>(d->Hp / 32, a, st);
   return dispatch_np<float, true>(d->Hp / 32, a, st);

@@ -98,13 +98,7 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
     if (q + 1 < nq_total) dma_chunk(p.w + (int64_t)(q + 1) * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
     if (q + 1 < nq1) load_B(q + 1, Bn);
     const char* buf = smem + (q & 1) * CHB + lane * 16;
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-      for (int m = 0; m < NT; ++m) {
-        const frag a = *(const frag*)(buf + (blk * NT + m) * 1024);
-        mma32(acc[m], a, Bc[blk]);
-      }
+    gemm_chunk<4 * NT, NT, 4>(buf, Bc, acc);
   }
 
   // relu -> operand fragments (and optional save for backward)

@@ -105,6 +105,59 @@ __device__ __forceinline__ void dma_chunk(const char* __restrict__ gsrc, char* l
   }
 }
 
+// One weight chunk of N fragment blocks (LDS image [i][lane][16 B], i = blk*NM + m) against the B fragments
+// of the chunk: acc[i % NM] += A_i . B[i / NM].  With one wave per SIMD nothing but the wave's own issue order
+// hides LDS latency, and hipcc collapses a source-level prefetch back into read-wait-mfma.  So the A reads are
+// inline-asm ds_read_b128 that run PD blocks ahead in a rotating register set, retired by counted
+// s_waitcnt lgkmcnt(n) statements that carry the destination as "+v" (cdna_hip_programming.md 5.7 form ii):
+// the MFMA consumes the wait's output, so it cannot be hoisted above it.  All reads are retired on exit.
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_wait(bf16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+
+template <int OFF, typename frag>
+__device__ __forceinline__ void lds_read_async(frag& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+// KMAJOR = false: block I = blk*NM + m   -> acc[I % NM] += A_I . B[I / NM]   (first GEMM: k-blocks outer)
+// KMAJOR = true : block I = mt*NB + kb   -> acc[I / NB] += A_I . B[I % NB]   (second GEMM: M-tiles outer)
+template <int I, int N, int NM, int PD, int NB, bool KMAJOR, typename frag>
+struct GemmChunkStep {
+  static __device__ __forceinline__ void run(unsigned addr, frag (&a)[PD], const frag (&B)[NB], f32x16 (&acc)[NM]) {
+    constexpr int remaining = N - 1 - I;                      // reads issued after block I
+    constexpr int cnt = remaining < PD - 1 ? remaining : PD - 1;
+    lds_wait<cnt>(a[I % PD]);
+    if constexpr (KMAJOR)
+      mma32(acc[I / NB], a[I % PD], B[I % NB]);
+    else
+      mma32(acc[I % NM], a[I % PD], B[I / NM]);
+    if constexpr (I + PD < N) lds_read_async<(I + PD) * 1024>(a[I % PD], addr);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 1 < N) GemmChunkStep<I + 1, N, NM, PD, NB, KMAJOR, frag>::run(addr, a, B, acc);
+  }
+};
+
+template <int I, int PD, typename frag>
+struct GemmChunkPrologue {
+  static __device__ __forceinline__ void run(unsigned addr, frag (&a)[PD]) {
+    lds_read_async<I * 1024>(a[I], addr);
+    if constexpr (I + 1 < PD) GemmChunkPrologue<I + 1, PD, frag>::run(addr, a);
+  }
+};
+
+template <int N, int NM, int NB, bool KMAJOR = false, typename frag>
+__device__ __forceinline__ void gemm_chunk(const char* buf, const frag (&B)[NB], f32x16 (&acc)[NM]) {
+  constexpr int PD = N < 8 ? N : 8;
+  static_assert((N - 1) * 1024 < 65536, "ds_read offset field is 16 bits");
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)buf;
+  frag a[PD];
+  __builtin_amdgcn_sched_barrier(0);
+  GemmChunkPrologue<0, PD, frag>::run(addr, a);
+  GemmChunkStep<0, N, NM, PD, NB, KMAJOR, frag>::run(addr, a, B, acc);
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

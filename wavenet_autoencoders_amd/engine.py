@@ -198,7 +198,7 @@ class WaeEngine:
     def decoder_forward(self, x: torch.Tensor, c: Optional[torch.Tensor], gid: Optional[torch.Tensor],
                         targets: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
                         want_logits: bool = True, train: bool = False, c_is_upsampled: bool = False,
-                        gvec: Optional[torch.Tensor] = None):
+                        gvec: Optional[torch.Tensor] = None, layer_events: Optional[list] = None):
         """WaveNet.forward (wavenet.py:164-216) on class ids.
 
         x: (B,T) int32 class ids (mulaw-quantize) or (B,T) fp32 scalars (scalar_input).
@@ -246,7 +246,9 @@ class WaeEngine:
         # gated residual stack
         es = self.w_glu.element_size()
         d = L.GluDesc(self.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, 1, 0)
-        nbuf = len(ws["x"])
+        if layer_events is not None:   # HIP events on the launch stream around the whole gated stack (bench.py)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         for i, dil in enumerate(g.dilations):
             d.dilation = dil
             last = i == g.layers - 1
@@ -258,6 +260,9 @@ class WaeEngine:
                                           g.layers * 2 * g.Hp, L.ptr(ws["z"][i]) if train else None,
                                           ctypes.c_void_p(self.w_glu.data_ptr() + i * self.glu_elems * es),
                                           ctypes.c_void_p(self.b_glu.data_ptr() + i * (g.Rp + g.Sp) * 4), st), f"glu layer {i}")
+        if layer_events is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            layer_events.append((e0, e1))
         # head (+ fused CE)
         hd = L.HeadDesc(self.dt, B, T, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
         logits = torch.empty(B, g.O, T, dtype=torch.float32, device=self.device) if want_logits else None
