@@ -42,7 +42,7 @@ def synth_inputs(rank, device):
     return x.to(device), lat.to(device), g.to(device)
 
 
-def cpu_baseline(sd, nclips=1):
+def cpu_baseline(sd, nclips=8):
     """Oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload."""
     import numpy as np
     import torch

@@ -37,7 +37,6 @@ extern "C" {
 #define WAE_BF16 1
 
 /* flags of wae_glu_desc.flags */
-#define WAE_GLU_SKIP_INIT 1 /* skip = s   instead of skip += s (first layer; replaces `skips = 0`, wavenet.py:204) */
 #define WAE_GLU_SAVE_Z 2    /* also store the pre-activation z (B,T,2Hp) for backward */
 #define WAE_GLU_NO_OUT 4    /* do not compute/store x' (last layer: the reference's x' is dead, wavenet.py:205-207) */
 
@@ -95,37 +94,48 @@ int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t la
 int wae_first_conv_fwd(const int32_t* idx, const float* xs, const float* table, const float* bias, void* x0,
                        int64_t BT, int32_t Rp, int32_t O, int32_t dtype, void* stream);
 
-/* ---- a6+a7 ResidualConv1dGLU._forward + skip accumulate (modules.py:115-163, wavenet.py:204-207) -------- */
+/* ---- a6 ResidualConv1dGLU._forward (modules.py:115-163) -------------------------------------------------
+ * One fused layer: dilated causal conv + 1x1(c) + hoisted 1x1(g) + gate + 1x1 out + residual.  The skip 1x1
+ * (modules.py:157) and `skips += h` (wavenet.py:204-207) are deferred: the layer stores its gated activation
+ * u_l = tanh(a)*sigmoid(b) and wae_head_fwd contracts all layers' u against [W_skip_0 .. W_skip_{L-1}] at once. */
 typedef struct wae_glu_desc {
   int32_t dtype;
   int32_t B, T;
-  int32_t Rp, Sp, Ccp, Hp; /* padded: Rp,Sp % 128 == 0, Ccp % 64 == 0 (may be 0), Hp % 32 == 0, Hp <= 256 */
-  int32_t ktaps;           /* kernel_size */
+  int32_t Rp, Ccp, Hp; /* padded: Rp % 128 == 0, Ccp % 64 == 0 (may be 0), Hp % 32 == 0, Hp <= 192 */
+  int32_t ktaps;       /* kernel_size */
   int32_t dilation;
   int32_t flags;
 } wae_glu_desc;
-/* x_in,x_out (B,T,Rp) dtype; c_up (B,T,Ccp) dtype; skip (B,T,Sp) fp32; zb (B,2Hp) fp32 for THIS layer
- * (row stride zb_stride floats); z_save (B,T,2Hp) dtype or NULL; w_packed = [W1 chunks | W2 chunks];
- * bias2 (Rp+Sp) fp32 = [out bias | skip bias]. */
-int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* x_out, const void* c_up, float* skip,
-                      const float* zb, int64_t zb_stride, void* z_save, const void* w_packed,
-                      const float* bias2, void* stream);
+/* x_in,x_out (B,T,Rp) dtype; c_up (B,T,Ccp) dtype; u_out: this layer's Hp columns inside a (B,T,u_stride) dtype
+ * buffer (pointer already offset to the layer's first column); zb (B,2Hp) fp32 for THIS layer (row stride
+ * zb_stride floats) = conv bias + hoisted global conditioning; z_save (B,T,2Hp) dtype or NULL;
+ * w_packed = [W1 chunks | W_out chunks] in fragment order; bias_out (Rp) fp32. */
+int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* x_out, const void* c_up, void* u_out,
+                      int64_t u_stride, const float* zb, int64_t zb_stride, void* z_save, const void* w_packed,
+                      const float* bias_out, void* stream);
 int64_t wae_glu_packed_bytes(const wae_glu_desc* d);
 
-/* ---- a8+a9 head (wavenet.py:136-141,208-214) + MaskedCrossEntropyLoss (vqwae_train.py:363-379,:764) ----
- * h = relu(skip*scale); h = relu(W1 h + b1); logits = W3 h + b3.  logits (B,O,T) fp32 or NULL.
+/* ---- a7+a8+a9 skip sum + head (wavenet.py:204-214) + MaskedCrossEntropyLoss (vqwae_train.py:363-379,:764) ---
+ * skips = sum_l (W_skip_l u_l + b_skip_l);  h0 = relu(skips * scale);  h1 = relu(W1 h0 + b1);  logits = W3 h1 + b3.
+ * u (B,T,Ku) dtype holds all layers' gated activations, Ku = L*Hp rounded up to 64 (pad columns zero).
+ * bias = [sum_l b_skip_l (Sp) | b1 (Sp) | b3 (Op)] fp32.  logits (B,O,T) fp32 or NULL.
  * If target != NULL: nll[b*T+t] = logsumexp(logits[:,t]) - logits[target[b*T+t+1], t] for t < T-1
- * (the reference's one-step shift), 0 at t = T-1. */
+ * (the reference's one-step shift), 0 at t = T-1.  h0_save/h1_save (B,T,Sp) dtype or NULL (for backward). */
 typedef struct wae_head_desc {
   int32_t dtype;
   int32_t B, T;
-  int32_t Sp, Op; /* padded to multiples of 64 */
+  int32_t Ku;     /* columns of u, multiple of 64 */
+  int32_t Sp, Op; /* padded to multiples of 128 */
   int32_t O;      /* true class count */
   float scale;    /* sqrt(1/L) */
 } wae_head_desc;
-int wae_head_fwd(const wae_head_desc* d, const float* skip, const void* w_packed, const float* bias,
-                 float* logits, const int32_t* target, float* nll, void* h1_save, void* stream);
+int wae_head_fwd(const wae_head_desc* d, const void* u, const void* w_packed, const float* bias, float* logits,
+                 const int32_t* target, float* nll, void* h0_save, void* h1_save, void* stream);
 int64_t wae_head_packed_bytes(const wae_head_desc* d);
+
+/* out[i] = sum_{l<L} src[off + l*stride + i] for i < n, 0 for n <= i < n_pad  (sum of the skip biases) */
+int wae_sum_rows(const float* src, int64_t off, int64_t stride, int32_t L, int32_t n, int32_t n_pad, float* out,
+                 void* stream);
 
 /* masked mean of per-sample losses: out[0] = sum_{b,t<len[b]-1} nll / sum mask  (vqwae_train.py:379) */
 int wae_masked_mean(const float* nll, const int32_t* lengths, float* out, int32_t B, int32_t T, void* stream);

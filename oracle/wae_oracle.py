@@ -145,6 +145,21 @@ def glu_layer_forward(sd: SD, prefix: str, x: torch.Tensor, c: Optional[torch.Te
     return (o + x) * math.sqrt(0.5), s
 
 
+def glu_layer_gate(sd: SD, prefix: str, x, c, g, dilation: int) -> torch.Tensor:
+    """The gated activation u = tanh(a)*sigmoid(b) of one layer (modules.py:134-154), i.e. the tensor both 1x1
+    output convs consume; the HIP path stores it per layer and contracts the skip 1x1 of all layers at once."""
+    T = x.shape[-1]
+    w = eff_weight(sd, prefix + "conv")
+    k = w.shape[-1]
+    z = F.conv1d(x, w, sd.get(prefix + "conv.bias"), padding=(k - 1) * dilation, dilation=dilation)[:, :, :T]
+    if c is not None:
+        z = z + F.conv1d(c, eff_weight(sd, prefix + "conv1x1c"))
+    if g is not None:
+        z = z + F.conv1d(g, eff_weight(sd, prefix + "conv1x1g"))
+    a, b = z.split(z.shape[1] // 2, dim=1)
+    return torch.tanh(a) * torch.sigmoid(b)
+
+
 def layer_dilations(layers: int, stacks: int) -> List[int]:
     """wavenet.py:117,126: d = 2 ** (layer % (layers // stacks))."""
     assert layers % stacks == 0

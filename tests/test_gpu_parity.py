@@ -89,30 +89,38 @@ def test_single_glu_layer(name, d, dtype, tol):
                                   eng.lay.off("wavenet.conv_layers.0.conv.bias"), eng.lay.layer_stride, None, 0,
                                   L.ptr(gvec), L.ptr(zb), B, g.layers, g.G, g.Hp, g.Cg, st))
     xout = torch.zeros_like(xin)
-    skip = torch.full((B, T, g.Sp), 7.0, device="cuda")
-    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, d, L.GLU_SKIP_INIT)
+    Ku = 2 * g.Hp + 64
+    ubuf = torch.full((B, T, Ku), 7.0, dtype=eng.tdtype, device="cuda")
+    zsave = torch.zeros(B, T, 2 * g.Hp, dtype=eng.tdtype, device="cuda")
+    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, d, L.GLU_SAVE_Z)
     i = 1  # golden uses the weights of conv_layers.1
     es = eng.w_glu.element_size()
-    L.check(eng.lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(xin), L.ptr(xout), L.ptr(cin), L.ptr(skip),
-                                      ctypes.c_void_p(zb.data_ptr() + i * 2 * g.Hp * 4), g.layers * 2 * g.Hp, None,
+    ucol = g.Hp  # store this layer's u at column offset Hp of the wider buffer
+    L.check(eng.lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(xin), L.ptr(xout), L.ptr(cin),
+                                      ctypes.c_void_p(ubuf.data_ptr() + ucol * es), Ku,
+                                      ctypes.c_void_p(zb.data_ptr() + i * 2 * g.Hp * 4), g.layers * 2 * g.Hp, L.ptr(zsave),
                                       ctypes.c_void_p(eng.w_glu.data_ptr() + i * eng.glu_elems * es),
-                                      ctypes.c_void_p(eng.b_glu.data_ptr() + i * (g.Rp + g.Sp) * 4), st))
+                                      ctypes.c_void_p(eng.b_glu.data_ptr() + i * g.Rp * 4), st))
     torch.cuda.synchronize()
     pt = torch.from_numpy(z["probe_t"])
     xo = xout[:, :, :g.R].float().transpose(1, 2).cpu()[:, :, pt]
-    so = skip[:, :, :g.S].transpose(1, 2).cpu()[:, :, pt]
     assert rel_err(xo, z[f"xo_d{d}_cg"]) < tol
+    # gated activation against the oracle, and the skip 1x1 of it against the golden skip output
+    u_ref = O.glu_layer_gate(sd, "wavenet.conv_layers.1.", x, c, gv, d)
+    u = ubuf[:, :, ucol:ucol + g.H].float().transpose(1, 2).cpu()
+    assert rel_err(u, u_ref) < tol
+    w_skip = O.eff_weight(sd, "wavenet.conv_layers.1.conv1x1_skip")
+    so = torch.nn.functional.conv1d(u, w_skip, sd["wavenet.conv_layers.1.conv1x1_skip.bias"])[:, :, pt]
     assert rel_err(so, z[f"so_d{d}_cg"]) < tol
-    # pad channels must stay exactly zero and the accumulate form must add
+    # pad channels stay exactly zero, neighbours of the u slice are untouched, z = pre-activation is consistent
     assert float(xout[:, :, g.R:].abs().max()) == 0.0
-    desc.flags = 0
-    L.check(eng.lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(xin), L.ptr(xout), L.ptr(cin), L.ptr(skip),
-                                      ctypes.c_void_p(zb.data_ptr() + i * 2 * g.Hp * 4), g.layers * 2 * g.Hp, None,
-                                      ctypes.c_void_p(eng.w_glu.data_ptr() + i * eng.glu_elems * es),
-                                      ctypes.c_void_p(eng.b_glu.data_ptr() + i * (g.Rp + g.Sp) * 4), st))
-    torch.cuda.synchronize()
-    so2 = skip[:, :, :g.S].transpose(1, 2).cpu()[:, :, pt]
-    assert rel_err(so2, 2 * torch.from_numpy(z[f"so_d{d}_cg"])) < tol
+    assert float(ubuf[:, :, ucol + g.H:ucol + g.Hp].float().abs().max()) == 0.0
+    assert float((ubuf[:, :, :ucol].float() - 7.0).abs().max()) == 0.0
+    assert float((ubuf[:, :, ucol + g.Hp:].float() - 7.0).abs().max()) == 0.0
+    za = zsave[:, :, :g.H].float()
+    zg = zsave[:, :, g.Hp:g.Hp + g.H].float()
+    u_from_z = (torch.tanh(za) * torch.sigmoid(zg)).transpose(1, 2).cpu()
+    assert rel_err(u_from_z, u_ref) < (tol if dtype == "fp32" else 5e-2)
 
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])

@@ -22,7 +22,7 @@ g = eng.g
 x = (torch.randn(B, T, g.Rp, device="cuda") * 0.5).to(eng.tdtype)
 c = (torch.randn(B, T, g.Ccp, device="cuda") * 0.5).to(eng.tdtype)
 xo = torch.empty_like(x)
-skip = torch.zeros(B, T, g.Sp, device="cuda")
+ubuf = torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype)
 zb = torch.zeros(B, 2 * g.Hp, device="cuda")
 st = eng.stream()
 variants = {"full": 0, "no_dma": 0x100, "no_bload": 0x200, "no_epi": 0x400, "no_gate": 0x800,
@@ -30,8 +30,8 @@ variants = {"full": 0, "no_dma": 0x100, "no_bload": 0x200, "no_epi": 0x400, "no_
 
 
 def run(flags, d):
-    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, d, flags)
-    L.check(eng.lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(x), L.ptr(xo), L.ptr(c), L.ptr(skip), L.ptr(zb), 0, None,
+    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, d, flags)
+    L.check(eng.lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(x), L.ptr(xo), L.ptr(c), L.ptr(ubuf), g.Hp, L.ptr(zb), 0, None,
                                       L.ptr(eng.w_glu), L.ptr(eng.b_glu), st))
 
 

@@ -23,7 +23,7 @@ g = eng.g
 x = (torch.randn(B, T, g.Rp, device="cuda") * 0.5).to(eng.tdtype)
 c = (torch.randn(B, T, g.Ccp, device="cuda") * 0.5).to(eng.tdtype)
 xo = torch.empty_like(x)
-skip = torch.zeros(B, T, g.Sp, device="cuda")
+ubuf = torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype)
 zb = torch.zeros(B, 2 * g.Hp, device="cuda")
 st = eng.stream()
 nwg = B * ((T + 127) // 128)
@@ -33,8 +33,8 @@ lib.wae_debug_set_stamps.argtypes = [ctypes.c_void_p]
 
 
 def run(fl, d=4):
-    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, d, fl)
-    L.check(lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(x), L.ptr(xo), L.ptr(c), L.ptr(skip), L.ptr(zb), 0, None,
+    desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, d, fl)
+    L.check(lib.wae_glu_layer_fwd(ctypes.byref(desc), L.ptr(x), L.ptr(xo), L.ptr(c), L.ptr(ubuf), g.Hp, L.ptr(zb), 0, None,
                                   L.ptr(eng.w_glu), L.ptr(eng.b_glu), st))
 
 
@@ -46,14 +46,11 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib.wae_debug_set_stamps(None)
 s = stamps.cpu().numpy().reshape(nwg, 16)
-names = ["init(zb, first dma/B issue)", "GEMM1", "gate", "GEMM2+epilogue"]
+names = ["init(zb, first dma/B issue)", "GEMM1", "z-save+gate+u-store", "GEMM2+epilogue"]
 d = np.diff(s[:, :5].astype(np.int64), axis=1)
 print(f"flags={flags:#x} workgroups={nwg}; cycles per phase (median / p10 / p90) over workgroups:")
 for i, nme in enumerate(names):
     v = np.sort(d[:, i])
-    print(f"  {nme:30s} {int(np.median(v)):8d} {int(v[len(v)//10]):8d} {int(v[len(v)*9//10]):8d}")
-for i, nme in zip(range(8, 12), ["  g2: wait+barrier", "  g2: dma/old-load issue+bias", "  g2: mfma chunk", "  g2: stage_finish"]):
-    v = np.sort(s[:, i].astype(np.int64))
     print(f"  {nme:30s} {int(np.median(v)):8d} {int(v[len(v)//10]):8d} {int(v[len(v)*9//10]):8d}")
 tot = np.sort(s[:, 4] - s[:, 0])
 print(f"  {'total':30s} {int(np.median(tot)):8d}")

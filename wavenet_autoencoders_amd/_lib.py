@@ -10,17 +10,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwae_hip.so")
 
 WAE_F32, WAE_BF16 = 0, 1
-GLU_SKIP_INIT, GLU_SAVE_Z, GLU_NO_OUT = 1, 2, 4
+GLU_SAVE_Z, GLU_NO_OUT = 2, 4
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
 
 class GluDesc(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Rp", "Sp", "Ccp", "Hp", "ktaps", "dilation", "flags")]
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Rp", "Ccp", "Hp", "ktaps", "dilation", "flags")]
 
 
 class HeadDesc(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Sp", "Op", "O")] + [("scale", c_f32)]
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Ku", "Sp", "Op", "O")] + [("scale", c_f32)]
 
 
 # name -> (restype, argtypes); mirrors include/wae.h one to one
@@ -36,9 +36,10 @@ SIGNATURES = {
     "wae_upsample_stage_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
     "wae_gproj_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
     "wae_first_conv_fwd": (c_i32, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_i32, c_vp]),
-    "wae_glu_layer_fwd": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "wae_glu_layer_fwd": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "wae_glu_packed_bytes": (c_i64, [ctypes.POINTER(GluDesc)]),
-    "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 8),
+    "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 9),
+    "wae_sum_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_masked_mean": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),

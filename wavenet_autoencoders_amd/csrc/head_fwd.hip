@@ -1,56 +1,40 @@
-// wae_head_fwd: decoder head + fused softmax cross-entropy (reference: wavenet.py:136-141,208-214;
-// vqwae_train.py:363-379 with the one-step shift of :764).
+// wae_head_fwd: skip contraction + decoder head + fused softmax cross-entropy
+// (reference: modules.py:157 conv1x1_skip, wavenet.py:204-214; vqwae_train.py:363-379 with the shift of :764).
 //
-//   h0 = relu(skip * sqrt(1/L))          (fp32 skip accumulators, converted to MFMA fragments on load)
-//   h1 = relu(b1 + W1[Sp,Sp] . h0)       (GEMM 1; stays in registers as the operand of GEMM 2)
-//   y  = b3 + W3[Op,Sp] . h1             (GEMM 2) -> logits (B,O,T) fp32 and/or nll[b,t] = lse(y) - y[target[t+1]]
+//   skips = sum_l b_skip_l + [W_skip_0 .. W_skip_{L-1}][Sp, Ku] . u[Ku, t]     (GEMM 0, K = all layers' gated
+//   h0 = relu(skips * sqrt(1/L))                                                activations; replaces L passes of
+//   h1 = relu(b1 + W1[Sp,Sp] . h0)                                (GEMM 1)      `skips += h`, wavenet.py:206)
+//   y  = b3 + W3[Op,Sp] . h1                                      (GEMM 2) -> logits (B,O,T) fp32 and/or
+//                                                                 nll[b,t] = lse(y) - y[target[t+1]]
 //
 // Same decomposition as glu_fwd.hip: 128 time steps per workgroup, one wave per 32 time columns, weights in
-// A-fragment order through a double-buffered LDS ring, accumulator tiles reused as the next MFMA's B operand.
+// A-fragment order through a double-buffered LDS ring, accumulator tiles reused as the next MFMA's B operand,
+// so skips, h0 and h1 never leave the register file.
 #include "wae_common.hpp"
 
 struct HeadArgs {
-  const float* skip;
+  const char* u;
   const char* w;
-  const float* bias;  // [Sp | Op]
+  const float* bias;  // [Sp skip-bias sum | Sp b1 | Op b3]
   float* logits;
   const int32_t* target;
   float* nll;
+  char* h0_save;
   char* h1_save;
-  int B, T, Sp, Op, O;
+  int B, T, Ku, Sp, Op, O;
   float scale;
 };
-
-template <typename E>
-__device__ __forceinline__ typename ET<E>::frag load_skip_frag(const float* p, float scale);
-template <>
-__device__ __forceinline__ f32x4 load_skip_frag<float>(const float* p, float scale) {
-  f32x4 v = *(const f32x4*)p;
-  v.x = fmaxf(v.x * scale, 0.f); v.y = fmaxf(v.y * scale, 0.f); v.z = fmaxf(v.z * scale, 0.f); v.w = fmaxf(v.w * scale, 0.f);
-  return v;
-}
-template <>
-__device__ __forceinline__ bf16x8 load_skip_frag<__bf16>(const float* p, float scale) {
-  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-  bf16x8 r;
-  r[0] = (__bf16)fmaxf(a.x * scale, 0.f); r[1] = (__bf16)fmaxf(a.y * scale, 0.f);
-  r[2] = (__bf16)fmaxf(a.z * scale, 0.f); r[3] = (__bf16)fmaxf(a.w * scale, 0.f);
-  r[4] = (__bf16)fmaxf(b.x * scale, 0.f); r[5] = (__bf16)fmaxf(b.y * scale, 0.f);
-  r[6] = (__bf16)fmaxf(b.z * scale, 0.f); r[7] = (__bf16)fmaxf(b.w * scale, 0.f);
-  return r;
-}
 
 template <typename E, int NT>
 __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   using T_ = ET<E>;
   using frag = typename T_::frag;
-  using vec4 = typename T_::vec4;
   constexpr int CHB = NT * 4 * 1024;
   constexpr int ES = sizeof(E);
   constexpr int KBU = T_::KBU;
   constexpr int NKB = NT * KBU;
   constexpr int MT2 = 4 / KBU;  // bf16: 2, f32: 1  (MT2 * NKB KiB == CHB)
-  constexpr int EPL = T_::EPL;
+  constexpr int NQ1 = NT / MT2;  // chunks of GEMM 1 (Sp output tiles)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -58,20 +42,24 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   const int n = lane & 31, h = lane >> 5;
   const int tiles_per_b = (p.T + 127) >> 7;
   const int b = blockIdx.x / tiles_per_b;
-  const int t = (blockIdx.x % tiles_per_b) * 128 + wave * 32 + n;
+  const int t0w = (blockIdx.x % tiles_per_b) * 128 + wave * 32;
+  const int t = t0w + n;
   const bool tvalid = t < p.T;
+  const int rows_valid = min(max(p.T - t0w, 0), 32);
 
-  const int nq1 = p.Sp / T_::CK;
+  const int nq0 = p.Ku / T_::CK;
   const int nq2 = (p.Op >> 5) / MT2;
-  const int nq_total = nq1 + nq2;
-  const float* srow = p.skip + ((int64_t)b * p.T + (tvalid ? t : 0)) * p.Sp;
+  const int nq_total = nq0 + NQ1 + nq2;
+  const char* urow = p.u + ((int64_t)b * p.T + (tvalid ? t : 0)) * p.Ku * ES + h * 16;
+  char* stg = smem + 2 * CHB + wave * STG_BYTES;
+  float* bias_lds = (float*)(smem + 2 * CHB + 4 * STG_BYTES);
 
   frag Bn[4], Bc[4];
   auto load_B = [&](int q, frag (&Bf)[4]) {
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
       if (tvalid) {
-        Bf[blk] = load_skip_frag<E>(srow + q * T_::CK + blk * 2 * EPL + h * EPL, p.scale);
+        Bf[blk] = *(const frag*)(urow + q * 128 + blk * 32);
       } else {
         frag zf = {};
         Bf[blk] = zf;
@@ -79,83 +67,94 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
     }
   };
 
-  f32x16 acc[NT];
-#pragma unroll
-  for (int m = 0; m < NT; ++m)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = *(const f32x4*)(p.bias + 32 * m + 8 * g + 4 * h);
-      acc[m][4 * g + 0] = v.x; acc[m][4 * g + 1] = v.y; acc[m][4 * g + 2] = v.z; acc[m][4 * g + 3] = v.w;
-    }
-
+  // biases -> LDS once (accumulator inits then never touch vmcnt)
+  for (int i = threadIdx.x * 4; i < 2 * p.Sp + p.Op; i += 1024) *(f32x4*)(bias_lds + i) = *(const f32x4*)(p.bias + i);
   dma_chunk(p.w, smem, CHB, wave, lane);
   load_B(0, Bn);
-  for (int q = 0; q < nq1; ++q) {
+
+  // ---- GEMM 0: skip contraction over all layers' u --------------------------------------------------------
+  f32x16 acc[NT];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) init_rows(acc[m], p.bias + 32 * m, h);
+  for (int q = 0; q < nq0; ++q) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
     if (q + 1 < nq_total) dma_chunk(p.w + (int64_t)(q + 1) * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
-    if (q + 1 < nq1) load_B(q + 1, Bn);
+    if (q + 1 < nq0) load_B(q + 1, Bn);
     const char* buf = smem + (q & 1) * CHB + lane * 16;
     gemm_chunk<4 * NT, NT, 4>(buf, Bc, acc);
   }
 
-  // relu -> operand fragments (and optional save for backward)
+  // ---- h0 = relu(skips * scale) -> operand fragments (+ optional save) ------------------------------------
   frag uf[NKB];
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = fmaxf(acc[m][r], 0.f);
-    if (p.h1_save && tvalid) {
-      char* hr = p.h1_save + (((int64_t)b * p.T + t) * p.Sp + 32 * m + 4 * h) * ES;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-        *(vec4*)(hr + 8 * g * ES) = from_f32x4<E>(v);
-      }
-    }
+    for (int r = 0; r < 16; ++r) acc[m][r] = fmaxf(acc[m][r] * p.scale, 0.f);
     frag tmp[KBU];
     acc_to_frags(acc[m], tmp);
 #pragma unroll
     for (int s = 0; s < KBU; ++s) uf[m * KBU + s] = tmp[s];
   }
+  if (p.h0_save && rows_valid > 0)
+    stage_store_tiles<E, NT>(stg, acc, p.h0_save + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
 
-  // GEMM 2 + logits store + online log-sum-exp
+  // ---- GEMM 1: h1 = relu(b1 + W1 . h0); all NT output tiles stay in registers --------------------------------
+#pragma unroll
+  for (int q1 = 0; q1 < NQ1; ++q1) {
+    const int qi = nq0 + q1;
+    if (q1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi + 1) & 1) * CHB, CHB, wave, lane);
+    const char* buf = smem + (qi & 1) * CHB + lane * 16;
+    f32x16(&y)[MT2] = *reinterpret_cast<f32x16(*)[MT2]>(&acc[q1 * MT2]);
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], bias_lds + p.Sp + 32 * (q1 * MT2 + mt), h);
+    gemm_chunk<MT2 * NKB, MT2, NKB, true>(buf, uf, y);
+  }
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = fmaxf(acc[m][r], 0.f);
+    frag tmp[KBU];
+    acc_to_frags(acc[m], tmp);
+#pragma unroll
+    for (int s = 0; s < KBU; ++s) uf[m * KBU + s] = tmp[s];
+  }
+  if (p.h1_save && rows_valid > 0)
+    stage_store_tiles<E, NT>(stg, acc, p.h1_save + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
+
+  // ---- GEMM 2 + logits store + online log-sum-exp ------------------------------------------------------------
   const bool want_ce = p.target != nullptr && p.nll != nullptr;
   int tgt = -1;
   if (want_ce && tvalid && t + 1 < p.T) tgt = p.target[(int64_t)b * p.T + t + 1];
   float run_m = -INFINITY, run_s = 0.f, picked = 0.f;
-  const float* b3 = p.bias + p.Sp;
+  const float* b3 = bias_lds + 2 * p.Sp;
   for (int q2 = 0; q2 < nq2; ++q2) {
-    const int qi = nq1 + q2;
+    const int qi = nq0 + NQ1 + q2;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi + 1) & 1) * CHB, CHB, wave, lane);
     const char* buf = smem + (qi & 1) * CHB + lane * 16;
+    f32x16 y[MT2];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], b3 + 32 * (q2 * MT2 + mt), h);
+    gemm_chunk<MT2 * NKB, MT2, NKB, true>(buf, uf, y);
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) {
       const int gm = q2 * MT2 + mt;
-      f32x16 y;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *(const f32x4*)(b3 + 32 * gm + 8 * g + 4 * h);
-        y[4 * g + 0] = v.x; y[4 * g + 1] = v.y; y[4 * g + 2] = v.z; y[4 * g + 3] = v.w;
-      }
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const frag a = *(const frag*)(buf + (mt * NKB + kb) * 1024);
-        mma32(y, a, uf[kb]);
-      }
       if (tvalid) {
         float tile_m = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cls = 32 * gm + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (cls < p.O) {
-            if (p.logits) p.logits[((int64_t)b * p.O + cls) * p.T + t] = y[r];
-            tile_m = fmaxf(tile_m, y[r]);
-            if (cls == tgt) picked = y[r];
+            if (p.logits) p.logits[((int64_t)b * p.O + cls) * p.T + t] = y[mt][r];
+            tile_m = fmaxf(tile_m, y[mt][r]);
+            if (cls == tgt) picked = y[mt][r];
           }
         }
         if (want_ce && tile_m > -INFINITY) {
@@ -164,7 +163,7 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int cls = 32 * gm + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (cls < p.O) s += __expf(y[r] - nm);
+            if (cls < p.O) s += __expf(y[mt][r] - nm);
           }
           run_m = nm;
           run_s = s;
@@ -190,15 +189,15 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
 template <typename E, int NT>
 static int launch_head(const HeadArgs& a, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
-  const size_t lds = 2 * CHB;
-  static bool attr_done = false;
-  if (!attr_done) {
+  const size_t lds = 2 * CHB + 4 * STG_BYTES + (size_t)(2 * a.Sp + a.Op) * 4;
+  static size_t attr_done = 0;
+  if (attr_done < lds) {
     if (hipFuncSetAttribute((const void*)head_fwd_kernel<E, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {
       wae_set_error("head_fwd: cannot raise dynamic LDS to %zu", lds);
       return WAE_EHIP;
     }
-    attr_done = true;
+    attr_done = lds;
   }
   const int tiles = (a.T + 127) / 128;
   hipLaunchKernelGGL((head_fwd_kernel<E, NT>), dim3(a.B * tiles), dim3(256), lds, st, a);
@@ -209,8 +208,9 @@ static int head_validate(const wae_head_desc* d) {
   WAE_REQUIRE(d != nullptr, "head: null desc");
   WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "head: bad dtype %d", d->dtype);
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->O > 0, "head: B,T,O must be positive");
-  WAE_REQUIRE(d->Sp % 128 == 0 && (d->Sp == 128 || d->Sp == 256), "head: Sp must be 128 or 256 (got %d)", d->Sp);
-  WAE_REQUIRE(d->Op % 128 == 0 && d->Op >= d->O, "head: Op must be a multiple of 128 and >= O");
+  WAE_REQUIRE(d->Ku > 0 && d->Ku % 64 == 0, "head: Ku must be a positive multiple of 64 (got %d)", d->Ku);
+  WAE_REQUIRE(d->Sp == 128 || d->Sp == 256, "head: Sp must be 128 or 256 (got %d)", d->Sp);
+  WAE_REQUIRE(d->Op % 128 == 0 && d->Op >= d->O && d->Op <= 8192, "head: Op must be a multiple of 128 and >= O");
   return WAE_OK;
 }
 
@@ -219,18 +219,19 @@ extern "C" int64_t wae_head_packed_bytes(const wae_head_desc* d) {
   const int ck = d->dtype == WAE_BF16 ? 64 : 32;
   const int mt2 = d->dtype == WAE_BF16 ? 2 : 1;
   const int64_t chb = (int64_t)(d->Sp / 32) * 4 * 1024;
-  return (int64_t)(d->Sp / ck + (d->Op / 32) / mt2) * chb;
+  return (int64_t)(d->Ku / ck + (d->Sp / 32) / mt2 + (d->Op / 32) / mt2) * chb;
 }
 
-extern "C" int wae_head_fwd(const wae_head_desc* d, const float* skip, const void* w_packed, const float* bias,
-                            float* logits, const int32_t* target, float* nll, void* h1_save, void* stream) {
+extern "C" int wae_head_fwd(const wae_head_desc* d, const void* u, const void* w_packed, const float* bias, float* logits,
+                            const int32_t* target, float* nll, void* h0_save, void* h1_save, void* stream) {
   int rc = head_validate(d);
   if (rc != WAE_OK) return rc;
-  WAE_REQUIRE(skip && w_packed && bias, "head: null pointer argument");
+  WAE_REQUIRE(u && w_packed && bias, "head: null pointer argument");
   WAE_REQUIRE(logits || (target && nll), "head: nothing to produce (logits and nll both null)");
   HeadArgs a;
-  a.skip = skip; a.w = (const char*)w_packed; a.bias = bias; a.logits = logits; a.target = target; a.nll = nll;
-  a.h1_save = (char*)h1_save; a.B = d->B; a.T = d->T; a.Sp = d->Sp; a.Op = d->Op; a.O = d->O; a.scale = d->scale;
+  a.u = (const char*)u; a.w = (const char*)w_packed; a.bias = bias; a.logits = logits; a.target = target; a.nll = nll;
+  a.h0_save = (char*)h0_save; a.h1_save = (char*)h1_save; a.B = d->B; a.T = d->T; a.Ku = d->Ku; a.Sp = d->Sp; a.Op = d->Op;
+  a.O = d->O; a.scale = d->scale;
   hipStream_t st = as_stream(stream);
   const int nt = d->Sp / 32;
   if (d->dtype == WAE_BF16) return nt == 4 ? launch_head<__bf16, 4>(a, st) : launch_head<__bf16, 8>(a, st);

@@ -394,6 +394,24 @@ extern "C" int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off,
   return wae_check_launch("gproj_fwd");
 }
 
+// sum of the per-layer skip biases (the head's GEMM 0 starts from it)
+__global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__ src, int64_t off, int64_t stride, int L, int n,
+                                                       int n_pad, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pad) return;
+  float s = 0.f;
+  if (i < n)
+    for (int l = 0; l < L; ++l) s += src[off + (int64_t)l * stride + i];
+  out[i] = s;
+}
+extern "C" int wae_sum_rows(const float* src, int64_t off, int64_t stride, int32_t L, int32_t n, int32_t n_pad, float* out,
+                            void* stream) {
+  WAE_REQUIRE(src && out && L > 0 && n > 0 && n_pad >= n, "sum_rows: bad arguments");
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, as_stream(stream), src, off, stride, L, n,
+                     n_pad, out);
+  return wae_check_launch("sum_rows");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // first_conv on a one-hot input == column gather + bias (wavenet.py:203); scalar input: w*x + b
 // ---------------------------------------------------------------------------------------------------

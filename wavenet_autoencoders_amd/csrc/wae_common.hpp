@@ -158,6 +158,95 @@ __device__ __forceinline__ void gemm_chunk(const char* buf, const frag (&B)[NB],
   GemmChunkStep<0, N, NM, PD, NB, KMAJOR, frag>::run(addr, a, B, acc);
 }
 
+// 16 accumulator registers of a tile start from a per-row constant table: rows 8g + 4h + j, j < 4
+__device__ __forceinline__ void init_rows(f32x16& acc, const float* tab /* 32 floats, 16-B aligned */, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v = *(const f32x4*)(tab + 8 * g + 4 * h);
+    acc[4 * g + 0] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage_store_tiles: one wave stores NT accumulator tiles (32 time rows x 32 channels each; lane = time column
+// n, register group g = channels 8g+4h..+3) as contiguous channel runs of its 32 time rows, through a
+// wave-private 8 KiB LDS tile (row pitch 256 B, 16-byte chunks XOR-swizzled by the row: conflict-free row
+// reads, 2-way column writes) so that every global store instruction writes full 16-byte-per-lane row segments.
+// Passes of up to 256 bytes per row: 4/2/1 tiles (bf16) or 2/1 tiles (f32).
+// ---------------------------------------------------------------------------------------------------
+#define STG_BYTES 8192
+template <typename EO, int NTP>
+__device__ __forceinline__ void stage_store_pass(char* stg, const f32x16* y, char* gout, int64_t row_stride, int rows_valid,
+                                                 int lane) {
+  using vec4 = typename ET<EO>::vec4;
+  constexpr int SEG = NTP * 32 * sizeof(EO);
+  static_assert(SEG <= 256 && SEG >= 64, "a staging pass covers 64..256 bytes per row");
+  constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 32 / RPI;
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < NTP; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int c16, sub;
+      if constexpr (sizeof(EO) == 2) { c16 = 4 * mt + g; sub = 8 * h; } else { c16 = 8 * mt + 2 * g + h; sub = 0; }
+      const f32x4 v = {y[mt][4 * g], y[mt][4 * g + 1], y[mt][4 * g + 2], y[mt][4 * g + 3]};
+      *(vec4*)(stg + n * 256 + ((c16 ^ (n & 15)) << 4) + sub) = from_f32x4<EO>(v);
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int rr = lane / LPR, ck = lane % LPR;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = i * RPI + rr;
+    const f32x4 v = *(const f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4));
+    if (row < rows_valid) *(f32x4*)(gout + row * row_stride + ck * 16) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <typename EO, int NT>
+__device__ __forceinline__ void stage_store_tiles(char* stg, const f32x16* y, char* gout, int64_t row_stride, int rows_valid,
+                                                  int lane) {
+  constexpr int PT = 256 / (32 * (int)sizeof(EO));  // tiles per full pass: 4 (bf16) / 2 (f32)
+  if constexpr (NT >= PT) {
+    stage_store_pass<EO, PT>(stg, y, gout, row_stride, rows_valid, lane);
+    if constexpr (NT > PT) stage_store_tiles<EO, NT - PT>(stg, y + PT, gout + 256, row_stride, rows_valid, lane);
+  } else if constexpr (NT >= 2) {
+    stage_store_pass<EO, 2>(stg, y, gout, row_stride, rows_valid, lane);
+    if constexpr (NT > 2) stage_store_tiles<EO, NT - 2>(stg, y + 2, gout + 64 * sizeof(EO), row_stride, rows_valid, lane);
+  } else {
+    stage_store_pass<EO, 1>(stg, y, gout, row_stride, rows_valid, lane);
+  }
+}
+
+// Residual x[t] arrives as operand-shaped 16-byte fragments: fragment f of lane (n, h) = row bytes
+// [32 f + 16 h, +16) of the chunk.  f32: that IS the accumulator layout (tile f/4, group f%4, channels 8g+4h+j).
+// bf16: 8 channels 16 f + 8 h + j; the accumulator layout wants channels 8g + 4h' + j' -> exchange register pairs
+// between the lane halves once (v_permlane32_swap), after which registers {0,1} hold group 2(f%2) and {2,3}
+// group 2(f%2)+1 of tile f/2 for this lane's half.
+template <int N>
+__device__ __forceinline__ void residual_to_acc_layout(f32x4 (&)[N]) {}
+template <int N>
+__device__ __forceinline__ void residual_to_acc_layout(bf16x8 (&res)[N]) {
+#pragma unroll
+  for (int f = 0; f < N; ++f) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 r = __builtin_bit_cast(u32x4, res[f]);
+    auto s0 = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
+    auto s1 = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
+    r.x = s0[0]; r.z = s0[1]; r.y = s1[0]; r.w = s1[1];
+    res[f] = __builtin_bit_cast(bf16x8, r);
+  }
+}
+template <typename E, int N>
+__device__ __forceinline__ f32x4 residual_piece(const f32x4 (&res)[N], int mt, int g) { return res[4 * mt + g]; }
+template <typename E, int N>
+__device__ __forceinline__ f32x4 residual_piece(const bf16x8 (&res)[N], int mt, int g) {
+  const bf16x8 v = res[2 * mt + (g >> 1)];
+  const int o = 4 * (g & 1);
+  f32x4 r = {(float)v[o], (float)v[o + 1], (float)v[o + 2], (float)v[o + 3]};
+  return r;
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

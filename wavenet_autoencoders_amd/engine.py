@@ -57,11 +57,11 @@ class WaeEngine:
         self.glu_elems = self.n_w1 + self.n_w2
         assert self.glu_elems == P.glu_packed_elems(g, self.dt)
         self.w_glu = torch.zeros(g.layers * self.glu_elems, dtype=self.tdtype, device=dev)
-        self.b_glu = torch.zeros(g.layers * (g.Rp + g.Sp), dtype=torch.float32, device=dev)
+        self.b_glu = torch.zeros(g.layers * g.Rp, dtype=torch.float32, device=dev)
         self.first_tab = torch.zeros(self.m_tab.numel(), dtype=torch.float32, device=dev)
         self.first_bias = torch.zeros(g.Rp, dtype=torch.float32, device=dev)
         self.w_head = torch.zeros(self.m_hw.numel(), dtype=self.tdtype, device=dev)
-        self.b_head = torch.zeros(g.Sp + g.Op, dtype=torch.float32, device=dev)
+        self.b_head = torch.zeros(2 * g.Sp + g.Op, dtype=torch.float32, device=dev)   # [sum skip bias | b1 | b3]
         self._ws: Dict[tuple, dict] = {}
         self.weights_dirty = True
 
@@ -102,16 +102,18 @@ class WaeEngine:
                                     lay.layer_stride, self.glu_elems, self.dt, st), "pack W1")
         L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_w2), w2, self.n_w2, g.layers, lay.layer_stride,
                                     self.glu_elems, self.dt, st), "pack W2")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_b2), L.ptr(self.b_glu), g.Rp + g.Sp, g.layers,
-                                    lay.layer_stride, g.Rp + g.Sp, L.WAE_F32, st), "pack bias2")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_b2), L.ptr(self.b_glu), g.Rp, g.layers,
+                                    lay.layer_stride, g.Rp, L.WAE_F32, st), "pack out bias")
         L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_tab), L.ptr(self.first_tab), self.m_tab.numel(), 1, 0, 0,
                                     L.WAE_F32, st), "pack first table")
         L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_fb), L.ptr(self.first_bias), g.Rp, 1, 0, 0, L.WAE_F32, st),
                 "pack first bias")
         L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hw), L.ptr(self.w_head), self.m_hw.numel(), 1, 0, 0,
                                     self.dt, st), "pack head W")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hb), L.ptr(self.b_head), g.Sp + g.Op, 1, 0, 0, L.WAE_F32,
-                                    st), "pack head bias")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hb), ctypes.c_void_p(self.b_head.data_ptr() + g.Sp * 4),
+                                    g.Sp + g.Op, 1, 0, 0, L.WAE_F32, st), "pack head bias")
+        L.check(lib.wae_sum_rows(L.ptr(self.eff), lay.off("wavenet.conv_layers.0.conv1x1_skip.bias"), lay.layer_stride,
+                                 g.layers, g.S, g.Sp, L.ptr(self.b_head), st), "sum skip bias")
         self.weights_dirty = False
 
     # ------------------------------------------------------------------ workspaces
@@ -122,7 +124,7 @@ class WaeEngine:
             g, dev, td = self.g, self.device, self.tdtype
             ws = dict(
                 x=[torch.empty(B, T, g.Rp, dtype=td, device=dev) for _ in range((g.layers + 1) if train else 2)],
-                skip=torch.empty(B, T, g.Sp, dtype=torch.float32, device=dev),
+                u=torch.zeros(B, T, g.Ku, dtype=td, device=dev),      # all layers' gated activations (pad columns stay 0)
                 zb=torch.empty(B, g.layers, 2 * g.Hp, dtype=torch.float32, device=dev),
                 c_up=torch.zeros(B, T, g.Ccp, dtype=td, device=dev) if g.Ccp else None,
                 nll=torch.zeros(B, T, dtype=torch.float32, device=dev),
@@ -130,6 +132,7 @@ class WaeEngine:
             )
             if train:
                 ws["z"] = [torch.empty(B, T, 2 * g.Hp, dtype=td, device=dev) for _ in range(g.layers)]
+                ws["h0"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
                 ws["h1"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
             self._ws[key] = ws
         return ws
@@ -245,31 +248,32 @@ class WaeEngine:
                                            B * T, g.Rp, g.O, self.dt, st), "first_conv")
         # gated residual stack
         es = self.w_glu.element_size()
-        d = L.GluDesc(self.dt, B, T, g.Rp, g.Sp, g.Ccp, g.Hp, g.k, 1, 0)
+        d = L.GluDesc(self.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, 1, 0)
         if layer_events is not None:   # HIP events on the launch stream around the whole gated stack (bench.py)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
         for i, dil in enumerate(g.dilations):
             d.dilation = dil
             last = i == g.layers - 1
-            d.flags = (L.GLU_SKIP_INIT if i == 0 else 0) | (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0)
+            d.flags = (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0)
             xin = ws["x"][i if train else i % 2]
             xout = ws["x"][(i + 1) if train else (i + 1) % 2]
             L.check(lib.wae_glu_layer_fwd(ctypes.byref(d), L.ptr(xin), None if last else L.ptr(xout), L.ptr(ws["c_up"]),
-                                          L.ptr(ws["skip"]), ctypes.c_void_p(ws["zb"].data_ptr() + i * 2 * g.Hp * 4),
+                                          ctypes.c_void_p(ws["u"].data_ptr() + i * g.Hp * es), g.Ku,
+                                          ctypes.c_void_p(ws["zb"].data_ptr() + i * 2 * g.Hp * 4),
                                           g.layers * 2 * g.Hp, L.ptr(ws["z"][i]) if train else None,
                                           ctypes.c_void_p(self.w_glu.data_ptr() + i * self.glu_elems * es),
-                                          ctypes.c_void_p(self.b_glu.data_ptr() + i * (g.Rp + g.Sp) * 4), st), f"glu layer {i}")
+                                          ctypes.c_void_p(self.b_glu.data_ptr() + i * g.Rp * 4), st), f"glu layer {i}")
         if layer_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
             layer_events.append((e0, e1))
         # head (+ fused CE)
-        hd = L.HeadDesc(self.dt, B, T, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
+        hd = L.HeadDesc(self.dt, B, T, g.Ku, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
         logits = torch.empty(B, g.O, T, dtype=torch.float32, device=self.device) if want_logits else None
         tg = targets.to(torch.int32).contiguous() if targets is not None else None
-        L.check(lib.wae_head_fwd(ctypes.byref(hd), L.ptr(ws["skip"]), L.ptr(self.w_head), L.ptr(self.b_head), L.ptr(logits),
+        L.check(lib.wae_head_fwd(ctypes.byref(hd), L.ptr(ws["u"]), L.ptr(self.w_head), L.ptr(self.b_head), L.ptr(logits),
                                  L.ptr(tg), L.ptr(ws["nll"]) if tg is not None else None,
-                                 L.ptr(ws["h1"]) if train else None, st), "head")
+                                 L.ptr(ws["h0"]) if train else None, L.ptr(ws["h1"]) if train else None, st), "head")
         out = dict(logits=logits, nll=None, loss=None)
         if tg is not None:
             ln = lengths.to(torch.int32).contiguous() if lengths is not None else None

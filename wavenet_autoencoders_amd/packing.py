@@ -67,6 +67,7 @@ class Geometry:
         self.Ccp = _ru(self.Cc, 64) if self.Cc > 0 else 0
         self.Hp = _ru(self.H, 32)
         self.NP = self.Hp // 32
+        self.Ku = _ru(self.layers * self.Hp, 64)       # columns of the (B,T,Ku) buffer of all layers' gated activations
         per = self.layers // self.stacks
         self.dilations = [2 ** (i % per) for i in range(self.layers)]   # wavenet.py:126
         self.receptive_field = (self.k - 1) * sum(self.dilations) + 1   # wavenet.py:42-60
@@ -213,29 +214,25 @@ def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
 
 
 def glu_w2_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    """GEMM-2 stream of one layer: conv1x1_out rows only (the skip 1x1 is contracted in the head)."""
     t = _traits(dtype)
     EPL, KBU, MT2 = t["EPL"], t["KBU"], t["MT2"]
     NKB = g.NP * KBU
-    n_mt = (g.Rp + g.Sp) // 32
-    assert n_mt % MT2 == 0 and (g.Rp // 32) % MT2 == 0
+    n_mt = g.Rp // 32
+    assert n_mt % MT2 == 0
     gm, kb, lane, j = np.meshgrid(np.arange(n_mt), np.arange(NKB), np.arange(64), np.arange(EPL), indexing="ij")
     i, h = lane & 31, lane >> 5
     ur = u_row_index(dtype, kb, h, j)
-    is_out = gm < g.Rp // 32
     r_out = 32 * gm + i
-    r_skip = 32 * gm + i - g.Rp
     src_out = lay.off("wavenet.conv_layers.0.conv1x1_out.weight_v") + r_out * g.H + ur
-    src_skip = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v") + r_skip * g.H + ur
-    out = np.where(is_out, np.where((r_out < g.R) & (ur < g.H), src_out, -1),
-                   np.where((r_skip < g.S) & (ur < g.H), src_skip, -1))
+    out = np.where((r_out < g.R) & (ur < g.H), src_out, -1)
     return out.astype(np.int32).reshape(-1)
 
 
 def glu_bias2_map(g: Geometry, lay: ParamLayout) -> np.ndarray:
-    r = np.arange(g.Rp + g.Sp)
+    r = np.arange(g.Rp)
     o = lay.off("wavenet.conv_layers.0.conv1x1_out.bias")
-    s = lay.off("wavenet.conv_layers.0.conv1x1_skip.bias")
-    return np.where(r < g.Rp, np.where(r < g.R, o + r, -1), np.where(r - g.Rp < g.S, s + r - g.Rp, -1)).astype(np.int32)
+    return np.where(r < g.R, o + r, -1).astype(np.int32)
 
 
 def first_conv_maps(g: Geometry, lay: ParamLayout):
@@ -249,27 +246,36 @@ def first_conv_maps(g: Geometry, lay: ParamLayout):
 
 
 def head_w_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    """[GEMM 0: all layers' conv1x1_skip, GEMM-1 order over K = (layer, u channel)] +
+       [GEMM 1: last_conv_layers.1, GEMM-2 order] + [GEMM 2: last_conv_layers.3, GEMM-2 order]."""
     t = _traits(dtype)
     EPL, CK, KBU = t["EPL"], t["CK"], t["KBU"]
     NT = g.Sp // 32
-    nq1 = g.Sp // CK
-    q, blk, m, lane, j = np.meshgrid(np.arange(nq1), np.arange(4), np.arange(NT), np.arange(64), np.arange(EPL),
+    nq0 = g.Ku // CK
+    q, blk, m, lane, j = np.meshgrid(np.arange(nq0), np.arange(4), np.arange(NT), np.arange(64), np.arange(EPL),
                                      indexing="ij")
     i, h = lane & 31, lane >> 5
     row = 32 * m + i
-    ch = q * CK + blk * 2 * EPL + h * EPL + j
-    w1 = np.where((row < g.S) & (ch < g.S), lay.off("wavenet.last_conv_layers.1.weight_v") + row * g.S + ch, -1)
+    kk = q * CK + blk * 2 * EPL + h * EPL + j
+    layer, ch = kk // g.Hp, kk % g.Hp
+    w0 = np.where((row < g.S) & (layer < g.layers) & (ch < g.H),
+                  lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v") + layer * lay.layer_stride + row * g.H + ch, -1)
     NKB = NT * KBU
-    n_mt = g.Op // 32
-    gm, kb, lane, j = np.meshgrid(np.arange(n_mt), np.arange(NKB), np.arange(64), np.arange(EPL), indexing="ij")
-    i, h = lane & 31, lane >> 5
-    ur = u_row_index(dtype, kb, h, j)
-    row = 32 * gm + i
-    w3 = np.where((row < g.O) & (ur < g.S), lay.off("wavenet.last_conv_layers.3.weight_v") + row * g.S + ur, -1)
-    return np.concatenate([w1.reshape(-1), w3.reshape(-1)]).astype(np.int32)
+
+    def second_gemm(name, rows, rows_p):
+        gm, kb, lane, j = np.meshgrid(np.arange(rows_p // 32), np.arange(NKB), np.arange(64), np.arange(EPL), indexing="ij")
+        i, h = lane & 31, lane >> 5
+        ur = u_row_index(dtype, kb, h, j)
+        r = 32 * gm + i
+        return np.where((r < rows) & (ur < g.S), lay.off(name) + r * g.S + ur, -1)
+
+    w1 = second_gemm("wavenet.last_conv_layers.1.weight_v", g.S, g.Sp)
+    w3 = second_gemm("wavenet.last_conv_layers.3.weight_v", g.O, g.Op)
+    return np.concatenate([w0.reshape(-1), w1.reshape(-1), w3.reshape(-1)]).astype(np.int32)
 
 
 def head_bias_map(g: Geometry, lay: ParamLayout) -> np.ndarray:
+    """[b1 (Sp) | b3 (Op)] -- stored after the Sp-float skip-bias sum produced by wae_sum_rows."""
     r = np.arange(g.Sp + g.Op)
     b1 = lay.off("wavenet.last_conv_layers.1.bias")
     b3 = lay.off("wavenet.last_conv_layers.3.bias")
@@ -280,7 +286,7 @@ def glu_packed_elems(g: Geometry, dtype: int) -> int:
     t = _traits(dtype)
     chb = 2 * g.NP * 4 * 1024
     nq1 = g.k * (g.Rp // t["CK"]) + g.Ccp // t["CK"]
-    nq2 = ((g.Rp + g.Sp) // 32) // t["MT2"]
+    nq2 = (g.Rp // 32) // t["MT2"]
     return (nq1 + nq2) * chb // t["ES"]
 
 
@@ -288,4 +294,4 @@ def head_packed_elems(g: Geometry, dtype: int) -> int:
     t = _traits(dtype)
     chb = (g.Sp // 32) * 4 * 1024
     mt2 = 4 // t["KBU"]
-    return (g.Sp // t["CK"] + (g.Op // 32) // mt2) * chb // t["ES"]
+    return (g.Ku // t["CK"] + (g.Sp // 32) // mt2 + (g.Op // 32) // mt2) * chb // t["ES"]
