@@ -140,9 +140,23 @@ int wae_sum_rows(const float* src, int64_t off, int64_t stride, int32_t L, int32
 /* masked mean of per-sample losses: out[0] = sum_{b,t<len[b]-1} nll / sum mask  (vqwae_train.py:379) */
 int wae_masked_mean(const float* nll, const int32_t* lengths, float* out, int32_t B, int32_t T, void* stream);
 
-/* ---- a10 discretized mixture of logistics (mixture.py:26-106) on (B,3M,T) fp32 logits ------------------ */
+/* ---- a10 discretized mixture of logistics (mixture.py:26-106; wrapper vqwae_train.py:382-401, shift :766) --
+ * y_hat (B,3M,T) fp32 = [logit pi | mu | log s]; y (B,T) fp32 in [-1,1].  nll[b,t] = -log p(y[b,t+shift] | y_hat[b,:,t])
+ * (0 where t+shift >= T); dy_hat (B,3M,T) or NULL = d nll[b,t] / d y_hat[b,:,t]. */
 int wae_dmol_loss_fwd(const float* y_hat, const float* y, float* nll, float* dy_hat, int32_t B, int32_t M,
                       int32_t T, int32_t num_classes, float log_scale_min, int32_t shift, void* stream);
+/* ---- a11 sample_from_discretized_mix_logistic (mixture.py:118-156) with caller-supplied U(1e-5,1-1e-5) draws:
+ * y (B,3M,Tn), u_mix (B,Tn,M), u_log (B,Tn) -> out (B,Tn) in [-1,1]. */
+int wae_dmol_sample(const float* y, const float* u_mix, const float* u_log, float* out, int32_t B, int32_t M,
+                    int32_t Tn, float log_scale_min, int32_t clamp_log_scale, void* stream);
+
+/* ---- a15 clip_grad_norm_ + Adam + EMA over the flat arena (vqwae_train.py:776-787, :339-350) ---------------
+ * coef = min(1, clip/(||g||+1e-6)) (clip <= 0: off); torch.optim.Adam update with bias correction for the
+ * 1-based `step`; shadow -= (1-ema_decay)*(shadow-p) when shadow != NULL.  scratch: one double.
+ * grad_norm_out (1 float) or NULL receives the pre-clip global L2 norm. */
+int wae_clip_adam_ema(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* shadow, int64_t n,
+                      double* scratch, float* grad_norm_out, int32_t step, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, double clip_thresh, double ema_decay, void* stream);
 
 /* layout helpers: (B,C,T) fp32 <-> (B,T,Cp) dtype */
 int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);

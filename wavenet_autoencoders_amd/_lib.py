@@ -41,6 +41,9 @@ SIGNATURES = {
     "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 9),
     "wae_sum_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
+    "wae_dmol_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "wae_dmol_sample": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "wae_clip_adam_ema": (c_i32, [c_vp] * 5 + [c_i64, c_vp, c_vp, c_i32] + [ctypes.c_double] * 7 + [c_vp]),
     "wae_masked_mean": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
     "wae_from_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),

@@ -1,0 +1,201 @@
+// Discretized mixture of logistics: loss (+ gradient wrt the network output) and sampler.
+// Reference: wavenet_vocoder/mixture.py:26-106 (loss), :118-156 (sampler); wrapper vqwae_train.py:382-401, shift :766.
+// One lane per (clip, time step); the mixture dimension (M = out_channels/3, 10 in every preset) is a register
+// loop, so the (B,3M,T) logits are read once, coalesced along T, and nothing but the per-sample loss is written.
+#include "wae_common.hpp"
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus, threshold 20
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+#define DMOL_MAX_M 32
+
+__global__ void __launch_bounds__(256) dmol_loss_kernel(const float* __restrict__ y_hat, const float* __restrict__ y,
+                                                        float* __restrict__ nll, float* __restrict__ dy_hat, int M, int T,
+                                                        float half_bin, float log_half_classes, float log_scale_min,
+                                                        int shift) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const float* yh = y_hat + (int64_t)b * 3 * M * T + t;
+  float* dyh = dy_hat ? dy_hat + (int64_t)b * 3 * M * T + t : nullptr;
+  const int ty = t + shift;
+  if (ty >= T) {  // no target for the last `shift` positions
+    nll[(int64_t)b * T + t] = 0.f;
+    if (dyh)
+      for (int i = 0; i < 3 * M; ++i) dyh[(int64_t)i * T] = 0.f;
+    return;
+  }
+  const float yy = y[(int64_t)b * T + ty];
+  float lp[DMOL_MAX_M], dmu[DMOL_MAX_M], dls[DMOL_MAX_M];
+  // log_softmax over the mixture logits (mixture.py:101)
+  float lmax = -INFINITY;
+  for (int i = 0; i < M; ++i) lmax = fmaxf(lmax, yh[(int64_t)i * T]);
+  float lsum = 0.f;
+  for (int i = 0; i < M; ++i) lsum += expf(yh[(int64_t)i * T] - lmax);
+  const float llse = lmax + logf(lsum);
+  float m = -INFINITY;
+  for (int i = 0; i < M; ++i) {
+    const float logit = yh[(int64_t)i * T];
+    const float mu = yh[(int64_t)(M + i) * T];
+    const float raw = yh[(int64_t)(2 * M + i) * T];
+    const float ls = fmaxf(raw, log_scale_min);                       // :53
+    const float pass = raw >= log_scale_min ? 1.f : 0.f;               // clamp gradient
+    const float inv = expf(-ls);
+    const float cen = yy - mu;
+    const float plus = inv * (cen + half_bin), mn = inv * (cen - half_bin), mid = inv * cen;
+    const float sp = sigmoid_f(plus), sm = sigmoid_f(mn);
+    const float delta = sp - sm;
+    float tval, tmu, tls;
+    if (yy < -0.999f) {                                                 // :99, log cdf of the first bin
+      tval = plus - softplus_f(plus);
+      tmu = -(1.f - sp) * inv;
+      tls = -(1.f - sp) * plus;
+    } else if (yy > 0.999f) {                                           // :97, last bin
+      tval = -softplus_f(mn);
+      tmu = sm * inv;
+      tls = sm * mn;
+    } else if (delta > 1e-5f) {                                         // :91-95
+      tval = logf(fmaxf(delta, 1e-12f));
+      const float dp = sp * (1.f - sp), dm = sm * (1.f - sm);
+      tmu = -inv * (dp - dm) / delta;
+      tls = (-dp * plus + dm * mn) / delta;
+    } else {                                                            // :79,:95 centre-of-bin density
+      const float smid = sigmoid_f(mid);
+      tval = mid - ls - 2.f * softplus_f(mid) - log_half_classes;
+      tmu = -(1.f - 2.f * smid) * inv;
+      tls = -(1.f - 2.f * smid) * mid - 1.f;
+    }
+    lp[i] = tval + (logit - llse);
+    dmu[i] = tmu;
+    dls[i] = tls * pass;
+    m = fmaxf(m, lp[i]);
+  }
+  float s = 0.f;
+  for (int i = 0; i < M; ++i) s += expf(lp[i] - m);
+  const float lse = m + logf(s);                                        // :17-23
+  nll[(int64_t)b * T + t] = -lse;
+  if (dyh) {
+    for (int i = 0; i < M; ++i) {
+      const float w = expf(lp[i] - lse);                                // posterior responsibility
+      const float pi = expf(yh[(int64_t)i * T] - llse);
+      dyh[(int64_t)i * T] = pi - w;
+      dyh[(int64_t)(M + i) * T] = -w * dmu[i];
+      dyh[(int64_t)(2 * M + i) * T] = -w * dls[i];
+    }
+  }
+}
+
+extern "C" int wae_dmol_loss_fwd(const float* y_hat, const float* y, float* nll, float* dy_hat, int32_t B, int32_t M,
+                                 int32_t T, int32_t num_classes, float log_scale_min, int32_t shift, void* stream) {
+  WAE_REQUIRE(y_hat && y && nll && B > 0 && T > 0, "dmol_loss: bad arguments");
+  WAE_REQUIRE(M > 0 && M <= DMOL_MAX_M, "dmol_loss: mixtures must be in 1..%d (got %d)", DMOL_MAX_M, M);
+  WAE_REQUIRE(num_classes > 1 && shift >= 0, "dmol_loss: bad num_classes/shift");
+  hipLaunchKernelGGL(dmol_loss_kernel, dim3((T + 255) / 256, B), dim3(256), 0, as_stream(stream), y_hat, y, nll, dy_hat, M, T,
+                     1.0f / (float)(num_classes - 1), logf((float)(num_classes - 1) * 0.5f), log_scale_min, shift);
+  return wae_check_launch("dmol_loss_fwd");
+}
+
+// sampler with caller-supplied uniforms in (1e-5, 1-1e-5): Gumbel-max mixture pick (mixture.py:138-140), logistic
+// draw (:151-152), clamp to [-1,1] (:154).  y (B,3M,Tn), u_mix (B,Tn,M), u_log (B,Tn) -> out (B,Tn).
+__global__ void __launch_bounds__(256) dmol_sample_kernel(const float* __restrict__ y, const float* __restrict__ u_mix,
+                                                          const float* __restrict__ u_log, float* __restrict__ out, int M,
+                                                          int Tn, float log_scale_min, int clamp_log_scale) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= Tn) return;
+  const float* yh = y + (int64_t)b * 3 * M * Tn + t;
+  const float* um = u_mix + ((int64_t)b * Tn + t) * M;
+  float best = -INFINITY;
+  int arg = 0;
+  for (int i = 0; i < M; ++i) {
+    const float v = yh[(int64_t)i * Tn] - logf(-logf(um[i]));
+    if (v > best) { best = v; arg = i; }
+  }
+  const float mu = yh[(int64_t)(M + arg) * Tn];
+  float ls = yh[(int64_t)(2 * M + arg) * Tn];
+  if (clamp_log_scale) ls = fmaxf(ls, log_scale_min);
+  const float u = u_log[(int64_t)b * Tn + t];
+  const float x = mu + expf(ls) * (logf(u) - logf(1.f - u));
+  out[(int64_t)b * Tn + t] = fminf(fmaxf(x, -1.f), 1.f);
+}
+
+extern "C" int wae_dmol_sample(const float* y, const float* u_mix, const float* u_log, float* out, int32_t B, int32_t M,
+                               int32_t Tn, float log_scale_min, int32_t clamp_log_scale, void* stream) {
+  WAE_REQUIRE(y && u_mix && u_log && out && B > 0 && M > 0 && Tn > 0, "dmol_sample: bad arguments");
+  hipLaunchKernelGGL(dmol_sample_kernel, dim3((Tn + 255) / 256, B), dim3(256), 0, as_stream(stream), y, u_mix, u_log, out, M,
+                     Tn, log_scale_min, clamp_log_scale);
+  return wae_check_launch("dmol_sample");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K15: clip_grad_norm_ + Adam + EMA over the flat parameter arena (vqwae_train.py:776-787, :339-350)
+//   pass 1 (grad_sqnorm): partial sums of g^2 per workgroup -> one fp64 atomic per workgroup
+//   pass 2 (clip_adam_ema): coef = min(1, thresh/(norm+1e-6)); Adam(lr, betas, eps, weight_decay), bias-corrected;
+//                           shadow -= (1-decay)*(shadow - p)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) grad_sqnorm_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ acc) {
+  double s = 0.0;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const f32x4 v = *(const f32x4*)(g + i);
+      s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      for (int64_t j = i; j < n; ++j) s += (double)g[j] * g[j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(256) clip_adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            float* __restrict__ shadow, int64_t n,
+                                                            const double* __restrict__ sqnorm, float* __restrict__ norm_out,
+                                                            float step_size, float b1, float omb1, float b2, float omb2,
+                                                            float eps, float wd, float bc2_sqrt, float clip,
+                                                            float ema_keep) {
+  const float norm = (float)sqrt(*sqnorm);
+  float coef = 1.f;
+  if (clip > 0.f) coef = fminf(1.f, clip / (norm + 1e-6f));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * coef;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    p[i] = pi;
+    if (shadow) {
+      const float sh = shadow[i];
+      shadow[i] = sh - ema_keep * (sh - pi);
+    }
+  }
+}
+
+extern "C" int wae_clip_adam_ema(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* shadow,
+                                 int64_t n, double* scratch, float* grad_norm_out, int32_t step, double lr, double beta1,
+                                 double beta2, double eps, double weight_decay, double clip_thresh, double ema_decay,
+                                 void* stream) {
+  WAE_REQUIRE(params && grads && exp_avg && exp_avg_sq && scratch && n > 0 && step >= 1, "clip_adam_ema: bad arguments");
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(scratch, 0, sizeof(double), st) != hipSuccess) {
+    wae_set_error("clip_adam_ema: memset failed");
+    return WAE_EHIP;
+  }
+  const int grid = (int)((n + 1023) / 1024 > 2048 ? 2048 : (n + 1023) / 1024);
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, st, grads, n, scratch);
+  // scalars are formed in double on the host exactly as torch.optim.Adam forms them, then rounded once to fp32
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(clip_adam_ema_kernel, dim3(2048), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, shadow, n, scratch,
+                     grad_norm_out, (float)(lr / bc1), (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                     (float)eps, (float)weight_decay, (float)sqrt(bc2), (float)clip_thresh, (float)(1.0 - ema_decay));
+  return wae_check_launch("clip_adam_ema");
+}
