@@ -158,6 +158,30 @@ int wae_clip_adam_ema(float* params, const float* grads, float* exp_avg, float* 
                       double* scratch, float* grad_norm_out, int32_t step, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double clip_thresh, double ema_decay, void* stream);
 
+/* ---- a12 incremental (autoregressive) decoding: Conv1d.incremental_forward (conv.py:17-62) and
+ * WaveNet.incremental_forward (wavenet.py:218-346) as ONE persistent launch, one workgroup per utterance ------
+ * mode 0: teacher-forced (the reference's test_inputs, softmax=False, quantize=False): logits out, inputs consumed
+ * mode 1: greedy, the argmax class is fed back          mode 2: categorical draw by inverse CDF from uniforms[b,t]
+ * Weights are blocked [k/EPL][rows padded to 64][EPL] (EPL = 8 bf16 / 4 fp32), per layer [W1 (G x (k*R+Cc)) | W2
+ * ((R+S) x H)] with layer_stride_bytes between layers; head = [S x S | O x S].  ring: B x ring_total floats of
+ * per-layer history, ring_off[l] = float offset of layer l ((k-1)*d_l+1 rows of R).  zb as in wae_gproj_fwd.
+ * first_tab (O, Rp) / first_bias as in wae_first_conv_fwd; c_up (B,T,Ccp) already upsampled (wavenet.py:276-280).
+ * inputs (B,T) int32 class ids or NULL (then init_idx starts every utterance, wavenet.py:288). */
+typedef struct wae_ar_desc {
+  int32_t dtype;
+  int32_t B, T;
+  int32_t L, R, Rp, G, Hp, S, O, Cc, Ccp, ktaps;
+  int32_t mode;
+  int32_t init_idx;
+  int32_t scalar_input; /* must be 0 for now */
+  float scale;          /* sqrt(1/L) */
+} wae_ar_desc;
+int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                    int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                    const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                    const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                    const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits, void* stream);
+
 /* layout helpers: (B,C,T) fp32 <-> (B,T,Cp) dtype */
 int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);
 int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);

@@ -19,6 +19,11 @@ class GluDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Rp", "Ccp", "Hp", "ktaps", "dilation", "flags")]
 
 
+class ArDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "L", "R", "Rp", "G", "Hp", "S", "O", "Cc", "Ccp", "ktaps", "mode",
+                                     "init_idx", "scalar_input")] + [("scale", c_f32)]
+
+
 class HeadDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Ku", "Sp", "Op", "O")] + [("scale", c_f32)]
 
@@ -44,6 +49,8 @@ SIGNATURES = {
     "wae_dmol_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "wae_dmol_sample": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "wae_clip_adam_ema": (c_i32, [c_vp] * 5 + [c_i64, c_vp, c_vp, c_i32] + [ctypes.c_double] * 7 + [c_vp]),
+    "wae_ar_generate": (c_i32, [ctypes.POINTER(ArDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7 + [c_i32]
+                        + [c_vp] * 5),
     "wae_masked_mean": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
     "wae_from_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),

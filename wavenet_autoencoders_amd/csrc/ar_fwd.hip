@@ -1,0 +1,281 @@
+// wae_ar_generate: autoregressive (sample-by-sample) decoding, the MI355X replacement of
+// Conv1d.incremental_forward (conv.py:17-62) + WaveNet.incremental_forward (wavenet.py:218-346).
+//
+// One persistent workgroup (512 threads) per utterance runs the whole T-step loop on the device: no per-sample
+// launches, no per-layer launches.  The reference shifts a (1+(k-1)d, R) buffer by one row per layer per sample
+// (an O(d) copy, conv.py:39); here every layer owns a ring of (k-1)d+1 rows in HBM/L2 that is written once and
+// read at two fixed lags -- O(1) per sample.  Per layer and sample the work is two matrix-vector products
+// (z = W1 [x taps ; c] + zb, [x' ; skip] = W2 u + b) streamed from L2 in a k-blocked, row-interleaved layout
+// [k/EPL][row][EPL] so that consecutive lanes read consecutive 16-byte weight packets; the k range is split over
+// NS thread slices whose partial sums meet in LDS.  Sampling (argmax / inverse-CDF categorical) is fused.
+// Utterances are independent: a batch runs as B workgroups (replicas only; no collective).
+#include "wae_common.hpp"
+
+#define AR_THREADS 512
+
+struct ArArgs {
+  int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp;
+  float scale;
+  const int32_t* dil;
+  const int64_t* ring_off;  // L+1 offsets (floats) into one utterance's ring arena
+  float* ring;
+  int64_t ring_total;
+  const char* w_layers;
+  int64_t layer_stride;  // bytes
+  int64_t w2_off;        // bytes from a layer's base to its second matrix
+  const float* bias2;    // (L, R+S)
+  const float* zb;       // (B, L, 2Hp)
+  const float* first_tab;   // (O, Rp)
+  const float* first_bias;  // (Rp)
+  const char* w_head;       // [S x S | O x S] blocked
+  const float* head_bias;   // [S | O]
+  const char* c_up;         // (B, T, Ccp) dtype_c
+  int c_dtype;
+  const int32_t* inputs;  // (B, T) teacher-forced class ids or null
+  int init_idx;
+  const float* uniforms;  // (B, T) or null
+  int32_t* out_idx;       // (B, T)
+  float* out_logits;      // (B, O, T) or null
+};
+
+template <typename E>
+__device__ __forceinline__ void load_w(const char* p, float (&w)[ET<E>::EPL]);
+template <>
+__device__ __forceinline__ void load_w<float>(const char* p, float (&w)[4]) {
+  const f32x4 v = *(const f32x4*)p;
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load_w<__bf16>(const char* p, float (&w)[8]) {
+  const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = (float)v[j];
+}
+
+// y[r] = sum_k W[r][k] v[k] for r < rows; W blocked [k/EPL][rows_pad][EPL]; v in LDS (K padded to EPL, zero filled).
+// Threads are laid out as (row = tid % RW, slice = tid / RW); partials go to psum[slice][row]; caller barriers and sums.
+template <typename E>
+__device__ __forceinline__ void gemv_partial(const char* __restrict__ W, const float* v, float* psum, int rows_pad, int K, int RW,
+                                             int NS) {
+  constexpr int EPL = ET<E>::EPL;
+  const int r = threadIdx.x % RW, s = threadIdx.x / RW;
+  if (s >= NS || r >= rows_pad) return;
+  const int nkb = (K + EPL - 1) / EPL;
+  const int per = (nkb + NS - 1) / NS;
+  const int kb0 = s * per, kb1 = min(nkb, kb0 + per);
+  float acc = 0.f;
+  const char* wp = W + ((int64_t)kb0 * rows_pad + r) * 16;
+  const int64_t step = (int64_t)rows_pad * 16;
+  int kb = kb0;
+  for (; kb + 4 <= kb1; kb += 4) {
+    float w0[EPL], w1[EPL], w2[EPL], w3[EPL];
+    load_w<E>(wp, w0); load_w<E>(wp + step, w1); load_w<E>(wp + 2 * step, w2); load_w<E>(wp + 3 * step, w3);
+    wp += 4 * step;
+    const float* vv = v + kb * EPL;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc = fmaf(w0[j], vv[j], acc);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc = fmaf(w1[j], vv[EPL + j], acc);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc = fmaf(w2[j], vv[2 * EPL + j], acc);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc = fmaf(w3[j], vv[3 * EPL + j], acc);
+  }
+  for (; kb < kb1; ++kb) {
+    float w0[EPL];
+    load_w<E>(wp, w0);
+    wp += step;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc = fmaf(w0[j], v[kb * EPL + j], acc);
+  }
+  psum[s * RW + r] = acc;
+}
+
+__device__ __forceinline__ float psum_total(const float* psum, int r, int RW, int NS) {
+  float a = 0.f;
+  for (int s = 0; s < NS; ++s) a += psum[s * RW + r];
+  return a;
+}
+
+__device__ __forceinline__ void layout_rows(int rows, int& rows_pad, int& RW, int& NS) {
+  rows_pad = (rows + 63) & ~63;
+  RW = rows_pad > AR_THREADS ? AR_THREADS : rows_pad;
+  NS = AR_THREADS / RW;
+  if (NS < 1) NS = 1;
+}
+
+template <typename E>
+__global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int EPL = ET<E>::EPL;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int H = p.G / 2;
+  const int K1 = p.ktaps * p.R + (p.Cc > 0 ? p.Cc : 0);
+  const int K1p = (K1 + EPL - 1) / EPL * EPL;
+  const int Hk = (H + EPL - 1) / EPL * EPL;
+  const int Sk = (p.S + EPL - 1) / EPL * EPL;
+  // LDS carve (floats)
+  float* vbuf = sm;                       // K1p
+  float* xbuf = vbuf + K1p;               // R
+  float* ubuf = xbuf + p.R;               // Hk
+  float* skipb = ubuf + Hk;               // Sk   (also the head's h0)
+  float* hbuf = skipb + Sk;               // Sk   (h1)
+  float* lbuf = hbuf + Sk;                // O    logits
+  float* psum = lbuf + ((p.O + 3) & ~3);  // 1024
+  int* ibuf = (int*)(psum + AR_THREADS);        // [0] = current input id
+
+  float* ring = p.ring + (int64_t)b * p.ring_total;
+  const float* zb_b = p.zb + (int64_t)b * p.L * 2 * p.Hp;
+  int gp, gRW, gNS, wp_, wRW, wNS, sp_, sRW, sNS, op_, oRW, oNS;
+  layout_rows(p.G, gp, gRW, gNS);
+  layout_rows(p.R + p.S, wp_, wRW, wNS);
+  layout_rows(p.S, sp_, sRW, sNS);
+  layout_rows(p.O, op_, oRW, oNS);
+
+  for (int i = tid; i < K1p; i += AR_THREADS) vbuf[i] = 0.f;
+  for (int i = tid; i < Hk; i += AR_THREADS) ubuf[i] = 0.f;
+  for (int i = tid; i < Sk; i += AR_THREADS) { skipb[i] = 0.f; hbuf[i] = 0.f; }
+  if (tid == 0) ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx;
+  __syncthreads();
+
+  for (int t = 0; t < p.T; ++t) {
+    // ---- first conv: one-hot input == column gather (wavenet.py:311) -------------------------------------
+    const int cur = ibuf[0];
+    if (tid < p.R) xbuf[tid] = p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
+    if (tid >= p.R && tid < p.R + p.Cc) {   // local conditioning of this step -> tail of the operand vector
+      const int cc = tid - p.R;
+      const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
+      vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : ((const float*)p.c_up)[ci];
+    }
+    for (int i = tid; i < p.S; i += AR_THREADS) skipb[i] = 0.f;
+    __syncthreads();
+
+    for (int l = 0; l < p.L; ++l) {
+      const int d = p.dil[l];
+      const int64_t roff = p.ring_off[l];
+      const int rlen = (p.ktaps - 1) * d + 1;
+      float* rl = ring + roff;
+      // ---- assemble [x[t-(k-1)d] .. x[t]] and push x[t] into the layer's ring (conv.py:35-44, O(1)) -------
+      for (int i = tid; i < p.ktaps * p.R; i += AR_THREADS) {
+        const int tap = i / p.R, ch = i - tap * p.R;
+        const int tt = t - (p.ktaps - 1 - tap) * d;
+        float v;
+        if (tap == p.ktaps - 1) {
+          v = xbuf[ch];
+          rl[(int64_t)(t % rlen) * p.R + ch] = v;
+        } else {
+          v = tt >= 0 ? rl[(int64_t)(tt % rlen) * p.R + ch] : 0.f;   // zero history before the clip starts
+        }
+        vbuf[i] = v;
+      }
+      __syncthreads();
+      const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
+      gemv_partial<E>(wl, vbuf, psum, gp, K1, gRW, gNS);
+      __syncthreads();
+      // ---- gate (modules.py:138-154): thread h owns channel h ------------------------------------------------
+      if (tid < H) {
+        const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
+        const float a = psum_total(psum, tid, gRW, gNS) + zbl[tid];
+        const float g = psum_total(psum, H + tid, gRW, gNS) + zbl[p.Hp + tid];
+        ubuf[tid] = tanhf(a) * (1.f / (1.f + expf(-g)));
+      }
+      __syncthreads();
+      gemv_partial<E>(wl + p.w2_off, ubuf, psum, wp_, H, wRW, wNS);
+      __syncthreads();
+      // ---- residual + skip (modules.py:157-162, wavenet.py:315) ------------------------------------------------
+      const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
+      for (int i = tid; i < p.R + p.S; i += AR_THREADS) {
+        const float y = psum_total(psum, i, wRW, wNS) + b2[i];
+        if (i < p.R) xbuf[i] = (y + xbuf[i]) * 0.70710678118654752440f;
+        else skipb[i - p.R] += y;
+      }
+      __syncthreads();
+    }
+    // ---- head (wavenet.py:316-322) ------------------------------------------------------------------------------
+    for (int i = tid; i < p.S; i += AR_THREADS) skipb[i] = fmaxf(skipb[i] * p.scale, 0.f);
+    __syncthreads();
+    gemv_partial<E>(p.w_head, skipb, psum, sp_, p.S, sRW, sNS);
+    __syncthreads();
+    for (int i = tid; i < p.S; i += AR_THREADS) hbuf[i] = fmaxf(psum_total(psum, i, sRW, sNS) + p.head_bias[i], 0.f);
+    __syncthreads();
+    gemv_partial<E>(p.w_head + (int64_t)((p.S + EPL - 1) / EPL) * sp_ * 16, hbuf, psum, op_, p.S, oRW, oNS);
+    __syncthreads();
+    for (int i = tid; i < p.O; i += AR_THREADS) {
+      const float y = psum_total(psum, i, oRW, oNS) + p.head_bias[p.S + i];
+      lbuf[i] = y;
+      if (p.out_logits) p.out_logits[((int64_t)b * p.O + i) * p.T + t] = y;
+    }
+    __syncthreads();
+    // ---- next input: teacher forcing / greedy / categorical draw (wavenet.py:300-338) -------------------------
+    if (tid == 0) {
+      int nxt;
+      float mx = -INFINITY;
+      int am = 0;
+      for (int i = 0; i < p.O; ++i)
+        if (lbuf[i] > mx) { mx = lbuf[i]; am = i; }
+      int produced = am;
+      if (p.mode == 2) {
+        // softmax in fp32 (F.softmax), then inverse CDF over a double cumulative sum
+        float den = 0.f;
+        for (int i = 0; i < p.O; ++i) den += expf(lbuf[i] - mx);
+        double tot = 0.0;
+        for (int i = 0; i < p.O; ++i) tot += (double)(expf(lbuf[i] - mx) / den);
+        const double thr = (double)p.uniforms[(int64_t)b * p.T + t] * tot;
+        double c = 0.0;
+        int cnt = 0;
+        for (int i = 0; i < p.O; ++i) {
+          c += (double)(expf(lbuf[i] - mx) / den);
+          if (c < thr) ++cnt;
+        }
+        produced = min(cnt, p.O - 1);
+      }
+      p.out_idx[(int64_t)b * p.T + t] = produced;
+      if (p.inputs && t + 1 < p.T) nxt = p.inputs[(int64_t)b * p.T + t + 1];
+      else nxt = produced;
+      ibuf[0] = nxt;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                               int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                               const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                               const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                               const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                               void* stream) {
+  WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias &&
+                  out_idx, "ar_generate: null pointer argument");
+  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate: bad dtype");
+  WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0 && d->O > 0,
+              "ar_generate: bad sizes");
+  WAE_REQUIRE(d->R + (d->Cc > 0 ? d->Cc : 0) <= AR_THREADS, "ar_generate: R+Cc must be <= %d", AR_THREADS);
+  WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate: Cc > 0 but c_up is null");
+  WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
+  WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate: sample mode needs uniforms");
+  WAE_REQUIRE(d->mode != 0 || inputs, "ar_generate: teacher-forced mode needs inputs");
+  WAE_REQUIRE(!d->scalar_input, "ar_generate: scalar-input (DMoL) decoding is not implemented yet");
+  ArArgs a;
+  a.dtype = d->dtype; a.B = d->B; a.T = d->T; a.L = d->L; a.R = d->R; a.G = d->G; a.S = d->S; a.O = d->O; a.Cc = d->Cc;
+  a.Ccp = d->Ccp; a.Hp = d->Hp; a.ktaps = d->ktaps; a.mode = d->mode; a.Rp = d->Rp; a.scale = d->scale; a.dil = dilations;
+  a.ring_off = ring_off; a.ring = ring; a.ring_total = ring_total; a.w_layers = (const char*)w_layers;
+  a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
+  a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
+  a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
+  a.out_logits = out_logits;
+  const int epl = d->dtype == WAE_BF16 ? 8 : 4;
+  const int H = d->G / 2;
+  auto ru = [](int x, int m) { return (x + m - 1) / m * m; };
+  const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
+                                              2 * ru(d->S, epl) + ru(d->O, 4) + AR_THREADS + 4);
+  hipStream_t st = as_stream(stream);
+  if (d->dtype == WAE_BF16) {
+    (void)hipFuncSetAttribute((const void*)ar_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_kernel<__bf16>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)ar_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_kernel<float>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
+  }
+  return wae_check_launch("ar_generate");
+}

@@ -282,6 +282,98 @@ class WaeEngine:
             out["loss"] = ws["loss"][0]
         return out
 
+    # ------------------------------------------------------------------ autoregressive synthesis
+    def _prepare_ar(self):
+        if getattr(self, "_ar_ready", False):
+            return
+        g, dev = self.g, self.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        lm, w2_off = P.ar_layer_map(g, self.lay, self.dt)
+        self.m_ar_layer, self.ar_w2_off, self.ar_layer_elems = up(lm), int(w2_off), int(lm.size)
+        self.m_ar_b2 = up(P.ar_bias2_map(g, self.lay))
+        self.m_ar_head = up(P.ar_head_map(g, self.lay, self.dt))
+        self.m_ar_hb = up(P.ar_head_bias_map(g, self.lay))
+        self.ar_w = torch.zeros(g.layers * self.ar_layer_elems, dtype=self.tdtype, device=dev)
+        self.ar_b2 = torch.zeros(g.layers * (g.R + g.S), dtype=torch.float32, device=dev)
+        self.ar_wh = torch.zeros(self.m_ar_head.numel(), dtype=self.tdtype, device=dev)
+        self.ar_hb = torch.zeros(g.S + g.O, dtype=torch.float32, device=dev)
+        roff = P.ar_ring_offsets(g)
+        self.ar_ring_off, self.ar_ring_total = up(roff), int(roff[-1])
+        self.ar_dil = torch.tensor(g.dilations, dtype=torch.int32, device=dev)
+        self._ar_ready = True
+        self._ar_packed = False
+
+    def pack_ar_weights(self):
+        """Effective (weight-normed) weights -> the matrix-vector layout of ar_fwd.hip; this is the engine's
+        make_generation_fast_() (wavenet.py:358-364): weight norm is folded once, not per sample."""
+        self._prepare_ar()
+        if self.weights_dirty:
+            self.prepare_weights()
+        lib, st, g, lay = self.lib, self.stream(), self.g, self.lay
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_ar_layer), L.ptr(self.ar_w), self.ar_layer_elems, g.layers,
+                                    lay.layer_stride, self.ar_layer_elems, self.dt, st), "pack AR layers")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_ar_b2), L.ptr(self.ar_b2), g.R + g.S, g.layers,
+                                    lay.layer_stride, g.R + g.S, L.WAE_F32, st), "pack AR bias2")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_ar_head), L.ptr(self.ar_wh), self.m_ar_head.numel(), 1, 0, 0,
+                                    self.dt, st), "pack AR head")
+        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_ar_hb), L.ptr(self.ar_hb), g.S + g.O, 1, 0, 0, L.WAE_F32, st),
+                "pack AR head bias")
+        self._ar_packed = True
+
+    def incremental_forward(self, c: Optional[torch.Tensor], gid: Optional[torch.Tensor], T: int, mode: str = "sample",
+                            test_inputs: Optional[torch.Tensor] = None, uniforms: Optional[torch.Tensor] = None,
+                            init_idx: int = 127, c_is_upsampled: bool = False, want_logits: bool = False,
+                            gvec: Optional[torch.Tensor] = None):
+        """WaveNet.incremental_forward (wavenet.py:218-346) as one persistent launch.
+
+        mode "logits": teacher-forced on test_inputs (B,T) class ids (softmax=False, quantize=False) -> logits (B,O,T);
+        "argmax": greedy feedback; "sample": categorical draw from `uniforms` (B,T) in [0,1) (torch.rand if None).
+        Returns dict(idx (B,T) int32, logits (B,O,T) | None)."""
+        g, lib = self.g, self.lib
+        if g.scalar_input:
+            raise NotImplementedError("autoregressive decoding of scalar-input (DMoL) models is not implemented yet")
+        if not getattr(self, "_ar_packed", False) or self.weights_dirty:
+            self.pack_ar_weights()
+        st = self.stream()
+        B = c.shape[0] if c is not None else (test_inputs.shape[0] if test_inputs is not None else 1)
+        m = {"logits": 0, "argmax": 1, "sample": 2}[mode]
+        dev = self.device
+        c_up = None
+        if g.Ccp:
+            c_up = torch.zeros(B, T, g.Ccp, dtype=self.tdtype, device=dev)
+            if c_is_upsampled or not g.upsample_scales:
+                assert c.shape[-1] == T, f"c {tuple(c.shape)} != T {T}"       # wavenet.py:278
+                L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(c_up), B, g.Cc, T, g.Ccp, self.dt, st), "to_btc")
+            else:
+                assert (c.shape[-1] - 2 * g.cin_pad) * int(np.prod(g.upsample_scales)) == T, "c does not upsample to T"
+                self.upsample_forward(c.float(), c_up)
+        zb = torch.empty(B, g.layers, 2 * g.Hp, dtype=torch.float32, device=dev)
+        wg_off = self.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
+        emb_off = self.lay.offsets.get("wavenet.embed_speakers.weight", 0)
+        use_gid = gid is not None and "wavenet.embed_speakers.weight" in self.lay.offsets
+        gid32 = gid.to(torch.int32).contiguous() if gid is not None else None
+        L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
+                                  self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
+                                  L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
+                                  L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
+        ring = torch.empty(B * self.ar_ring_total, dtype=torch.float32, device=dev)
+        inputs = test_inputs.to(torch.int32).contiguous() if test_inputs is not None else None
+        if m == 2 and uniforms is None:
+            uniforms = torch.rand(B, T, device=dev)
+        uni = uniforms.float().contiguous() if uniforms is not None else None
+        out_idx = torch.empty(B, T, dtype=torch.int32, device=dev)
+        logits = torch.empty(B, g.O, T, dtype=torch.float32, device=dev) if (want_logits or m == 0) else None
+        es = self.ar_w.element_size()
+        d = L.ArDesc(self.dt, B, T, g.layers, g.R, g.Rp, g.G, g.Hp, g.S, g.O, max(g.Cc, 0), g.Ccp, g.k, m, int(init_idx), 0,
+                     math.sqrt(1.0 / g.layers))
+        L.check(lib.wae_ar_generate(ctypes.byref(d), L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring), self.ar_ring_total,
+                                    L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es, L.ptr(self.ar_b2), L.ptr(zb),
+                                    L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(self.ar_wh), L.ptr(self.ar_hb),
+                                    L.ptr(c_up), self.dt, L.ptr(inputs), L.ptr(uni), L.ptr(out_idx), L.ptr(logits), st),
+                "ar_generate")
+        self._ar_keep = (c_up, zb, ring, inputs, uni, gid32)   # keep device buffers alive until the stream has run
+        return dict(idx=out_idx, logits=logits)
+
     # ------------------------------------------------------------------ full autoencoder
     def forward(self, x: torch.Tensor, c: torch.Tensor, gid: Optional[torch.Tensor], targets=None, lengths=None,
                 want_logits=True, train=False, beta: float = 0.25):

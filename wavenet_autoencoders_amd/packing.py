@@ -295,3 +295,70 @@ def head_packed_elems(g: Geometry, dtype: int) -> int:
     chb = (g.Sp // 32) * 4 * 1024
     mt2 = 4 // t["KBU"]
     return (g.Ku // t["CK"] + (g.Sp // 32) // mt2 + (g.Op // 32) // mt2) * chb // t["ES"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# autoregressive kernel (csrc/ar_fwd.hip): matrix-vector layout [k/EPL][rows padded to 64][EPL]
+# ---------------------------------------------------------------------------------------------------
+def _ar_block(rows, rows_valid_fn, K, src_fn, EPL):
+    """generic blocked map: element (kb, r, j) -> src_fn(r, kb*EPL + j) or -1"""
+    rp = _ru(rows, 64)
+    nkb = (K + EPL - 1) // EPL
+    kb, r, j = np.meshgrid(np.arange(nkb), np.arange(rp), np.arange(EPL), indexing="ij")
+    kk = kb * EPL + j
+    ok = (r < rows) & (kk < K)
+    return np.where(ok, src_fn(np.minimum(r, rows - 1), np.minimum(kk, K - 1)), -1).reshape(-1), nkb * rp * EPL
+
+
+def ar_layer_map(g: Geometry, lay: ParamLayout, dtype: int):
+    """-> (map of one layer [W1 | W2], element offset of W2).  W1: G x (k*R + Cc) with k ordered
+    [tap 0 .. tap k-1 | c] (tap j multiplies x[t-(k-1-j)d], conv.py:51-62); W2: [conv1x1_out (R) ; conv1x1_skip (S)] x H."""
+    EPL = _traits(dtype)["EPL"]
+    Cc = max(g.Cc, 0)
+    K1 = g.k * g.R + Cc
+    conv = lay.off("wavenet.conv_layers.0.conv.weight_v")
+    cw = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v") if Cc else 0
+
+    def src1(r, kk):
+        tap, ch = kk // g.R, kk % g.R
+        return np.where(kk < g.k * g.R, conv + (r * g.R + ch) * g.k + np.minimum(tap, g.k - 1),
+                        cw + r * max(Cc, 1) + (kk - g.k * g.R))
+
+    m1, n1 = _ar_block(g.G, None, K1, src1, EPL)
+    out = lay.off("wavenet.conv_layers.0.conv1x1_out.weight_v")
+    skp = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v")
+
+    def src2(r, kk):
+        return np.where(r < g.R, out + r * g.H + kk, skp + (r - g.R) * g.H + kk)
+
+    m2, n2 = _ar_block(g.R + g.S, None, g.H, src2, EPL)
+    return np.concatenate([m1, m2]).astype(np.int32), n1
+
+
+def ar_bias2_map(g: Geometry, lay: ParamLayout) -> np.ndarray:
+    r = np.arange(g.R + g.S)
+    return np.where(r < g.R, lay.off("wavenet.conv_layers.0.conv1x1_out.bias") + r,
+                    lay.off("wavenet.conv_layers.0.conv1x1_skip.bias") + r - g.R).astype(np.int32)
+
+
+def ar_head_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    EPL = _traits(dtype)["EPL"]
+    w1 = lay.off("wavenet.last_conv_layers.1.weight_v")
+    w3 = lay.off("wavenet.last_conv_layers.3.weight_v")
+    m1, _ = _ar_block(g.S, None, g.S, lambda r, kk: w1 + r * g.S + kk, EPL)
+    m3, _ = _ar_block(g.O, None, g.S, lambda r, kk: w3 + r * g.S + kk, EPL)
+    return np.concatenate([m1, m3]).astype(np.int32)
+
+
+def ar_head_bias_map(g: Geometry, lay: ParamLayout) -> np.ndarray:
+    r = np.arange(g.S + g.O)
+    return np.where(r < g.S, lay.off("wavenet.last_conv_layers.1.bias") + r,
+                    lay.off("wavenet.last_conv_layers.3.bias") + r - g.S).astype(np.int32)
+
+
+def ar_ring_offsets(g: Geometry) -> np.ndarray:
+    """float offsets of each layer's history ring ((k-1)*d+1 rows of R) inside one utterance's arena; last = total"""
+    off = [0]
+    for d in g.dilations:
+        off.append(off[-1] + ((g.k - 1) * d + 1) * g.R)
+    return np.asarray(off, dtype=np.int64)
