@@ -1,0 +1,159 @@
+"""CPU-only checks of the host logic: C-ABI exports, parameter arena, fragment-order index maps (emulated MFMA
+contraction in numpy against the oracle layer), config surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wae_oracle as O
+from wavenet_autoencoders_amd import packing as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(layers=4, stacks=2, R=32, G=48, S=32, O=64, Cc=16, Cg=8, k=3, n_speakers=5,
+           upsample_scales=[4, 4, 8, 5], encoder_hid=32, c_in=39, K=32, cin_pad=0)
+
+
+def test_library_exports_every_declared_symbol():
+    from wavenet_autoencoders_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "wae.h")).read()
+    declared = set(re.findall(r"\b(wae_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared <= set(_lib.SIGNATURES) | {"wae_debug_set_stamps"}, declared - set(_lib.SIGNATURES)
+    assert b"gfx950" in _lib.lib().wae_version()
+
+
+def test_param_layout_matches_reference_state_dict():
+    g = P.Geometry.from_cfg(CFG)
+    lay = P.ParamLayout(g)
+    sd = O.make_state_dict(CFG, 1)
+    assert set(lay.offsets) == set(sd)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(lay.shapes[k]), k
+    full = P.Geometry(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, n_speakers=153,
+                      upsample_scales=[4, 4, 8, 5], c_in=39, encoder_hid=256, K=256)
+    fl = P.ParamLayout(full)
+    assert len(fl.offsets) == 302 and sum(fl.numel(k) for k in fl.offsets) == 7555218
+    assert full.receptive_field == 4093
+    assert len(fl.wn_cols) == sum(s[0] for n, s, v in P.param_specs(full) if v)
+
+
+def _arena(lay, sd):
+    a = np.zeros(lay.total, dtype=np.float64)
+    for k in lay.offsets:
+        w = O.eff_weight(sd, k[:-9]) if k.endswith(".weight_v") else sd[k]
+        a[lay.off(k):lay.off(k) + lay.numel(k)] = w.double().reshape(-1).numpy()
+    return a
+
+
+@pytest.mark.parametrize("dtype", [P.F32, P.BF16])
+def test_fragment_maps_reproduce_the_layer(dtype):
+    """Contract the packed streams exactly as the kernels do (A fragment element j of lane (i,h) meets B element j
+    of lane (n,h)) and compare with the oracle's layer."""
+    g = P.Geometry.from_cfg(CFG)
+    lay = P.ParamLayout(g)
+    sd = O.make_state_dict(CFG, 1)
+    eff = _arena(lay, sd)
+    t = P._traits(dtype)
+    EPL, CK, KBU = t["EPL"], t["CK"], t["KBU"]
+    li = 2
+    base = li * lay.layer_stride
+
+    def gather(m):
+        return np.where(m >= 0, eff[np.maximum(m, 0) + base], 0.0)
+
+    T, d = 40, 2
+    x = O.hash_fill((1, g.R, T), 5, 1.0)
+    c = O.hash_fill((1, g.Cc, T), 6, 1.0)
+    p = f"wavenet.conv_layers.{li}."
+    sdz = dict(sd)
+    u_ref = O.glu_layer_gate(sdz, p, x, c, None, d)[0].double().numpy()           # (H, T)
+    xo_ref, so_ref = O.glu_layer_forward(sdz, p, x, c, None, d)
+    # operand vectors per time step in padded channel space
+    xp = np.zeros((T, g.Rp)); xp[:, :g.R] = x[0].double().numpy().T
+    cp = np.zeros((T, g.Ccp)); cp[:, :g.Cc] = c[0].double().numpy().T
+    NM = 2 * g.NP
+    w1 = gather(P.glu_w1_map(g, lay, dtype)).reshape(-1, 4, NM, 2, 32, EPL)        # [q][blk][m][h][i][j]
+    cpr = g.Rp // CK
+    z = np.zeros((NM * 32, T))
+    for q in range(w1.shape[0]):
+        for n in range(T):
+            if q < g.k * cpr:
+                tap, cblk = divmod(q, cpr)
+                ts = n - (g.k - 1 - tap) * d
+                row = xp[ts] if ts >= 0 else np.zeros(g.Rp)
+            else:
+                cblk = q - g.k * cpr
+                row = cp[n]
+            v = row[cblk * CK:(cblk + 1) * CK].reshape(4, 2, EPL)                  # [blk][h][j]
+            z[:, n] += np.einsum("bmhij,bhj->mi", w1[q], v).reshape(-1)
+    bias = sd[p + "conv.bias"].double().numpy()
+    a = z[:g.H] + bias[:g.H, None]
+    b = z[g.Hp:g.Hp + g.H] + bias[g.H:, None]
+    u = np.tanh(a) / (1 + np.exp(-b))
+    assert np.abs(u - u_ref).max() < 1e-5                                    # oracle is fp32
+    assert np.abs(z[g.H:g.Hp]).max() == 0 and np.abs(z[g.Hp + g.H:]).max() == 0     # padded rows stay zero
+    # second GEMM: k index of (kb, h, j) is the accumulator-tile row order
+    NKB = g.NP * KBU
+    w2 = gather(P.glu_w2_map(g, lay, dtype)).reshape(g.Rp // 32, NKB, 2, 32, EPL)   # [gm][kb][h][i][j]
+    up = np.zeros((g.Hp, T)); up[:g.H] = u
+    kb, h, j = np.meshgrid(np.arange(NKB), np.arange(2), np.arange(EPL), indexing="ij")
+    ur = P.u_row_index(dtype, kb, h, j)
+    assert sorted(ur.reshape(-1).tolist()) == list(range(g.Hp))                     # bijection onto the rows of u
+    y = np.einsum("gkhij,khjn->gin", w2, up[ur]).reshape(g.Rp, T)
+    bo = gather(P.glu_bias2_map(g, lay))
+    xo = (y + bo[:, None] + xp.T) * np.sqrt(0.5)
+    assert np.abs(xo[:g.R] - xo_ref[0].double().numpy()).max() < 1e-5
+    assert np.abs(xo[g.R:]).max() == 0
+
+
+@pytest.mark.parametrize("dtype", [P.F32, P.BF16])
+def test_head_and_ar_maps(dtype):
+    g = P.Geometry.from_cfg(CFG)
+    lay = P.ParamLayout(g)
+    sd = O.make_state_dict(CFG, 1)
+    eff = _arena(lay, sd)
+    t = P._traits(dtype)
+    EPL, CK, KBU = t["EPL"], t["CK"], t["KBU"]
+    hw = P.head_w_map(g, lay, dtype)
+    assert hw.size == P.head_packed_elems(g, dtype)
+    NT = g.Sp // 32
+    n0 = (g.Ku // CK) * 4 * NT * 64 * EPL
+    w0 = np.where(hw[:n0] >= 0, eff[np.maximum(hw[:n0], 0)], 0.0).reshape(-1, 4, NT, 2, 32, EPL)
+    # skip contraction: sum_l W_skip_l u_l for random u
+    u = np.random.default_rng(0).standard_normal((g.layers, g.H))
+    uvec = np.zeros(g.Ku)
+    for l in range(g.layers):
+        uvec[l * g.Hp:l * g.Hp + g.H] = u[l]
+    got = np.einsum("qbmhij,qbhj->mi", w0, uvec.reshape(-1, 4, 2, EPL)).reshape(-1)[:g.S]
+    want = sum(O.eff_weight(sd, f"wavenet.conv_layers.{l}.conv1x1_skip")[:, :, 0].double().numpy() @ u[l] for l in range(g.layers))
+    assert np.abs(got - want).max() < 1e-9
+    # AR matrix-vector layout
+    lm, w2_off = P.ar_layer_map(g, lay, dtype)
+    K1 = g.k * g.R + g.Cc
+    gp = (g.G + 63) // 64 * 64
+    nkb = (K1 + EPL - 1) // EPL
+    W1 = np.where(lm[:w2_off] >= 0, eff[np.maximum(lm[:w2_off], 0)], 0.0).reshape(nkb, gp, EPL)
+    v = np.random.default_rng(1).standard_normal(nkb * EPL); v[K1:] = 0
+    got = np.einsum("krj,kj->r", W1, v.reshape(nkb, EPL))[:g.G]
+    conv = O.eff_weight(sd, "wavenet.conv_layers.0.conv").double().numpy()          # (G, R, k)
+    cw = O.eff_weight(sd, "wavenet.conv_layers.0.conv1x1c").double().numpy()[:, :, 0]
+    want = sum(conv[:, :, tap] @ v[tap * g.R:(tap + 1) * g.R] for tap in range(g.k)) + cw @ v[g.k * g.R:K1]
+    assert np.abs(got - want).max() < 1e-9
+    roff = P.ar_ring_offsets(g)
+    assert roff[-1] == sum(((g.k - 1) * d + 1) * g.R for d in g.dilations)
+
+
+def test_engine_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    from wavenet_autoencoders_amd._lib import WaeError
+    with pytest.raises(WaeError):
+        WaeEngine(P.Geometry.from_cfg(CFG))
