@@ -57,7 +57,7 @@ int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, i
 /* dst[i + b*dst_stride] = (dtype) (map[i] < 0 ? 0 : src[map[i] + b*src_stride]),  i < n, b < nbatch */
 int wae_pack_gather(const float* src, const int32_t* map, void* dst, int64_t n, int32_t nbatch,
                     int64_t src_stride, int64_t dst_stride, int32_t dtype, void* stream);
-/* inverse (gradients): dst[map[i] + b*dst_stride] += src[i + b*src_stride] (fp32, map[i] >= 0 unique) */
+/* inverse (gradients): dst[map[i] + b*dst_stride] += src[i + b*src_stride] (fp32 atomics; several i may share a slot) */
 int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int64_t n, int32_t nbatch,
                            int64_t src_stride, int64_t dst_stride, void* stream);
 
@@ -87,6 +87,13 @@ int wae_upsample_stage_fwd(const float* in, const float* w, void* out, int32_t B
 int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride, const int32_t* gid,
                   int64_t emb_off, const float* gvec, float* zb, int32_t B, int32_t L, int32_t G, int32_t Hp,
                   int32_t Cg, void* stream);
+
+/* backward of wae_gproj_fwd.  c1: the per-layer dW1 tiles of wae_gemm_tn (L x 2Hp x ld fp32) whose columns
+ * ones_col + b hold sum_t dz[b,t,row] = d loss / d zb[b][l][row]; adds into d_eff: conv bias, conv1x1g weight and
+ * (gid != NULL) the embedding rows. */
+int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride,
+                  const int32_t* gid, int64_t emb_off, const float* gvec, const float* c1, int64_t c_layer_stride,
+                  int64_t ld, int32_t ones_col, int32_t B, int32_t L, int32_t G, int32_t Hp, int32_t Cg, void* stream);
 
 /* ---- a5 first_conv on one-hot input = column gather + bias (wavenet.py:119-122,203) --------------------
  * idx (B*T) int32 class ids; table (O,Rp) fp32 = W^T ; x0 (B,T,Rp) dtype.  scalar mode: xs (B*T) fp32,
@@ -120,7 +127,8 @@ int64_t wae_glu_packed_bytes(const wae_glu_desc* d);
  * u (B,T,Ku) dtype holds all layers' gated activations, Ku = L*Hp rounded up to 64 (pad columns zero).
  * bias = [sum_l b_skip_l (Sp) | b1 (Sp) | b3 (Op)] fp32.  logits (B,O,T) fp32 or NULL.
  * If target != NULL: nll[b*T+t] = logsumexp(logits[:,t]) - logits[target[b*T+t+1], t] for t < T-1
- * (the reference's one-step shift), 0 at t = T-1.  h0_save/h1_save (B,T,Sp) dtype or NULL (for backward). */
+ * (the reference's one-step shift), 0 at t = T-1; lse (B,T) or NULL receives logsumexp(logits[:,t]).
+ * h0_save/h1_save (B,T,Sp) dtype or NULL (for backward). */
 typedef struct wae_head_desc {
   int32_t dtype;
   int32_t B, T;
@@ -130,7 +138,15 @@ typedef struct wae_head_desc {
   float scale;    /* sqrt(1/L) */
 } wae_head_desc;
 int wae_head_fwd(const wae_head_desc* d, const void* u, const void* w_packed, const float* bias, float* logits,
-                 const int32_t* target, float* nll, void* h0_save, void* h1_save, void* stream);
+                 const int32_t* target, float* nll, float* lse, void* h0_save, void* h1_save, void* stream);
+/* backward of the head down to dskip (csrc/head_bwd.hip).  CE mode (ext_dy == NULL): logits are recomputed from h1,
+ * dy = (softmax - onehot(target[t+1])) * [t < len-1] * inv_count with the forward's lse (B,T); DMoL mode: ext_dy
+ * (B,T,Op) dtype is the loss gradient.  Outputs, all time-major dtype: dy_out (B,T,Op), dh1_out (B,T,Sp) (pre-ReLU
+ * gradient of h1), dskip_out (B,T,Sp) = d loss / d skips.  w_packed = [W3 first-order | W3^T | W1^T second-order]. */
+int wae_head_bwd(const wae_head_desc* d, const void* h0, const void* h1, const void* w_packed, const float* b3,
+                 const float* lse, const int32_t* target, const int32_t* lengths, float inv_count, const void* ext_dy,
+                 void* dy_out, void* dh1_out, void* dskip_out, void* stream);
+int64_t wae_head_bwd_packed_bytes(const wae_head_desc* d);
 int64_t wae_head_packed_bytes(const wae_head_desc* d);
 
 /* out[i] = sum_{l<L} src[off + l*stride + i] for i < n, 0 for n <= i < n_pad  (sum of the skip biases) */
@@ -181,6 +197,42 @@ int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_
                     const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
                     const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
                     const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits, void* stream);
+
+/* ---- backward data path of the gated stack: C[t][M] = sum_s W_s . X_s[t + shift_s] on time-major operands ----
+ * (autograd of modules.py:115-163; see csrc/gemm_tm.hip).  mode 0: out (t, M) = acc.  mode 1 (residual):
+ * out = alpha * (acc + aux[t]).  mode 2 (gate backward): acc = du over M = Hp rows, aux = z (t, 2Hp),
+ * out (t, 2Hp) = [du*sigmoid(b)*(1-tanh(a)^2) | du*tanh(a)*sigmoid(b)*(1-sigmoid(b))].
+ * The four *_host arguments are HOST arrays of nsrc entries (device pointers, strides, cols, shifts).
+ * Sources: nsrc <= 4 time-major arrays (row stride in elements, cols a multiple of 64 bf16 / 32 fp32), row t+shift,
+ * zero outside the clip.  w_packed: [sum cols / CK] chunks of (M/32) x 4 fragment blocks (first-GEMM order). */
+typedef struct wae_tm_desc {
+  int32_t dtype;
+  int32_t B, T;
+  int32_t M;    /* output rows, multiple of 32, M/32 in {1,2,3,4,6,8} */
+  int32_t nsrc;
+  int32_t mode;
+  float alpha;
+} wae_tm_desc;
+int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
+                const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,
+                int64_t out_stride, const void* aux, int64_t aux_stride, void* stream);
+
+/* ---- weight gradients: C[m][n] += alpha * sum_{b,t} P[b,t][m] * Q[b,t+shift][n]  (csrc/gemm_tn.hip) ----------
+ * P (B,T,p_stride) and Q (B,T,q_stride) time-major dtype arrays of which the first M / N columns take part (pointers
+ * may be pre-offset to a column block).  onehot_idx != NULL: P[t][m] = (onehot_idx[b*T+t] == m) (first-conv gradient).
+ * ones_col >= N: a virtual all-ones Q column; clip b accumulates sum_t P[b,t][m] into C[m][ones_col + b]
+ * (bias and per-clip conditioning-bias gradients).  C fp32, leading dimension ldc; fp32 atomics (not bitwise
+ * reproducible run to run). */
+typedef struct wae_tn_desc {
+  int32_t dtype;
+  int32_t B, T;
+  int32_t M, N;
+  int32_t shift;
+  int32_t ones_col;
+  float alpha;
+} wae_tn_desc;
+int wae_gemm_tn(const wae_tn_desc* d, const void* P, int64_t p_stride, const int32_t* onehot_idx, const void* Q,
+                int64_t q_stride, float* C, int64_t ldc, void* stream);
 
 /* layout helpers: (B,C,T) fp32 <-> (B,T,Cp) dtype */
 int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);

@@ -24,6 +24,14 @@ class ArDesc(ctypes.Structure):
                                      "init_idx", "scalar_input")] + [("scale", c_f32)]
 
 
+class TmDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "M", "nsrc", "mode")] + [("alpha", c_f32)]
+
+
+class TnDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "M", "N", "shift", "ones_col")] + [("alpha", c_f32)]
+
+
 class HeadDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Ku", "Sp", "Op", "O")] + [("scale", c_f32)]
 
@@ -40,10 +48,15 @@ SIGNATURES = {
     "wae_vq_nearest": (c_i32, [c_vp] * 6 + [c_i32] * 4 + [c_f32, c_vp]),
     "wae_upsample_stage_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
     "wae_gproj_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
+    "wae_gproj_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64] + [c_i32] * 6 + [c_vp]),
     "wae_first_conv_fwd": (c_i32, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_i32, c_vp]),
     "wae_glu_layer_fwd": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "wae_glu_packed_bytes": (c_i64, [ctypes.POINTER(GluDesc)]),
-    "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 9),
+    "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 10),
+    "wae_head_bwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 7 + [c_f32] + [c_vp] * 5),
+    "wae_head_bwd_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
+    "wae_gemm_tm": (c_i32, [ctypes.POINTER(TmDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "wae_gemm_tn": (c_i32, [ctypes.POINTER(TnDesc), c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "wae_sum_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_dmol_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),

@@ -1,0 +1,215 @@
+"""Backward pass of the decoder hot path (host orchestration; all arithmetic in libwae_hip.so).
+
+Gradient flow (autograd of wavenet.py:164-216 + vqwae_train.py:758-766), with "hat" = gradient already carrying the
+layer's sqrt(.5):
+    head_bwd:   dy, dh1, dskip                                                    (csrc/head_bwd.hip)
+    layer l = L-1 .. 0:
+        du/dz:  dz_l  = gate'(z_l) * (W_out_l^T dxhat_{l+1} + W_skip_l^T dskip)   (wae_gemm_tm, GATE_BWD)
+        wgrad:  dW1_l, dWc_l, dzb_l (ones columns), dW_out_l                      (wae_gemm_tn)
+        dx:     dxhat_l = sqrt(.5) * (dxhat_{l+1} + sum_tap W1_tap^T dz_l[t+s])   (wae_gemm_tm, RESIDUAL)
+    dc = sum_l Wc_l^T dz_l  (one GEMM over all layers),  dW_skip of all layers (one GEMM), head + first-conv weights,
+    scatter into the gradient arena, gproj backward, weight-norm backward.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import packing as P
+
+RS = math.sqrt(0.5)
+
+
+def _prepare_bwd(eng):
+    if getattr(eng, "_bwd_ready", False):
+        return
+    g, dev, lay = eng.g, eng.device, eng.lay
+    if g.scalar_input:
+        raise NotImplementedError("backward for scalar-input (DMoL) models is not implemented yet")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
+    eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
+    eng.m_bc = up(P.bwd_c_map(g, lay, eng.dt)) if g.Ccp else None
+    eng.m_hb_w = up(P.head_bwd_map(g, lay, eng.dt))
+    eng.n_bu, eng.n_bx = eng.m_bu.numel(), eng.m_bx.numel()
+    eng.w_bu = torch.zeros(g.layers * eng.n_bu, dtype=eng.tdtype, device=dev)
+    eng.w_bx = torch.zeros(g.layers * eng.n_bx, dtype=eng.tdtype, device=dev)
+    eng.w_bc = torch.zeros(eng.m_bc.numel(), dtype=eng.tdtype, device=dev) if g.Ccp else None
+    eng.w_hb = torch.zeros(eng.m_hb_w.numel(), dtype=eng.tdtype, device=dev)
+    sm = P.grad_scatter_maps(g, lay)
+    eng.sm = {k: (up(v) if isinstance(v, np.ndarray) else v) for k, v in sm.items()}
+    eng.d_eff = torch.zeros_like(eng.params)
+    eng.grads = torch.zeros_like(eng.params)
+    # dense weight-gradient tiles (fp32), one allocation so a single memset clears them
+    sizes = dict(c1=g.layers * 2 * g.Hp * sm["ld1"], co=g.layers * g.Rp * sm["ldo"], cs=g.Sp * sm["lds"],
+                 c3=g.Op * sm["ldh"], c1h=g.Sp * sm["ldh"], ctab=P._ru(g.O, 128) * g.Rp, fb=g.Rp)
+    total = sum(sizes.values())
+    eng.cbuf = torch.zeros(total, dtype=torch.float32, device=dev)
+    eng.cview, off = {}, 0
+    for k, n in sizes.items():
+        eng.cview[k] = eng.cbuf[off:off + n]
+        off += n
+    eng._bwd_ready = True
+
+
+def pack_bwd_weights(eng):
+    _prepare_bwd(eng)
+    lib, st, g, lay = eng.lib, eng.stream(), eng.g, eng.lay
+    L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bu), L.ptr(eng.w_bu), eng.n_bu, g.layers, lay.layer_stride, eng.n_bu,
+                                eng.dt, st), "pack bwd U")
+    L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bx), L.ptr(eng.w_bx), eng.n_bx, g.layers, lay.layer_stride, eng.n_bx,
+                                eng.dt, st), "pack bwd X")
+    if g.Ccp:
+        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bc), L.ptr(eng.w_bc), eng.m_bc.numel(), 1, 0, 0, eng.dt, st),
+                "pack bwd C")
+    L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_hb_w), L.ptr(eng.w_hb), eng.m_hb_w.numel(), 1, 0, 0, eng.dt, st),
+            "pack head bwd")
+
+
+def _arr(ctype, vals):
+    return (ctype * len(vals))(*vals)
+
+
+def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=None, aux_stride=0):
+    """srcs: list of (device ptr int, row stride elems, cols, shift)"""
+    d = L.TmDesc(eng.dt, B, T, M, len(srcs), mode, alpha)
+    ptrs = _arr(ctypes.c_void_p, [s[0] for s in srcs])
+    strides = _arr(ctypes.c_int64, [s[1] for s in srcs])
+    cols = _arr(ctypes.c_int32, [s[2] for s in srcs])
+    shifts = _arr(ctypes.c_int32, [s[3] for s in srcs])
+    L.check(eng.lib.wae_gemm_tm(ctypes.byref(d), ptrs, strides, cols, shifts, ctypes.c_void_p(w_ptr), ctypes.c_void_p(out_ptr),
+                                out_stride, ctypes.c_void_p(aux_ptr) if aux_ptr else None, aux_stride, eng.stream()), "gemm_tm")
+
+
+def _tn(eng, B, T, M, N, shift, ones_col, alpha, p_ptr, p_stride, q_ptr, q_stride, c_ptr, ldc, onehot=None):
+    d = L.TnDesc(eng.dt, B, T, M, N, shift, ones_col, alpha)
+    L.check(eng.lib.wae_gemm_tn(ctypes.byref(d), ctypes.c_void_p(p_ptr) if p_ptr else None, p_stride, L.ptr(onehot),
+                                ctypes.c_void_p(q_ptr), q_stride, ctypes.c_void_p(c_ptr), ldc, eng.stream()), "gemm_tn")
+
+
+def bwd_workspace(eng, B, T):
+    key = ("bwd", B, T)
+    ws = eng._ws.get(key)
+    if ws is None:
+        g, dev, td = eng.g, eng.device, eng.tdtype
+        ws = dict(dz=torch.zeros(B, T, g.layers * 2 * g.Hp, dtype=td, device=dev),
+                  gx=[torch.zeros(B, T, g.Rp, dtype=td, device=dev) for _ in range(2)],
+                  gzero=torch.zeros(B, T, g.Rp, dtype=td, device=dev),
+                  dy=torch.zeros(B, T, g.Op, dtype=td, device=dev),
+                  dh1=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
+                  dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
+                  dc=torch.zeros(B, T, max(g.Ccp, 64), dtype=td, device=dev))
+        eng._ws[key] = ws
+    return ws
+
+
+def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: Optional[torch.Tensor],
+                     gid: Optional[torch.Tensor], gvec: Optional[torch.Tensor] = None, ext_dy: Optional[torch.Tensor] = None,
+                     loss_scale: float = 1.0):
+    """Backward of the last ``decoder_forward(..., train=True)`` with the same (B, T).  Fills ``eng.grads`` (flat arena,
+    reference parameter layout incl. weight_g / weight_v) for every decoder parameter and returns dc (B,T,Ccp): the
+    gradient wrt the upsampled local conditioning.  ``ext_dy`` (B,T,Op): external d loss / d logits (DMoL)."""
+    _prepare_bwd(eng)
+    g, lib, lay, st = eng.g, eng.lib, eng.lay, eng.stream()
+    B, T = x_ids.shape
+    fw = eng._ws[(B, T, True)]
+    ws = bwd_workspace(eng, B, T)
+    es = eng.w_glu.element_size()
+    sm = eng.sm
+    pack_bwd_weights(eng)
+    eng.d_eff.zero_()
+    eng.cbuf.zero_()
+    if lengths is None:
+        count = B * (T - 1)
+    else:
+        count = int(torch.clamp(lengths.detach().to("cpu", torch.int64).clamp(max=T) - 1, min=0).sum())
+    inv_count = loss_scale / max(count, 1)
+    xi = x_ids.to(torch.int32).contiguous()
+    tg = targets.to(torch.int32).contiguous() if targets is not None else None
+    ln = lengths.to(torch.int32).to(eng.device).contiguous() if lengths is not None else None
+    keep = [xi, tg, ln]
+
+    # ---- head --------------------------------------------------------------------------------------------------
+    hd = L.HeadDesc(eng.dt, B, T, g.Ku, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
+    b3 = ctypes.c_void_p(eng.b_head.data_ptr() + 2 * g.Sp * 4)
+    L.check(lib.wae_head_bwd(ctypes.byref(hd), L.ptr(fw["h0"]), L.ptr(fw["h1"]), L.ptr(eng.w_hb), b3, L.ptr(fw["lse"]), L.ptr(tg),
+                             L.ptr(ln), inv_count, L.ptr(ext_dy), L.ptr(ws["dy"]), L.ptr(ws["dh1"]), L.ptr(ws["dskip"]), st),
+            "head_bwd")
+    dy = ext_dy if ext_dy is not None else ws["dy"]
+    c3, c1h, cs = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"]
+    _tn(eng, B, T, g.Op, g.Sp, 0, g.Sp, 1.0, dy.data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
+    _tn(eng, B, T, g.Sp, g.Sp, 0, g.Sp, 1.0, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
+    _tn(eng, B, T, g.Sp, g.Ku, 0, g.Ku, 1.0, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
+
+    # ---- gated stack, last layer first ---------------------------------------------------------------------------
+    Z2 = 2 * g.Hp
+    dzs = g.layers * Z2
+    c1, co = eng.cview["c1"], eng.cview["co"]
+    g_next = ws["gzero"]                      # dxhat_{L} = 0: the last layer's x' is dead (wavenet.py:205-207)
+    for l in range(g.layers - 1, -1, -1):
+        d = g.dilations[l]
+        dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
+        # du -> dz
+        _tm(eng, B, T, g.Hp, 2, 1.0, [(g_next.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
+            eng.w_bu.data_ptr() + l * eng.n_bu * es, dz_ptr, dzs, fw["z"][l].data_ptr(), Z2)
+        # weight gradients of the dilated conv (+ conditioning 1x1, + per-clip zb sums)
+        c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
+        xl = fw["x"][l]
+        for tap in range(g.k):
+            last = tap == g.k - 1 and not g.Ccp
+            _tn(eng, B, T, Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), 1.0, dz_ptr, dzs, xl.data_ptr(), g.Rp,
+                c1l + tap * g.Rp * 4, sm["ld1"])
+        if g.Ccp:
+            _tn(eng, B, T, Z2, g.Ccp, 0, g.Ccp, 1.0, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
+        if l < g.layers - 1:
+            _tn(eng, B, T, g.Rp, g.Hp, 0, g.Hp, 1.0, g_next.data_ptr(), g.Rp, fw["u"].data_ptr() + l * g.Hp * es, g.Ku,
+                co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
+        # dx
+        g_cur = ws["gx"][l % 2]
+        srcs = [(dz_ptr, dzs, Z2, (g.k - 1 - tap) * d) for tap in range(g.k)]
+        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, g_cur.data_ptr(), g.Rp, g_next.data_ptr(), g.Rp)
+        g_next = g_cur
+    # ---- local-conditioning gradient over all layers at once ---------------------------------------------------------
+    if g.Ccp:
+        _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), dzs, dzs, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
+    # ---- first conv: dW[r][class] = sum_t dx0[t][r] onehot(id[t])[class];  dx0 = dxhat_0 / sqrt(.5) -----------------------
+    ctab, fb = eng.cview["ctab"], eng.cview["fb"]
+    _tn(eng, B, T, g.O, g.Rp, 0, -1, 1.0 / RS, None, 0, g_next.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp, onehot=xi)
+    L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
+
+    # ---- scatter the dense tiles into the effective-weight gradient arena ----------------------------------------------
+    def scat(src, mp, n, nb=1, ss=0, ds=0):
+        L.check(lib.wae_unpack_scatter_add(L.ptr(src), L.ptr(mp), L.ptr(eng.d_eff), n, nb, ss, ds, st), "scatter")
+    scat(c1, sm["w1"], Z2 * sm["ld1"], g.layers, Z2 * sm["ld1"], lay.layer_stride)
+    scat(co, sm["wo"], g.Rp * sm["ldo"], g.layers, g.Rp * sm["ldo"], lay.layer_stride)
+    scat(cs, sm["ws"], g.Sp * sm["lds"])
+    scat(cs, sm["bs"], g.Sp * sm["lds"], g.layers, 0, lay.layer_stride)
+    scat(c3, sm["w3"], g.Op * sm["ldh"])
+    scat(c1h, sm["w1h"], g.Sp * sm["ldh"])
+    scat(ctab, sm["tab"], sm["tab"].numel())
+    scat(fb, sm["fb"], g.Rp)
+    # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
+    wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
+    emb_off = lay.offsets.get("wavenet.embed_speakers.weight", 0)
+    use_gid = gid is not None and "wavenet.embed_speakers.weight" in lay.offsets
+    gid32 = gid.to(torch.int32).contiguous() if gid is not None else None
+    keep.append(gid32)
+    L.check(lib.wae_gproj_bwd(L.ptr(eng.eff), L.ptr(eng.d_eff), wg_off, lay.off("wavenet.conv_layers.0.conv.bias"),
+                              lay.layer_stride, L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec), L.ptr(c1),
+                              Z2 * sm["ld1"], sm["ld1"], g.k * g.Rp + g.Ccp, B, g.layers, g.G, g.Hp, max(g.Cg, 0), st),
+            "gproj_bwd")
+    eng._bwd_keep = keep
+    return ws["dc"]
+
+
+def finish_grads(eng):
+    """d_eff (gradient wrt effective weights) -> grads (wrt weight_g / weight_v and plain parameters)."""
+    lay = eng.lay
+    L.check(eng.lib.wae_weight_norm_bwd(L.ptr(eng.params), L.ptr(eng.d_eff), L.ptr(eng.grads), lay.total, L.ptr(eng.wn_v),
+                                        L.ptr(eng.wn_g), L.ptr(eng.wn_c), len(lay.wn_cols), eng.stream()), "weight_norm_bwd")
+    return eng.grads

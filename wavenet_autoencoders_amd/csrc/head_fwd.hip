@@ -19,6 +19,7 @@ struct HeadArgs {
   float* logits;
   const int32_t* target;
   float* nll;
+  float* lse;
   char* h0_save;
   char* h1_save;
   int B, T, Ku, Sp, Op, O;
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
       float v = 0.f;
       if (tgt >= 0) v = (nm + __logf(s)) - (picked + op);
       p.nll[(int64_t)b * p.T + t] = v;
+      if (p.lse) p.lse[(int64_t)b * p.T + t] = nm + __logf(s);
     }
   }
 }
@@ -223,13 +225,13 @@ extern "C" int64_t wae_head_packed_bytes(const wae_head_desc* d) {
 }
 
 extern "C" int wae_head_fwd(const wae_head_desc* d, const void* u, const void* w_packed, const float* bias, float* logits,
-                            const int32_t* target, float* nll, void* h0_save, void* h1_save, void* stream) {
+                            const int32_t* target, float* nll, float* lse, void* h0_save, void* h1_save, void* stream) {
   int rc = head_validate(d);
   if (rc != WAE_OK) return rc;
   WAE_REQUIRE(u && w_packed && bias, "head: null pointer argument");
   WAE_REQUIRE(logits || (target && nll), "head: nothing to produce (logits and nll both null)");
   HeadArgs a;
-  a.u = (const char*)u; a.w = (const char*)w_packed; a.bias = bias; a.logits = logits; a.target = target; a.nll = nll;
+  a.u = (const char*)u; a.w = (const char*)w_packed; a.bias = bias; a.logits = logits; a.target = target; a.nll = nll; a.lse = lse;
   a.h0_save = (char*)h0_save; a.h1_save = (char*)h1_save; a.B = d->B; a.T = d->T; a.Ku = d->Ku; a.Sp = d->Sp; a.Op = d->Op;
   a.O = d->O; a.scale = d->scale;
   hipStream_t st = as_stream(stream);

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) unpack_scatter_add_kernel(const float* __
   const int b = blockIdx.y;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int32_t m = map[i];
-    if (m >= 0) dst[m + b * dst_stride] += src[i + b * src_stride];
+    if (m >= 0) atomicAdd(dst + m + b * dst_stride, src[i + b * src_stride]);
   }
 }
 
@@ -392,6 +392,47 @@ extern "C" int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off,
   hipLaunchKernelGGL(gproj_fwd_kernel, dim3(L, B), dim3(256), 0, as_stream(stream), eff, wg_off, bias_off, layer_stride,
                      gid, emb_off, gvec, zb, L, G, Hp, Cg);
   return wae_check_launch("gproj_fwd");
+}
+
+// backward of gproj: the per-clip column sums of dz (the "ones columns" of the dW1 tile of wae_gemm_tn) are the
+// gradient of zb[b][l][:]; chain into the conv bias, conv1x1g and the speaker embedding (modules.py:148-152).
+__global__ void __launch_bounds__(256) gproj_bwd_kernel(const float* __restrict__ eff, float* __restrict__ d_eff, int64_t wg_off,
+                                                        int64_t bias_off, int64_t layer_stride, const int32_t* __restrict__ gid,
+                                                        int64_t emb_off, const float* __restrict__ gvec,
+                                                        const float* __restrict__ c1, int64_t c_layer_stride, int64_t ld,
+                                                        int ones_col, int B, int G, int Hp, int Cg) {
+  const int l = blockIdx.x;
+  const int H = G / 2;
+  const float* cl = c1 + (int64_t)l * c_layer_stride;
+  for (int r = threadIdx.x; r < 2 * Hp; r += 256) {
+    const int half = r >= Hp, i = r - half * Hp;
+    if (i >= H) continue;
+    const int ch = half * H + i;
+    float sb = 0.f;
+    for (int b = 0; b < B; ++b) sb += cl[(int64_t)r * ld + ones_col + b];
+    atomicAdd(d_eff + bias_off + (int64_t)l * layer_stride + ch, sb);
+    if (wg_off < 0 || Cg <= 0) continue;
+    const float* wg = eff + wg_off + (int64_t)l * layer_stride + (int64_t)ch * Cg;
+    float* dwg = d_eff + wg_off + (int64_t)l * layer_stride + (int64_t)ch * Cg;
+    for (int c = 0; c < Cg; ++c) {
+      float a = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float dz = cl[(int64_t)r * ld + ones_col + b];
+        const float e = gid ? eff[emb_off + (int64_t)gid[b] * Cg + c] : gvec[(int64_t)b * Cg + c];
+        a = fmaf(dz, e, a);
+        if (gid) atomicAdd(d_eff + emb_off + (int64_t)gid[b] * Cg + c, dz * wg[c]);
+      }
+      atomicAdd(dwg + c, a);
+    }
+  }
+}
+extern "C" int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride,
+                             const int32_t* gid, int64_t emb_off, const float* gvec, const float* c1, int64_t c_layer_stride,
+                             int64_t ld, int32_t ones_col, int32_t B, int32_t L, int32_t G, int32_t Hp, int32_t Cg, void* stream) {
+  WAE_REQUIRE(eff && d_eff && c1 && B > 0 && L > 0 && G > 0 && G % 2 == 0, "gproj_bwd: bad arguments");
+  hipLaunchKernelGGL(gproj_bwd_kernel, dim3(L), dim3(256), 0, as_stream(stream), eff, d_eff, (gid || gvec) ? wg_off : -1, bias_off,
+                     layer_stride, gid, emb_off, gvec, c1, c_layer_stride, ld, ones_col, B, G, Hp, Cg);
+  return wae_check_launch("gproj_bwd");
 }
 
 // sum of the per-layer skip biases (the head's GEMM 0 starts from it)

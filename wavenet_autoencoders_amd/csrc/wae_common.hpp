@@ -218,6 +218,56 @@ __device__ __forceinline__ void stage_store_tiles(char* stg, const f32x16* y, ch
   }
 }
 
+// stage_load_tiles: the inverse -- NT tiles (32 rows x 32 channels) of a time-major (rows, channels) array into the
+// accumulator layout (lane = time column, register group g = channels 8g+4h..+3): coalesced 16-B row loads -> LDS ->
+// per-lane column pieces.  Rows at or beyond rows_valid read row rows_valid-1 (callers never use them).
+template <typename EO, int NTP>
+__device__ __forceinline__ void stage_load_pass(char* stg, f32x16* y, const char* gin, int64_t row_stride, int rows_valid,
+                                                int lane) {
+  using vec4 = typename ET<EO>::vec4;
+  constexpr int SEG = NTP * 32 * sizeof(EO);
+  static_assert(SEG <= 256 && SEG >= 64, "a staging pass covers 64..256 bytes per row");
+  constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 32 / RPI;
+  const int n = lane & 31, h = lane >> 5;
+  const int rr = lane / LPR, ck = lane % LPR;
+  f32x4 tmp[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = min(i * RPI + rr, rows_valid - 1);
+    tmp[i] = *(const f32x4*)(gin + row * row_stride + ck * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = i * RPI + rr;
+    *(f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4)) = tmp[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int mt = 0; mt < NTP; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int c16, sub;
+      if constexpr (sizeof(EO) == 2) { c16 = 4 * mt + g; sub = 8 * h; } else { c16 = 8 * mt + 2 * g + h; sub = 0; }
+      const f32x4 v = to_f32x4(*(const vec4*)(stg + n * 256 + ((c16 ^ (n & 15)) << 4) + sub));
+      y[mt][4 * g] = v.x; y[mt][4 * g + 1] = v.y; y[mt][4 * g + 2] = v.z; y[mt][4 * g + 3] = v.w;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <typename EO, int NT>
+__device__ __forceinline__ void stage_load_tiles(char* stg, f32x16* y, const char* gin, int64_t row_stride, int rows_valid,
+                                                 int lane) {
+  constexpr int PT = 256 / (32 * (int)sizeof(EO));
+  if constexpr (NT >= PT) {
+    stage_load_pass<EO, PT>(stg, y, gin, row_stride, rows_valid, lane);
+    if constexpr (NT > PT) stage_load_tiles<EO, NT - PT>(stg, y + PT, gin + 256, row_stride, rows_valid, lane);
+  } else if constexpr (NT >= 2) {
+    stage_load_pass<EO, 2>(stg, y, gin, row_stride, rows_valid, lane);
+    if constexpr (NT > 2) stage_load_tiles<EO, NT - 2>(stg, y + 2, gin + 64 * sizeof(EO), row_stride, rows_valid, lane);
+  } else {
+    stage_load_pass<EO, 1>(stg, y, gin, row_stride, rows_valid, lane);
+  }
+}
+
 // Residual x[t] arrives as operand-shaped 16-byte fragments: fragment f of lane (n, h) = row bytes
 // [32 f + 16 h, +16) of the chunk.  f32: that IS the accumulator layout (tile f/4, group f%4, channels 8g+4h+j).
 // bf16: 8 channels 16 f + 8 h + j; the accumulator layout wants channels 8g + 4h' + j' -> exchange register pairs

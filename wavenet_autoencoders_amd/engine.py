@@ -132,6 +132,7 @@ class WaeEngine:
             )
             if train:
                 ws["z"] = [torch.empty(B, T, 2 * g.Hp, dtype=td, device=dev) for _ in range(g.layers)]
+                ws["lse"] = torch.zeros(B, T, dtype=torch.float32, device=dev)
                 ws["h0"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
                 ws["h1"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
             self._ws[key] = ws
@@ -273,6 +274,7 @@ class WaeEngine:
         tg = targets.to(torch.int32).contiguous() if targets is not None else None
         L.check(lib.wae_head_fwd(ctypes.byref(hd), L.ptr(ws["u"]), L.ptr(self.w_head), L.ptr(self.b_head), L.ptr(logits),
                                  L.ptr(tg), L.ptr(ws["nll"]) if tg is not None else None,
+                                 L.ptr(ws["lse"]) if (train and tg is not None) else None,
                                  L.ptr(ws["h0"]) if train else None, L.ptr(ws["h1"]) if train else None, st), "head")
         out = dict(logits=logits, nll=None, loss=None)
         if tg is not None:

@@ -362,3 +362,135 @@ def ar_ring_offsets(g: Geometry) -> np.ndarray:
     for d in g.dilations:
         off.append(off[-1] + ((g.k - 1) * d + 1) * g.R)
     return np.asarray(off, dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward: transposed weight streams (csrc/gemm_tm.hip, csrc/head_bwd.hip) and the scatter maps that
+# bring the dense weight-gradient tiles of csrc/gemm_tn.hip back into the flat gradient arena
+# ---------------------------------------------------------------------------------------------------
+def first_gemm_map(Mp: int, Kp: int, dtype: int, src_fn) -> np.ndarray:
+    """[q][blk][m][lane][j] stream of an (Mp x Kp) matrix; src_fn(row, kk) -> arena offset or -1 (vectorised)."""
+    t = _traits(dtype)
+    EPL, CK = t["EPL"], t["CK"]
+    assert Mp % 32 == 0 and Kp % CK == 0, (Mp, Kp)
+    q, blk, m, lane, j = np.meshgrid(np.arange(Kp // CK), np.arange(4), np.arange(Mp // 32), np.arange(64), np.arange(EPL),
+                                     indexing="ij")
+    row = 32 * m + (lane & 31)
+    kk = q * CK + blk * 2 * EPL + (lane >> 5) * EPL + j
+    return src_fn(row, kk).astype(np.int32).reshape(-1)
+
+
+def second_gemm_map(Mp: int, Kp: int, dtype: int, src_fn) -> np.ndarray:
+    """[gm][kb][lane][j] stream; k index follows the accumulator-tile row order (u_row_index)."""
+    t = _traits(dtype)
+    EPL, KBU = t["EPL"], t["KBU"]
+    assert Mp % 32 == 0 and Kp % 32 == 0
+    gm, kb, lane, j = np.meshgrid(np.arange(Mp // 32), np.arange(Kp // 32 * KBU), np.arange(64), np.arange(EPL), indexing="ij")
+    row = 32 * gm + (lane & 31)
+    kk = u_row_index(dtype, kb, lane >> 5, j)
+    return src_fn(row, kk).astype(np.int32).reshape(-1)
+
+
+def _gate_row(g: Geometry, c2):
+    """padded gate column (0..2Hp) -> (reference row of the (G, ...) conv weight, valid)"""
+    half = (c2 >= g.Hp).astype(np.int64)
+    i = c2 - half * g.Hp
+    return half * g.H + i, i < g.H
+
+
+def bwd_u_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    """du = W_out^T dx-hat + W_skip^T dskip: rows h (Hp), K = [Rp | Sp]."""
+    o = lay.off("wavenet.conv_layers.0.conv1x1_out.weight_v")
+    s = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v")
+
+    def src(h, kk):
+        r, sk = kk, kk - g.Rp
+        return np.where(kk < g.Rp, np.where((r < g.R) & (h < g.H), o + r * g.H + h, -1),
+                        np.where((sk < g.S) & (h < g.H), s + sk * g.H + h, -1))
+    return first_gemm_map(g.Hp, g.Rp + g.Sp, dtype, src)
+
+
+def bwd_x_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    """dx = sum_tap W1_tap^T dz[t + (k-1-tap) d]: rows r (Rp), K = k sources of 2Hp gate columns."""
+    conv = lay.off("wavenet.conv_layers.0.conv.weight_v")
+
+    def src(r, kk):
+        tap, c2 = kk // (2 * g.Hp), kk % (2 * g.Hp)
+        row, ok = _gate_row(g, c2)
+        return np.where(ok & (r < g.R), conv + (row * g.R + r) * g.k + tap, -1)
+    return first_gemm_map(g.Rp, g.k * 2 * g.Hp, dtype, src)
+
+
+def bwd_c_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    """dc = sum_l Wc_l^T dz_l: rows cc (Ccp), K = L * 2Hp (absolute offsets)."""
+    cw = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
+
+    def src(cc, kk):
+        l, c2 = kk // (2 * g.Hp), kk % (2 * g.Hp)
+        row, ok = _gate_row(g, c2)
+        return np.where(ok & (cc < g.Cc), cw + l * lay.layer_stride + row * g.Cc + cc, -1)
+    return first_gemm_map(g.Ccp, g.layers * 2 * g.Hp, dtype, src)
+
+
+def head_bwd_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    w3 = lay.off("wavenet.last_conv_layers.3.weight_v")
+    w1 = lay.off("wavenet.last_conv_layers.1.weight_v")
+    a = first_gemm_map(g.Op, g.Sp, dtype, lambda o, kk: np.where((o < g.O) & (kk < g.S), w3 + o * g.S + kk, -1))
+    b = second_gemm_map(g.Sp, g.Op, dtype, lambda s, kk: np.where((s < g.S) & (kk < g.O), w3 + kk * g.S + s, -1))
+    c = second_gemm_map(g.Sp, g.Sp, dtype, lambda s, kk: np.where((s < g.S) & (kk < g.S), w1 + kk * g.S + s, -1))
+    return np.concatenate([a, b, c]).astype(np.int32)
+
+
+ONES_PAD = 128   # spare C columns that receive the per-clip "ones column" sums (B <= 128)
+
+
+def grad_scatter_maps(g: Geometry, lay: ParamLayout) -> dict:
+    """C-buffer element -> gradient-arena offset (or -1).  Layer maps are relative to layer 0."""
+    out = {}
+    # dW1 | dWc : rows = padded gate rows (2Hp), cols = [tap*Rp + r | k*Rp + cc | ones...]
+    ld1 = g.k * g.Rp + g.Ccp + ONES_PAD
+    row, col = np.meshgrid(np.arange(2 * g.Hp), np.arange(ld1), indexing="ij")
+    grow, ok = _gate_row(g, row)
+    conv = lay.off("wavenet.conv_layers.0.conv.weight_v")
+    tap, r = col // g.Rp, col % g.Rp
+    m = np.where(ok & (col < g.k * g.Rp) & (r < g.R), conv + (grow * g.R + r) * g.k + np.minimum(tap, g.k - 1), -1)
+    if g.Cc > 0:
+        cw = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
+        cc = col - g.k * g.Rp
+        m = np.where(ok & (cc >= 0) & (cc < g.Cc), cw + grow * g.Cc + cc, m)
+    out["w1"], out["ld1"] = m.astype(np.int32).reshape(-1), ld1
+    # dW_out: rows r (Rp), cols h (Hp) | ones -> bias (every clip column adds into the same slot)
+    ldo = g.Hp + ONES_PAD
+    row, col = np.meshgrid(np.arange(g.Rp), np.arange(ldo), indexing="ij")
+    wo = lay.off("wavenet.conv_layers.0.conv1x1_out.weight_v")
+    bo = lay.off("wavenet.conv_layers.0.conv1x1_out.bias")
+    m = np.where((row < g.R) & (col < g.H), wo + row * g.H + col, -1)
+    m = np.where((row < g.R) & (col >= g.Hp), bo + row, m)
+    out["wo"], out["ldo"] = m.astype(np.int32).reshape(-1), ldo
+    # dW_skip of all layers: rows s (Sp), cols l*Hp + h | ones -> skip bias (applied per layer separately)
+    lds = g.Ku + ONES_PAD
+    row, col = np.meshgrid(np.arange(g.Sp), np.arange(lds), indexing="ij")
+    ws = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v")
+    l, hh = col // g.Hp, col % g.Hp
+    m = np.where((row < g.S) & (col < g.layers * g.Hp) & (hh < g.H), ws + l * lay.layer_stride + row * g.H + hh, -1)
+    out["ws"], out["lds"] = m.astype(np.int32).reshape(-1), lds
+    bs = lay.off("wavenet.conv_layers.0.conv1x1_skip.bias")
+    out["bs"] = np.where((row < g.S) & (col >= g.Ku), bs + row, -1).astype(np.int32).reshape(-1)   # relative to layer 0
+    # head
+    ldh = g.Sp + ONES_PAD
+    row, col = np.meshgrid(np.arange(g.Op), np.arange(ldh), indexing="ij")
+    w3, b3 = lay.off("wavenet.last_conv_layers.3.weight_v"), lay.off("wavenet.last_conv_layers.3.bias")
+    m = np.where((row < g.O) & (col < g.S), w3 + row * g.S + col, -1)
+    out["w3"] = np.where((row < g.O) & (col >= g.Sp), b3 + row, m).astype(np.int32).reshape(-1)
+    row, col = np.meshgrid(np.arange(g.Sp), np.arange(ldh), indexing="ij")
+    w1, b1 = lay.off("wavenet.last_conv_layers.1.weight_v"), lay.off("wavenet.last_conv_layers.1.bias")
+    m = np.where((row < g.S) & (col < g.S), w1 + row * g.S + col, -1)
+    out["w1h"] = np.where((row < g.S) & (col >= g.Sp), b1 + row, m).astype(np.int32).reshape(-1)
+    out["ldh"] = ldh
+    # first conv table gradient (O or 1, Rp) -> weight_v (R, O, 1)
+    nin = 1 if g.scalar_input else g.O
+    o, r = np.meshgrid(np.arange(nin), np.arange(g.Rp), indexing="ij")
+    out["tab"] = np.where(r < g.R, lay.off("wavenet.first_conv.weight_v") + r * nin + o, -1).astype(np.int32).reshape(-1)
+    rr = np.arange(g.Rp)
+    out["fb"] = np.where(rr < g.R, lay.off("wavenet.first_conv.bias") + rr, -1).astype(np.int32)
+    return out
