@@ -234,6 +234,18 @@ typedef struct wae_tn_desc {
 int wae_gemm_tn(const wae_tn_desc* d, const void* P, int64_t p_stride, const int32_t* onehot_idx, const void* Q,
                 int64_t q_stride, float* C, int64_t ldc, void* stream);
 
+/* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
+ * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).
+ * conv block: dpre = dy * [relu ? (y - (residual ? x : 0)) > 0 : 1]; dx (or NULL), dw +=, dbias += (or NULL).
+ * VQ: dlat = dquant + loss_scale*2*beta*(x-q)/N; demb[idx] += loss_scale*2*(q-x)/N (straight-through estimator). */
+int wae_upsample_stage_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, int32_t B,
+                           int32_t C, int32_t Tin, int32_t s, void* stream);
+int wae_enc_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                     float* dbias, int32_t B, int32_t Cin, int32_t Tin, int32_t Cout, int32_t k, int32_t stride,
+                     int32_t pad, int32_t relu, int32_t residual, void* stream);
+int wae_vq_bwd(const float* lat, const float* quant, const int64_t* idx, const float* dquant, float* dlat, float* demb,
+               int32_t B, int32_t D, int32_t Tq, float beta, float loss_scale, void* stream);
+
 /* layout helpers: (B,C,T) fp32 <-> (B,T,Cp) dtype */
 int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);
 int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);

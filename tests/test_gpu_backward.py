@@ -55,3 +55,35 @@ def test_decoder_backward_bf16_is_close():
     # cancelling sum over layers and gate channels of bf16-rounded dz: 30 %)
     bad = {k: v for k, v in res.items() if v[0] > (0.3 if k == "dc" else 8e-2) * max(v[1], 1e-6) + 1e-6}
     assert not bad, bad
+
+
+def test_full_train_step_against_golden():
+    """(7) of SURVEY 8c: parameter gradients of one step, post-Adam weights and EMA shadow of the reference."""
+    from helpers import load_npz
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    z = load_npz("train_A")
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype="fp32")
+    eng.load_state_dict(sd)
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    T = x.shape[1]
+    res = eng.train_step(x, c, g, lengths=torch.tensor([T, T]), lr=4e-4, clip_thresh=100.0, ema_decay=0.9999)
+    torch.cuda.synchronize()
+    assert abs(float(res["loss"]) - float(z["loss"])) < 1e-4
+    assert abs(float(res["vq_loss"]) - float(z["vq_loss"])) < 1e-5
+    assert abs(float(res["grad_norm"]) - float(z["grad_norm"])) < 1e-3 * float(z["grad_norm"])
+    import json
+    gsq = json.loads(str(z["grad_sq_by_key"]))
+    lay = eng.lay
+    bad = {}
+    for k, want in gsq.items():
+        got = float((eng.grads[lay.off(k):lay.off(k) + lay.numel(k)].double() ** 2).sum())
+        if abs(got - want) > 5e-3 * max(want, 1e-12) + 1e-14:
+            bad[k] = (got, want)
+    assert not bad, bad
+    for key in [k[5:] for k in z if k.startswith("grad:")]:
+        view = lambda a: a[lay.off(key):lay.off(key) + lay.numel(key)].view(lay.shapes[key]).cpu()  # noqa: E731
+        assert rel_err(view(eng.grads), z["grad:" + key]) < 2e-3, key
+        assert rel_err(view(eng.params), z["new:" + key]) < 5e-5, key   # first Adam step ~ lr*sign(g): tiny-|g| elements are eps-sensitive
+        assert rel_err(view(eng.shadow), z["ema:" + key]) < 1e-6, key

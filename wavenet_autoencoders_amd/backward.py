@@ -213,3 +213,58 @@ def finish_grads(eng):
     L.check(eng.lib.wae_weight_norm_bwd(L.ptr(eng.params), L.ptr(eng.d_eff), L.ptr(eng.grads), lay.total, L.ptr(eng.wn_v),
                                         L.ptr(eng.wn_g), L.ptr(eng.wn_c), len(lay.wn_cols), eng.stream()), "weight_norm_bwd")
     return eng.grads
+
+
+def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0):
+    """dc (B,T,Ccp) -> upsample stages -> conv_in -> [VQ straight-through + vq_loss -> encoder]; adds the weight
+    gradients into eng.d_eff.  Uses the activations kept by the last train-mode forward."""
+    g, lib, lay, st = eng.g, eng.lib, eng.lay, eng.stream()
+    B, T = dc.shape[0], dc.shape[1]
+    dev = eng.device
+    d = torch.empty(B, g.Cc, T, dtype=torch.float32, device=dev)
+    L.check(lib.wae_from_btc(L.ptr(dc), L.ptr(d), B, g.Cc, T, g.Ccp, eng.dt, st), "from_btc")
+    acts = eng._up_acts                      # [conv_in input, stage-0 input, stage-1 input, ...]
+    keep = [d]
+    for i in range(len(g.upsample_scales) - 1, -1, -1):
+        s = g.upsample_scales[i]
+        xin = acts[1 + i]
+        name = f"wavenet.upsample_net.upsample.up_layers.{2 * i + 1}.weight_v"
+        din = torch.empty_like(xin)
+        L.check(lib.wae_upsample_stage_bwd(L.ptr(d), L.ptr(xin), L.ptr(eng.eff[lay.off(name):]), L.ptr(din),
+                                           L.ptr(eng.d_eff[lay.off(name):]), B, g.Cc, xin.shape[-1], s, st), "upsample_stage_bwd")
+        d = din
+        keep.append(d)
+    cin = acts[0]
+    kin = 2 * g.cin_pad + 1
+    name = "wavenet.upsample_net.conv_in.weight"
+    dq = torch.empty_like(cin)
+    L.check(lib.wae_enc_conv_bwd(L.ptr(cin), L.ptr(eng.eff[lay.off(name):]), None, L.ptr(d), L.ptr(dq),
+                                 L.ptr(eng.d_eff[lay.off(name):]), None, B, g.Cc, cin.shape[-1], g.Cc, kin, 1, 0, 0, 0, st), "conv_in bwd")
+    keep.append(dq)
+    fe = getattr(eng, "_fe", None)
+    if fe is not None and g.has_encoder:
+        lat, quant, idx = fe["lat"], fe["quant"], fe["idx"]
+        Tq = lat.shape[-1]
+        dlat = torch.empty_like(lat)
+        en = "vq.embedding.weight"
+        L.check(lib.wae_vq_bwd(L.ptr(lat), L.ptr(quant), L.ptr(idx), L.ptr(dq), L.ptr(dlat), L.ptr(eng.d_eff[lay.off(en):]), B, g.Cc,
+                               Tq, fe["beta"], loss_scale, st), "vq_bwd")
+        ea = eng._enc_acts                   # ea[i] = input of block i, ea[10] = output of block 9
+        dx = torch.empty_like(ea[10])
+        L.check(lib.wae_enc_conv_bwd(L.ptr(ea[10]), L.ptr(eng.eff[lay.off("encoder.lin.weight"):]), None, L.ptr(dlat), L.ptr(dx),
+                                     L.ptr(eng.d_eff[lay.off("encoder.lin.weight"):]), L.ptr(eng.d_eff[lay.off("encoder.lin.bias"):]),
+                                     B, g.encoder_hid, Tq, g.Cc, 1, 1, 0, 0, 0, st), "lin bwd")
+        keep += [dlat, dx]
+        dcur = dx
+        for i in range(len(P.ENCODER_BLOCKS) - 1, -1, -1):
+            k, s = P.ENCODER_BLOCKS[i]
+            wn_, bn_ = f"encoder.net.{i}.conv.weight", f"encoder.net.{i}.conv.bias"
+            co, ci, _ = lay.shapes[wn_]
+            xin, yout = ea[i], ea[i + 1]
+            dxi = torch.empty_like(xin) if i > 0 else None
+            L.check(lib.wae_enc_conv_bwd(L.ptr(xin), L.ptr(eng.eff[lay.off(wn_):]), L.ptr(yout), L.ptr(dcur), L.ptr(dxi),
+                                         L.ptr(eng.d_eff[lay.off(wn_):]), L.ptr(eng.d_eff[lay.off(bn_):]), B, ci, xin.shape[-1], co,
+                                         k, s, k // 2, 1, int(s == 1 and ci == co), st), "enc block bwd")
+            keep.append(dxi)
+            dcur = dxi
+    eng._fe_keep = keep

@@ -1,0 +1,153 @@
+// Backward of the low-rate front end: conditioning upsample stages (upsample.py:19-21,39-46), plain / ReLU /
+// residual Conv1d blocks of the encoder and conv_in (vqvae_model.py:17-23,50; upsample.py:77-78) and the vector
+// quantizer (vector_quantization.py:38-45).  These run at 1/160 .. 1/640 of the audio rate (the last upsample stage
+// excepted) and are plain fp32 VALU kernels; weight gradients are accumulated with fp32 atomics into the
+// effective-weight gradient arena.
+#include "wae_common.hpp"
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- upsample stage: out[t] = sum_j w[j] * in[(t + j - s) / s]  (0 <= t + j - s < Tin*s) ---------------------------------
+__global__ void __launch_bounds__(256) upsample_stage_bwd_in_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                                   float* __restrict__ din, int C, int Tin, int s) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (i >= Tin) return;
+  const int Tout = Tin * s;
+  const float* dr = dout + ((int64_t)b * C + c) * Tout;
+  float acc = 0.f;
+  for (int u = i * s; u < (i + 1) * s; ++u)
+    for (int j = 0; j <= 2 * s; ++j) {
+      const int t = u - j + s;
+      if (t >= 0 && t < Tout) acc = fmaf(w[j], dr[t], acc);
+    }
+  din[((int64_t)b * C + c) * Tin + i] = acc;
+}
+__global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* __restrict__ dout, const float* __restrict__ in,
+                                                                  float* __restrict__ dw, int BC, int Tin, int s) {
+  const int j = blockIdx.y;
+  const int Tout = Tin * s;
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)BC * Tout; e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / Tout;
+    const int t = (int)(e % Tout);
+    const int u = t + j - s;
+    if (u >= 0 && u < Tout) acc = fmaf(dout[e], in[row * Tin + u / s], acc);
+  }
+  acc = wave_sum_f(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(dw + j, acc);
+}
+extern "C" int wae_upsample_stage_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, int32_t B,
+                                      int32_t C, int32_t Tin, int32_t s, void* stream) {
+  WAE_REQUIRE(dout && in && w && din && dw && B > 0 && C > 0 && Tin > 0 && s > 0, "upsample_stage_bwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(upsample_stage_bwd_in_kernel, dim3((Tin + 255) / 256, C, B), dim3(256), 0, st, dout, w, din, C, Tin, s);
+  const int64_t n = (int64_t)B * C * Tin * s;
+  const int gx = (int)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256);
+  hipLaunchKernelGGL(upsample_stage_bwd_w_kernel, dim3(gx, 2 * s + 1), dim3(256), 0, st, dout, in, dw, B * C, Tin, s);
+  return wae_check_launch("upsample_stage_bwd");
+}
+
+// ---- Conv1d (+ReLU) (+residual) backward ------------------------------------------------------------------------------
+// dpre = dy * [relu ? (y - (residual ? x : 0)) > 0 : 1]
+__device__ __forceinline__ float conv_dpre(const float* dy, const float* y, const float* x, int64_t yi, int64_t xi_same, int relu,
+                                           int residual) {
+  float g = dy[yi];
+  if (relu) {
+    const float act = residual ? y[yi] - x[xi_same] : y[yi];
+    if (!(act > 0.f)) g = 0.f;
+  }
+  return g;
+}
+__global__ void __launch_bounds__(256) conv_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ y, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int Cin, int Tin, int Cout, int Tout, int k,
+                                                         int stride, int pad, int relu, int residual) {
+  const int ti = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ci = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (ci >= Cin || ti >= Tin) return;
+  const float* xb = x + (int64_t)b * Cin * Tin;
+  const float* yb = y ? y + (int64_t)b * Cout * Tout : nullptr;
+  const float* dyb = dy + (int64_t)b * Cout * Tout;
+  float acc = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const int num = ti + pad - j;
+    if (num < 0 || num % stride != 0) continue;
+    const int to = num / stride;
+    if (to >= Tout) continue;
+    for (int co = 0; co < Cout; ++co) {
+      const float g = conv_dpre(dyb, yb, xb, (int64_t)co * Tout + to, (int64_t)co * Tin + to, relu, residual);
+      acc = fmaf(w[((int64_t)co * Cin + ci) * k + j], g, acc);
+    }
+  }
+  if (residual) acc += dyb[(int64_t)ci * Tout + ti];
+  dx[((int64_t)b * Cin + ci) * Tin + ti] = acc;
+}
+__global__ void __launch_bounds__(64) conv_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ dy, float* __restrict__ dw,
+                                                        float* __restrict__ dbias, int B, int Cin, int Tin, int Cout, int Tout,
+                                                        int k, int stride, int pad, int relu, int residual) {
+  // one wave per (co, ci, j); lanes stride over (b, to)
+  const int j = blockIdx.x % k, ci = (blockIdx.x / k) % Cin, co = blockIdx.x / (k * Cin);
+  float acc = 0.f, accb = 0.f;
+  for (int e = threadIdx.x; e < B * Tout; e += 64) {
+    const int b = e / Tout, to = e % Tout;
+    const float* xb = x + (int64_t)b * Cin * Tin;
+    const float g = conv_dpre(dy + (int64_t)b * Cout * Tout, y ? y + (int64_t)b * Cout * Tout : nullptr, xb,
+                              (int64_t)co * Tout + to, (int64_t)co * Tin + to, relu, residual);
+    const int ti = to * stride + j - pad;
+    if (ti >= 0 && ti < Tin) acc = fmaf(g, xb[(int64_t)ci * Tin + ti], acc);
+    accb += g;
+  }
+  acc = wave_sum_f(acc);
+  accb = wave_sum_f(accb);
+  if (threadIdx.x == 0) {
+    atomicAdd(dw + ((int64_t)co * Cin + ci) * k + j, acc);
+    if (dbias && ci == 0 && j == 0) atomicAdd(dbias + co, accb);
+  }
+}
+extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                                float* dbias, int32_t B, int32_t Cin, int32_t Tin, int32_t Cout, int32_t k, int32_t stride,
+                                int32_t pad, int32_t relu, int32_t residual, void* stream) {
+  WAE_REQUIRE(x && w && dy && dw && B > 0 && Cin > 0 && Tin > 0 && Cout > 0 && k > 0 && stride > 0 && pad >= 0,
+              "enc_conv_bwd: bad arguments");
+  WAE_REQUIRE(!relu || y, "enc_conv_bwd: relu needs the forward output y");
+  const int Tout = (Tin + 2 * pad - k) / stride + 1;
+  hipStream_t st = as_stream(stream);
+  if (dx)
+    hipLaunchKernelGGL(conv_bwd_x_kernel, dim3((Tin + 63) / 64, (Cin + 3) / 4, B), dim3(256), 0, st, x, w, y, dy, dx, Cin, Tin,
+                       Cout, Tout, k, stride, pad, relu, residual);
+  hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(Cout * Cin * k), dim3(64), 0, st, x, y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, k,
+                     stride, pad, relu, residual);
+  return wae_check_launch("enc_conv_bwd");
+}
+
+// ---- VQ backward: straight-through + both halves of vq_loss (vector_quantization.py:41-45) ---------------------------------
+// dlat = dquant + loss_scale * 2*beta*(x - q)/N ;  demb[idx] += loss_scale * 2*(q - x)/N ,  N = B*Tq*D
+__global__ void __launch_bounds__(256) vq_bwd_kernel(const float* __restrict__ lat, const float* __restrict__ quant,
+                                                     const int64_t* __restrict__ idx, const float* __restrict__ dquant,
+                                                     float* __restrict__ dlat, float* __restrict__ demb, int D, int Tq, float c_x,
+                                                     float c_e, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int t = (int)(e % Tq);
+  const int dch = (int)((e / Tq) % D);
+  const int b = (int)(e / ((int64_t)Tq * D));
+  const float diff = lat[e] - quant[e];
+  dlat[e] = (dquant ? dquant[e] : 0.f) + c_x * diff;
+  atomicAdd(demb + idx[(int64_t)b * Tq + t] * D + dch, -c_e * diff);
+}
+extern "C" int wae_vq_bwd(const float* lat, const float* quant, const int64_t* idx, const float* dquant, float* dlat, float* demb,
+                          int32_t B, int32_t D, int32_t Tq, float beta, float loss_scale, void* stream) {
+  WAE_REQUIRE(lat && quant && idx && dlat && demb && B > 0 && D > 0 && Tq > 0, "vq_bwd: bad arguments");
+  const int64_t total = (int64_t)B * D * Tq;
+  const float n = (float)total;
+  hipLaunchKernelGGL(vq_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), lat, quant, idx, dquant,
+                     dlat, demb, D, Tq, loss_scale * 2.f * beta / n, loss_scale * 2.f / n, total);
+  return wae_check_launch("vq_bwd");
+}

@@ -144,6 +144,7 @@ class WaeEngine:
         g, lib, st = self.g, self.lib, self.stream()
         x = c.contiguous().float()
         B = x.shape[0]
+        acts = [x]
         for i, (k, s) in enumerate(P.ENCODER_BLOCKS):
             wname = f"encoder.net.{i}.conv.weight"
             co, ci, _ = self.lay.shapes[wname]
@@ -155,11 +156,13 @@ class WaeEngine:
             L.check(lib.wae_enc_conv_fwd(L.ptr(x), L.ptr(w), L.ptr(bb), L.ptr(y), B, ci, Tin, co, k, s, k // 2, 1,
                                          int(s == 1 and ci == co), st), "enc_conv")
             x = y
+            acts.append(x)
         Tq = x.shape[-1]
         lat = torch.empty(B, g.Cc, Tq, dtype=torch.float32, device=self.device)
         L.check(lib.wae_enc_conv_fwd(L.ptr(x), L.ptr(self.eff[self.lay.off("encoder.lin.weight"):]),
                                      L.ptr(self.eff[self.lay.off("encoder.lin.bias"):]), L.ptr(lat), B, g.encoder_hid, Tq,
                                      g.Cc, 1, 1, 0, 0, 0, st), "enc_lin")
+        self._enc_acts = acts          # inputs of every block (+ the last block's output): backward needs them
         return lat
 
     def vq_forward(self, lat: torch.Tensor, beta: float = 0.25):
@@ -185,6 +188,7 @@ class WaeEngine:
         L.check(lib.wae_enc_conv_fwd(L.ptr(c.contiguous()), L.ptr(self.eff[self.lay.off("wavenet.upsample_net.conv_in.weight"):]),
                                      None, L.ptr(x), B, Cc, Tc, Cc, kin, 1, 0, 0, 0, st), "conv_in")
         n = len(g.upsample_scales)
+        self._up_acts = [c.contiguous(), x]     # conv_in input, then every stage's input
         for i, s in enumerate(g.upsample_scales):
             w = self.eff[self.lay.off(f"wavenet.upsample_net.upsample.up_layers.{2 * i + 1}.weight_v"):]
             last = i == n - 1
@@ -196,6 +200,8 @@ class WaeEngine:
             L.check(lib.wae_upsample_stage_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, Cc, Tin, s, int(last), g.Ccp, self.dt, st),
                     "upsample_stage")
             x, Tin = y, Tin * s
+            if not last:
+                self._up_acts.append(x)
         return out
 
     # ------------------------------------------------------------------ decoder
@@ -278,7 +284,7 @@ class WaeEngine:
                                  L.ptr(ws["h0"]) if train else None, L.ptr(ws["h1"]) if train else None, st), "head")
         out = dict(logits=logits, nll=None, loss=None)
         if tg is not None:
-            ln = lengths.to(torch.int32).contiguous() if lengths is not None else None
+            ln = lengths.to(self.device, torch.int32).contiguous() if lengths is not None else None
             L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, st), "masked_mean")
             out["nll"] = ws["nll"]
             out["loss"] = ws["loss"][0]
@@ -386,4 +392,50 @@ class WaeEngine:
         quant, idx, stats = self.vq_forward(lat, beta)
         out = self.decoder_forward(x, quant, gid, targets, lengths, want_logits, train)
         out.update(latents=lat, quant=quant, idx=idx, vq_loss=stats[0], perp=stats[1])
+        self._fe = dict(lat=lat, quant=quant, idx=idx, beta=beta)
         return out
+
+    # ------------------------------------------------------------------ training step (vqwae_train.py:709-798)
+    def init_optimizer(self, ema: bool = True):
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.shadow = self.params.clone() if ema else None        # ExponentialMovingAverage.register (:343-344)
+        self.opt_scratch = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.opt_step = 0
+
+    def backward(self, x, gid, targets, lengths, gvec=None, loss_scale: float = 1.0):
+        """Gradients of (masked CE [+ vq_loss]) of the last train-mode forward -> self.grads (flat arena)."""
+        from . import backward as BW
+        dc = BW.decoder_backward(self, x, targets, lengths, gid, gvec, loss_scale=loss_scale)
+        if self.g.Ccp and self.g.upsample_scales:
+            BW.frontend_backward(self, dc, loss_scale)
+        return BW.finish_grads(self)
+
+    def train_step(self, x, c, gid, lengths=None, lr: float = 4e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                   weight_decay: float = 0.0, clip_thresh: float = 100.0, ema_decay: float = 0.9999, grad_hook=None):
+        """One optimisation step: forward (teacher forced, targets = x shifted by one), backward, [grad_hook(grads) e.g.
+        the data-parallel all-reduce], clip_grad_norm_ + Adam + EMA.  Returns dict(loss, ce, vq_loss, perp, grad_norm)."""
+        if not hasattr(self, "exp_avg"):
+            self.init_optimizer()
+        self.prepare_weights()
+        if self.g.has_encoder:
+            out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True)
+        else:
+            out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True)
+            self._fe = None
+        grads = self.backward(x, gid, x, lengths)
+        if grad_hook is not None:
+            grad_hook(grads)
+        self.opt_step += 1
+        L.check(self.lib.wae_clip_adam_ema(L.ptr(self.params), L.ptr(grads), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                           L.ptr(self.shadow), self.lay.total, L.ptr(self.opt_scratch), L.ptr(self.grad_norm),
+                                           self.opt_step, lr, betas[0], betas[1], eps, weight_decay, clip_thresh, ema_decay,
+                                           self.stream()), "clip_adam_ema")
+        self.weights_dirty = True
+        res = dict(ce=out["loss"], grad_norm=self.grad_norm[0])
+        if self.g.has_encoder:
+            res.update(vq_loss=out["vq_loss"], perp=out["perp"], loss=out["loss"] + out["vq_loss"])
+        else:
+            res["loss"] = out["loss"]
+        return res
