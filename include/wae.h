@@ -57,9 +57,10 @@ int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, i
 /* dst[i + b*dst_stride] = (dtype) (map[i] < 0 ? 0 : src[map[i] + b*src_stride]),  i < n, b < nbatch */
 int wae_pack_gather(const float* src, const int32_t* map, void* dst, int64_t n, int32_t nbatch,
                     int64_t src_stride, int64_t dst_stride, int32_t dtype, void* stream);
-/* inverse (gradients): dst[map[i] + b*dst_stride] += src[i + b*src_stride] (fp32 atomics; several i may share a slot) */
+/* inverse (gradients): dst[map[i] + b*dst_stride] += src[s(i) + b*src_stride] (fp32 atomics; several i may share a
+ * slot); s(i) = i, or with src_cols > 0 the element (i / src_cols, i % src_cols) of a row-major tile of pitch src_ld */
 int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int64_t n, int32_t nbatch,
-                           int64_t src_stride, int64_t dst_stride, void* stream);
+                           int64_t src_stride, int64_t dst_stride, int32_t src_cols, int64_t src_ld, void* stream);
 
 /* ---- a1 encoder block (vqvae_model.py:17-23): y = relu(conv1d(x,w,b,stride,pad=k/2)) (+x) ; fp32 (B,C,T)
  * relu/residual/pad selectable so the same entry serves Encoder.lin (vqvae_model.py:50, k=1) and the
@@ -218,21 +219,27 @@ int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t
                 int64_t out_stride, const void* aux, int64_t aux_stride, void* stream);
 
 /* ---- weight gradients: C[m][n] += alpha * sum_{b,t} P[b,t][m] * Q[b,t+shift][n]  (csrc/gemm_tn.hip) ----------
- * P (B,T,p_stride) and Q (B,T,q_stride) time-major dtype arrays of which the first M / N columns take part (pointers
- * may be pre-offset to a column block).  onehot_idx != NULL: P[t][m] = (onehot_idx[b*T+t] == m) (first-conv gradient).
- * ones_col >= N: a virtual all-ones Q column; clip b accumulates sum_t P[b,t][m] into C[m][ones_col + b]
- * (bias and per-clip conditioning-bias gradients).  C fp32, leading dimension ldc; fp32 atomics (not bitwise
- * reproducible run to run). */
-typedef struct wae_tn_desc {
-  int32_t dtype;
-  int32_t B, T;
-  int32_t M, N;
+ * The work is described as an array of 128x128 output tiles in DEVICE memory; one launch processes them all (the
+ * several weight gradients of a layer share a launch).  P, Q: time-major dtype arrays, pointers already offset to the
+ * tile's first column, of which the first m_valid / n_valid columns take part.  onehot != NULL: P[t][m] =
+ * (onehot[b*T+t] == m0 + m) (first-conv gradient).  ones_col >= 0: a virtual all-ones Q column at that tile-local
+ * index; clip b accumulates sum_t P[b,t][m] into C[m][ones_col + b] (bias / per-clip conditioning-bias gradients).
+ * Each tile is contracted over the time range of one clip split `splits` ways; results are added with fp32 atomics
+ * (not bitwise reproducible run to run). */
+typedef struct wae_tn_tile {
+  const void* P;
+  const void* Q;
+  const int32_t* onehot;
+  float* C;
+  int64_t p_stride, q_stride, ldc;
+  int32_t m_valid, n_valid;
+  int32_t m0;
   int32_t shift;
   int32_t ones_col;
   float alpha;
-} wae_tn_desc;
-int wae_gemm_tn(const wae_tn_desc* d, const void* P, int64_t p_stride, const int32_t* onehot_idx, const void* Q,
-                int64_t q_stride, float* C, int64_t ldc, void* stream);
+} wae_tn_tile;
+int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, int32_t ntiles, int32_t B, int32_t T, int32_t splits,
+                      void* stream);
 
 /* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
  * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).

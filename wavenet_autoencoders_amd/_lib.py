@@ -28,8 +28,9 @@ class TmDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "M", "nsrc", "mode")] + [("alpha", c_f32)]
 
 
-class TnDesc(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "M", "N", "shift", "ones_col")] + [("alpha", c_f32)]
+class TnTile(ctypes.Structure):          # include/wae.h: wae_tn_tile (device array element)
+    _fields_ = [("P", c_vp), ("Q", c_vp), ("onehot", c_vp), ("C", c_vp), ("p_stride", c_i64), ("q_stride", c_i64), ("ldc", c_i64),
+                ("m_valid", c_i32), ("n_valid", c_i32), ("m0", c_i32), ("shift", c_i32), ("ones_col", c_i32), ("alpha", c_f32)]
 
 
 class HeadDesc(ctypes.Structure):
@@ -43,7 +44,7 @@ SIGNATURES = {
     "wae_weight_norm_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "wae_weight_norm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "wae_pack_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_vp]),
-    "wae_unpack_scatter_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp]),
+    "wae_unpack_scatter_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i64, c_vp]),
     "wae_enc_conv_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp]),
     "wae_vq_nearest": (c_i32, [c_vp] * 6 + [c_i32] * 4 + [c_f32, c_vp]),
     "wae_upsample_stage_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
@@ -59,7 +60,7 @@ SIGNATURES = {
     "wae_head_bwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 7 + [c_f32] + [c_vp] * 5),
     "wae_head_bwd_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_gemm_tm": (c_i32, [ctypes.POINTER(TmDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
-    "wae_gemm_tn": (c_i32, [ctypes.POINTER(TnDesc), c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "wae_gemm_tn_tiles": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "wae_sum_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_dmol_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),

@@ -86,10 +86,35 @@ def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=Non
                                 out_stride, ctypes.c_void_p(aux_ptr) if aux_ptr else None, aux_stride, eng.stream()), "gemm_tm")
 
 
-def _tn(eng, B, T, M, N, shift, ones_col, alpha, p_ptr, p_stride, q_ptr, q_stride, c_ptr, ldc, onehot=None):
-    d = L.TnDesc(eng.dt, B, T, M, N, shift, ones_col, alpha)
-    L.check(eng.lib.wae_gemm_tn(ctypes.byref(d), ctypes.c_void_p(p_ptr) if p_ptr else None, p_stride, L.ptr(onehot),
-                                ctypes.c_void_p(q_ptr), q_stride, ctypes.c_void_p(c_ptr), ldc, eng.stream()), "gemm_tn")
+class TileTable:
+    """Host builder of a device array of wae_tn_tile (include/wae.h): each add() is one contraction
+    C[M][N (+ones)] += alpha * P^T Q, cut into 128x128 output tiles."""
+
+    def __init__(self, eng):
+        self.eng, self.tiles = eng, []
+
+    def add(self, M, N, shift, ones_col, alpha, p_ptr, p_stride, q_ptr, q_stride, c_ptr, ldc, onehot_ptr=0):
+        es = self.eng.w_glu.element_size()
+        nmax = max(N, ones_col + 1) if ones_col >= 0 else N
+        for mt in range((M + 127) // 128):
+            for nt in range((nmax + 127) // 128):
+                oc = ones_col - 128 * nt if (ones_col >= 0 and 0 <= ones_col - 128 * nt < 128) else -1
+                self.tiles.append(L.TnTile(
+                    (p_ptr + mt * 128 * es) if p_ptr else None, q_ptr + nt * 128 * es, onehot_ptr or None,
+                    c_ptr + (mt * 128 * ldc + nt * 128) * 4, p_stride, q_stride, ldc,
+                    min(128, M - 128 * mt), max(0, min(128, N - 128 * nt)), 128 * mt, shift, oc, alpha))
+
+    def finalize(self, B):
+        arr = (L.TnTile * len(self.tiles))(*self.tiles)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.dev = host.to(self.eng.device)
+        self.n = len(self.tiles)
+        self.splits = max(1, min(4, round(512 / max(1, self.n * B))))
+        return self
+
+    def launch(self, B, T):
+        eng = self.eng
+        L.check(eng.lib.wae_gemm_tn_tiles(eng.dt, L.ptr(self.dev), self.n, B, T, self.splits, eng.stream()), "gemm_tn_tiles")
 
 
 def bwd_workspace(eng, B, T):
@@ -103,9 +128,49 @@ def bwd_workspace(eng, B, T):
                   dy=torch.zeros(B, T, g.Op, dtype=td, device=dev),
                   dh1=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
                   dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
-                  dc=torch.zeros(B, T, max(g.Ccp, 64), dtype=td, device=dev))
+                  dc=torch.zeros(B, T, max(g.Ccp, 64), dtype=td, device=dev),
+                  ids=torch.zeros(B, T, dtype=torch.int32, device=dev))
+        _build_tile_tables(eng, ws, eng._ws[(B, T, True)], B, T)
         eng._ws[key] = ws
     return ws
+
+
+def _build_tile_tables(eng, ws, fw, B, T):
+    """All weight-gradient contractions of a step as two kinds of launches: one table per layer (dW1 taps, dWc + zb sums,
+    dW_out + bias) and one global table (dW_skip of every layer + bias, head matrices + biases, first-conv table)."""
+    g, sm = eng.g, eng.sm
+    es = eng.w_glu.element_size()
+    Z2 = 2 * g.Hp
+    dzs = g.layers * Z2
+    c1, co = eng.cview["c1"], eng.cview["co"]
+    ws["tt_layer"] = []
+    for l in range(g.layers):
+        d = g.dilations[l]
+        tt = TileTable(eng)
+        dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
+        c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
+        xl = fw["x"][l]
+        for tap in range(g.k):
+            last = tap == g.k - 1 and not g.Ccp
+            tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), 1.0, dz_ptr, dzs, xl.data_ptr(), g.Rp,
+                   c1l + tap * g.Rp * 4, sm["ld1"])
+        if g.Ccp:
+            tt.add(Z2, g.Ccp, 0, g.Ccp, 1.0, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
+        if l < g.layers - 1:
+            g_next = ws["gx"][(l + 1) % 2]
+            tt.add(g.Rp, g.Hp, 0, g.Hp, 1.0, g_next.data_ptr(), g.Rp, fw["u"].data_ptr() + l * g.Hp * es, g.Ku,
+                   co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
+        ws["tt_layer"].append(tt.finalize(B))
+    tt = TileTable(eng)
+    c3, c1h, cs, ctab = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"], eng.cview["ctab"]
+    tt.add(g.Op, g.Sp, 0, g.Sp, 1.0, ws["dy"].data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
+    tt.add(g.Sp, g.Sp, 0, g.Sp, 1.0, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
+    tt.add(g.Sp, g.Ku, 0, g.Ku, 1.0, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
+    ws["tt_head"] = tt.finalize(B)
+    tt = TileTable(eng)
+    g0 = ws["gx"][0]                                    # dxhat_0 lands in gx[0 % 2]
+    tt.add(g.O, g.Rp, 0, -1, 1.0 / RS, 0, 0, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp, onehot_ptr=ws["ids"].data_ptr())
+    ws["tt_first"] = tt.finalize(B)
 
 
 def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: Optional[torch.Tensor],
@@ -140,11 +205,10 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     L.check(lib.wae_head_bwd(ctypes.byref(hd), L.ptr(fw["h0"]), L.ptr(fw["h1"]), L.ptr(eng.w_hb), b3, L.ptr(fw["lse"]), L.ptr(tg),
                              L.ptr(ln), inv_count, L.ptr(ext_dy), L.ptr(ws["dy"]), L.ptr(ws["dh1"]), L.ptr(ws["dskip"]), st),
             "head_bwd")
-    dy = ext_dy if ext_dy is not None else ws["dy"]
+    if ext_dy is not None:
+        ws["dy"].copy_(ext_dy)                # the tile table points at ws["dy"]
     c3, c1h, cs = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"]
-    _tn(eng, B, T, g.Op, g.Sp, 0, g.Sp, 1.0, dy.data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
-    _tn(eng, B, T, g.Sp, g.Sp, 0, g.Sp, 1.0, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
-    _tn(eng, B, T, g.Sp, g.Ku, 0, g.Ku, 1.0, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
+    ws["tt_head"].launch(B, T)
 
     # ---- gated stack, last layer first ---------------------------------------------------------------------------
     Z2 = 2 * g.Hp
@@ -153,22 +217,13 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     g_next = ws["gzero"]                      # dxhat_{L} = 0: the last layer's x' is dead (wavenet.py:205-207)
     for l in range(g.layers - 1, -1, -1):
         d = g.dilations[l]
+        assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % 2].data_ptr()
         dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
         # du -> dz
         _tm(eng, B, T, g.Hp, 2, 1.0, [(g_next.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
             eng.w_bu.data_ptr() + l * eng.n_bu * es, dz_ptr, dzs, fw["z"][l].data_ptr(), Z2)
-        # weight gradients of the dilated conv (+ conditioning 1x1, + per-clip zb sums)
-        c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
-        xl = fw["x"][l]
-        for tap in range(g.k):
-            last = tap == g.k - 1 and not g.Ccp
-            _tn(eng, B, T, Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), 1.0, dz_ptr, dzs, xl.data_ptr(), g.Rp,
-                c1l + tap * g.Rp * 4, sm["ld1"])
-        if g.Ccp:
-            _tn(eng, B, T, Z2, g.Ccp, 0, g.Ccp, 1.0, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
-        if l < g.layers - 1:
-            _tn(eng, B, T, g.Rp, g.Hp, 0, g.Hp, 1.0, g_next.data_ptr(), g.Rp, fw["u"].data_ptr() + l * g.Hp * es, g.Ku,
-                co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
+        # weight gradients of the dilated conv, the conditioning 1x1 (+ per-clip zb sums) and conv1x1_out: one launch
+        ws["tt_layer"][l].launch(B, T)
         # dx
         g_cur = ws["gx"][l % 2]
         srcs = [(dz_ptr, dzs, Z2, (g.k - 1 - tap) * d) for tap in range(g.k)]
@@ -179,16 +234,19 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), dzs, dzs, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
     # ---- first conv: dW[r][class] = sum_t dx0[t][r] onehot(id[t])[class];  dx0 = dxhat_0 / sqrt(.5) -----------------------
     ctab, fb = eng.cview["ctab"], eng.cview["fb"]
-    _tn(eng, B, T, g.O, g.Rp, 0, -1, 1.0 / RS, None, 0, g_next.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp, onehot=xi)
+    assert g_next.data_ptr() == ws["gx"][0].data_ptr()
+    ws["ids"].copy_(xi)
+    ws["tt_first"].launch(B, T)
     L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
 
     # ---- scatter the dense tiles into the effective-weight gradient arena ----------------------------------------------
-    def scat(src, mp, n, nb=1, ss=0, ds=0):
-        L.check(lib.wae_unpack_scatter_add(L.ptr(src), L.ptr(mp), L.ptr(eng.d_eff), n, nb, ss, ds, st), "scatter")
+    def scat(src, mp, n, nb=1, ss=0, ds=0, cols=0, ld=0, off=0):
+        L.check(lib.wae_unpack_scatter_add(ctypes.c_void_p(src.data_ptr() + off * 4), L.ptr(mp), L.ptr(eng.d_eff), n, nb, ss, ds,
+                                           cols, ld, st), "scatter")
     scat(c1, sm["w1"], Z2 * sm["ld1"], g.layers, Z2 * sm["ld1"], lay.layer_stride)
     scat(co, sm["wo"], g.Rp * sm["ldo"], g.layers, g.Rp * sm["ldo"], lay.layer_stride)
-    scat(cs, sm["ws"], g.Sp * sm["lds"])
-    scat(cs, sm["bs"], g.Sp * sm["lds"], g.layers, 0, lay.layer_stride)
+    scat(cs, sm["ws"], g.Sp * g.Ku, cols=g.Ku, ld=sm["lds"])
+    scat(cs, sm["bs"], g.Sp * P.ONES_PAD, g.layers, 0, lay.layer_stride, cols=P.ONES_PAD, ld=sm["lds"], off=g.Ku)
     scat(c3, sm["w3"], g.Op * sm["ldh"])
     scat(c1h, sm["w1h"], g.Sp * sm["ldh"])
     scat(ctab, sm["tab"], sm["tab"].numel())

@@ -39,7 +39,10 @@ __global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* 
     if (u >= 0 && u < Tout) acc = fmaf(dout[e], in[row * Tin + u / s], acc);
   }
   acc = wave_sum_f(acc);
-  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(dw + j, acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dw + j, part[0] + part[1] + part[2] + part[3]);   // one atomic per block: 11 hot addresses
 }
 extern "C" int wae_upsample_stage_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, int32_t B,
                                       int32_t C, int32_t Tin, int32_t s, void* stream) {
@@ -47,7 +50,7 @@ extern "C" int wae_upsample_stage_bwd(const float* dout, const float* in, const 
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(upsample_stage_bwd_in_kernel, dim3((Tin + 255) / 256, C, B), dim3(256), 0, st, dout, w, din, C, Tin, s);
   const int64_t n = (int64_t)B * C * Tin * s;
-  const int gx = (int)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256);
+  const int gx = (int)((n + 255) / 256 > 96 ? 96 : (n + 255) / 256);
   hipLaunchKernelGGL(upsample_stage_bwd_w_kernel, dim3(gx, 2 * s + 1), dim3(256), 0, st, dout, in, dw, B * C, Tin, s);
   return wae_check_launch("upsample_stage_bwd");
 }

@@ -14,52 +14,79 @@
 // (rows of 32 consecutive n per half-wave = full-rate shape, MI355X_MICROARCH.md "Global float atomics").
 #include "wae_common.hpp"
 
-struct TnArgs {
-  const char* P;
-  const char* Q;
-  const int32_t* onehot_idx;  // if set, P[t][m] = (idx[b*T+t] == m) and P is ignored
-  float* C;
-  int64_t p_stride, q_stride;  // elements per row
-  int64_t ldc;
-  int B, T, M, N;  // valid columns of P and Q
-  int shift;       // Q row = t + shift
-  int ones_col;    // < 0: off
-  int tchunk;      // time steps per workgroup
-  int ntiles;      // tiles along N
+// One 128x128 output tile of one contraction; a launch processes an array of them (several weight gradients of a
+// layer, or all the one-off ones, share one launch so that the chip is filled without splitting k finely: fp32
+// atomics cap at ~1.3 TB/s chip-wide, so each workgroup must contract a long k-range per byte it adds to C).
+struct TnTile {
+  const char* P;          // time-major (B,T,p_stride), already offset to the tile's first column
+  const char* Q;          // time-major (B,T,q_stride), already offset to the tile's first column
+  const int32_t* onehot;  // if set: P[t][m] = (onehot[b*T+t] == m0 + m)
+  float* C;               // top-left of the tile in the fp32 output
+  int64_t p_stride, q_stride, ldc;
+  int m_valid, n_valid;   // valid columns of P / Q inside this tile (<= 128)
+  int m0;                 // first P column of the tile (one-hot compare only)
+  int shift;              // Q row = t + shift
+  int ones_col;           // tile-local index (< 128) of the virtual all-ones Q column, or -1
   float alpha;
+};
+struct TnArgs {
+  const TnTile* tiles;
+  int B, T;
+  int tchunk;  // time steps per workgroup
 };
 
 #define TN_KT 32      // time rows per LDS slab
 #define TN_PITCH_BF16 320   // bytes per slab row (128 bf16 + pad): conflict-free transposed reads
 #define TN_PITCH_F32 528    // 128 fp32 + 16 B pad
 
-template <typename E>
-__device__ __forceinline__ void tn_load_frag(const char* slab, int k0, int cbase, int lane, typename ET<E>::frag& f);
-
-// bf16: 8 consecutive k (time rows k0 + 8h + 0..7) of column cbase + (lane & 31)
-template <>
-__device__ __forceinline__ void tn_load_frag<__bf16>(const char* slab, int k0, int cbase, int lane, bf16x8& f) {
+// Operand fragments of one k-step for a wave's 64x64 sub-tile: 2 A (P columns wm, wm+32) and 2 B (Q columns wn, wn+32).
+// bf16: 8 consecutive k (time rows k0 + 8h + 0..7) of column cbase + (lane & 31): two ds_read_b64_tr_b16 each; all eight
+// reads are issued back to back and retired by ONE wait that carries every destination (cdna_hip_programming.md 5.7 ii).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ void tn_load_frags(const char* sp, const char* sq, int k0, int wm, int wn, int lane, bf16x8 (&a)[2],
+                                              bf16x8 (&b)[2]) {
   const int grp = (lane >> 4) & 1, h = lane >> 5, q = (lane & 15) >> 2, pp = lane & 3;
-  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)slab +
-                        (k0 + 8 * h + q) * TN_PITCH_BF16 + (cbase + 16 * grp + 4 * pp) * 2;
-  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-  u32x2 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(lo), "=&v"(hi)
-               : "v"(addr), "n"(4 * TN_PITCH_BF16));
+  const unsigned rowoff = (k0 + 8 * h + q) * TN_PITCH_BF16 + (16 * grp + 4 * pp) * 2;
+  const unsigned ap = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)sp + rowoff + wm * 2;
+  const unsigned bp = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)sq + rowoff + wn * 2;
+  u32x2 r[8];
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r[0]) : "v"(ap));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r[1]) : "v"(ap), "n"(4 * TN_PITCH_BF16));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:64" : "=v"(r[2]) : "v"(ap));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r[3]) : "v"(ap), "n"(4 * TN_PITCH_BF16 + 64));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r[4]) : "v"(bp));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r[5]) : "v"(bp), "n"(4 * TN_PITCH_BF16));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:64" : "=v"(r[6]) : "v"(bp));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r[7]) : "v"(bp), "n"(4 * TN_PITCH_BF16 + 64));
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  u32x4 r = {lo.x, lo.y, hi.x, hi.y};
-  f = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    u32x4 va = {r[2 * i].x, r[2 * i].y, r[2 * i + 1].x, r[2 * i + 1].y};
+    u32x4 vb = {r[4 + 2 * i].x, r[4 + 2 * i].y, r[4 + 2 * i + 1].x, r[4 + 2 * i + 1].y};
+    a[i] = __builtin_bit_cast(bf16x8, va);
+    b[i] = __builtin_bit_cast(bf16x8, vb);
+  }
 }
-// fp32: fragment = 4 k-pairs; element j pairs time rows (k0 + 2j + h) -> one ds_read_b32 each
-template <>
-__device__ __forceinline__ void tn_load_frag<float>(const char* slab, int k0, int cbase, int lane, f32x4& f) {
+// fp32: fragment = 4 k-pairs; element j pairs time rows (k0 + 2j + h) -> one ds_read_b32 each (compiler scheduled)
+__device__ __forceinline__ f32x4 tn_frag_f32(const char* slab, int k0, int cbase, int lane) {
   const int i = lane & 31, h = lane >> 5;
   const float* base = (const float*)(slab + (k0 + h) * TN_PITCH_F32) + cbase + i;
+  f32x4 f;
   f.x = base[0];
   f.y = base[2 * TN_PITCH_F32 / 4];
   f.z = base[4 * TN_PITCH_F32 / 4];
   f.w = base[6 * TN_PITCH_F32 / 4];
+  return f;
+}
+__device__ __forceinline__ void tn_load_frags(const char* sp, const char* sq, int k0, int wm, int wn, int lane, f32x4 (&a)[2],
+                                              f32x4 (&b)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a[i] = tn_frag_f32(sp, k0, wm + 32 * i, lane);
+    b[i] = tn_frag_f32(sq, k0, wn + 32 * i, lane);
+  }
 }
 
 template <typename E>
@@ -73,10 +100,9 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabP = smem;            // [2][SLAB]
   char* slabQ = smem + 2 * SLAB; // [2][SLAB]
+  const TnTile tl = p.tiles[blockIdx.x];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int mt = blockIdx.x / p.ntiles, nt = blockIdx.x % p.ntiles;
-  const int m0 = mt * 128, n0 = nt * 128;
   const int splits = (p.T + p.tchunk - 1) / p.tchunk;
   const int b = blockIdx.y / splits;
   const int tbeg = (blockIdx.y % splits) * p.tchunk;
@@ -96,42 +122,41 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
   constexpr int NPASS = TN_KT / RPP;
   const int lrow = threadIdx.x / CPR, lpc = threadIdx.x % CPR;
   constexpr int EP = 16 / ES;         // elements per piece
+  const int colp = lpc * EP, colq = lpc * EP;
   f32x4 rp[NPASS], rq[NPASS];
   auto fetch = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int t = t0 + i * RPP + lrow;
-      const int colp = m0 + lpc * EP, colq = n0 + lpc * EP;
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
       rp[i] = z;
       rq[i] = z;
       if (t < tend) {
-        if (p.onehot_idx) {
-          const int id = p.onehot_idx[(int64_t)b * p.T + t];
+        if (tl.onehot) {
+          const int id = tl.onehot[(int64_t)b * p.T + t] - tl.m0;
           if (id >= colp && id < colp + EP) {
             if constexpr (ES == 2) {
               bf16x8 oh = {};
               oh[id - colp] = (__bf16)1.0f;
               rp[i] = __builtin_bit_cast(f32x4, oh);
             } else {
-              float o4[4] = {0.f, 0.f, 0.f, 0.f};
+              float* o4 = (float*)&rp[i];
               o4[id - colp] = 1.0f;
-              rp[i].x = o4[0]; rp[i].y = o4[1]; rp[i].z = o4[2]; rp[i].w = o4[3];
             }
           }
-        } else if (colp < p.M) {
-          rp[i] = *(const f32x4*)(p.P + (((int64_t)b * p.T + t) * p.p_stride + colp) * ES);
+        } else if (colp < tl.m_valid) {
+          rp[i] = *(const f32x4*)(tl.P + (((int64_t)b * p.T + t) * tl.p_stride + colp) * ES);
         }
-        const int tq = t + p.shift;
-        if (colq < p.N && tq >= 0 && tq < p.T) rq[i] = *(const f32x4*)(p.Q + (((int64_t)b * p.T + tq) * p.q_stride + colq) * ES);
-        if (p.ones_col >= colq && p.ones_col < colq + EP) {   // virtual all-ones column
+        const int tq = t + tl.shift;
+        if (colq < tl.n_valid && tq >= 0 && tq < p.T) rq[i] = *(const f32x4*)(tl.Q + (((int64_t)b * p.T + tq) * tl.q_stride + colq) * ES);
+        if (tl.ones_col >= colq && tl.ones_col < colq + EP) {   // virtual all-ones column
           if constexpr (ES == 2) {
             bf16x8 v = __builtin_bit_cast(bf16x8, rq[i]);
-            v[p.ones_col - colq] = (__bf16)1.0f;
+            v[tl.ones_col - colq] = (__bf16)1.0f;
             rq[i] = __builtin_bit_cast(f32x4, v);
           } else {
             float* v = (float*)&rq[i];
-            v[p.ones_col - colq] = 1.0f;
+            v[tl.ones_col - colq] = 1.0f;
           }
         }
       }
@@ -159,11 +184,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
 #pragma unroll
     for (int k0 = 0; k0 < TN_KT; k0 += KSTEP) {
       frag a[2], bq[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        tn_load_frag<E>(sp, k0, wm + 32 * i, lane, a[i]);
-        tn_load_frag<E>(sq, k0, wn + 32 * i, lane, bq[i]);
-      }
+      tn_load_frags(sp, sq, k0, wm, wn, lane, a, bq);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -179,50 +200,39 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int col = n0 + wn + 32 * j + nl;
-      const bool ones = p.ones_col >= 0 && col == p.ones_col;
-      if (!(col < p.N || ones)) continue;
+      int col = wn + 32 * j + nl;
+      const bool ones = tl.ones_col >= 0 && col == tl.ones_col;
+      if (!(col < tl.n_valid || ones)) continue;
       if (ones) col += b;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int rows_ok = p.onehot_idx ? p.M : p.M;
-        if (row < rows_ok) atomicAdd(p.C + (int64_t)row * p.ldc + col, p.alpha * acc[i][j][r]);
+        const int row = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < tl.m_valid) atomicAdd(tl.C + (int64_t)row * tl.ldc + col, tl.alpha * acc[i][j][r]);
       }
     }
 }
 
-extern "C" int wae_gemm_tn(const wae_tn_desc* d, const void* P, int64_t p_stride, const int32_t* onehot_idx, const void* Q,
-                           int64_t q_stride, float* C, int64_t ldc, void* stream) {
-  WAE_REQUIRE(d && Q && C && (P || onehot_idx), "gemm_tn: null pointer argument");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "gemm_tn: bad dtype");
-  WAE_REQUIRE(d->B > 0 && d->T > 0 && d->M > 0 && d->N > 0, "gemm_tn: bad sizes");
-  const int ep = d->dtype == WAE_BF16 ? 8 : 4;
-  WAE_REQUIRE(d->M % ep == 0 && d->N % ep == 0, "gemm_tn: M and N must be multiples of %d", ep);
-  WAE_REQUIRE(d->ones_col < 0 || (d->ones_col >= d->N && d->ones_col + d->B <= ldc), "gemm_tn: ones_col must lie in [N, ldc-B]");
+extern "C" int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, int32_t ntiles, int32_t B, int32_t T,
+                                 int32_t splits, void* stream) {
+  WAE_REQUIRE(tiles_dev && ntiles > 0 && B > 0 && T > 0 && splits >= 1, "gemm_tn_tiles: bad arguments");
+  WAE_REQUIRE(dtype == WAE_F32 || dtype == WAE_BF16, "gemm_tn_tiles: bad dtype");
+  static_assert(sizeof(wae_tn_tile) == sizeof(TnTile), "wae_tn_tile and TnTile must have the same layout");
   TnArgs a;
-  a.P = (const char*)P; a.Q = (const char*)Q; a.onehot_idx = onehot_idx; a.C = C; a.p_stride = p_stride; a.q_stride = q_stride;
-  a.ldc = ldc; a.B = d->B; a.T = d->T; a.M = d->M; a.N = d->N; a.shift = d->shift; a.ones_col = d->ones_col; a.alpha = d->alpha;
-  const int nmax = d->ones_col >= 0 ? d->ones_col + 1 : d->N;
-  const int mtiles = (d->M + 127) / 128, ntiles = (nmax + 127) / 128;
-  a.ntiles = ntiles;
-  // k-split: enough workgroups to fill 256 CUs twice, at least 256 time steps each
-  int splits = (2 * 256 + mtiles * ntiles * d->B - 1) / (mtiles * ntiles * d->B);
-  if (splits < 1) splits = 1;
-  int tchunk = (d->T + splits - 1) / splits;
+  a.tiles = (const TnTile*)tiles_dev;
+  a.B = B; a.T = T;
+  int tchunk = (T + splits - 1) / splits;
   tchunk = (tchunk + TN_KT - 1) / TN_KT * TN_KT;
-  if (tchunk < 256) tchunk = 256;
   a.tchunk = tchunk;
-  splits = (d->T + tchunk - 1) / tchunk;
-  const int pitch = d->dtype == WAE_BF16 ? TN_PITCH_BF16 : TN_PITCH_F32;
+  const int nsp = (T + tchunk - 1) / tchunk;
+  const int pitch = dtype == WAE_BF16 ? TN_PITCH_BF16 : TN_PITCH_F32;
   const size_t lds = (size_t)4 * TN_KT * pitch;
   hipStream_t st = as_stream(stream);
-  dim3 grid(mtiles * ntiles, d->B * splits);
-  if (d->dtype == WAE_BF16) {
+  dim3 grid(ntiles, B * nsp);
+  if (dtype == WAE_BF16) {
     hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, dim3(256), lds, st, a);
   } else {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), lds, st, a);
   }
-  return wae_check_launch("gemm_tn");
+  return wae_check_launch("gemm_tn_tiles");
 }

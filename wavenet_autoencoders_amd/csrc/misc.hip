@@ -147,20 +147,22 @@ extern "C" int wae_pack_gather(const float* src, const int32_t* map, void* dst, 
 
 __global__ void __launch_bounds__(256) unpack_scatter_add_kernel(const float* __restrict__ src,
                                                                  const int32_t* __restrict__ map, float* __restrict__ dst,
-                                                                 int64_t n, int64_t src_stride, int64_t dst_stride) {
+                                                                 int64_t n, int64_t src_stride, int64_t dst_stride, int src_cols,
+                                                                 int64_t src_ld) {
   const int b = blockIdx.y;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int32_t m = map[i];
-    if (m >= 0) atomicAdd(dst + m + b * dst_stride, src[i + b * src_stride]);
+    const int64_t si = src_cols > 0 ? (i / src_cols) * src_ld + (i % src_cols) : i;
+    if (m >= 0) atomicAdd(dst + m + b * dst_stride, src[si + b * src_stride]);
   }
 }
 
 extern "C" int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int64_t n, int32_t nbatch,
-                                      int64_t src_stride, int64_t dst_stride, void* stream) {
+                                      int64_t src_stride, int64_t dst_stride, int32_t src_cols, int64_t src_ld, void* stream) {
   WAE_REQUIRE(src && map && dst && n > 0 && nbatch > 0, "unpack_scatter_add: bad arguments");
   const int gx = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(unpack_scatter_add_kernel, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
-                     src_stride, dst_stride);
+                     src_stride, dst_stride, src_cols, src_ld);
   return wae_check_launch("unpack_scatter_add");
 }
 
@@ -403,26 +405,37 @@ __global__ void __launch_bounds__(256) gproj_bwd_kernel(const float* __restrict_
                                                         int ones_col, int B, int G, int Hp, int Cg) {
   const int l = blockIdx.x;
   const int H = G / 2;
-  const float* cl = c1 + (int64_t)l * c_layer_stride;
+  const float* cl = c1 + (int64_t)l * c_layer_stride + ones_col;
+  // phase 1: one thread per gate row: bias gradient and the row of dWg
   for (int r = threadIdx.x; r < 2 * Hp; r += 256) {
     const int half = r >= Hp, i = r - half * Hp;
     if (i >= H) continue;
     const int ch = half * H + i;
     float sb = 0.f;
-    for (int b = 0; b < B; ++b) sb += cl[(int64_t)r * ld + ones_col + b];
-    atomicAdd(d_eff + bias_off + (int64_t)l * layer_stride + ch, sb);
+    for (int b = 0; b < B; ++b) sb += cl[(int64_t)r * ld + b];
+    d_eff[bias_off + (int64_t)l * layer_stride + ch] += sb;           // this (layer,row) slot is touched by one thread only
     if (wg_off < 0 || Cg <= 0) continue;
-    const float* wg = eff + wg_off + (int64_t)l * layer_stride + (int64_t)ch * Cg;
     float* dwg = d_eff + wg_off + (int64_t)l * layer_stride + (int64_t)ch * Cg;
     for (int c = 0; c < Cg; ++c) {
       float a = 0.f;
       for (int b = 0; b < B; ++b) {
-        const float dz = cl[(int64_t)r * ld + ones_col + b];
         const float e = gid ? eff[emb_off + (int64_t)gid[b] * Cg + c] : gvec[(int64_t)b * Cg + c];
-        a = fmaf(dz, e, a);
-        if (gid) atomicAdd(d_eff + emb_off + (int64_t)gid[b] * Cg + c, dz * wg[c]);
+        a = fmaf(cl[(int64_t)r * ld + b], e, a);
       }
-      atomicAdd(dwg + c, a);
+      dwg[c] += a;
+    }
+  }
+  // phase 2: embedding rows: thread per (clip, feature) reduces over the gate rows first -> one atomic each
+  if (gid && wg_off >= 0 && Cg > 0) {
+    for (int e = threadIdx.x; e < B * Cg; e += 256) {
+      const int b = e / Cg, c = e % Cg;
+      float a = 0.f;
+      for (int r = 0; r < 2 * Hp; ++r) {
+        const int half = r >= Hp, i = r - half * Hp;
+        if (i >= H) continue;
+        a = fmaf(cl[(int64_t)r * ld + b], eff[wg_off + (int64_t)l * layer_stride + (int64_t)(half * H + i) * Cg + c], a);
+      }
+      atomicAdd(d_eff + emb_off + (int64_t)gid[b] * Cg + c, a);
     }
   }
 }

@@ -473,9 +473,10 @@ def grad_scatter_maps(g: Geometry, lay: ParamLayout) -> dict:
     ws = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v")
     l, hh = col // g.Hp, col % g.Hp
     m = np.where((row < g.S) & (col < g.layers * g.Hp) & (hh < g.H), ws + l * lay.layer_stride + row * g.H + hh, -1)
-    out["ws"], out["lds"] = m.astype(np.int32).reshape(-1), lds
+    out["ws"], out["lds"] = m[:, :g.Ku].astype(np.int32).reshape(-1), lds          # (Sp, Ku) sub-tile of the (Sp, lds) buffer
     bs = lay.off("wavenet.conv_layers.0.conv1x1_skip.bias")
-    out["bs"] = np.where((row < g.S) & (col >= g.Ku), bs + row, -1).astype(np.int32).reshape(-1)   # relative to layer 0
+    rowb = np.arange(g.Sp)[:, None] + np.zeros((1, ONES_PAD), dtype=np.int64)
+    out["bs"] = np.where(rowb < g.S, bs + rowb, -1).astype(np.int32).reshape(-1)   # (Sp, ONES_PAD) ones columns, layer 0
     # head
     ldh = g.Sp + ONES_PAD
     row, col = np.meshgrid(np.arange(g.Op), np.arange(ldh), indexing="ij")
