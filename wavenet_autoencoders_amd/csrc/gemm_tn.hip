@@ -123,14 +123,17 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
   const int lrow = threadIdx.x / CPR, lpc = threadIdx.x % CPR;
   constexpr int EP = 16 / ES;         // elements per piece
   const int colp = lpc * EP, colq = lpc * EP;
-  f32x4 rp[NPASS], rq[NPASS];
-  auto fetch = [&](int t0) {
+  // Register prefetch ring: the loads of slab s + PF are in flight while slab s is contracted.  A slab is only 8 MFMAs
+  // per wave (256 cycles), far less than one HBM/L2 round trip, so several slabs must be outstanding per workgroup.
+  constexpr int PF = 4;
+  f32x4 rp[PF][NPASS], rq[PF][NPASS];
+  auto fetch = [&](int t0, f32x4 (&xp)[NPASS], f32x4 (&xq)[NPASS]) {
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int t = t0 + i * RPP + lrow;
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      rp[i] = z;
-      rq[i] = z;
+      xp[i] = z;
+      xq[i] = z;
       if (t < tend) {
         if (tl.onehot) {
           const int id = tl.onehot[(int64_t)b * p.T + t] - tl.m0;
@@ -138,60 +141,64 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
             if constexpr (ES == 2) {
               bf16x8 oh = {};
               oh[id - colp] = (__bf16)1.0f;
-              rp[i] = __builtin_bit_cast(f32x4, oh);
+              xp[i] = __builtin_bit_cast(f32x4, oh);
             } else {
-              float* o4 = (float*)&rp[i];
+              float* o4 = (float*)&xp[i];
               o4[id - colp] = 1.0f;
             }
           }
         } else if (colp < tl.m_valid) {
-          rp[i] = *(const f32x4*)(tl.P + (((int64_t)b * p.T + t) * tl.p_stride + colp) * ES);
+          xp[i] = *(const f32x4*)(tl.P + (((int64_t)b * p.T + t) * tl.p_stride + colp) * ES);
         }
         const int tq = t + tl.shift;
-        if (colq < tl.n_valid && tq >= 0 && tq < p.T) rq[i] = *(const f32x4*)(tl.Q + (((int64_t)b * p.T + tq) * tl.q_stride + colq) * ES);
+        if (colq < tl.n_valid && tq >= 0 && tq < p.T) xq[i] = *(const f32x4*)(tl.Q + (((int64_t)b * p.T + tq) * tl.q_stride + colq) * ES);
         if (tl.ones_col >= colq && tl.ones_col < colq + EP) {   // virtual all-ones column
           if constexpr (ES == 2) {
-            bf16x8 v = __builtin_bit_cast(bf16x8, rq[i]);
+            bf16x8 v = __builtin_bit_cast(bf16x8, xq[i]);
             v[tl.ones_col - colq] = (__bf16)1.0f;
-            rq[i] = __builtin_bit_cast(f32x4, v);
+            xq[i] = __builtin_bit_cast(f32x4, v);
           } else {
-            float* v = (float*)&rq[i];
+            float* v = (float*)&xq[i];
             v[tl.ones_col - colq] = 1.0f;
           }
         }
       }
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const f32x4 (&xp)[NPASS], const f32x4 (&xq)[NPASS]) {
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int row = i * RPP + lrow;
-      *(f32x4*)(slabP + buf * SLAB + row * PITCH + lpc * 16) = rp[i];
-      *(f32x4*)(slabQ + buf * SLAB + row * PITCH + lpc * 16) = rq[i];
+      *(f32x4*)(slabP + buf * SLAB + row * PITCH + lpc * 16) = xp[i];
+      *(f32x4*)(slabQ + buf * SLAB + row * PITCH + lpc * 16) = xq[i];
     }
   };
 
   const int nslab = (tend - tbeg + TN_KT - 1) / TN_KT;
-  if (nslab > 0) {
-    fetch(tbeg);
-    stash(0);
-  }
-  __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) fetch(tbeg + (s + 1) * TN_KT);
-    const char* sp = slabP + (s & 1) * SLAB;
-    const char* sq = slabQ + (s & 1) * SLAB;
 #pragma unroll
-    for (int k0 = 0; k0 < TN_KT; k0 += KSTEP) {
-      frag a[2], bq[2];
-      tn_load_frags(sp, sq, k0, wm, wn, lane, a, bq);
+  for (int j = 0; j < PF; ++j)
+    if (j < nslab) fetch(tbeg + j * TN_KT, rp[j], rq[j]);
+  for (int s0 = 0; s0 < nslab; s0 += PF) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < PF; ++j) {
+      const int s = s0 + j;
+      if (s < nslab) {                                   // workgroup-uniform
+        stash(s & 1, rp[j], rq[j]);
+        if (s + PF < nslab) fetch(tbeg + (s + PF) * TN_KT, rp[j], rq[j]);
+        __syncthreads();                                 // slab s visible; every wave is past its reads of slab s-1
+        const char* sp = slabP + (s & 1) * SLAB;
+        const char* sq = slabQ + (s & 1) * SLAB;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma32(acc[i][j], a[i], bq[j]);
+        for (int k0 = 0; k0 < TN_KT; k0 += KSTEP) {
+          frag a[2], bq[2];
+          tn_load_frags(sp, sq, k0, wm, wn, lane, a, bq);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) mma32(acc[i][jj], a[i], bq[jj]);
+        }
+      }
     }
-    if (s + 1 < nslab) stash((s + 1) & 1);
-    __syncthreads();
   }
 
   // C += alpha * acc   (lane = column n, registers = rows m)

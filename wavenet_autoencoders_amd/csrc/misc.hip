@@ -406,27 +406,32 @@ __global__ void __launch_bounds__(256) gproj_bwd_kernel(const float* __restrict_
   const int l = blockIdx.x;
   const int H = G / 2;
   const float* cl = c1 + (int64_t)l * c_layer_stride + ones_col;
-  // phase 1: one thread per gate row: bias gradient and the row of dWg
-  for (int r = threadIdx.x; r < 2 * Hp; r += 256) {
+  // phase 1: blockIdx.y owns 32 gate rows; thread = (row, feature slice): bias gradient and the row of dWg
+  {
+    const int r = blockIdx.y * 32 + (threadIdx.x >> 3), cs = threadIdx.x & 7;
     const int half = r >= Hp, i = r - half * Hp;
-    if (i >= H) continue;
-    const int ch = half * H + i;
-    float sb = 0.f;
-    for (int b = 0; b < B; ++b) sb += cl[(int64_t)r * ld + b];
-    d_eff[bias_off + (int64_t)l * layer_stride + ch] += sb;           // this (layer,row) slot is touched by one thread only
-    if (wg_off < 0 || Cg <= 0) continue;
-    float* dwg = d_eff + wg_off + (int64_t)l * layer_stride + (int64_t)ch * Cg;
-    for (int c = 0; c < Cg; ++c) {
-      float a = 0.f;
-      for (int b = 0; b < B; ++b) {
-        const float e = gid ? eff[emb_off + (int64_t)gid[b] * Cg + c] : gvec[(int64_t)b * Cg + c];
-        a = fmaf(cl[(int64_t)r * ld + b], e, a);
+    if (r < 2 * Hp && i < H) {
+      const int ch = half * H + i;
+      if (cs == 0) {
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) sb += cl[(int64_t)r * ld + b];
+        d_eff[bias_off + (int64_t)l * layer_stride + ch] += sb;       // this (layer,row) slot is touched by one thread only
       }
-      dwg[c] += a;
+      if (wg_off >= 0 && Cg > 0) {
+        float* dwg = d_eff + wg_off + (int64_t)l * layer_stride + (int64_t)ch * Cg;
+        for (int c = cs; c < Cg; c += 8) {
+          float a = 0.f;
+          for (int b = 0; b < B; ++b) {
+            const float e = gid ? eff[emb_off + (int64_t)gid[b] * Cg + c] : gvec[(int64_t)b * Cg + c];
+            a = fmaf(cl[(int64_t)r * ld + b], e, a);
+          }
+          dwg[c] += a;
+        }
+      }
     }
   }
-  // phase 2: embedding rows: thread per (clip, feature) reduces over the gate rows first -> one atomic each
-  if (gid && wg_off >= 0 && Cg > 0) {
+  // phase 2 (blockIdx.y == 0): embedding rows: thread per (clip, feature) reduces over the gate rows -> one atomic each
+  if (blockIdx.y == 0 && gid && wg_off >= 0 && Cg > 0) {
     for (int e = threadIdx.x; e < B * Cg; e += 256) {
       const int b = e / Cg, c = e % Cg;
       float a = 0.f;
@@ -443,7 +448,7 @@ extern "C" int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int
                              const int32_t* gid, int64_t emb_off, const float* gvec, const float* c1, int64_t c_layer_stride,
                              int64_t ld, int32_t ones_col, int32_t B, int32_t L, int32_t G, int32_t Hp, int32_t Cg, void* stream) {
   WAE_REQUIRE(eff && d_eff && c1 && B > 0 && L > 0 && G > 0 && G % 2 == 0, "gproj_bwd: bad arguments");
-  hipLaunchKernelGGL(gproj_bwd_kernel, dim3(L), dim3(256), 0, as_stream(stream), eff, d_eff, (gid || gvec) ? wg_off : -1, bias_off,
+  hipLaunchKernelGGL(gproj_bwd_kernel, dim3(L, (2 * Hp + 31) / 32), dim3(256), 0, as_stream(stream), eff, d_eff, (gid || gvec) ? wg_off : -1, bias_off,
                      layer_stride, gid, emb_off, gvec, c1, c_layer_stride, ld, ones_col, B, G, Hp, Cg);
   return wae_check_launch("gproj_bwd");
 }
