@@ -5,13 +5,16 @@ Workload (BASELINE.json configs[1], "C2"): IN-WAE decoder dimensions (hps/inae_h
 Cc=64, Cg=64, k=3, upsample x320) with 24 layers / 2 stacks, batch 8 x 8000 samples per GPU, bf16 storage with
 fp32 accumulate.  A step = one teacher-forced pass over one batch: weight-norm + fragment packing of all
 parameters, conditioning upsample, speaker projection, first-conv gather, 24 fused gated layers, head and the
-fused shifted cross-entropy (mean loss on device).  Inputs are resident in HBM before the timed region.
+fused shifted cross-entropy (mean loss on device), then the full backward pass (head, 24 x {du/dz, weight gradients,
+dx}, conditioning/upsample gradients, weight-norm backward), [N > 1: bucketed RCCL all-reduce of the gradient arena]
+and the fused clip_grad_norm_ + Adam + EMA update.  Inputs are resident in HBM before the timed region.
+`--mode forward` times the teacher-forced forward pass alone.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--mode train|forward] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, each rank runs its own shard of the global
-batch (weak scaling; the forward path has no data-path collective), barrier + synchronize on both sides, MAX
+Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, each rank trains on its own shard of the global
+batch (weak scaling: 8 clips per GPU), gradients all-reduced over RCCL, barrier + synchronize on both sides, MAX
 over ranks.
 """
 import argparse
@@ -40,6 +43,36 @@ def synth_inputs(rank, device):
     lat = torch.from_numpy(rng.standard_normal((B_PER_GPU, C2["Cc"], T // 320)).astype(np.float32))
     g = torch.from_numpy(rng.integers(0, C2["n_speakers"], size=(B_PER_GPU,), dtype=np.int64))
     return x.to(device), lat.to(device), g.to(device)
+
+
+def cpu_baseline_train(sd, nclips=8):
+    """Oracle train step (autograd through the CPU restatement + its Adam/EMA), bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from oracle import wae_oracle as O
+    nthreads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nthreads)
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy(rng.integers(0, 256, size=(nclips, T), dtype=np.int64))
+    lat = torch.from_numpy(rng.standard_normal((nclips, C2["Cc"], T // 320)).astype(np.float32))
+    g = torch.from_numpy(rng.integers(0, C2["n_speakers"], size=(nclips,), dtype=np.int64))
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    ocfg = dict(layers=C2["layers"], stacks=C2["stacks"], upsample_scales=C2["upsample_scales"], cin_pad=0)
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    sh = {k: v.clone() for k, v in sd.items()}
+    t0 = time.perf_counter()
+    y = O.wavenet_forward(psd, ocfg, xin, lat, g)
+    loss = O.masked_ce_loss(y, x.unsqueeze(-1), torch.full((nclips,), T))
+    loss.backward()
+    with torch.no_grad():
+        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in psd.items()}
+        O.clip_adam_ema_step({k: p.data for k, p in psd.items()}, grads, m, v2, sh, 1, 4e-4)
+    dt = time.perf_counter() - t0
+    return dict(value=nclips * T / dt, unit="samples/s", cores=nthreads, kind="port",
+                sample=f"{nclips} of the {B_PER_GPU} clips x {T} samples, 1 train step (forward+CE+autograd backward+clip/Adam/EMA), "
+                       f"oracle/wae_oracle.py on torch CPU fp32, {nthreads} threads of {os.cpu_count()} cores ({dt:.1f} s)"), float(loss)
 
 
 def cpu_baseline(sd, nclips=8):
@@ -71,6 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -100,13 +134,29 @@ def main():
     lengths = torch.full((B_PER_GPU,), T, dtype=torch.int32, device=device)
     xi = x.to(torch.int32)
 
-    ev = []
+    ev, ev_tn = [], []
+    hook = None
+    if args.mode == "train":
+        eng.init_optimizer()
+        if dist is not None:
+            from wavenet_autoencoders_amd.distributed import GradBucketer, broadcast_params
+            broadcast_params(eng.params)
+            bucketer = {}
+
+            def hook(grads):   # noqa: E306
+                if "b" not in bucketer:
+                    bucketer["b"] = GradBucketer(grads)
+                bucketer["b"].finish()
 
     def step(record=False):
-        eng.prepare_weights()
-        out = eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False,
-                                  layer_events=ev if record else None)
-        return out["loss"]
+        if args.mode == "forward":
+            eng.prepare_weights()
+            out = eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False,
+                                      layer_events=ev if record else None)
+            return out["loss"]
+        eng._layer_events = ev if record else None
+        eng._tn_events = ev_tn if record else None
+        return eng.train_step(xi, lat, g, lengths=None, grad_hook=hook)["loss"]
 
     def sync():
         if dist is not None:
@@ -138,30 +188,45 @@ def main():
     flops_per_launch = 2 * (C2["G"] * C2["R"] * C2["k"] + C2["G"] * C2["Cc"] + H * C2["R"] + H * C2["S"]) * samples
     achieved_gbs = bytes_per_launch / (glu_ms * 1e-3) / 1e9
     achieved_tf = flops_per_launch / (glu_ms * 1e-3) / 1e12
+    peak_tf = MFMA_PEAK_TF if args.dtype == "bf16" else FP32_MFMA_PEAK_TF
+    fwd_roof = {"bound": "hbm", "kernel": "glu_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": glu_ms,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "mfma_achieved_tflops": achieved_tf,
+                "mfma_frac": achieved_tf / peak_tf,
+                "note": "SURVEY 8(d) forward bytes per layer (2R+2S+Cc)*e x 64000 samples; HIP events around the 24-layer stack"}
+    roof = fwd_roof
+    if args.mode == "train" and ev_tn:
+        # dominant kernel of the train step: gemm_tn_kernel (per-layer weight gradients), one launch per layer.
+        # algorithmic bytes per launch = the operands it must read once: dz (G), x (R), c (Cc), dxhat (R), u (H)
+        tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn)
+        tn_bytes = (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) * es * samples
+        tn_flops = 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H) * samples
+        tn_gbs = tn_bytes / (tn_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "gemm_tn_kernel", "achieved": tn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": tn_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": tn_ms, "algorithmic_bytes_per_launch": tn_bytes,
+                "mfma_achieved_tflops": tn_flops / (tn_ms * 1e-3) / 1e12, "mfma_frac": tn_flops / (tn_ms * 1e-3) / 1e12 / peak_tf,
+                "note": "per-layer weight-gradient launch (dW1 taps, dWc, dW_out); operands read once = (G+2R+Cc+H)*e per sample"}
     fwd_bytes_per_sample = geom.layers * (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es + (C2["S"] + 0) * es + 4 + 1
     value = world * samples * args.steps / dt
 
     if rank == 0:
         res = {
-            "metric": "teacher-forced audio samples/sec (24-layer decoder, forward + CE)",
+            "metric": "teacher-forced audio samples/sec (24-layer decoder), " + ("train step" if args.mode == "train" else "forward + CE"),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "C2: IN-WAE decoder dims (R256 G368 S256 Cc64 Cg64 k3), 24 layers/2 stacks, "
-                                   f"batch {B_PER_GPU}x{T} per GPU, teacher-forced forward incl. weight-norm+pack, upsample, "
-                                   "head and fused CE; closed-form random weights",
+                                   f"batch {B_PER_GPU}x{T} per GPU, " + ("full train step: weight-norm+pack, forward, fused CE, backward, "
+                                   "clip+Adam+EMA" if args.mode == "train" else "teacher-forced forward incl. weight-norm+pack, upsample, head and fused CE")
+                                   + "; closed-form random weights",
                        "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
             "samples_per_sec_per_gpu": value / world,
             "loss": loss_v,
-            "roofline": {"bound": "hbm", "kernel": "glu_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": glu_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "mfma_achieved_tflops": achieved_tf,
-                         "mfma_frac": achieved_tf / (MFMA_PEAK_TF if args.dtype == "bf16" else FP32_MFMA_PEAK_TF)},
-            "whole_forward_hbm_frac": fwd_bytes_per_sample * samples * args.steps / dt / 1e9 / HBM_PEAK_GBS * world / world,
+            "roofline": roof,
+            "roofline_glu_fwd": fwd_roof,
         }
         if not args.no_cpu and world == 1:
-            cb, cpu_loss = cpu_baseline(sd)
+            cb, cpu_loss = cpu_baseline_train(sd) if args.mode == "train" else cpu_baseline(sd)
             res["cpu_baseline"] = cb
         print(json.dumps(res))
     if dist is not None:

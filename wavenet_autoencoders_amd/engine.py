@@ -422,7 +422,8 @@ class WaeEngine:
         if self.g.has_encoder:
             out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True)
         else:
-            out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True)
+            out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
+                                       layer_events=getattr(self, "_layer_events", None))
             self._fe = None
         grads = self.backward(x, gid, x, lengths)
         if grad_hook is not None:
