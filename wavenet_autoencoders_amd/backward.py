@@ -280,7 +280,7 @@ def finish_grads(eng):
     return eng.grads
 
 
-def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0):
+def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0, stop_at_quant: bool = False):
     """dc (B,T,Ccp) -> upsample stages -> conv_in -> [VQ straight-through + vq_loss -> encoder]; adds the weight
     gradients into eng.d_eff.  Uses the activations kept by the last train-mode forward."""
     g, lib, lay, st = eng.g, eng.lib, eng.lay, eng.stream()
@@ -306,7 +306,10 @@ def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0):
     L.check(lib.wae_enc_conv_bwd(L.ptr(cin), L.ptr(eng.eff[lay.off(name):]), None, L.ptr(d), L.ptr(dq),
                                  L.ptr(eng.d_eff[lay.off(name):]), None, B, g.Cc, cin.shape[-1], g.Cc, kin, 1, 0, 0, 0, st), "conv_in bwd")
     keep.append(dq)
+    eng._fe_keep = keep
     fe = getattr(eng, "_fe", None)
+    if stop_at_quant:
+        return dq
     if fe is not None and g.has_encoder:
         lat, quant, idx = fe["lat"], fe["quant"], fe["idx"]
         Tq = lat.shape[-1]
@@ -333,3 +336,4 @@ def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0):
             keep.append(dxi)
             dcur = dxi
     eng._fe_keep = keep
+    return dq

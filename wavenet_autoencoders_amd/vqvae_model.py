@@ -1,0 +1,96 @@
+"""Drop-in ``VQVAE`` = Encoder + VectorQuantize + WaveNet (reference: vqvae_model.py:27-84) on the MI355X engine.
+
+``state_dict`` keys: ``encoder.net.<i>.conv.{weight,bias}``, ``encoder.lin.{weight,bias}``, ``vq.embedding.weight``,
+``wavenet.*`` -- the reference's, so its checkpoints load unchanged."""
+import torch
+
+from . import packing as P
+from .wavenet_vocoder._base import ArenaModel
+from .wavenet_vocoder.wavenet import WaveNet, _ids_from_input
+
+
+class _VQVAEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, ids, c, gid, train, *params):
+        eng = model.engine()
+        out = eng.forward(ids, c, gid, want_logits=True, train=train)
+        ctx.model, ctx.ids, ctx.gid = model, ids, gid
+        return out["logits"], out["vq_loss"].reshape(()), out["perp"].reshape(())
+
+    @staticmethod
+    def backward(ctx, dy, dvq, dperp):
+        from . import _lib as L
+        from . import backward as BW
+        model = ctx.model
+        eng = model._engine
+        g = eng.g
+        B, O, T = dy.shape
+        ext = torch.zeros(B, T, g.Op, dtype=eng.tdtype, device=dy.device)
+        dyc = dy.contiguous().float()
+        L.check(eng.lib.wae_to_btc(L.ptr(dyc), L.ptr(ext), B, O, T, g.Op, eng.dt, eng.stream()), "to_btc")
+        dc = BW.decoder_backward(eng, ctx.ids, None, None, ctx.gid, None, ext_dy=ext)
+        BW.frontend_backward(eng, dc, float(dvq) if dvq is not None else 0.0)
+        BW.finish_grads(eng)
+        _, views = model._grad_views(eng)
+        return (None, None, None, None, None) + tuple(v.clone() for v in views)
+
+
+class VQVAE(ArenaModel):
+    """VQVAE(c_in, hid, K, wavenet, encoder_hid).forward(x, c, g, softmax=False) -> (y_hat, vq_loss, perp)."""
+
+    def __init__(self, c_in=39, hid=64, K=256, wavenet=None, encoder_hid=768):
+        super().__init__()
+        if not isinstance(wavenet, WaveNet):
+            raise TypeError("wavenet must be a wavenet_autoencoders_amd.wavenet_vocoder.WaveNet")
+        wg = wavenet.geom
+        if wg.Cc != hid:
+            raise ValueError(f"wavenet.cin_channels ({wg.Cc}) must equal hid ({hid})")
+        geom = P.Geometry(layers=wg.layers, stacks=wg.stacks, R=wg.R, G=wg.G, S=wg.S, O=wg.O, Cc=wg.Cc, Cg=wg.Cg, k=wg.k,
+                          n_speakers=wg.n_speakers, upsample_scales=wg.upsample_scales, cin_pad=wg.cin_pad,
+                          scalar_input=wg.scalar_input, use_speaker_embedding=wg.use_speaker_embedding, c_in=c_in,
+                          encoder_hid=encoder_hid, K=K)
+        self.out_channels, self.scalar_input = wavenet.out_channels, wavenet.scalar_input
+        self._init_arena(geom, "")
+        # keep the decoder's initial values (the reference builds the WaveNet first: vqwae_train.py:926-946)
+        own = dict(self.named_parameters())
+        for n, p in wavenet.named_parameters():
+            own["wavenet." + n].data.copy_(p.data)
+
+    def _params(self):
+        params = dict(self.named_parameters())
+        return [params[r] for r in self._pnames]
+
+    def forward(self, x, c, g, softmax=False):
+        ids = _ids_from_input(x, self.out_channels, self.scalar_input)
+        gid = g.reshape(-1) if g is not None else None
+        params = self._params()
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (inside Function.forward grad mode is off)
+        y, vq_loss, perp = _VQVAEFn.apply(self, ids, c.float(), gid, train, *params)
+        if softmax:
+            y = torch.softmax(y, dim=1)
+        return y, vq_loss, perp
+
+    def incremental_forward(self, initial_input, c, g, T, softmax, quantize, tqdm, log_scale_min):
+        """encoder -> VQ -> autoregressive decoder (vqvae_model.py:73-79)."""
+        eng = self.engine()
+        with torch.no_grad():
+            if eng.weights_dirty:
+                eng.prepare_weights()
+            lat = eng.encoder_forward(c.float())
+            quant, idx, stats = eng.vq_forward(lat)
+            init = 127
+            if initial_input is not None:
+                init = int(initial_input.reshape(initial_input.shape[0], -1)[0].argmax())
+            gid = g.reshape(-1) if g is not None else None
+            out = eng.incremental_forward(quant, gid, int(T), mode="sample" if quantize else "argmax", init_idx=init)
+            idxs = out["idx"].long()
+            return torch.nn.functional.one_hot(idxs, self.out_channels).float().transpose(1, 2).contiguous()
+
+    def encode(self, x):
+        """quantised latents of MFCC features (vqvae_model.py:80-84; inference_2019.py:243-262)."""
+        eng = self.engine()
+        with torch.no_grad():
+            if eng.weights_dirty:
+                eng.prepare_weights()
+            lat = eng.encoder_forward(x.float())
+            return eng.vq_forward(lat)[0]

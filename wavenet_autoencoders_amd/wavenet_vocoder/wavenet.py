@@ -1,0 +1,159 @@
+"""Drop-in ``WaveNet`` (reference: wavenet_vocoder/wavenet.py:63-364) on the MI355X engine.
+
+Same constructor arguments, same ``state_dict`` keys (``first_conv.weight_g`` ...), same call conventions; the
+arithmetic is libwae_hip.so.  Inputs must live on a ROCm GPU -- there is no CPU path.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import packing as P
+from ._base import ArenaModel
+
+
+def receptive_field_size(total_layers, num_cycles, kernel_size, dilation=lambda x: 2 ** x):
+    """(kernel_size - 1) * sum(dilations) + 1 (wavenet.py:42-60)."""
+    assert total_layers % num_cycles == 0
+    per = total_layers // num_cycles
+    return (kernel_size - 1) * sum(dilation(i % per) for i in range(total_layers)) + 1
+
+
+def _ids_from_input(x, out_channels, scalar_input):
+    """Reference inputs are one-hot (B, C, T) floats (or (B, 1, T) scalars); the kernels take class ids."""
+    if scalar_input:
+        return x.reshape(x.shape[0], -1).float()
+    if x.dim() == 3:
+        if x.shape[1] != out_channels and x.shape[2] == out_channels:
+            x = x.transpose(1, 2)
+        return x.argmax(dim=1).to(torch.int32)
+    return x.to(torch.int32)
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, ids, c, g, c_is_up, train, *params):
+        eng = model.engine()
+        ctx.model, ctx.ids, ctx.g, ctx.c_is_up = model, ids, g, c_is_up
+        ctx.c_shape = None if c is None else tuple(c.shape)
+        ctx.train = train
+        gid = g if (g is not None and g.dtype in (torch.int32, torch.int64)) else None
+        gvec = None if (g is None or gid is not None) else g.reshape(g.shape[0], -1).float().contiguous()
+        ctx.gid, ctx.gvec = gid, gvec
+        out = eng.decoder_forward(ids, c, gid, want_logits=True, train=train, c_is_upsampled=c_is_up, gvec=gvec)
+        return out["logits"]
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib as L
+        from .. import backward as BW
+        model = ctx.model
+        eng = model._engine
+        g = eng.g
+        B, O, T = dy.shape
+        ext = torch.zeros(B, T, g.Op, dtype=eng.tdtype, device=dy.device)
+        dyc = dy.contiguous().float()
+        L.check(eng.lib.wae_to_btc(L.ptr(dyc), L.ptr(ext), B, O, T, g.Op, eng.dt, eng.stream()), "to_btc")
+        dc = BW.decoder_backward(eng, ctx.ids, None, None, ctx.gid, ctx.gvec, ext_dy=ext)
+        dc_in = None
+        if ctx.c_shape is not None:
+            if ctx.c_is_up or not g.upsample_scales:
+                dc_in = torch.empty(B, g.Cc, T, dtype=torch.float32, device=dy.device)
+                L.check(eng.lib.wae_from_btc(L.ptr(dc), L.ptr(dc_in), B, g.Cc, T, g.Ccp, eng.dt, eng.stream()), "from_btc")
+            else:
+                dc_in = BW.frontend_backward(eng, dc, 1.0, stop_at_quant=True)
+        grads = BW.finish_grads(eng)
+        _, views = model._grad_views(eng)
+        return (None, None, dc_in, None, None, None) + tuple(v.clone() for v in views)
+
+
+class WaveNet(ArenaModel):
+    def __init__(self, out_channels=256, layers=20, stacks=2, residual_channels=512, gate_channels=512,
+                 skip_out_channels=512, kernel_size=3, dropout=1 - 0.95, cin_channels=-1, gin_channels=-1, n_speakers=None,
+                 upsample_conditional_features=False, upsample_net="ConvInUpsampleNetwork",
+                 upsample_params={"upsample_scales": [4, 4, 4, 4]}, scalar_input=False, use_speaker_embedding=False,
+                 output_distribution="Logistic", cin_pad=0, _prefix=""):
+        super().__init__()
+        if dropout not in (0, 0.0):
+            # every shipped preset has dropout 0.0 (hps/*.json); the fused layer kernel has no dropout stage
+            raise NotImplementedError("dropout > 0 is not supported by the fused layer kernel (all presets use 0.0)")
+        if upsample_conditional_features and upsample_net != "ConvInUpsampleNetwork":
+            raise NotImplementedError("only ConvInUpsampleNetwork (the reference default) is implemented")
+        self.scalar_input = scalar_input
+        self.out_channels = out_channels
+        self.cin_channels = cin_channels
+        self.output_distribution = output_distribution
+        scales = list(upsample_params.get("upsample_scales", [])) if upsample_conditional_features else None
+        geom = P.Geometry(layers=layers, stacks=stacks, R=residual_channels, G=gate_channels, S=skip_out_channels,
+                          O=out_channels, Cc=cin_channels, Cg=gin_channels, k=kernel_size,
+                          n_speakers=n_speakers if (gin_channels > 0 and use_speaker_embedding) else None,
+                          upsample_scales=scales, cin_pad=cin_pad, scalar_input=scalar_input,
+                          use_speaker_embedding=bool(use_speaker_embedding))
+        self._init_arena(geom, "wavenet.")
+        self.receptive_field = receptive_field_size(layers, stacks, kernel_size)
+
+    # ------------------------------------------------------------------ reference API
+    def has_speaker_embedding(self):
+        return "embed_speakers" in self._modules
+
+    def local_conditioning_enabled(self):
+        return self.cin_channels > 0
+
+    def forward(self, x, c=None, g=None, softmax=False):
+        """x (B, C, T) one-hot / (B, 1, T) scalar / (B, T) ids; c (B, Cc, Tc); g (B,) ids or (B, Cg, 1) features.
+        Returns (B, out_channels, T) logits (probabilities if softmax)  -- wavenet.py:164-216."""
+        ids = _ids_from_input(x, self.out_channels, self.scalar_input)
+        if g is not None and g.dtype in (torch.int32, torch.int64):
+            g = g.reshape(-1)
+        c_is_up = not bool(self.geom.upsample_scales)
+        params = [p for _, p in sorted(((n, p) for n, p in self.named_parameters()), key=lambda kv: self._pnames.index(kv[0]))]
+        train = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or (c is not None and c.requires_grad))
+        y = _DecoderFn.apply(self, ids, c, g, c_is_up, train, *params)
+        return torch.softmax(y, dim=1) if softmax else y
+
+    def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None, tqdm=lambda x: x,
+                            softmax=True, quantize=True, log_scale_min=-50.0):
+        """wavenet.py:218-346 as one persistent kernel launch.  Supported: sampling (quantize=True) -> one-hot
+        (B, C, T); teacher forcing (test_inputs, quantize=False) -> logits / softmax (B, C, T)."""
+        if self.training:
+            raise RuntimeError("incremental_forward only supports eval mode")          # conv.py:19-20
+        if self.scalar_input:
+            raise NotImplementedError("autoregressive decoding of scalar-input models is not implemented yet")
+        eng = self.engine()
+        tf = None
+        if test_inputs is not None:
+            tf = _ids_from_input(test_inputs, self.out_channels, False)
+            T = max(int(T or 0), tf.shape[1])
+        init = 127                                                                      # wavenet.py:288
+        if initial_input is not None:
+            ii = initial_input
+            if ii.dim() == 3:
+                ii = ii.reshape(ii.shape[0], -1)
+            init = int(ii[0].argmax())
+        gid = g.reshape(-1) if (g is not None and g.dtype in (torch.int32, torch.int64)) else None
+        gvec = None if (g is None or gid is not None) else g.reshape(g.shape[0], -1).float().contiguous()
+        c_is_up = c is not None and (not self.geom.upsample_scales or c.shape[-1] == int(T))
+        with torch.no_grad():
+            if quantize:
+                if tf is not None and tf.shape[1] < T:
+                    raise NotImplementedError("partial teacher forcing followed by sampling is not implemented")
+                out = eng.incremental_forward(c, gid, int(T), mode="sample" if tf is None else "logits", test_inputs=tf,
+                                              init_idx=init, c_is_upsampled=c_is_up, gvec=gvec)
+                idx = out["idx"].long()
+                return torch.nn.functional.one_hot(idx, self.out_channels).float().transpose(1, 2).contiguous()
+            if tf is None:
+                raise NotImplementedError("feeding soft probabilities back (quantize=False without test_inputs) is not implemented")
+            out = eng.incremental_forward(c, gid, int(T), mode="logits", test_inputs=tf, init_idx=init, c_is_upsampled=c_is_up,
+                                          gvec=gvec)
+            y = out["logits"]
+            return torch.softmax(y, dim=1) if softmax else y
+
+    def clear_buffer(self):
+        """The per-layer history lives inside one kernel launch; nothing persists between calls (wavenet.py:348-356)."""
+
+    def make_generation_fast_(self):
+        """Weight norm is folded once into the packed weights at synthesis time (wavenet.py:358-364 removes the hooks);
+        parameters keep their weight_g / weight_v form."""
+        if self._engine is not None:
+            self._engine._ar_packed = False
+        return self
