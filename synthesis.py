@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Synthesis waveform from trained WaveNet autoencoder (entry point of the reference's synthesis.py:2-17).
+
+usage: synthesis.py [options] <dump_root> <checkpoint> <dst_dir> <syn_list> <speaker2ind> <lan> <up_factor> <frame_rate> <start_ind>
+
+options:
+    --hparams=<parmas>       Hyper parameters [default: ].
+    --preset=<json>          Path of preset parameters (json).
+    --length=<T>             Steps to generate (default: computed from the conditioning features).
+    --initial-value=<n>      Initial mu-law class id (default: mulaw_quantize(0) = 127).
+    --dtype=<fp32|bf16>      Compute precision [default: fp32].
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from wavenet_autoencoders_amd.data import inv_mulaw_quantize  # noqa: E402
+from wavenet_autoencoders_amd.hparams import hparams  # noqa: E402
+
+
+def inv_preemphasis(x, coef=0.85):
+    """audio.py inv_preemphasis: y[n] = x[n] + coef * y[n-1] (scipy.signal.lfilter([1], [1, -coef], x))."""
+    from scipy import signal
+    return signal.lfilter([1], [1, -coef], x)
+
+
+def wavegen(eng, length, c, g, initial_value=127):
+    """wavegen (synthesis.py:295-396): c (Tc, D) features, g speaker id -> float waveform in [-1, 1]."""
+    device = eng.device
+    ct = torch.from_numpy(np.ascontiguousarray(c.T[None]).astype(np.float32)).to(device)      # (1, D, Tc)  :342
+    gid = torch.tensor([g], dtype=torch.int64, device=device) if g is not None else None
+    if eng.weights_dirty:
+        eng.prepare_weights()
+    lat = eng.encoder_forward(ct)
+    quant, _, _ = eng.vq_forward(lat)
+    out = eng.incremental_forward(quant, gid, int(length), mode="sample", init_idx=int(initial_value))
+    idx = out["idx"][0].cpu().numpy()
+    y = inv_mulaw_quantize(idx, hparams.quantize_channels)                                    # synthesis.py:382-384 uses 256
+    if hparams.postprocess not in ("", None, "none"):
+        y = inv_preemphasis(y, 0.85)                                                          # :390-391
+    if hparams.global_gain_scale > 0:
+        y = y / hparams.global_gain_scale                                                     # :393-394
+    return y.astype(np.float32)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    for a in ("dump_root", "checkpoint", "dst_dir", "syn_list", "speaker2ind", "lan", "up_factor", "frame_rate", "start_ind"):
+        ap.add_argument(a)
+    ap.add_argument("--hparams", default="")
+    ap.add_argument("--preset")
+    ap.add_argument("--length", type=int)
+    ap.add_argument("--initial-value", type=int, default=127)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    args = ap.parse_args(argv)
+    if args.preset:
+        with open(args.preset) as f:
+            hparams.parse_json(f.read())
+    hparams.parse(args.hparams)
+    from vqwae_train import build_geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    eng = WaeEngine(build_geometry(hparams), dtype=args.dtype)
+    ck = torch.load(args.checkpoint, map_location="cpu")
+    eng.load_state_dict(ck["state_dict"])
+    with open(args.speaker2ind) as f:
+        sp2ind = json.load(f)
+    os.makedirs(args.dst_dir, exist_ok=True)
+    up = int(args.up_factor)
+    with open(args.syn_list) as f:
+        pairs = [ln.split() for ln in f if ln.strip()][int(args.start_ind):]
+    from scipy.io import wavfile
+    for src, tar in pairs:
+        c = np.load(os.path.join(args.dump_root, src, "mfcc.norm.npy"))
+        mult = max(1, 100 // int(args.frame_rate))
+        if len(c) % (4 * mult):                                                               # pad frames (:483-490)
+            c = np.pad(c, ((0, 4 * mult - len(c) % (4 * mult)), (0, 0)), mode="edge")
+        length = args.length or (len(c) // 4) * up * 1                                        # latent frames * up_factor
+        y = wavegen(eng, length, c, sp2ind[tar], args.initial_value)
+        out = os.path.join(args.dst_dir, f"{tar}_{os.path.basename(src)}.wav")
+        wavfile.write(out, hparams.sample_rate, y)
+        print("wrote", out)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -92,3 +92,27 @@ def test_cpu_call_fails_loudly():
     model, _ = _build(cfg)
     with pytest.raises(WaeError):
         model(ins["xin"], ins["c"], ins["g"], False)
+
+
+def test_mixture_module_functions():
+    from wavenet_autoencoders_amd.wavenet_vocoder.mixture import (discretized_mix_logistic_loss,
+                                                                  sample_from_discretized_mix_logistic)
+    z = load_npz("dmol")
+    y_hat = torch.from_numpy(z["y_hat"]).cuda().requires_grad_(True)
+    y = torch.from_numpy(z["y"]).cuda()
+    loss = discretized_mix_logistic_loss(y_hat, y, 256, -7.0, reduce=True)
+    loss.backward()
+    assert abs(float(loss) - float(z["loss_sum_7"])) < 1e-3 * abs(float(z["loss_sum_7"]))
+    assert rel_err(y_hat.grad.cpu(), z["grad_7"]) < 1e-3
+    el = discretized_mix_logistic_loss(y_hat.detach(), y, 256, -7.0, reduce=False)
+    assert el.shape == y.shape and rel_err(el.cpu(), z["loss_el_7"]) < 1e-4
+    s = sample_from_discretized_mix_logistic(y_hat.detach(), -7.0)
+    assert s.shape == (2, 96) and float(s.abs().max()) <= 1.0
+    from wavenet_autoencoders_amd.losses import DiscretizedMixturelogisticLoss, MaskedCrossEntropyLoss
+    lengths = torch.tensor([96, 80]).cuda()
+    got = DiscretizedMixturelogisticLoss(256, -7.0)(y_hat.detach(), y, lengths=lengths)
+    mask = O.sequence_mask(lengths.cpu(), 96).unsqueeze(-1)
+    want = (torch.from_numpy(z["loss_el_7"]) * mask).sum() / mask.sum()
+    assert abs(float(got) - float(want)) < 1e-4 * abs(float(want))
+    with pytest.raises(RuntimeError):
+        MaskedCrossEntropyLoss()(y_hat, y)
