@@ -96,20 +96,22 @@ class TileTable:
     def add(self, M, N, shift, ones_col, alpha, p_ptr, p_stride, q_ptr, q_stride, c_ptr, ldc, onehot_ptr=0):
         es = self.eng.w_glu.element_size()
         nmax = max(N, ones_col + 1) if ones_col >= 0 else N
+        TN = 128                                     # csrc/gemm_tn.hip: 128 x 128 output tiles
         for mt in range((M + 127) // 128):
-            for nt in range((nmax + 127) // 128):
-                oc = ones_col - 128 * nt if (ones_col >= 0 and 0 <= ones_col - 128 * nt < 128) else -1
+            for nt in range((nmax + TN - 1) // TN):
+                oc = ones_col - TN * nt if (ones_col >= 0 and 0 <= ones_col - TN * nt < TN) else -1
                 self.tiles.append(L.TnTile(
-                    (p_ptr + mt * 128 * es) if p_ptr else None, q_ptr + nt * 128 * es, onehot_ptr or None,
-                    c_ptr + (mt * 128 * ldc + nt * 128) * 4, p_stride, q_stride, ldc,
-                    min(128, M - 128 * mt), max(0, min(128, N - 128 * nt)), 128 * mt, shift, oc, alpha))
+                    (p_ptr + mt * 128 * es) if p_ptr else None, q_ptr + nt * TN * es, onehot_ptr or None,
+                    c_ptr + (mt * 128 * ldc + nt * TN) * 4, p_stride, q_stride, ldc,
+                    min(128, M - 128 * mt), max(0, min(TN, N - TN * nt)), 128 * mt, shift, oc, alpha))
 
     def finalize(self, B):
         arr = (L.TnTile * len(self.tiles))(*self.tiles)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.dev = host.to(self.eng.device)
         self.n = len(self.tiles)
-        self.splits = max(1, min(4, round(512 / max(1, self.n * B))))
+        # measured on C2 (tools/ablate_tn.py): ~1200 workgroups (2-3 per slot) beat fewer, longer ones; keep >= 512 steps each
+        self.splits = max(1, min(16, round(1200 / max(1, self.n * B))))
         return self
 
     def launch(self, B, T):
@@ -247,17 +249,21 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
 
     # ---- scatter the dense tiles into the effective-weight gradient arena ----------------------------------------------
-    def scat(src, mp, n, nb=1, ss=0, ds=0, cols=0, ld=0, off=0):
-        L.check(lib.wae_unpack_scatter_add(ctypes.c_void_p(src.data_ptr() + off * 4), L.ptr(mp), L.ptr(eng.d_eff), n, nb, ss, ds,
-                                           cols, ld, st), "scatter")
-    scat(c1, sm["w1"], Z2 * sm["ld1"], g.layers, Z2 * sm["ld1"], lay.layer_stride)
-    scat(co, sm["wo"], g.Rp * sm["ldo"], g.layers, g.Rp * sm["ldo"], lay.layer_stride)
-    scat(cs, sm["ws"], g.Sp * g.Ku, cols=g.Ku, ld=sm["lds"])
-    scat(cs, sm["bs"], g.Sp * P.ONES_PAD, g.layers, 0, lay.layer_stride, cols=P.ONES_PAD, ld=sm["lds"], off=g.Ku)
-    scat(c3, sm["w3"], g.Op * sm["ldh"])
-    scat(c1h, sm["w1h"], g.Sp * sm["ldh"])
-    scat(ctab, sm["tab"], sm["tab"].numel())
-    scat(fb, sm["fb"], g.Rp)
+    def scat(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1):
+        L.check(lib.wae_unpack_scatter_add(ctypes.c_void_p(src.data_ptr() + off * 4), L.ptr(mp), L.ptr(eng.d_eff), rows * cols, nb,
+                                           ss, ds, cols, ld, unique, st), "scatter")
+    OP = P.ONES_PAD
+    scat(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], nb=g.layers, ss=Z2 * sm["ld1"], ds=lay.layer_stride)
+    scat(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride)
+    scat(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=0)
+    scat(cs, sm["ws"], g.Sp, g.Ku, sm["lds"])
+    scat(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=0)
+    scat(c3, sm["w3"], g.Op, g.Sp, sm["ldh"])
+    scat(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=0)
+    scat(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"])
+    scat(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=0)
+    scat(ctab, sm["tab"], P._ru(g.O, 128) if False else g.O, g.Rp, g.Rp)
+    scat(fb, sm["fb"], 1, g.Rp, g.Rp)
     # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
     wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
     emb_off = lay.offsets.get("wavenet.embed_speakers.weight", 0)

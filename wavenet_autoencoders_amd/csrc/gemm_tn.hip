@@ -33,7 +33,10 @@ struct TnArgs {
   const TnTile* tiles;
   int B, T;
   int tchunk;  // time steps per workgroup
+  int dbg;     // timing-only ablation bits (tools/ablate_tn.py): 1 no global loads, 2 no LDS reads/MFMA, 4 no atomics
 };
+static int g_tn_dbg = 0;
+extern "C" void wae_debug_set_tn(int bits) { g_tn_dbg = bits; }
 
 #define TN_KT 32      // time rows per LDS slab
 #define TN_PITCH_BF16 320   // bytes per slab row (128 bf16 + pad): conflict-free transposed reads
@@ -90,7 +93,7 @@ __device__ __forceinline__ void tn_load_frags(const char* sp, const char* sq, in
 }
 
 template <typename E>
-__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
+__global__ void __launch_bounds__(256, sizeof(E) == 2 ? 2 : 1) gemm_tn_kernel(TnArgs p) {
   using frag = typename ET<E>::frag;
   constexpr int ES = sizeof(E);
   constexpr int PITCH = ES == 2 ? TN_PITCH_BF16 : TN_PITCH_F32;
@@ -100,12 +103,21 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabP = smem;            // [2][SLAB]
   char* slabQ = smem + 2 * SLAB; // [2][SLAB]
-  const TnTile tl = p.tiles[blockIdx.x];
+  // XCD-aware mapping (speed only): workgroups are dealt round-robin over the 8 XCDs in launch order, so the tiles that
+  // contract the SAME k-range (they share their P and Q slabs) get flat ids that are congruent mod 8 and meet in one L2.
+  int tile_i = blockIdx.x, kr = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int flat = blockIdx.y * gridDim.x + blockIdx.x;
+    const int j = flat >> 3;
+    tile_i = j % gridDim.x;
+    kr = (flat & 7) + 8 * (j / gridDim.x);
+  }
+  const TnTile tl = p.tiles[tile_i];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int splits = (p.T + p.tchunk - 1) / p.tchunk;
-  const int b = blockIdx.y / splits;
-  const int tbeg = (blockIdx.y % splits) * p.tchunk;
+  const int b = kr / splits;
+  const int tbeg = (kr % splits) * p.tchunk;
   const int tend = min(p.T, tbeg + p.tchunk);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
@@ -177,15 +189,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
   const int nslab = (tend - tbeg + TN_KT - 1) / TN_KT;
 #pragma unroll
   for (int j = 0; j < PF; ++j)
-    if (j < nslab) fetch(tbeg + j * TN_KT, rp[j], rq[j]);
+    if (j < nslab && !(p.dbg & 1)) fetch(tbeg + j * TN_KT, rp[j], rq[j]);
   for (int s0 = 0; s0 < nslab; s0 += PF) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int s = s0 + j;
       if (s < nslab) {                                   // workgroup-uniform
         stash(s & 1, rp[j], rq[j]);
-        if (s + PF < nslab) fetch(tbeg + (s + PF) * TN_KT, rp[j], rq[j]);
+        if (s + PF < nslab && !(p.dbg & 1)) fetch(tbeg + (s + PF) * TN_KT, rp[j], rq[j]);
         __syncthreads();                                 // slab s visible; every wave is past its reads of slab s-1
+        if (p.dbg & 2) continue;
         const char* sp = slabP + (s & 1) * SLAB;
         const char* sq = slabQ + (s & 1) * SLAB;
 #pragma unroll
@@ -202,6 +215,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs p) {
   }
 
   // C += alpha * acc   (lane = column n, registers = rows m)
+  if ((p.dbg & 4) && acc[0][0][0] != 12345.f) return;
   const int nl = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -226,7 +240,7 @@ extern "C" int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, in
   static_assert(sizeof(wae_tn_tile) == sizeof(TnTile), "wae_tn_tile and TnTile must have the same layout");
   TnArgs a;
   a.tiles = (const TnTile*)tiles_dev;
-  a.B = B; a.T = T;
+  a.B = B; a.T = T; a.dbg = g_tn_dbg;
   int tchunk = (T + splits - 1) / splits;
   tchunk = (tchunk + TN_KT - 1) / TN_KT * TN_KT;
   a.tchunk = tchunk;

@@ -148,21 +148,25 @@ extern "C" int wae_pack_gather(const float* src, const int32_t* map, void* dst, 
 __global__ void __launch_bounds__(256) unpack_scatter_add_kernel(const float* __restrict__ src,
                                                                  const int32_t* __restrict__ map, float* __restrict__ dst,
                                                                  int64_t n, int64_t src_stride, int64_t dst_stride, int src_cols,
-                                                                 int64_t src_ld) {
+                                                                 int64_t src_ld, int unique) {
   const int b = blockIdx.y;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int32_t m = map[i];
     const int64_t si = src_cols > 0 ? (i / src_cols) * src_ld + (i % src_cols) : i;
-    if (m >= 0) atomicAdd(dst + m + b * dst_stride, src[si + b * src_stride]);
+    if (m >= 0) {
+      if (unique) dst[m + b * dst_stride] += src[si + b * src_stride];   // every slot has exactly one source in this launch
+      else atomicAdd(dst + m + b * dst_stride, src[si + b * src_stride]);
+    }
   }
 }
 
 extern "C" int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int64_t n, int32_t nbatch,
-                                      int64_t src_stride, int64_t dst_stride, int32_t src_cols, int64_t src_ld, void* stream) {
+                                      int64_t src_stride, int64_t dst_stride, int32_t src_cols, int64_t src_ld, int32_t unique,
+                                      void* stream) {
   WAE_REQUIRE(src && map && dst && n > 0 && nbatch > 0, "unpack_scatter_add: bad arguments");
   const int gx = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(unpack_scatter_add_kernel, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
-                     src_stride, dst_stride, src_cols, src_ld);
+                     src_stride, dst_stride, src_cols, src_ld, unique);
   return wae_check_launch("unpack_scatter_add");
 }
 

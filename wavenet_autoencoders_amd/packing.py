@@ -445,11 +445,15 @@ ONES_PAD = 128   # spare C columns that receive the per-clip "ones column" sums 
 
 
 def grad_scatter_maps(g: Geometry, lay: ParamLayout) -> dict:
-    """C-buffer element -> gradient-arena offset (or -1).  Layer maps are relative to layer 0."""
+    """C-buffer element -> gradient-arena offset (or -1).  Layer maps are relative to layer 0.  ``*_w`` maps cover the
+    weight sub-tile (rows x cols, every slot written once: plain adds); ``*_b`` maps cover the ONES_PAD ones-columns
+    (rows x ONES_PAD, every clip column adds into the same bias slot: atomics)."""
     out = {}
-    # dW1 | dWc : rows = padded gate rows (2Hp), cols = [tap*Rp + r | k*Rp + cc | ones...]
+    ones = np.zeros((1, ONES_PAD), dtype=np.int64)
+    # dW1 | dWc : rows = padded gate rows (2Hp), cols = [tap*Rp + r | k*Rp + cc]  (the ones columns feed gproj_bwd)
     ld1 = g.k * g.Rp + g.Ccp + ONES_PAD
-    row, col = np.meshgrid(np.arange(2 * g.Hp), np.arange(ld1), indexing="ij")
+    ncol1 = g.k * g.Rp + g.Ccp
+    row, col = np.meshgrid(np.arange(2 * g.Hp), np.arange(ncol1), indexing="ij")
     grow, ok = _gate_row(g, row)
     conv = lay.off("wavenet.conv_layers.0.conv.weight_v")
     tap, r = col // g.Rp, col % g.Rp
@@ -458,35 +462,37 @@ def grad_scatter_maps(g: Geometry, lay: ParamLayout) -> dict:
         cw = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
         cc = col - g.k * g.Rp
         m = np.where(ok & (cc >= 0) & (cc < g.Cc), cw + grow * g.Cc + cc, m)
-    out["w1"], out["ld1"] = m.astype(np.int32).reshape(-1), ld1
-    # dW_out: rows r (Rp), cols h (Hp) | ones -> bias (every clip column adds into the same slot)
+    out["w1"], out["ld1"], out["ncol1"] = m.astype(np.int32).reshape(-1), ld1, ncol1
+    # dW_out: rows r (Rp), cols h (Hp) ; ones -> bias
     ldo = g.Hp + ONES_PAD
-    row, col = np.meshgrid(np.arange(g.Rp), np.arange(ldo), indexing="ij")
+    row, col = np.meshgrid(np.arange(g.Rp), np.arange(g.Hp), indexing="ij")
     wo = lay.off("wavenet.conv_layers.0.conv1x1_out.weight_v")
     bo = lay.off("wavenet.conv_layers.0.conv1x1_out.bias")
-    m = np.where((row < g.R) & (col < g.H), wo + row * g.H + col, -1)
-    m = np.where((row < g.R) & (col >= g.Hp), bo + row, m)
-    out["wo"], out["ldo"] = m.astype(np.int32).reshape(-1), ldo
-    # dW_skip of all layers: rows s (Sp), cols l*Hp + h | ones -> skip bias (applied per layer separately)
+    out["wo"], out["ldo"] = np.where((row < g.R) & (col < g.H), wo + row * g.H + col, -1).astype(np.int32).reshape(-1), ldo
+    rowb = np.arange(g.Rp)[:, None] + ones
+    out["bo"] = np.where(rowb < g.R, bo + rowb, -1).astype(np.int32).reshape(-1)
+    # dW_skip of all layers: rows s (Sp), cols l*Hp + h ; ones -> skip bias (applied per layer separately)
     lds = g.Ku + ONES_PAD
-    row, col = np.meshgrid(np.arange(g.Sp), np.arange(lds), indexing="ij")
+    row, col = np.meshgrid(np.arange(g.Sp), np.arange(g.Ku), indexing="ij")
     ws = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v")
     l, hh = col // g.Hp, col % g.Hp
     m = np.where((row < g.S) & (col < g.layers * g.Hp) & (hh < g.H), ws + l * lay.layer_stride + row * g.H + hh, -1)
-    out["ws"], out["lds"] = m[:, :g.Ku].astype(np.int32).reshape(-1), lds          # (Sp, Ku) sub-tile of the (Sp, lds) buffer
+    out["ws"], out["lds"] = m.astype(np.int32).reshape(-1), lds
     bs = lay.off("wavenet.conv_layers.0.conv1x1_skip.bias")
-    rowb = np.arange(g.Sp)[:, None] + np.zeros((1, ONES_PAD), dtype=np.int64)
+    rowb = np.arange(g.Sp)[:, None] + ones
     out["bs"] = np.where(rowb < g.S, bs + rowb, -1).astype(np.int32).reshape(-1)   # (Sp, ONES_PAD) ones columns, layer 0
     # head
     ldh = g.Sp + ONES_PAD
-    row, col = np.meshgrid(np.arange(g.Op), np.arange(ldh), indexing="ij")
+    row, col = np.meshgrid(np.arange(g.Op), np.arange(g.Sp), indexing="ij")
     w3, b3 = lay.off("wavenet.last_conv_layers.3.weight_v"), lay.off("wavenet.last_conv_layers.3.bias")
-    m = np.where((row < g.O) & (col < g.S), w3 + row * g.S + col, -1)
-    out["w3"] = np.where((row < g.O) & (col >= g.Sp), b3 + row, m).astype(np.int32).reshape(-1)
-    row, col = np.meshgrid(np.arange(g.Sp), np.arange(ldh), indexing="ij")
+    out["w3"] = np.where((row < g.O) & (col < g.S), w3 + row * g.S + col, -1).astype(np.int32).reshape(-1)
+    rowb = np.arange(g.Op)[:, None] + ones
+    out["b3"] = np.where(rowb < g.O, b3 + rowb, -1).astype(np.int32).reshape(-1)
+    row, col = np.meshgrid(np.arange(g.Sp), np.arange(g.Sp), indexing="ij")
     w1, b1 = lay.off("wavenet.last_conv_layers.1.weight_v"), lay.off("wavenet.last_conv_layers.1.bias")
-    m = np.where((row < g.S) & (col < g.S), w1 + row * g.S + col, -1)
-    out["w1h"] = np.where((row < g.S) & (col >= g.Sp), b1 + row, m).astype(np.int32).reshape(-1)
+    out["w1h"] = np.where((row < g.S) & (col < g.S), w1 + row * g.S + col, -1).astype(np.int32).reshape(-1)
+    rowb = np.arange(g.Sp)[:, None] + ones
+    out["b1h"] = np.where(rowb < g.S, b1 + rowb, -1).astype(np.int32).reshape(-1)
     out["ldh"] = ldh
     # first conv table gradient (O or 1, Rp) -> weight_v (R, O, 1)
     nin = 1 if g.scalar_input else g.O
