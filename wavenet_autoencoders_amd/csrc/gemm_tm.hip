@@ -83,6 +83,22 @@ __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
+  // rows the epilogue needs (residual, or the saved pre-activations z): fetched now, they arrive under the MFMAs
+  constexpr int NAUX = MODE == TM_GATE_BWD ? 2 * NT : (MODE == TM_RESIDUAL ? NT : 1);
+  constexpr int NPASS_AUX = StagePasses<NAUX, E>::N;
+  f32x4 pre_a[NPASS_AUX][8];
+  [[maybe_unused]] f32x4 pre_b[NPASS_AUX][8];
+  if constexpr (MODE == TM_RESIDUAL) {
+    if (rows_valid > 0)
+      stage_fetch_tiles<E, NT>(pre_a, p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES, p.aux_stride * ES, rows_valid, lane);
+  } else if constexpr (MODE == TM_GATE_BWD) {
+    if (rows_valid > 0) {
+      const char* zrow = p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES;
+      stage_fetch_tiles<E, NT>(pre_a, zrow, p.aux_stride * ES, rows_valid, lane);
+      stage_fetch_tiles<E, NT>(pre_b, zrow + (int64_t)NT * 32 * ES, p.aux_stride * ES, rows_valid, lane);
+    }
+  }
+
   dma_chunk(p.w, smem, CHB, wave, lane);
   load_B(0, Bn);
   for (int q = 0; q < nq; ++q) {
@@ -104,7 +120,7 @@ __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
     stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
   } else if constexpr (MODE == TM_RESIDUAL) {
     f32x16 res[NT];
-    stage_load_tiles<E, NT>(stg, res, p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES, p.aux_stride * ES, rows_valid, lane);
+    stage_unpack_tiles<E, NT>(stg, res, pre_a, lane);
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
@@ -113,26 +129,30 @@ __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
     stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
   } else {
     // gate backward (modules.py:154: u = tanh(a) * sigmoid(b)):  da = du * s * (1 - th^2),  db = du * th * s * (1 - s)
-    const char* zrow = p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES;
     char* orow = p.out + ((int64_t)b * p.T + t0w) * p.out_stride * ES;
-    const int Hp = NT * 32;
+    f32x16 za[NT], zg[NT];
+    stage_unpack_tiles<E, NT>(stg, za, pre_a, lane);
+    stage_unpack_tiles<E, NT>(stg, zg, pre_b, lane);
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-      f32x16 za[1], zg[1];
-      stage_load_tiles<E, 1>(stg, za, zrow + (int64_t)m * 32 * ES, p.aux_stride * ES, rows_valid, lane);
-      stage_load_tiles<E, 1>(stg, zg, zrow + (int64_t)(Hp + m * 32) * ES, p.aux_stride * ES, rows_valid, lane);
-      f32x16 da[1], db[1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float th = tanhf(za[0][r]);
-        const float sg = 1.0f / (1.0f + expf(-zg[0][r]));
+        float th, sg;
+        if constexpr (sizeof(E) == 4) {
+          th = tanhf(za[m][r]);
+          sg = 1.0f / (1.0f + expf(-zg[m][r]));
+        } else {
+          const float ea = __builtin_amdgcn_exp2f(fmaxf(za[m][r], -15.0f) * -2.885390081777927f);
+          th = (1.0f - ea) * fast_rcp(1.0f + ea);
+          sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(zg[m][r] * -1.4426950408889634f));
+        }
         const float du = acc[m][r];
-        da[0][r] = du * sg * (1.0f - th * th);
-        db[0][r] = du * th * sg * (1.0f - sg);
+        za[m][r] = du * sg * (1.0f - th * th);
+        zg[m][r] = du * th * sg * (1.0f - sg);
       }
-      stage_store_tiles<E, 1>(stg, da, orow + (int64_t)m * 32 * ES, p.out_stride * ES, rows_valid, lane);
-      stage_store_tiles<E, 1>(stg, db, orow + (int64_t)(Hp + m * 32) * ES, p.out_stride * ES, rows_valid, lane);
     }
+    stage_store_tiles<E, NT>(stg, za, orow, p.out_stride * ES, rows_valid, lane);
+    stage_store_tiles<E, NT>(stg, zg, orow + (int64_t)NT * 32 * ES, p.out_stride * ES, rows_valid, lane);
   }
 }
 

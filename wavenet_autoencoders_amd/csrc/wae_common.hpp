@@ -268,6 +268,65 @@ __device__ __forceinline__ void stage_load_tiles(char* stg, f32x16* y, const cha
   }
 }
 
+// Split form of stage_load_tiles for kernels that know early which rows they will need at the end: stage_fetch_tiles
+// issues the coalesced row loads into registers (call before the GEMM; the data arrives under the MFMAs) and
+// stage_unpack_tiles turns them into accumulator-layout tiles through the LDS tile afterwards.  One f32x4[8] per pass.
+template <int NT, typename EO>
+struct StagePasses {
+  static constexpr int PT = 256 / (32 * (int)sizeof(EO));
+  static constexpr int N = (NT + PT - 1) / PT + (NT % PT == 3 ? 1 : 0);   // e.g. bf16: 6 -> {4,2}; 3 -> {2,1}
+};
+template <typename EO, int NTP>
+__device__ __forceinline__ void stage_fetch_pass(f32x4 (&r)[8], const char* gin, int64_t row_stride, int rows_valid, int lane) {
+  constexpr int SEG = NTP * 32 * sizeof(EO);
+  constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 32 / RPI;
+  const int rr = lane / LPR, ck = lane % LPR;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = min(i * RPI + rr, rows_valid - 1);
+    r[i] = *(const f32x4*)(gin + row * row_stride + ck * 16);
+  }
+}
+template <typename EO, int NTP>
+__device__ __forceinline__ void stage_unpack_pass(char* stg, f32x16* y, const f32x4 (&r)[8], int lane) {
+  using vec4 = typename ET<EO>::vec4;
+  constexpr int SEG = NTP * 32 * sizeof(EO);
+  constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 32 / RPI;
+  const int n = lane & 31, h = lane >> 5;
+  const int rr = lane / LPR, ck = lane % LPR;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = i * RPI + rr;
+    *(f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4)) = r[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int mt = 0; mt < NTP; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int c16, sub;
+      if constexpr (sizeof(EO) == 2) { c16 = 4 * mt + g; sub = 8 * h; } else { c16 = 8 * mt + 2 * g + h; sub = 0; }
+      const f32x4 v = to_f32x4(*(const vec4*)(stg + n * 256 + ((c16 ^ (n & 15)) << 4) + sub));
+      y[mt][4 * g] = v.x; y[mt][4 * g + 1] = v.y; y[mt][4 * g + 2] = v.z; y[mt][4 * g + 3] = v.w;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <typename EO, int NT, int PI = 0, int NP>
+__device__ __forceinline__ void stage_fetch_tiles(f32x4 (&r)[NP][8], const char* gin, int64_t row_stride, int rows_valid, int lane) {
+  constexpr int PT = 256 / (32 * (int)sizeof(EO));
+  constexpr int NTP = NT >= PT ? PT : (NT >= 2 ? 2 : 1);
+  static_assert(PI < NP, "pass array too small");
+  stage_fetch_pass<EO, NTP>(r[PI], gin, row_stride, rows_valid, lane);
+  if constexpr (NT > NTP) stage_fetch_tiles<EO, NT - NTP, PI + 1>(r, gin + NTP * 32 * sizeof(EO), row_stride, rows_valid, lane);
+}
+template <typename EO, int NT, int PI = 0, int NP>
+__device__ __forceinline__ void stage_unpack_tiles(char* stg, f32x16* y, const f32x4 (&r)[NP][8], int lane) {
+  constexpr int PT = 256 / (32 * (int)sizeof(EO));
+  constexpr int NTP = NT >= PT ? PT : (NT >= 2 ? 2 : 1);
+  stage_unpack_pass<EO, NTP>(stg, y, r[PI], lane);
+  if constexpr (NT > NTP) stage_unpack_tiles<EO, NT - NTP, PI + 1>(stg, y + NTP, r, lane);
+}
+
 // Residual x[t] arrives as operand-shaped 16-byte fragments: fragment f of lane (n, h) = row bytes
 // [32 f + 16 h, +16) of the chunk.  f32: that IS the accumulator layout (tile f/4, group f%4, channels 8g+4h+j).
 // bf16: 8 channels 16 f + 8 h + j; the accumulator layout wants channels 8g + 4h' + j' -> exchange register pairs
