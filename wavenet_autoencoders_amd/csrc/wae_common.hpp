@@ -93,16 +93,26 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& u, f32x4 (&f)[4]) {
   }
 }
 
-// Linear global -> LDS copy of `bytes` (multiple of 256 threads * 16 B) by LDS-DMA: every wave instruction
-// moves 1 KiB to a wave-uniform LDS base + lane*16 (cdna_hip_programming.md section 5, Caveat).
+// Linear global -> LDS copy of `bytes` (a multiple of 4 KiB) by LDS-DMA: every wave instruction moves 1 KiB to a
+// wave-uniform LDS base + lane*16 (cdna_hip_programming.md section 5, Caveat).  Each of the 4 waves copies one contiguous
+// quarter, 1 KiB per instruction; the instruction offset field (which advances the global AND the LDS address) covers
+// four pieces, so one M0 write and one address computation serve four DMAs.
 __device__ __forceinline__ void dma_chunk(const char* __restrict__ gsrc, char* lds_dst, int bytes, int wave, int lane) {
-  const int per_pass = 256 * 16;
-  for (int off = 0; off < bytes; off += per_pass) {
-    const char* g = gsrc + off + wave * 1024 + lane * 16;
-    char* l = lds_dst + off + wave * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  const int per_wave = bytes >> 2;
+  const char* g = gsrc + wave * per_wave + lane * 16;
+  char* l = lds_dst + wave * per_wave;
+  int off = 0;
+  for (; off + 4096 <= per_wave; off += 4096) {
+    const __attribute__((address_space(1))) void* gp = (const __attribute__((address_space(1))) void*)(g + off);
+    __attribute__((address_space(3))) void* lp = (__attribute__((address_space(3))) void*)(l + off);
+    __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
   }
+  for (; off < per_wave; off += 1024)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off),
+                                     (__attribute__((address_space(3))) void*)(l + off), 16, 0, 0);
 }
 
 // One weight chunk of N fragment blocks (LDS image [i][lane][16 B], i = blk*NM + m) against the B fragments
