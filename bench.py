@@ -209,6 +209,19 @@ def main():
     fwd_bytes_per_sample = geom.layers * (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es + (C2["S"] + 0) * es + 4 + 1
     value = world * samples * args.steps / dt
 
+    # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (profiles/*pmc_traffic.json;
+    # bench.py cannot run the profiler on itself).  Only applied when the run matches the profiled configuration.
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)["kernels"]
+        if args.dtype == "bf16" and args.mode == "train":
+            for rf in (roof, fwd_roof):
+                for k, v in pmc.items():
+                    if rf["kernel"] in k and ("Li6ELb0" in k or "gemm_tn" in k):
+                        rf["traffic"] = v["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         res = {
             "metric": "teacher-forced audio samples/sec (24-layer decoder), " + ("train step" if args.mode == "train" else "forward + CE"),
