@@ -90,7 +90,7 @@ int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t la
                   int64_t emb_off, const float* gvec, float* zb, int32_t B, int32_t L, int32_t G, int32_t Hp,
                   int32_t Cg, void* stream);
 
-/* backward of wae_gproj_fwd.  c1: the per-layer dW1 tiles of wae_gemm_tn (L x 2Hp x ld fp32) whose columns
+/* backward of wae_gproj_fwd.  c1: the per-layer dW1 tiles of wae_gemm_tn_tiles (L x 2Hp x ld fp32) whose columns
  * ones_col + b hold sum_t dz[b,t,row] = d loss / d zb[b][l][row]; adds into d_eff: conv bias, conv1x1g weight and
  * (gid != NULL) the embedding rows. */
 int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride,

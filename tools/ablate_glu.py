@@ -1,5 +1,8 @@
 #!/usr/bin/env python
 """Timing-only ablation of wae_glu_layer_fwd at the C2 shape (run on the GPU box).
+Needs the library built with the ablation bits compiled in:
+    touch wavenet_autoencoders_amd/csrc/glu_fwd.hip && make -C wavenet_autoencoders_amd/csrc EXTRA=-DWAE_GLU_ABLATE
+Usage: ablate_glu.py [bf16|fp32] [waves per workgroup: 4|8]
 Interleaved rounds in one process (cdna_hip_programming.md 5.4 rule 24)."""
 import ctypes
 import os
@@ -25,8 +28,10 @@ xo = torch.empty_like(x)
 ubuf = torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype)
 zb = torch.zeros(B, 2 * g.Hp, device="cuda")
 st = eng.stream()
+eng.lib.wae_debug_set_glu_waves.argtypes = [ctypes.c_int]
+eng.lib.wae_debug_set_glu_waves(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
 variants = {"full": 0, "no_dma": 0x100, "no_bload": 0x200, "no_epi": 0x400, "no_gate": 0x800,
-            "no_dma_bload": 0x300, "mfma_only": 0xF00}
+            "no_dma_bload": 0x300, "coalesced_b": 0x1000, "coalesced_b_no_dma": 0x1100, "mfma_only": 0xF00}
 
 
 def run(flags, d):
@@ -36,8 +41,8 @@ def run(flags, d):
 
 
 res = {k: [] for k in variants}
-for d in (1, 64):
-    for rnd in range(6):
+for d in (1,):
+    for rnd in range(5):
         for name, fl in variants.items():
             for _ in range(2):
                 run(fl, d)

@@ -26,10 +26,13 @@ xo = torch.empty_like(x)
 ubuf = torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype)
 zb = torch.zeros(B, 2 * g.Hp, device="cuda")
 st = eng.stream()
-nwg = B * ((T + 127) // 128)
+NW = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+nwg = B * ((T + 32 * NW - 1) // (32 * NW))
 stamps = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 lib = eng.lib
 lib.wae_debug_set_stamps.argtypes = [ctypes.c_void_p]
+lib.wae_debug_set_glu_waves.argtypes = [ctypes.c_int]
+lib.wae_debug_set_glu_waves(NW)
 
 
 def run(fl, d=4):
@@ -46,16 +49,19 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib.wae_debug_set_stamps(None)
 s = stamps.cpu().numpy().reshape(nwg, 16)
-names = ["init(zb, first dma/B issue)", "GEMM1", "z-save+gate+u-store", "GEMM2+epilogue"]
+names = ["init(zb, first dma/B issue)", "GEMM1 pass 0", "z-save+gate+u-store (+ later passes)", "GEMM2+epilogue"]
 d = np.diff(s[:, :5].astype(np.int64), axis=1)
-print(f"flags={flags:#x} workgroups={nwg}; cycles per phase (median / p10 / p90) over workgroups:")
+print(f"flags={flags:#x} workgroups={nwg}; s_memtime ticks per phase (median / p10 / p90) over workgroups:")
 for i, nme in enumerate(names):
     v = np.sort(d[:, i])
-    print(f"  {nme:30s} {int(np.median(v)):8d} {int(v[len(v)//10]):8d} {int(v[len(v)*9//10]):8d}")
-tot = np.sort(s[:, 4] - s[:, 0])
-print(f"  {'total':30s} {int(np.median(tot)):8d}")
-rt = s[:, 5].astype(np.int64)
-start = s[:, 0].astype(np.int64)
-print("  wall span of launch by s_memrealtime (100 MHz ticks):", int(rt.max() - rt.min()), "-> us", (rt.max() - rt.min()) / 100.0)
-order = np.argsort(rt)
-print("  end times (us, sorted) first/median/last:", (rt[order[0]] - rt.min()) / 100., (rt[order[nwg // 2]] - rt.min()) / 100., (rt[order[-1]] - rt.min()) / 100.)
+    print(f"  {nme:38s} {int(np.median(v)):8d} {int(v[len(v)//10]):8d} {int(v[len(v)*9//10]):8d}")
+tot = (s[:, 4] - s[:, 0]).astype(np.int64)
+rt = (s[:, 5] - s[:, 14]).astype(np.int64)   # 100 MHz ticks over the same interval
+print(f"  total ticks median {int(np.median(tot))}; workgroup life {np.median(rt) / 100.0:.2f} us; "
+      f"s_memtime rate {np.median(tot / np.maximum(rt, 1)) * 100:.0f} MHz")
+print("  GEMM-1 chunk loop, wave 0, ticks summed over chunks (median): vmcnt wait", int(np.median(s[:, 6])), " barrier", int(np.median(s[:, 7])),
+      " DMA+B issue", int(np.median(s[:, 8])), " ds_read+MFMA", int(np.median(s[:, 9])))
+end = s[:, 5].astype(np.int64)
+start = s[:, 14].astype(np.int64)
+print(f"  launch span {(end.max() - start.min()) / 100.0:.2f} us; starts (us after first): median "
+      f"{(np.median(start) - start.min()) / 100.0:.2f}, max {(start.max() - start.min()) / 100.0:.2f}")

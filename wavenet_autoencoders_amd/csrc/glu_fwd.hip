@@ -12,21 +12,32 @@
 // a (B,T,S) fp32 buffer: per sample and layer the kernel reads R+Cc and writes R+H elements instead of
 // reading R+Cc+2S and writing R+2S.
 //
-// Work decomposition: one workgroup = 128 consecutive time steps of one clip, 4 waves (one per SIMD), each
-// wave owns 32 time columns and ALL channels, so the gate and the second GEMM need no cross-wave exchange:
-// the 32x32 accumulator tiles of GEMM 1 (column = time on the lane, rows = channels in the registers)
-// are converted in place into the B operand of GEMM 2 (cdna_hip_programming.md section 3, "An accumulator
-// tile as the next MFMA's operand").  Weights arrive pre-packed in A-fragment order and are streamed through
-// a double-buffered LDS ring by LDS-DMA, shared by the 4 waves; the activation (B) operand is read straight
-// from HBM/L2 as 16-byte fragments (time-major rows, channels innermost), zero-filled before t=0 (causal pad).
-// Outputs leave through a wave-private swizzled LDS tile so that every global store is a full-row 16-B access.
+// Work decomposition: one workgroup = NW*32 consecutive time steps of one clip, NW waves, each wave owns 32 time
+// columns and ALL channels of its columns, so the gate and the second GEMM need no cross-wave exchange: the 32x32
+// accumulator tiles of GEMM 1 (column = time on the lane, rows = channels in the registers) are converted in place
+// into the B operand of GEMM 2 (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
+// GEMM 1 runs in NPASS passes over the gate channels (pass p = tanh rows and sigmoid rows of channels
+// [p*NPH*32, (p+1)*NPH*32)), so only 2*NPH accumulator tiles are live: a wave fits in 256 registers and TWO waves
+// share each SIMD -- one wave's DMA issue, operand loads, gate VALU work and store epilogues run under the other's
+// MFMAs (measured with s_memtime stamps before this split: at one wave per SIMD the MFMA pipe idled for 2/3 of a
+// workgroup's life).  The price is that the activation operand is read NPASS times (L2 hits).
+// Weights arrive pre-packed in A-fragment order and are streamed through a double-buffered LDS ring by LDS-DMA,
+// shared by the NW waves; the activation (B) operand is read straight from HBM/L2 as 16-byte fragments (time-major
+// rows, channels innermost), zero-filled before t=0 (causal pad).  Outputs leave through a wave-private swizzled
+// LDS tile so that every global store is a full-row 16-B access.
 #include "wae_common.hpp"
 
-// timing-only ablation bits (tools/ablate_glu.py); outputs are wrong when any is set
+// timing-only ablation bits (tools/ablate_glu.py): compiled in only with -DWAE_GLU_ABLATE (a run-time test of these
+// bits inside the gate loop cost 2x on that phase); outputs are wrong when any is set
 #define DBG_NO_DMA 0x100
 #define DBG_NO_BLOAD 0x200
 #define DBG_NO_EPI 0x400
 #define DBG_NO_GATE 0x800
+#ifdef WAE_GLU_ABLATE
+#define ABL(flags, bit) ((flags) & (bit))
+#else
+#define ABL(flags, bit) false
+#endif
 
 struct GluArgs {
   const char* x_in;
@@ -40,11 +51,13 @@ struct GluArgs {
   int64_t zb_stride;
   int64_t u_stride;  // elements per time row of u_out
   int B, T, Rp, Ccp, Hp, ktaps, dilation, flags;
+  int nslot;  // LDS ring slots (>= 2); weight chunk q lives in slot q % nslot and is requested nslot-1 chunks ahead
   unsigned long long* stamps;  // diagnostic only (wae_debug_set_stamps): 16 x u64 per workgroup, else null
 };
 
 static unsigned long long* g_stamps = nullptr;
 extern "C" void wae_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = dev_buf; }
+#ifdef WAE_GLU_STAMPS
 #define STAMP(i)                                                              \
   do {                                                                        \
     if (p.stamps) {                                                           \
@@ -53,29 +66,57 @@ extern "C" void wae_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = d
       __builtin_amdgcn_sched_barrier(0);                                      \
     }                                                                         \
   } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
-template <typename E, int NP, bool EXACT>
-__global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
+// s_waitcnt vmcnt(min(w, 15)) for a wave-uniform run-time w (the count is an immediate in the ISA)
+__device__ __forceinline__ void wait_vmcnt_upto(int w) {
+#define WAE_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (w < 15 ? w : 15) {
+    WAE_VMC(0) WAE_VMC(1) WAE_VMC(2) WAE_VMC(3) WAE_VMC(4) WAE_VMC(5) WAE_VMC(6) WAE_VMC(7)
+    WAE_VMC(8) WAE_VMC(9) WAE_VMC(10) WAE_VMC(11) WAE_VMC(12) WAE_VMC(13) WAE_VMC(14)
+    default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+  }
+#undef WAE_VMC
+}
+
+__device__ __forceinline__ float vmax_nocanon(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// NPH = gate-channel tiles per pass (per half); NW = waves per workgroup
+template <typename E, int NP, int NPH, bool EXACT, int NW>
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) glu_fwd_kernel(GluArgs p) {
   using T_ = ET<E>;
   using frag = typename T_::frag;
-  constexpr int NM = 2 * NP;
+  static_assert(NP % NPH == 0, "passes must tile the gate channels");
+  constexpr int NPASS = NP / NPH;
+  constexpr int NM = 2 * NPH;
   constexpr int CHB = NM * 4 * 1024;  // bytes per weight chunk
   constexpr int ES = sizeof(E);
   constexpr int KBU = T_::KBU;
-  constexpr int MT2 = T_::MT2;
-  constexpr int NKB = NP * KBU;  // 16-B k-blocks of GEMM 2
-  static_assert(MT2 * NKB * 1024 == CHB, "GEMM-2 chunk must equal GEMM-1 chunk");
+  constexpr int NKB = NP * KBU;              // 16-B k-blocks of GEMM 2
+  constexpr int MT2 = CHB / (NKB * 1024);    // GEMM-2 M-tiles per chunk
+  static_assert(MT2 >= 1 && MT2 * NKB * 1024 == CHB, "GEMM-2 chunk must equal GEMM-1 chunk");
+  constexpr int PITCH = 128, STG = 32 * PITCH;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef WAE_GLU_STAMPS
   unsigned long long st_[16] = {};
+  if (p.stamps) st_[14] = __builtin_amdgcn_s_memrealtime();
+#endif
   STAMP(0);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 31, h = lane >> 5;
-  const int tiles_per_b = (p.T + 127) >> 7;
+  constexpr int TW = NW * 32;
+  const int tiles_per_b = (p.T + TW - 1) / TW;
   const int b = blockIdx.x / tiles_per_b;
-  const int t0w = (blockIdx.x % tiles_per_b) * 128 + wave * 32;
+  const int t0w = (blockIdx.x % tiles_per_b) * TW + wave * 32;
   const int t = t0w + n;
   const bool tvalid = t < p.T;
   const int rows_valid = min(max(p.T - t0w, 0), 32);
@@ -84,121 +125,251 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
   const int nq_conv = p.ktaps * cpr;
   const int nq1 = nq_conv + p.Ccp / T_::CK;
   const int nq2 = (p.flags & WAE_GLU_NO_OUT) ? 0 : (p.Rp >> 5) / MT2;
-  const int nq_total = nq1 + nq2;
+  const int nq_total = NPASS * nq1 + nq2;
 
   const int64_t row_x = (int64_t)p.Rp * ES;
   const int64_t row_c = (int64_t)p.Ccp * ES;
   const char* xb = p.x_in + (int64_t)b * p.T * row_x;
   const char* cb = p.c_up ? p.c_up + (int64_t)b * p.T * row_c : nullptr;
 
-  const bool dbg_dma = !(p.flags & DBG_NO_DMA);
-  frag Bn[4], Bc[4];
-  auto load_B = [&](int q, frag (&Bf)[4]) {
-    const char* src;
-    bool ok = tvalid && !(p.flags & DBG_NO_BLOAD);
+  const bool dbg_dma = !ABL(p.flags, DBG_NO_DMA);
+  // The activation operand is requested TWO chunks ahead into a rotating set of three fragment groups (an L2/HBM
+  // round trip under load is longer than one chunk of MFMAs).  Loads are always issued (rows clamped into the clip)
+  // so that the number of outstanding VMEM ops is known; columns outside [0, T) are zeroed at use (causal pad).
+  frag S0[4], S1[4], S2[4];
+  // per-lane address of this lane's first fragment of activation chunk q (its row clamped into the clip)
+  auto b_src = [&](int q) -> const char* {
+    const char* base;
+    int64_t rp;
+    int ts = t;
     if (q < nq_conv) {
       const int tap = q / cpr, cblk = q - tap * cpr;
-      const int ts = t - (p.ktaps - 1 - tap) * p.dilation;
-      ok = ok && ts >= 0;
-      src = xb + (int64_t)ts * row_x + cblk * 128 + h * 16;
+      ts = t - (p.ktaps - 1 - tap) * p.dilation;
+      base = xb + cblk * 128 + h * 16;
+      rp = row_x;
     } else {
-      src = cb + (int64_t)t * row_c + (q - nq_conv) * 128 + h * 16;
+      base = cb + (q - nq_conv) * 128 + h * 16;
+      rp = row_c;
     }
+    return base + (int64_t)min(max(ts, 0), p.T - 1) * rp;
+  };
+  auto load_B = [&](int q, frag (&Bf)[4]) {
+    if (ABL(p.flags, DBG_NO_BLOAD)) return;
+    const char* src = b_src(q);
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
-      if (ok) {
-        Bf[blk] = *(const frag*)(src + blk * 32);
-      } else {
-        frag zf = {};
-        Bf[blk] = zf;
-      }
+    for (int blk = 0; blk < 4; ++blk) Bf[blk] = *(const frag*)(src + blk * 32);
+  };
+  auto fix_B = [&](int q, frag (&Bf)[4]) {
+    const int shift = q < nq_conv ? (p.ktaps - 1 - q / cpr) * p.dilation : 0;
+    const bool ok = tvalid && t - shift >= 0 && !ABL(p.flags, DBG_NO_BLOAD);
+    if (__any(!ok)) {
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+        if (!ok) {
+          frag zf = {};
+          Bf[blk] = zf;
+        }
     }
   };
 
-  // ---- accumulators start from zb = conv bias + hoisted global conditioning -------------------------
-  f32x16 acc[NM];
+  // out bias and this clip's zb -> LDS once (read back with ds_read: keeps accumulator inits off vmcnt, where they
+  // would drain the LDS-DMA queue)
+  constexpr int PPW = CHB / NW / 1024;  // LDS-DMA instructions per wave and chunk
+  const int D = p.nslot - 1;            // weight prefetch distance in chunks
+  char* ring_end = smem + p.nslot * CHB;
+  char* stg = ring_end + wave * STG;
+  float* bias_lds = (float*)(ring_end + NW * STG);
+  float* zb_lds = bias_lds + p.Rp;
   {
     const float* zbb = p.zb + (int64_t)b * p.zb_stride;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) init_rows(acc[m], zbb + (m < NP ? 32 * m : p.Hp + 32 * (m - NP)), h);
+    if (nq2 > 0)
+      for (int i = threadIdx.x * 4; i < p.Rp; i += NW * 256) *(f32x4*)(bias_lds + i) = *(const f32x4*)(p.bias_out + i);
+    for (int i = threadIdx.x * 4; i < 2 * p.Hp; i += NW * 256) *(f32x4*)(zb_lds + i) = *(const f32x4*)(zbb + i);
   }
-
-  // out bias -> LDS once (read back per chunk with ds_read: keeps the second GEMM's accumulator init off vmcnt,
-  // where it would drain the LDS-DMA and residual-prefetch queues)
-  float* bias_lds = (float*)(smem + 2 * CHB + 4 * STG_BYTES);
-  if (nq2 > 0)
-    for (int i = threadIdx.x * 4; i < p.Rp; i += 1024) *(f32x4*)(bias_lds + i) = *(const f32x4*)(p.bias_out + i);
-  if (dbg_dma) dma_chunk(p.w, smem, CHB, wave, lane);
-  load_B(0, Bn);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads retired: from here on VMEM ops are counted by hand
+  if (dbg_dma) dma_chunk<NW>(p.w, smem, CHB, wave, lane);
+  load_B(0, S0);
+  load_B(1, S1);
   STAMP(1);
 
-  // ---- GEMM 1 ----------------------------------------------------------------------------------------
-  for (int q = 0; q < nq1; ++q) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
-    if (q + 1 < nq_total && dbg_dma) dma_chunk(p.w + (int64_t)(q + 1) * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
-    if (q + 1 < nq1) load_B(q + 1, Bn);
-    const char* buf = smem + (q & 1) * CHB + lane * 16;
-    gemm_chunk<4 * NM, NM, 4>(buf, Bc, acc);
-  }
-  STAMP(2);
-
-  char* stg = smem + 2 * CHB + wave * STG_BYTES;
-  const bool no_epi = p.flags & DBG_NO_EPI;
-
-  // ---- optional z save (training): rows of 2Hp elements, a-half then b-half ------------------------------
-  if ((p.flags & WAE_GLU_SAVE_Z) && rows_valid > 0) {
-    char* zr = p.z_save + ((int64_t)b * p.T + t0w) * (2 * p.Hp) * ES;
-    stage_store_tiles<E, NP>(stg, &acc[0], zr, (int64_t)2 * p.Hp * ES, rows_valid, lane);
-    stage_store_tiles<E, NP>(stg, &acc[NP], zr + (int64_t)p.Hp * ES, (int64_t)2 * p.Hp * ES, rows_valid, lane);
-  }
-
-  // ---- gate: u = tanh(a) * sigmoid(b); stored once for the head's skip GEMM, and converted in place to the
-  //      operand fragments of GEMM 2 -----------------------------------------------------------------------
+  const bool no_epi = ABL(p.flags, DBG_NO_EPI);
   frag uf[NKB];
-#pragma unroll
-  for (int pr = 0; pr < NP; ++pr) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float a = acc[pr][r], g = acc[NP + pr][r];
-      float u;
-      if (p.flags & DBG_NO_GATE) {
-        u = a * g;
-      } else if constexpr (EXACT) {
-        u = tanhf(a) * (1.0f / (1.0f + expf(-g)));
-      } else {
-        // tanh(a)*sigmoid(g) = (1-ea) / ((1+ea)(1+eg)), ea = e^-2a, eg = e^-g.  a is clamped from below so that
-        // ea stays finite (tanh(-15) == -1 in fp32); eg = inf gives rcp(inf) = 0, the correct limit.
-        const float ea = __builtin_amdgcn_exp2f(fmaxf(a, -15.0f) * -2.885390081777927f);
-        const float eg = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
-        u = (1.0f - ea) * fast_rcp((1.0f + ea) * (1.0f + eg));
-      }
-      acc[pr][r] = u;
+  // ring bookkeeping: slot_c = slot of the current chunk, slot_n = slot the next DMA goes to (chunk qi + D)
+  int slot_c = 0, slot_n = 1 % p.nslot;
+  // Top of chunk qi: retire B(qi) and DMA(qi), meet the other waves.  The requests for later chunks -- the weights
+  // D chunks ahead (PPW LDS-DMA pieces per wave) and the activations two chunks ahead (4 loads) -- are then issued
+  // BETWEEN the MFMAs of chunk qi (every SP-th step), pieces first: a burst of 10 VMEM instructions per wave at the
+  // chunk top queued at the CU's texture-address unit for ~1000 cycles per chunk with the matrix pipe idle.
+  // Loads retire in order, so B(qi) -- the last thing issued in chunk qi-2 -- and everything older (DMA(qi) included,
+  // D >= 2) have landed once at most w_next = (ops issued during chunk qi-1) VMEM ops are outstanding.  Stores issued
+  // in between only make the wait stricter.  D == 1: DMA(qi) is itself part of chunk qi-1, only that chunk's B loads
+  // may stay in flight.
+  constexpr int NSTEP = 4 * NM, NOPS = PPW + 4, SP = NSTEP / NOPS >= 1 ? NSTEP / NOPS : 1;
+  static_assert(NOPS * SP <= NSTEP + SP - 1 && NOPS <= NSTEP, "not enough MFMA steps to carry the chunk's VMEM issue");
+  const int per_wave = CHB / NW;
+  const char* w_lane = p.w + wave * per_wave + lane * 16;
+  int w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : 4;  // the prologue's B(1)
+  const char* dsrc = nullptr;  // this chunk's DMA request (wave-uniform validity), per-lane source
+  char* ddst = nullptr;
+  const char* bsrc = nullptr;  // this chunk's activation request
+#ifdef WAE_GLU_STAMPS
+  unsigned long long acc_wait = 0, acc_bar = 0, acc_issue = 0, acc_gemm = 0;
+#define TICK() (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime())
+#endif
+  auto chunk_top = [&](int qi, int q_load) {
+#ifdef WAE_GLU_STAMPS
+    const unsigned long long c0 = TICK();
+#endif
+    wait_vmcnt_upto(w_next);
+#ifdef WAE_GLU_STAMPS
+    const unsigned long long c1 = TICK();
+#endif
+    __syncthreads();
+#ifdef WAE_GLU_STAMPS
+    const unsigned long long c2 = TICK();
+    acc_wait += c1 - c0;
+    acc_bar += c2 - c1;
+#endif
+    int issued = 0;
+    dsrc = nullptr;
+    if (qi == 0) {
+      for (int j = 1; j <= D; ++j)
+        if (j < nq_total && dbg_dma) {
+          dma_chunk<NW>(p.w + (int64_t)j * CHB, smem + slot_n * CHB, CHB, wave, lane);
+          slot_n = slot_n + 1 == p.nslot ? 0 : slot_n + 1;
+          issued += PPW;
+        }
+    } else if (qi + D < nq_total && dbg_dma) {
+      dsrc = w_lane + (int64_t)(qi + D) * CHB;
+      ddst = smem + slot_n * CHB + wave * per_wave;
+      slot_n = slot_n + 1 == p.nslot ? 0 : slot_n + 1;
+      issued += PPW;
     }
-    frag tmp[KBU];
-    acc_to_frags(acc[pr], tmp);
+    const bool lb = q_load >= 0 && !ABL(p.flags, DBG_NO_BLOAD);
+    bsrc = lb ? b_src(q_load) : nullptr;
+    const int nb = lb ? 4 : 0;
+    // at chunk 1 DMA(1) -- the oldest chunk of chunk 0's burst -- must have landed as well
+    w_next = D == 1 ? nb : (qi == 0 && issued > 0 ? issued - PPW + nb : issued + nb);
+#ifdef WAE_GLU_STAMPS
+    acc_issue += TICK() - c2;
+#endif
+  };
+
 #pragma unroll
-    for (int s = 0; s < KBU; ++s) uf[pr * KBU + s] = tmp[s];
-  }
-  if (!no_epi && rows_valid > 0) {
-    char* ur = p.u_out + ((int64_t)b * p.T + t0w) * p.u_stride * ES;
-    stage_store_tiles<E, NP>(stg, &acc[0], ur, p.u_stride * ES, rows_valid, lane);
+  for (int ps = 0; ps < NPASS; ++ps) {
+    // ---- accumulators start from zb = conv bias + hoisted global conditioning ---------------------------
+    f32x16 acc[NM];
+    if (ps == 0) __syncthreads();  // zb/bias tables visible
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+      init_rows(acc[m], zb_lds + (m < NPH ? 32 * (ps * NPH + m) : p.Hp + 32 * (ps * NPH + m - NPH)), h);
+
+    // ---- GEMM 1, pass ps -----------------------------------------------------------------------------------
+    // Chunks run in statically unrolled triples so that the three fragment groups rotate without register moves
+    // (a move of a group whose load is still in flight would stall on it): chunk q computes from group q % 3 while
+    // chunk q + 2 is requested into group (q + 2) % 3.  Every pass restarts the rotation at group 0.
+    {
+      auto step = [&](int q, frag (&Bcur)[4], frag (&Bload)[4]) {
+        chunk_top(ps * nq1 + q, q + 2 < nq1 ? q + 2 : -1);
+        fix_B(q, Bcur);
+        const char* buf = smem + slot_c * CHB + lane * 16;
+        auto filler = [&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          if constexpr (I % SP == 0 && I / SP < NOPS) {
+            constexpr int k = I / SP;
+            if constexpr (k < PPW) {
+              if (dsrc) dma_piece(dsrc + k * 1024, ddst + k * 1024);
+            } else {
+              if (bsrc) Bload[k - PPW] = *(const frag*)(bsrc + (k - PPW) * 32);
+            }
+          }
+        };
+#ifdef WAE_GLU_STAMPS
+        const unsigned long long g0 = TICK();
+#endif
+        gemm_chunk_fill<NSTEP, NM, 4, false, 4>(buf, Bcur, acc, filler);
+#ifdef WAE_GLU_STAMPS
+        acc_gemm += TICK() - g0;
+#endif
+        slot_c = slot_c + 1 == p.nslot ? 0 : slot_c + 1;
+      };
+      int q = 0;
+      for (; q + 3 <= nq1; q += 3) {
+        step(q, S0, S2);
+        step(q + 1, S1, S0);
+        step(q + 2, S2, S1);
+      }
+      if (q < nq1) step(q, S0, S2);
+      if (q + 1 < nq1) step(q + 1, S1, S0);
+      if (ps + 1 < NPASS) {  // the next pass's first two chunks travel under the gate
+        load_B(0, S0);
+        load_B(1, S1);
+        w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : 4;
+      }
+    }
+    if (ps == 0) STAMP(2);
+
+    // ---- optional z save (training): rows of 2Hp elements, a-half then b-half --------------------------
+    if ((p.flags & WAE_GLU_SAVE_Z) && rows_valid > 0) {
+      char* zr = p.z_save + (((int64_t)b * p.T + t0w) * (2 * p.Hp) + ps * NPH * 32) * ES;
+      stage_store_tiles<E, NPH, PITCH>(stg, &acc[0], zr, (int64_t)2 * p.Hp * ES, rows_valid, lane);
+      stage_store_tiles<E, NPH, PITCH>(stg, &acc[NPH], zr + (int64_t)p.Hp * ES, (int64_t)2 * p.Hp * ES, rows_valid, lane);
+    }
+
+    // ---- gate: u = tanh(a) * sigmoid(b); stored once for the head's skip GEMM, and converted in place to the
+    //      operand fragments of GEMM 2 -------------------------------------------------------------------
+#pragma unroll
+    for (int pr = 0; pr < NPH; ++pr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a = acc[pr][r], g = acc[NPH + pr][r];
+        float u;
+        if (ABL(p.flags, DBG_NO_GATE)) {
+          u = a * g;
+        } else if constexpr (EXACT) {
+          u = tanhf(a) * (1.0f / (1.0f + expf(-g)));
+        } else {
+          // tanh(a)*sigmoid(g) = (1-ea) / ((1+ea)(1+eg)), ea = e^-2a, eg = e^-g.  a is clamped from below so that
+          // ea stays finite (tanh(-15) == -1 in fp32); eg = inf gives rcp(inf) = 0, the correct limit.
+          const f32x2 sc = {-2.885390081777927f, -1.4426950408889634f};
+          f32x2 ag = {vmax_nocanon(a, -15.0f), g};
+          ag = ag * sc;
+          const float ea = __builtin_amdgcn_exp2f(ag.x);
+          const float eg = __builtin_amdgcn_exp2f(ag.y);
+          const f32x2 one = {1.0f, 1.0f};
+          const f32x2 e2 = {ea, eg};
+          const f32x2 d = e2 + one;
+          u = (1.0f - ea) * fast_rcp(d.x * d.y);
+        }
+        acc[pr][r] = u;
+      }
+      frag tmp[KBU];
+      acc_to_frags(acc[pr], tmp);
+#pragma unroll
+      for (int s = 0; s < KBU; ++s) uf[(ps * NPH + pr) * KBU + s] = tmp[s];
+      __builtin_amdgcn_sched_barrier(0);  // one tile at a time: keeps the gate's temporaries from piling up
+    }
+    if (!no_epi && rows_valid > 0) {
+      char* ur = p.u_out + (((int64_t)b * p.T + t0w) * p.u_stride + ps * NPH * 32) * ES;
+      stage_store_tiles<E, NPH, PITCH>(stg, &acc[0], ur, p.u_stride * ES, rows_valid, lane);
+    }
   }
   STAMP(3);
 
   // ---- GEMM 2 + residual epilogue ------------------------------------------------------------------------
-  // Each chunk = MT2 M-tiles (MT2*32 output channels = 256 bytes per time row) against all of u.
+  // Each chunk = MT2 M-tiles (MT2*32 output channels = one staging pass per time row) against all of u.
   for (int q2 = 0; q2 < nq2; ++q2) {
-    const int qi = nq1 + q2;
-    // the only VMEM ops younger than DMA(qi) are the previous epilogue's row stores: a counted wait retires
-    // the DMA without waiting for those stores to be acknowledged (8 stores per 256-byte pass)
-    if (q2 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    const int qi = NPASS * nq1 + q2;
+    // DMA(qi) was requested D chunks ago.  If that was before this phase's first drain (q2 == 0) nothing is pending
+    // for it any more; otherwise drain (the previous epilogue's stores and residual loads are younger than it).
+    if (q2 == 0 || q2 - D >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (qi + 1 < nq_total && dbg_dma) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi + 1) & 1) * CHB, CHB, wave, lane);
-    const char* buf = smem + (qi & 1) * CHB + lane * 16;
+    if (qi + D < nq_total && dbg_dma) {
+      dma_chunk<NW>(p.w + (int64_t)(qi + D) * CHB, smem + slot_n * CHB, CHB, wave, lane);
+      slot_n = slot_n + 1 == p.nslot ? 0 : slot_n + 1;
+    }
+    const char* buf = smem + slot_c * CHB + lane * 16;
+    slot_c = slot_c + 1 == p.nslot ? 0 : slot_c + 1;
     const int gm0 = q2 * MT2;
     // residual x[t] for this chunk's channels, as operand-shaped 16-byte fragments (L2 hits: tap k-1 of GEMM 1
     // read the same bytes); issued now, consumed after the MFMAs
@@ -218,64 +389,90 @@ __global__ void __launch_bounds__(256, 1) glu_fwd_kernel(GluArgs p) {
       continue;
     }
     // x' = (y + x) * sqrt(.5) in the accumulator layout
-    const float rs = 0.70710678118654752440f;
+    const f32x2 rs = {0.70710678118654752440f, 0.70710678118654752440f};
     residual_to_acc_layout(res);
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 r4 = residual_piece<E>(res, mt, g);
-        y[mt][4 * g + 0] = (y[mt][4 * g + 0] + r4.x) * rs;
-        y[mt][4 * g + 1] = (y[mt][4 * g + 1] + r4.y) * rs;
-        y[mt][4 * g + 2] = (y[mt][4 * g + 2] + r4.z) * rs;
-        y[mt][4 * g + 3] = (y[mt][4 * g + 3] + r4.w) * rs;
+        f32x2 lo = {y[mt][4 * g + 0], y[mt][4 * g + 1]}, hi = {y[mt][4 * g + 2], y[mt][4 * g + 3]};
+        const f32x2 rlo = {r4.x, r4.y}, rhi = {r4.z, r4.w};
+        lo = (lo + rlo) * rs;
+        hi = (hi + rhi) * rs;
+        y[mt][4 * g + 0] = lo.x; y[mt][4 * g + 1] = lo.y; y[mt][4 * g + 2] = hi.x; y[mt][4 * g + 3] = hi.y;
       }
     }
     if (rows_valid > 0) {
       char* orow = p.x_out + ((int64_t)b * p.T + t0w) * row_x + (int64_t)gm0 * 32 * ES;
-      stage_store_tiles<E, MT2>(stg, y, orow, row_x, rows_valid, lane);
+      stage_store_tiles<E, MT2, PITCH>(stg, y, orow, row_x, rows_valid, lane);
     }
   }
   STAMP(4);
+#ifdef WAE_GLU_STAMPS
   if (p.stamps && threadIdx.x == 0) {
     st_[5] = __builtin_amdgcn_s_memrealtime();
+    st_[6] = acc_wait; st_[7] = acc_bar; st_[8] = acc_issue; st_[9] = acc_gemm;
 #pragma unroll
     for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 16 + i] = st_[i];
   }
+#endif
 }
 
-template <typename E, int NP, bool EXACT>
-static int launch_glu(const GluArgs& a, hipStream_t st) {
-  constexpr int CHB = 2 * NP * 4 * 1024;
-  const size_t lds = 2 * CHB + 4 * STG_BYTES + (size_t)a.Rp * 4;
-  if (lds > 160 * 1024) {
-    wae_set_error("glu_fwd: needs %zu bytes of LDS (> 160 KiB): Hp=%d with Rp=%d is not supported yet", lds, NP * 32, a.Rp);
+static int g_glu_nw = 4;  // waves per workgroup: 4 (two workgroups per CU) or 8 (one 256-step workgroup per CU)
+extern "C" void wae_debug_set_glu_waves(int nw) { g_glu_nw = nw == 8 ? 8 : 4; }
+
+static int g_glu_slots = 0;  // 0 = as many ring slots as fit (<= 6)
+extern "C" void wae_debug_set_glu_slots(int n) { g_glu_slots = n; }
+
+template <typename E, int NP, int NPH, bool EXACT, int NW>
+static int launch_glu_nw(GluArgs a, hipStream_t st) {
+  constexpr int CHB = 2 * NPH * 4 * 1024;
+  const size_t fixed = NW * 4096 + (size_t)(a.Rp + 2 * a.Hp) * 4;
+  const size_t budget = ((NW == 4 && sizeof(E) == 2) ? 80 : 160) * 1024;   // bf16, NW == 4: two workgroups share a CU
+  int nslot = fixed + 2 * CHB <= budget ? (int)((budget - fixed) / CHB) : 0;
+  if (nslot > 6) nslot = 6;
+  if (g_glu_slots >= 2 && g_glu_slots < nslot) nslot = g_glu_slots;
+  if (nslot < 2) {
+    wae_set_error("glu_fwd: needs %zu bytes of LDS: Hp=%d with Rp=%d is not supported", fixed + 2 * CHB, NP * 32, a.Rp);
     return WAE_EUNSUPPORTED;
   }
+  a.nslot = nslot;
+  const size_t lds = fixed + (size_t)nslot * CHB;
   static size_t attr_done = 0;
   if (attr_done < lds) {
-    if (hipFuncSetAttribute((const void*)glu_fwd_kernel<E, NP, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)glu_fwd_kernel<E, NP, NPH, EXACT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       wae_set_error("glu_fwd: cannot raise dynamic LDS to %zu", lds);
       return WAE_EHIP;
     }
     attr_done = lds;
   }
-  const int tiles = (a.T + 127) / 128;
-  hipLaunchKernelGGL((glu_fwd_kernel<E, NP, EXACT>), dim3(a.B * tiles), dim3(256), lds, st, a);
+  const int tiles = (a.T + NW * 32 - 1) / (NW * 32);
+  hipLaunchKernelGGL((glu_fwd_kernel<E, NP, NPH, EXACT, NW>), dim3(a.B * tiles), dim3(NW * 64), lds, st, a);
   return wae_check_launch("glu_fwd");
+}
+
+template <typename E, int NP, int NPH, bool EXACT>
+static int launch_glu(const GluArgs& a, hipStream_t st) {
+  // fp32 (the parity mode) keeps 4 waves with 512 registers each: its operand fragments are twice as many
+  if constexpr (sizeof(E) == 2)
+    if (g_glu_nw == 8) return launch_glu_nw<E, NP, NPH, EXACT, 8>(a, st);
+  return launch_glu_nw<E, NP, NPH, EXACT, 4>(a, st);
 }
 
 template <typename E, bool EXACT>
 static int dispatch_np(int np, const GluArgs& a, hipStream_t st) {
   switch (np) {
-    case 1: return launch_glu<E, 1, EXACT>(a, st);
-    case 2: return launch_glu<E, 2, EXACT>(a, st);
-    case 3: return launch_glu<E, 3, EXACT>(a, st);
-    case 4: return launch_glu<E, 4, EXACT>(a, st);
-    case 6: return launch_glu<E, 6, EXACT>(a, st);
+    // (NP, NPH): gate-channel tiles, tiles per pass -- packing.py: glu_pass_tiles() must agree
+    case 1: return launch_glu<E, 1, 1, EXACT>(a, st);
+    case 2: return launch_glu<E, 2, 1, EXACT>(a, st);
+    case 3: return launch_glu<E, 3, 3, EXACT>(a, st);
+    case 4: return launch_glu<E, 4, 2, EXACT>(a, st);
+    case 6: return launch_glu<E, 6, 3, EXACT>(a, st);
+    case 8: return launch_glu<E, 8, 4, EXACT>(a, st);
     default:
-      wae_set_error("glu_fwd: unsupported Hp=%d (Hp/32 must be 1,2,3,4 or 6)", np * 32);
+      wae_set_error("glu_fwd: unsupported Hp=%d (Hp/32 must be 1,2,3,4,6 or 8)", np * 32);
       return WAE_EUNSUPPORTED;
   }
 }
@@ -294,11 +491,12 @@ static int glu_validate(const wae_glu_desc* d) {
 extern "C" int64_t wae_glu_packed_bytes(const wae_glu_desc* d) {
   if (glu_validate(d) != WAE_OK) return WAE_EINVAL;
   const int ck = d->dtype == WAE_BF16 ? 64 : 32;
-  const int mt2 = d->dtype == WAE_BF16 ? 4 : 2;
-  const int64_t chb = (int64_t)2 * (d->Hp / 32) * 4 * 1024;
+  const int np = d->Hp / 32, nph = np == 3 ? 3 : (np % 2 == 0 ? np / 2 : np);
+  const int mt2 = (d->dtype == WAE_BF16 ? 4 : 2) * nph / np;
+  const int64_t chb = (int64_t)2 * nph * 4 * 1024;
   const int64_t nq1 = (int64_t)d->ktaps * (d->Rp / ck) + d->Ccp / ck;
   const int64_t nq2 = (d->Rp / 32) / mt2;
-  return (nq1 + nq2) * chb;
+  return ((np / nph) * nq1 + nq2) * chb;
 }
 
 extern "C" int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* x_out, const void* c_up, void* u_out,

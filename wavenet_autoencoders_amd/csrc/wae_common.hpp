@@ -97,8 +97,9 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& u, f32x4 (&f)[4]) {
 // wave-uniform LDS base + lane*16 (cdna_hip_programming.md section 5, Caveat).  Each of the 4 waves copies one contiguous
 // quarter, 1 KiB per instruction; the instruction offset field (which advances the global AND the LDS address) covers
 // four pieces, so one M0 write and one address computation serve four DMAs.
+template <int NWAVES = 4>
 __device__ __forceinline__ void dma_chunk(const char* __restrict__ gsrc, char* lds_dst, int bytes, int wave, int lane) {
-  const int per_wave = bytes >> 2;
+  const int per_wave = bytes / NWAVES;
   const char* g = gsrc + wave * per_wave + lane * 16;
   char* l = lds_dst + wave * per_wave;
   int off = 0;
@@ -133,9 +134,19 @@ __device__ __forceinline__ void lds_read_async(frag& dst, unsigned addr) {
 
 // KMAJOR = false: block I = blk*NM + m   -> acc[I % NM] += A_I . B[I / NM]   (first GEMM: k-blocks outer)
 // KMAJOR = true : block I = mt*NB + kb   -> acc[I / NB] += A_I . B[I % NB]   (second GEMM: M-tiles outer)
-template <int I, int N, int NM, int PD, int NB, bool KMAJOR, typename frag>
+// filler(std::integral_constant<int, I>) runs after MFMA I: callers spread their VMEM issue (LDS-DMA pieces, operand
+// loads for later chunks) over the MFMAs of a chunk instead of issuing it as a burst that queues at the CU's one
+// texture-address unit while the matrix pipe idles.
+struct NoFiller {
+  template <typename T>
+  __device__ __forceinline__ void operator()(T) const {}
+};
+template <int V>
+struct IntC { static constexpr int value = V; };
+
+template <int I, int N, int NM, int PD, int NB, bool KMAJOR, typename frag, typename F>
 struct GemmChunkStep {
-  static __device__ __forceinline__ void run(unsigned addr, frag (&a)[PD], const frag (&B)[NB], f32x16 (&acc)[NM]) {
+  static __device__ __forceinline__ void run(unsigned addr, frag (&a)[PD], const frag (&B)[NB], f32x16 (&acc)[NM], F& filler) {
     constexpr int remaining = N - 1 - I;                      // reads issued after block I
     constexpr int cnt = remaining < PD - 1 ? remaining : PD - 1;
     lds_wait<cnt>(a[I % PD]);
@@ -144,8 +155,9 @@ struct GemmChunkStep {
     else
       mma32(acc[I % NM], a[I % PD], B[I / NM]);
     if constexpr (I + PD < N) lds_read_async<(I + PD) * 1024>(a[I % PD], addr);
+    filler(IntC<I>{});
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (I + 1 < N) GemmChunkStep<I + 1, N, NM, PD, NB, KMAJOR, frag>::run(addr, a, B, acc);
+    if constexpr (I + 1 < N) GemmChunkStep<I + 1, N, NM, PD, NB, KMAJOR, frag, F>::run(addr, a, B, acc, filler);
   }
 };
 
@@ -157,15 +169,26 @@ struct GemmChunkPrologue {
   }
 };
 
-template <int N, int NM, int NB, bool KMAJOR = false, typename frag>
-__device__ __forceinline__ void gemm_chunk(const char* buf, const frag (&B)[NB], f32x16 (&acc)[NM]) {
-  constexpr int PD = N < 8 ? N : 8;
+template <int N, int NM, int NB, bool KMAJOR = false, int PDMAX = 8, typename frag, typename F>
+__device__ __forceinline__ void gemm_chunk_fill(const char* buf, const frag (&B)[NB], f32x16 (&acc)[NM], F& filler) {
+  constexpr int PD = N < PDMAX ? N : PDMAX;
   static_assert((N - 1) * 1024 < 65536, "ds_read offset field is 16 bits");
   const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)buf;
   frag a[PD];
   __builtin_amdgcn_sched_barrier(0);
   GemmChunkPrologue<0, PD, frag>::run(addr, a);
-  GemmChunkStep<0, N, NM, PD, NB, KMAJOR, frag>::run(addr, a, B, acc);
+  GemmChunkStep<0, N, NM, PD, NB, KMAJOR, frag, F>::run(addr, a, B, acc, filler);
+}
+template <int N, int NM, int NB, bool KMAJOR = false, int PDMAX = 8, typename frag>
+__device__ __forceinline__ void gemm_chunk(const char* buf, const frag (&B)[NB], f32x16 (&acc)[NM]) {
+  NoFiller nf;
+  gemm_chunk_fill<N, NM, NB, KMAJOR, PDMAX>(buf, B, acc, nf);
+}
+
+// one 1-KiB LDS-DMA piece: lane l copies 16 bytes from g (per-lane address) to lds_base (wave-uniform) + 16 l
+__device__ __forceinline__ void dma_piece(const char* g, char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
 // 16 accumulator registers of a tile start from a per-row constant table: rows 8g + 4h + j, j < 4
@@ -185,13 +208,15 @@ __device__ __forceinline__ void init_rows(f32x16& acc, const float* tab /* 32 fl
 // Passes of up to 256 bytes per row: 4/2/1 tiles (bf16) or 2/1 tiles (f32).
 // ---------------------------------------------------------------------------------------------------
 #define STG_BYTES 8192
-template <typename EO, int NTP>
+// PITCH = bytes per staged row (256: 8 KiB tile; 128: 4 KiB tile for kernels that run two workgroups per CU)
+template <typename EO, int NTP, int PITCH = 256>
 __device__ __forceinline__ void stage_store_pass(char* stg, const f32x16* y, char* gout, int64_t row_stride, int rows_valid,
                                                  int lane) {
   using vec4 = typename ET<EO>::vec4;
   constexpr int SEG = NTP * 32 * sizeof(EO);
-  static_assert(SEG <= 256 && SEG >= 64, "a staging pass covers 64..256 bytes per row");
+  static_assert(SEG <= PITCH && SEG >= 64, "a staging pass covers 64..PITCH bytes per row");
   constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 32 / RPI;
+  constexpr int KEY = PITCH / 16 - 1;
   const int n = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int mt = 0; mt < NTP; ++mt)
@@ -200,31 +225,31 @@ __device__ __forceinline__ void stage_store_pass(char* stg, const f32x16* y, cha
       int c16, sub;
       if constexpr (sizeof(EO) == 2) { c16 = 4 * mt + g; sub = 8 * h; } else { c16 = 8 * mt + 2 * g + h; sub = 0; }
       const f32x4 v = {y[mt][4 * g], y[mt][4 * g + 1], y[mt][4 * g + 2], y[mt][4 * g + 3]};
-      *(vec4*)(stg + n * 256 + ((c16 ^ (n & 15)) << 4) + sub) = from_f32x4<EO>(v);
+      *(vec4*)(stg + n * PITCH + ((c16 ^ (n & KEY)) << 4) + sub) = from_f32x4<EO>(v);
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int rr = lane / LPR, ck = lane % LPR;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int row = i * RPI + rr;
-    const f32x4 v = *(const f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4));
+    const f32x4 v = *(const f32x4*)(stg + row * PITCH + ((ck ^ (row & KEY)) << 4));
     if (row < rows_valid) *(f32x4*)(gout + row * row_stride + ck * 16) = v;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <typename EO, int NT>
+template <typename EO, int NT, int PITCH = 256>
 __device__ __forceinline__ void stage_store_tiles(char* stg, const f32x16* y, char* gout, int64_t row_stride, int rows_valid,
                                                   int lane) {
-  constexpr int PT = 256 / (32 * (int)sizeof(EO));  // tiles per full pass: 4 (bf16) / 2 (f32)
+  constexpr int PT = PITCH / (32 * (int)sizeof(EO));  // tiles per full pass: 4 (bf16) / 2 (f32) at PITCH 256
   if constexpr (NT >= PT) {
-    stage_store_pass<EO, PT>(stg, y, gout, row_stride, rows_valid, lane);
-    if constexpr (NT > PT) stage_store_tiles<EO, NT - PT>(stg, y + PT, gout + 256, row_stride, rows_valid, lane);
+    stage_store_pass<EO, PT, PITCH>(stg, y, gout, row_stride, rows_valid, lane);
+    if constexpr (NT > PT) stage_store_tiles<EO, NT - PT, PITCH>(stg, y + PT, gout + PITCH, row_stride, rows_valid, lane);
   } else if constexpr (NT >= 2) {
-    stage_store_pass<EO, 2>(stg, y, gout, row_stride, rows_valid, lane);
-    if constexpr (NT > 2) stage_store_tiles<EO, NT - 2>(stg, y + 2, gout + 64 * sizeof(EO), row_stride, rows_valid, lane);
+    stage_store_pass<EO, 2, PITCH>(stg, y, gout, row_stride, rows_valid, lane);
+    if constexpr (NT > 2) stage_store_tiles<EO, NT - 2, PITCH>(stg, y + 2, gout + 64 * sizeof(EO), row_stride, rows_valid, lane);
   } else {
-    stage_store_pass<EO, 1>(stg, y, gout, row_stride, rows_valid, lane);
+    stage_store_pass<EO, 1, PITCH>(stg, y, gout, row_stride, rows_valid, lane);
   }
 }
 

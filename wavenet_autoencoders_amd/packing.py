@@ -8,11 +8,12 @@ Fragment order (must match csrc/glu_fwd.hip and csrc/head_fwd.hip)
 A *fragment block* is 64 lanes x 16 bytes = one A operand of a 32x32 MFMA tile: lane l = (i = l & 31, h = l >> 5)
 holds, for output row ``32*m + i`` of M-tile m, EPL consecutive-in-k elements (EPL = 8 bf16 / 4 f32).
 
-GEMM 1 stream ``[q][blk][m][lane][j]`` (chunk q = one 128-byte slice of an activation row):
+GEMM 1 stream ``[pass][q][blk][m][lane][j]`` (chunk q = one 128-byte slice of an activation row; pass p covers the
+gate channels [p*NPH*32, (p+1)*NPH*32), NPH = glu_pass_tiles(NP); m < NPH: tanh rows, m >= NPH: sigmoid rows):
     q <  k*(Rp/CK): tap = q // (Rp/CK), cblk = q % (Rp/CK)   -> conv weight (G, R, k)
     q >=          : c chunk                                   -> conv1x1c weight (G, Cc)
     channel = cblk*CK + blk*2*EPL + h*EPL + j          (CK = 64 bf16 / 32 f32 channels per chunk)
-    M-tile m < NP is gate-a rows 32m.., m >= NP gate-b rows (reference row = half*H + i)
+    gate-a row = 32*(p*NPH + m) + i, gate-b row = H + 32*(p*NPH + m - NPH) + i (reference row = half*H + i)
 GEMM 2 stream ``[q2][mt][kb][lane][j]``: M-tile gm = q2*MT2 + mt over [out rows (Rp) | skip rows (Sp)],
     k index = row of u inside accumulator tile ut = kb // KBU, sub-block s = kb % KBU:
       bf16: u_row = 32*ut + 16*s + 8*(j >> 2) + 4*h + (j & 3)
@@ -181,19 +182,27 @@ def u_row_index(dtype: int, kb: np.ndarray, h: np.ndarray, j: np.ndarray) -> np.
     return 32 * ut + 8 * s + 4 * h + j
 
 
+def glu_pass_tiles(NP: int) -> int:
+    """Gate-channel tiles per GEMM-1 pass (csrc/glu_fwd.hip dispatch_np must agree)."""
+    if NP not in (1, 2, 3, 4, 6, 8):
+        raise ValueError(f"gate_channels/2 padded to {32 * NP} is not supported by the fused layer kernel (Hp/32 must be 1,2,3,4,6,8)")
+    return {1: 1, 2: 1, 3: 3, 4: 2, 6: 3, 8: 4}[NP]
+
+
 def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     """int32 map (relative to arena start, layer 0) for the GEMM-1 stream of one GLU layer."""
     t = _traits(dtype)
     EPL, CK = t["EPL"], t["CK"]
-    NM = 2 * g.NP
+    NPH = glu_pass_tiles(g.NP)
+    NM = 2 * NPH
     cpr = g.Rp // CK
     nq_conv = g.k * cpr
     nq1 = nq_conv + g.Ccp // CK
-    q, blk, m, lane, j = np.meshgrid(np.arange(nq1), np.arange(4), np.arange(NM), np.arange(64), np.arange(EPL),
-                                     indexing="ij")
+    ps, q, blk, m, lane, j = np.meshgrid(np.arange(g.NP // NPH), np.arange(nq1), np.arange(4), np.arange(NM), np.arange(64),
+                                         np.arange(EPL), indexing="ij")
     i, h = lane & 31, lane >> 5
-    half = (m >= g.NP).astype(np.int64)
-    ig = 32 * (m - half * g.NP) + i
+    half = (m >= NPH).astype(np.int64)
+    ig = 32 * (ps * NPH + m - half * NPH) + i
     row = half * g.H + ig
     is_conv = q < nq_conv
     tap = np.where(is_conv, q // cpr, 0)
@@ -216,10 +225,9 @@ def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
 def glu_w2_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     """GEMM-2 stream of one layer: conv1x1_out rows only (the skip 1x1 is contracted in the head)."""
     t = _traits(dtype)
-    EPL, KBU, MT2 = t["EPL"], t["KBU"], t["MT2"]
+    EPL, KBU = t["EPL"], t["KBU"]
     NKB = g.NP * KBU
     n_mt = g.Rp // 32
-    assert n_mt % MT2 == 0
     gm, kb, lane, j = np.meshgrid(np.arange(n_mt), np.arange(NKB), np.arange(64), np.arange(EPL), indexing="ij")
     i, h = lane & 31, lane >> 5
     ur = u_row_index(dtype, kb, h, j)
@@ -284,10 +292,12 @@ def head_bias_map(g: Geometry, lay: ParamLayout) -> np.ndarray:
 
 def glu_packed_elems(g: Geometry, dtype: int) -> int:
     t = _traits(dtype)
-    chb = 2 * g.NP * 4 * 1024
+    nph = glu_pass_tiles(g.NP)
+    chb = 2 * nph * 4 * 1024
     nq1 = g.k * (g.Rp // t["CK"]) + g.Ccp // t["CK"]
-    nq2 = (g.Rp // 32) // t["MT2"]
-    return (nq1 + nq2) * chb // t["ES"]
+    mt2 = t["MT2"] * nph // g.NP
+    nq2 = (g.Rp // 32) // mt2
+    return ((g.NP // nph) * nq1 + nq2) * chb // t["ES"]
 
 
 def head_packed_elems(g: Geometry, dtype: int) -> int:
