@@ -143,6 +143,29 @@ def test_ragged_T_and_wrong_cond_length(dtype, tol):
         eng.decoder_forward(x.cuda(), c[:, :, :-5].cuda(), g.cuda(), c_is_upsampled=True)
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("G,R", [(192, 128), (256, 128), (368, 256), (512, 128)])
+def test_gate_channel_widths_against_oracle(G, R, dtype, tol):
+    """Every gate-channel tiling of csrc/glu_fwd.hip (Hp/32 = 3, 4, 6, 8; one and two GEMM-1 passes) on seeded inputs
+    against the oracle's full decoder forward (wavenet.py:164-216)."""
+    cfg, sd, ins, z, ocfg = golden_model("B")
+    cfg = dict(cfg, G=G, R=R, layers=4, stacks=2)
+    sd = O.make_state_dict(cfg, 31)
+    ocfg = dict(ocfg, layers=4, stacks=2)
+    eng = _engine(cfg, sd, dtype)
+    B, T = 2, 700
+    x = ((O.hash_fill((B, T), 15) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+    c = O.hash_fill((B, cfg["Cc"], T), 16, 1.0)
+    g = torch.tensor([2, 3])
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    sd2 = {k: v for k, v in sd.items() if "upsample_net" not in k}
+    with torch.no_grad():
+        ref = O.wavenet_forward(sd2, dict(ocfg, upsample_scales=None), xin, c, g)
+    out = eng.decoder_forward(x.cuda(), c.cuda(), g.cuda(), c_is_upsampled=True)
+    torch.cuda.synchronize()
+    assert rel_err(out["logits"].cpu(), ref) < tol
+
+
 def test_vqwae_fullsize_probe_fp32():
     """hps/vqwae.json geometry (R=G=S=256, L=20), sparse golden probe from the reference."""
     import json

@@ -456,8 +456,11 @@ static int launch_glu_nw(GluArgs a, hipStream_t st) {
 template <typename E, int NP, int NPH, bool EXACT>
 static int launch_glu(const GluArgs& a, hipStream_t st) {
   // fp32 (the parity mode) keeps 4 waves with 512 registers each: its operand fragments are twice as many
-  if constexpr (sizeof(E) == 2)
-    if (g_glu_nw == 8) return launch_glu_nw<E, NP, NPH, EXACT, 8>(a, st);
+  if constexpr (sizeof(E) == 2) {
+    // two 4-wave workgroups per CU need a two-slot ring in 80 KiB each; wider layers take the whole CU with 8 waves
+    const bool fits4 = 4 * 4096 + (size_t)(a.Rp + 2 * a.Hp) * 4 + 2 * (2 * NPH * 4096) <= 80 * 1024;
+    if (g_glu_nw == 8 || !fits4) return launch_glu_nw<E, NP, NPH, EXACT, 8>(a, st);
+  }
   return launch_glu_nw<E, NP, NPH, EXACT, 4>(a, st);
 }
 
