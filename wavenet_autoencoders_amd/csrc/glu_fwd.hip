@@ -224,7 +224,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
 #ifdef WAE_GLU_STAMPS
     const unsigned long long c1 = TICK();
 #endif
-    __syncthreads();
+    // a bare s_barrier: __syncthreads() is fence + barrier, and hipcc lowers the fence to s_waitcnt vmcnt(0), which
+    // would drain the very prefetch queue the counted wait above leaves in flight.  Every wave has retired its LDS
+    // reads of the previous chunk (gemm_chunk exits with lgkmcnt(0)), and its own DMA pieces by the counted wait.
+    __builtin_amdgcn_s_barrier();
 #ifdef WAE_GLU_STAMPS
     const unsigned long long c2 = TICK();
     acc_wait += c1 - c0;
