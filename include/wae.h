@@ -246,8 +246,10 @@ int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, int32_t ntile
  * Same contraction as wae_gemm_tn_tiles, C[m][n] += alpha * sum_{b,t} P[b,t][m] * Q[b,t+shift][n], cut differently:
  * a job is one 384 x 256 output region over the whole batch; the (job, 32-row time slab) list is cut into one
  * contiguous share per workgroup (segments), so a launch of nwg ~ #CUs workgroups finishes all jobs together and adds
- * each region to C once per (workgroup, job) boundary.  jobs/segs/wg_seg are device arrays built by the host
- * (backward.py: StreamTable); wg_seg has nwg + 1 prefix offsets into segs; slabs are numbered b * ceil(T/32) + t / 32.
+ * each region to C once per (workgroup, job) boundary.  jobs/segs/team_seg are device arrays built by the host
+ * (backward.py: StreamTable).  team_size consecutive workgroups form a team that walks one segment list, member m on
+ * job (segment job + m) -- the jobs of one layer share operands; team_seg has nteams + 1 prefix offsets into segs;
+ * slabs are numbered b * ceil(T/32) + t / 32; a job with m_valid == 0 is skipped; nwg >= nteams * team_size.
  * m_valid <= 384, n_valid <= 256; n_valid % 8 == 0 when ones_col >= 0 (n_valid <= ones_col < 256). */
 typedef struct wae_ts_job {
   const void* P;
@@ -263,8 +265,8 @@ typedef struct wae_ts_job {
 typedef struct wae_ts_seg {
   int32_t job, slab_begin, slab_end;
 } wae_ts_seg;
-int wae_gemm_tn_stream(const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* wg_seg_dev, int32_t nwg,
-                       int32_t B, int32_t T, void* stream);
+int wae_gemm_tn_stream(const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
+                       int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, void* stream);
 
 /* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
  * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).

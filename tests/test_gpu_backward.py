@@ -57,6 +57,40 @@ def test_decoder_backward_bf16_is_close():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name,lengths", [("A", [1280, 1280 - 137]), ("B", [640, 500])])
+def test_stream_weight_gradients_match_per_layer_tiles(name, lengths, monkeypatch):
+    """bf16: wae_gemm_tn_stream (all layers, one launch, 384x256 regions) against wae_gemm_tn_tiles (per layer, 128x128 tiles):
+    same bf16 operands, fp32 accumulation in a different order -> 2e-4 of each gradient tensor's range."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model(name)
+    x, g = ins["x"].cuda(), ins["g"].cuda()
+    c_up = torch.from_numpy(z["c_up"]).cuda()
+    ln = torch.tensor(lengths)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WAE_TN_STREAM", mode)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+        eng.load_state_dict(sd)
+        eng.decoder_forward(x, c_up, g, targets=x, lengths=ln.cuda(), train=True, c_is_upsampled=True, want_logits=False)
+        BW.decoder_backward(eng, x, x, ln, g)
+        assert (BW.bwd_workspace(eng, *x.shape)["stream"] is not None) == (mode == "1")
+        got[mode] = BW.finish_grads(eng).clone()
+        torch.cuda.synchronize()
+    lay = eng.lay
+    bad = {}
+    for k in lay.offsets:
+        if not k.startswith("wavenet.conv_layers."):
+            continue
+        a = got["0"][lay.off(k):lay.off(k) + lay.numel(k)]
+        b = got["1"][lay.off(k):lay.off(k) + lay.numel(k)]
+        err, ref = float((a - b).abs().max()), float(a.abs().max())
+        if err > 2e-4 * max(ref, 1e-6) + 1e-7:
+            bad[k] = (err, ref)
+    assert not bad, bad
+
+
 def test_full_train_step_against_golden():
     """(7) of SURVEY 8c: parameter gradients of one step, post-Adam weights and EMA shadow of the reference."""
     from helpers import load_npz

@@ -119,13 +119,87 @@ class TileTable:
         L.check(eng.lib.wae_gemm_tn_tiles(eng.dt, L.ptr(self.dev), self.n, B, T, self.splits, eng.stream()), "gemm_tn_tiles")
 
 
+class StreamTable:
+    """Host builder for wae_gemm_tn_stream (csrc/gemm_tn_stream.hip): the weight-gradient contractions of every layer as
+    ONE launch.  A *group* is the list of jobs of one layer (every dilated-conv tap, the conditioning 1x1 with the per-clip
+    zb sums, conv1x1_out with its bias), each cut into 384 x 256 output regions; all groups have the same number of jobs.
+    The (group, 32-row time slab) list is cut into equal contiguous shares, one per *team* of len(group) workgroups."""
+    RM, RN, KT = 384, 256, 32
+
+    def __init__(self, eng, B, T):
+        self.eng, self.B, self.T = eng, B, T
+        self.groups = []          # list of lists of L.TsJob
+        self.shifts = []          # most negative shift per group (slabs that pair only with rows before the clip are skipped)
+
+    def begin_group(self):
+        self.groups.append([])
+
+    def add(self, M, N, shift, ones_col, alpha, p_ptr, p_stride, q_ptr, q_stride, c_ptr, ldc):
+        """C[M][N (+ B ones columns at ones_col)] += alpha * P^T Q ; p_ptr == 0: placeholder jobs that do nothing."""
+        es = 2
+        nmax = max(N, ones_col + self.B) if ones_col >= 0 else N
+        for mt in range((M + self.RM - 1) // self.RM):
+            for nt in range((nmax + self.RN - 1) // self.RN):
+                nv = max(0, min(self.RN, N - self.RN * nt))
+                oc = -1
+                if ones_col >= 0 and 0 <= ones_col - self.RN * nt < self.RN:
+                    oc = ones_col - self.RN * nt
+                    assert oc + self.B <= self.RN and nv % 8 == 0 and oc >= nv, "ones columns must fit behind the region's data"
+                if nv == 0 and oc < 0:
+                    continue
+                mv = min(self.RM, M - self.RM * mt) if p_ptr else 0
+                self.groups[-1].append(L.TsJob((p_ptr + mt * self.RM * es) if p_ptr else None, q_ptr + nt * self.RN * es,
+                                               c_ptr + (mt * self.RM * ldc + nt * self.RN) * 4, p_stride, q_stride, ldc,
+                                               mv, nv, shift, oc, alpha, 0))
+
+    def finalize(self):
+        eng, B, T = self.eng, self.B, self.T
+        gs = len(self.groups[0])
+        assert all(len(g) == gs for g in self.groups), "every layer must contribute the same list of jobs"
+        ncu = torch.cuda.get_device_properties(eng.device).multi_processor_count
+        self.team_size = gs
+        self.nteams = max(1, ncu // gs)
+        self.nwg = ncu if ncu % 8 == 0 and ncu >= self.nteams * gs else self.nteams * gs
+        spc = (T + self.KT - 1) // self.KT
+        # Every member of a team sweeps the same slab range; a slab is skipped by a member when all of its rows pair with
+        # rows before the clip (kernel: useful()).  Shares are cut on the raw slab count: the skipped slabs differ by tap.
+        total = len(self.groups) * B * spc
+        segs, team_seg = [], [0]
+        for t in range(self.nteams):
+            lo, hi = total * t // self.nteams, total * (t + 1) // self.nteams
+            while lo < hi:
+                grp = lo // (B * spc)
+                end = min(hi, (grp + 1) * B * spc)
+                segs.append(L.TsSeg(grp * gs, lo - grp * B * spc, end - grp * B * spc))
+                lo = end
+            team_seg.append(len(segs))
+        jobs = [j for g in self.groups for j in g]
+        dev = eng.device
+        self.jobs_dev = torch.frombuffer(bytearray(bytes((L.TsJob * len(jobs))(*jobs))), dtype=torch.uint8).to(dev)
+        self.segs_dev = torch.frombuffer(bytearray(bytes((L.TsSeg * len(segs))(*segs))), dtype=torch.uint8).to(dev)
+        self.team_seg_dev = torch.tensor(team_seg, dtype=torch.int32, device=dev)
+        return self
+
+    def launch(self):
+        eng = self.eng
+        L.check(eng.lib.wae_gemm_tn_stream(L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
+                                           self.team_size, self.nwg, self.B, self.T, eng.stream()), "gemm_tn_stream")
+
+
+def use_stream_tn(eng):
+    """bf16 runs take every layer's weight gradients in one wae_gemm_tn_stream launch after the backward sweep (needs the
+    residual-stream gradient of every layer kept); fp32 (the parity mode) keeps one wae_gemm_tn_tiles launch per layer."""
+    import os
+    return eng.dt == L.WAE_BF16 and os.environ.get("WAE_TN_STREAM", "1") != "0"
+
+
 def bwd_workspace(eng, B, T):
     key = ("bwd", B, T)
     ws = eng._ws.get(key)
     if ws is None:
         g, dev, td = eng.g, eng.device, eng.tdtype
         ws = dict(dz=torch.zeros(B, T, g.layers * 2 * g.Hp, dtype=td, device=dev),
-                  gx=[torch.zeros(B, T, g.Rp, dtype=td, device=dev) for _ in range(2)],
+                  gx=[torch.zeros(B, T, g.Rp, dtype=td, device=dev) for _ in range(g.layers if use_stream_tn(eng) else 2)],
                   gzero=torch.zeros(B, T, g.Rp, dtype=td, device=dev),
                   dy=torch.zeros(B, T, g.Op, dtype=td, device=dev),
                   dh1=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
@@ -146,7 +220,26 @@ def _build_tile_tables(eng, ws, fw, B, T):
     dzs = g.layers * Z2
     c1, co = eng.cview["c1"], eng.cview["co"]
     ws["tt_layer"] = []
-    for l in range(g.layers):
+    ws["stream"] = None
+    if use_stream_tn(eng):
+        stt = StreamTable(eng, B, T)
+        for l in range(g.layers):
+            d = g.dilations[l]
+            stt.begin_group()
+            dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
+            c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
+            xl = fw["x"][l]
+            for tap in range(g.k):
+                last = tap == g.k - 1 and not g.Ccp
+                stt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), 1.0, dz_ptr, dzs, xl.data_ptr(), g.Rp,
+                        c1l + tap * g.Rp * 4, sm["ld1"])
+            if g.Ccp:
+                stt.add(Z2, g.Ccp, 0, g.Ccp, 1.0, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
+            has_out = l < g.layers - 1
+            stt.add(g.Rp, g.Hp, 0, g.Hp, 1.0, ws["gx"][l + 1].data_ptr() if has_out else 0, g.Rp,
+                    fw["u"].data_ptr() + l * g.Hp * es, g.Ku, co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
+        ws["stream"] = stt.finalize()
+    for l in range(g.layers if ws["stream"] is None else 0):
         d = g.dilations[l]
         tt = TileTable(eng)
         dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
@@ -159,7 +252,7 @@ def _build_tile_tables(eng, ws, fw, B, T):
         if g.Ccp:
             tt.add(Z2, g.Ccp, 0, g.Ccp, 1.0, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
         if l < g.layers - 1:
-            g_next = ws["gx"][(l + 1) % 2]
+            g_next = ws["gx"][(l + 1) % len(ws["gx"])]
             tt.add(g.Rp, g.Hp, 0, g.Hp, 1.0, g_next.data_ptr(), g.Rp, fw["u"].data_ptr() + l * g.Hp * es, g.Ku,
                    co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
         ws["tt_layer"].append(tt.finalize(B))
@@ -219,7 +312,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     g_next = ws["gzero"]                      # dxhat_{L} = 0: the last layer's x' is dead (wavenet.py:205-207)
     for l in range(g.layers - 1, -1, -1):
         d = g.dilations[l]
-        assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % 2].data_ptr()
+        assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % len(ws["gx"])].data_ptr()
         dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
         # du -> dz
         _tm(eng, B, T, g.Hp, 2, 1.0, [(g_next.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
@@ -229,15 +322,25 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(eng.device))
-        ws["tt_layer"][l].launch(B, T)
+        if ws["stream"] is None:
+            ws["tt_layer"][l].launch(B, T)
         if ev is not None:
             e1.record(torch.cuda.current_stream(eng.device))
             ev.append((e0, e1))
         # dx
-        g_cur = ws["gx"][l % 2]
+        g_cur = ws["gx"][l % len(ws["gx"])]
         srcs = [(dz_ptr, dzs, Z2, (g.k - 1 - tap) * d) for tap in range(g.k)]
         _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, g_cur.data_ptr(), g.Rp, g_next.data_ptr(), g.Rp)
         g_next = g_cur
+    if ws["stream"] is not None:          # every layer's dW1 taps, dWc + zb sums, dW_out + bias: one launch
+        ev = getattr(eng, "_tn_events", None)
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(eng.device))
+        ws["stream"].launch()
+        if ev is not None:
+            e1.record(torch.cuda.current_stream(eng.device))
+            ev.append((e0, e1))
     # ---- local-conditioning gradient over all layers at once ---------------------------------------------------------
     if g.Ccp:
         _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), dzs, dzs, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)

@@ -30,12 +30,13 @@ struct TsJob {
   int pad_;
 };
 struct TsSeg {
-  int job, slab_begin, slab_end;     // slabs are numbered b * slabs_per_clip + t / 32
+  int job, slab_begin, slab_end;     // job of team member 0; slabs are numbered b * slabs_per_clip + t / 32
 };
 struct TsArgs {
   const TsJob* jobs;
   const TsSeg* segs;
-  const int* wg_seg;   // [nwg + 1] prefix offsets into segs
+  const int* team_seg;   // [nteams + 1] prefix offsets into segs
+  int nteams, team_size;
   int B, T, spc;
 };
 
@@ -72,14 +73,24 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
   const int wm = (wave % 6) * 64, wn = (wave / 6) * 128;
   const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
 
-  const int seg_b = p.wg_seg[blockIdx.x], seg_e = p.wg_seg[blockIdx.x + 1];
+  // Teams: team_size consecutive *logical* workgroups walk the same segment list, member m on job (segment job + m):
+  // the jobs of one layer share operands (dz is read by every tap), and members that sweep the same time range at
+  // the same pace find them in L2.  Workgroups are dealt round-robin over the 8 XCDs in launch order, so logical ids
+  // are chosen to make a team's members land in ONE XCD (speed only).
+  int logical = blockIdx.x;
+  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int team = logical / p.team_size, member = logical - team * p.team_size;
+  if (team >= p.nteams) return;
+  const int seg_b = p.team_seg[team], seg_e = p.team_seg[team + 1];
   for (int si = seg_b; si < seg_e; ++si) {
     const TsSeg sg = p.segs[si];
-    const TsJob jb = p.jobs[sg.job];
+    const TsJob jb = p.jobs[sg.job + member];
+    if (jb.m_valid <= 0) continue;   // null job (e.g. the last layer has no conv1x1_out gradient)
     const int up_valid = (jb.m_valid + 7) >> 3, uq_valid = (jb.n_valid + 7) >> 3;
-    // this wave's DMA pieces: piece pc = wave + 12 j of the slot image [P slab | Q slab]; lane -> 16-byte unit.
-    // (row, unit) of a lane are recomputed from the lane id at every use: values kept live across the MFMA blocks
-    // would be spilled (168 registers, 128 of them accumulators), and a scratch reload drains the DMA queue.
+    // This wave's DMA pieces: piece pc = wave + 12 j of the slot image [P slab | Q slab]; lane -> one 16-byte unit.
+    // Per lane and piece: validity bit and byte offset from the slab's first row (kept in 5 registers across the MFMA
+    // blocks; the slab loop itself must stay lean: at 3 waves per SIMD every 100 scalar/vector instructions per
+    // slab and wave cost as much issue time as a third of the slab's MFMAs).
     auto piece_geom = [&](int ln, int j, int& row, int& col) -> bool {
       const int pc = wave + TS_NW * j;
       if (pc < TS_NPP) {
@@ -95,11 +106,21 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
       return false;
     };
     int np_issued = 0;
+    unsigned vbits = 0;
+    unsigned poff[TS_MAXPC];
 #pragma unroll
     for (int j = 0; j < TS_MAXPC; ++j) {
       int r_, c_;
-      if (__any(piece_geom(lane, j, r_, c_))) ++np_issued;
+      const bool v = piece_geom(lane, j, r_, c_);
+      if (v) vbits |= 1u << j;
+      const int64_t stride_b = (wave + TS_NW * j < TS_NPP ? jb.p_stride : jb.q_stride) * 2;
+      poff[j] = (unsigned)(r_ * stride_b + c_ * 16);
+      if (__any(v)) ++np_issued;
     }
+    // transposed-read lane geometry (see csrc/gemm_tn.hip tn_load_frags)
+    const int hh2 = lane >> 5, grp = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned a_lane = lds0 + (8 * hh2 + q4) * TS_PP + (16 * grp + 4 * pp) * 2 + wm * 2;
+    const unsigned b_lane = lds0 + TS_SP + (8 * hh2 + q4) * TS_QP + (16 * grp + 4 * pp) * 2 + wn * 2;
     // active MFMA tiles of this wave (wave-uniform)
     const int n_end = jb.ones_col >= 0 ? jb.ones_col + p.B : jb.n_valid;
     const int nmt = min(max((jb.m_valid - wm + 31) >> 5, 0), 2);
@@ -125,41 +146,61 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // slabs whose every row pairs with a Q row outside the clip contribute nothing: both cursors skip them
-    auto useful = [&](int s) {
-      const int t0 = (s % p.spc) * TS_KT;
-      return t0 + TS_KT - 1 + jb.shift >= 0 && t0 + jb.shift < p.T;
+    // Slab cursors (clip b, first row t0, linear slab number s), advanced without divisions.  Slabs whose every row pairs
+    // with a Q row outside the clip contribute nothing: the useful rows of a clip are [t_lo, t_hi), both cursors skip
+    // the rest.
+    const int t_lo = max(0, (-jb.shift - (TS_KT - 1) + TS_KT - 1) & ~(TS_KT - 1));
+    const int t_hi = jb.shift > 0 ? min(p.spc * TS_KT, (p.T - jb.shift + TS_KT - 1) & ~(TS_KT - 1)) : p.spc * TS_KT;
+    struct Cur { int b, t0, s; };
+    auto cur_fix = [&](Cur& c) {   // move to the first useful slab at or after the current position
+      if (c.t0 < t_lo) c.t0 = t_lo;
+      if (c.t0 >= t_hi) { ++c.b; c.t0 = t_lo; }
+      c.s = c.b * p.spc + (c.t0 >> 5);
     };
-    auto next_useful = [&](int s) {
-      while (s < sg.slab_end && !useful(s)) ++s;
-      return s;
+    auto cur_adv = [&](Cur& c) {
+      c.t0 += TS_KT; ++c.s;
+      if (c.t0 >= t_hi) { ++c.b; c.t0 = t_lo; c.s = c.b * p.spc + (t_lo >> 5); }
     };
-    auto issue = [&](int s, int slot) {
-      const int b = s / p.spc, t0 = (s - b * p.spc) * TS_KT;
+    Cur ci, cc;
+    ci.b = sg.slab_begin / p.spc; ci.t0 = (sg.slab_begin - ci.b * p.spc) * TS_KT; ci.s = sg.slab_begin;
+    cur_fix(ci);
+    cc = ci;
+
+    auto issue = [&](const Cur& c, int slot) {
       char* dst = smem + slot * TS_SLOT;
-      int ln = threadIdx.x & 63;
-      asm volatile("" : "+v"(ln));   // keeps the geometry below from being hoisted out of the slab loop
+      const bool whole = c.t0 + TS_KT <= p.T && c.t0 + jb.shift >= 0 && c.t0 + TS_KT - 1 + jb.shift < p.T;
+      if (whole) {   // every row of the slab inside the clip (all but the first/last slabs of a clip): uniform bases
+        const char* pb = jb.P + (((int64_t)c.b * p.T + c.t0) * jb.p_stride) * 2;
+        const char* qb = jb.Q + (((int64_t)c.b * p.T + c.t0 + jb.shift) * jb.q_stride) * 2;
 #pragma unroll
-      for (int j = 0; j < TS_MAXPC; ++j) {
-        const int pc = wave + TS_NW * j;
-        int row, col;
-        if (piece_geom(ln, j, row, col)) {
-          const char* src;
-          if (pc < TS_NPP) {
-            const int t = min(t0 + row, p.T - 1);
-            src = jb.P + (((int64_t)b * p.T + t) * jb.p_stride) * 2 + col * 16;
-          } else {
-            const int t = min(max(t0 + row + jb.shift, 0), p.T - 1);
-            src = jb.Q + (((int64_t)b * p.T + t) * jb.q_stride) * 2 + col * 16;
+        for (int j = 0; j < TS_MAXPC; ++j) {
+          const int pc = wave + TS_NW * j;
+          if (vbits & (1u << j)) dma_piece((pc < TS_NPP ? pb : qb) + poff[j], dst + pc * 1024);
+        }
+      } else {       // rows clamped into the clip one by one
+        int ln = threadIdx.x & 63;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < TS_MAXPC; ++j) {
+          const int pc = wave + TS_NW * j;
+          int row, col;
+          if (piece_geom(ln, j, row, col)) {
+            const char* src;
+            if (pc < TS_NPP) {
+              const int t = min(c.t0 + row, p.T - 1);
+              src = jb.P + (((int64_t)c.b * p.T + t) * jb.p_stride) * 2 + col * 16;
+            } else {
+              const int t = min(max(c.t0 + row + jb.shift, 0), p.T - 1);
+              src = jb.Q + (((int64_t)c.b * p.T + t) * jb.q_stride) * 2 + col * 16;
+            }
+            dma_piece(src, dst + pc * 1024);
           }
-          dma_piece(src, dst + pc * 1024);
         }
       }
     };
     // rows of P outside the clip, or paired with a Q row outside it, must not contribute: zero them once landed
-    auto zero_invalid_rows = [&](int s, int slot) {
-      const int t0 = (s % p.spc) * TS_KT;
-      if (t0 + TS_KT <= p.T && t0 + jb.shift >= 0 && t0 + TS_KT - 1 + jb.shift < p.T) return;
+    auto zero_invalid_rows = [&](const Cur& c, int slot) {
+      if (c.t0 + TS_KT <= p.T && c.t0 + jb.shift >= 0 && c.t0 + TS_KT - 1 + jb.shift < p.T) return;
       int ln = threadIdx.x & 63;
       asm volatile("" : "+v"(ln));
 #pragma unroll
@@ -167,7 +208,7 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
         const int pc = wave + TS_NW * j;
         int row, col;
         if (pc < TS_NPP && piece_geom(ln, j, row, col)) {
-          const int t = t0 + row;
+          const int t = c.t0 + row;
           if (t >= p.T || t + jb.shift < 0 || t + jb.shift >= p.T) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             *(f32x4*)(smem + slot * TS_SLOT + pc * 1024 + ln * 16) = z;
@@ -177,88 +218,85 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
     };
 
     // ---- pipeline: slab k of the sequence lives in slot k % NS; requests run NS-1 slabs ahead -------------------
-    int s_issue = next_useful(sg.slab_begin), s_comp = s_issue;
-    int k_issue = 0, k_comp = 0, cur_b = -1;
-    for (; k_issue < TS_NS - 1 && s_issue < sg.slab_end; ++k_issue) {
-      issue(s_issue, k_issue % TS_NS);
-      s_issue = next_useful(s_issue + 1);
+    int slot_i = 0, slot_c = 0, ahead = 0, cur_b = -1;   // ahead = slabs requested and not yet consumed
+    for (; ahead < TS_NS - 1 && ci.s < sg.slab_end; ++ahead) {
+      issue(ci, slot_i);
+      slot_i = slot_i + 1 == TS_NS ? 0 : slot_i + 1;
+      cur_adv(ci);
     }
-    while (s_comp < sg.slab_end) {
-      const int slot = k_comp % TS_NS;
-      ts_wait_vmcnt(np_issued * (k_issue - k_comp - 1));   // slab k_comp landed; younger requests stay in flight
-      zero_invalid_rows(s_comp, slot);
+    while (cc.s < sg.slab_end) {
+      ts_wait_vmcnt(np_issued * (ahead - 1));   // the oldest requested slab has landed; younger requests stay in flight
+      zero_invalid_rows(cc, slot_c);
       // bare barrier (not __syncthreads(): its fence is lowered to s_waitcnt vmcnt(0) and would drain the prefetch);
       // the zero-fill stores, if any, are retired first
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (s_issue < sg.slab_end) {
-        issue(s_issue, k_issue % TS_NS);
-        ++k_issue;
-        s_issue = next_useful(s_issue + 1);
+      if (ci.s < sg.slab_end) {
+        issue(ci, slot_i);
+        slot_i = slot_i + 1 == TS_NS ? 0 : slot_i + 1;
+        cur_adv(ci);
+        ++ahead;
       }
-      const int b = s_comp / p.spc;
-      if (jb.ones_col >= 0 && b != cur_b) {   // clip change (workgroup-uniform): move the ones to the new clip's column
+      if (jb.ones_col >= 0 && cc.b != cur_b) {   // clip change (workgroup-uniform): move the ones to the new clip's column
         if (threadIdx.x < TS_NS * TS_KT) {
           const int slot2 = threadIdx.x / TS_KT, r = threadIdx.x - slot2 * TS_KT;
           __bf16* qrow = (__bf16*)(smem + slot2 * TS_SLOT + TS_SP + r * TS_QP) + jb.ones_col;
           if (cur_b >= 0) qrow[cur_b] = (__bf16)0.0f;
-          qrow[b] = (__bf16)1.0f;
+          qrow[cc.b] = (__bf16)1.0f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      cur_b = b;
+      cur_b = cc.b;
       if (active) {
-        const unsigned sp = lds0 + slot * TS_SLOT, sq = sp + TS_SP;
-        int ln = threadIdx.x & 63;
-        asm volatile("" : "+v"(ln));
-        // transposed-read lane geometry (see csrc/gemm_tn.hip tn_load_frags)
-        const int hh2 = ln >> 5, grp = (ln >> 4) & 1, q4 = (ln & 15) >> 2, pp = ln & 3;
-#pragma unroll
-        for (int k0 = 0; k0 < TS_KT; k0 += 16) {
-          const unsigned ap = sp + (k0 + 8 * hh2 + q4) * TS_PP + (16 * grp + 4 * pp) * 2 + wm * 2;
-          const unsigned bp = sq + (k0 + 8 * hh2 + q4) * TS_QP + (16 * grp + 4 * pp) * 2 + wn * 2;
-          // One k-step (16 time rows) of the wave's 2 x 4 tiles.  Hand-allocated operand registers: a transposed read
-          // returns half an MFMA operand, and letting the compiler pair the halves costs a copy of every fragment
-          // (24 VGPRs this 168-register kernel does not have).  v[144:151] = A fragments of M-tiles 0,1;
-          // v[152:167] = B fragments of N-tiles 0..3.  Tiles beyond the job's valid region are computed too (their
-          // results are never written out).
-          asm volatile(
-              "ds_read_b64_tr_b16 v[144:145], %8\n\t"
-              "ds_read_b64_tr_b16 v[146:147], %8 offset:%10\n\t"
-              "ds_read_b64_tr_b16 v[152:153], %9\n\t"
-              "ds_read_b64_tr_b16 v[154:155], %9 offset:%11\n\t"
-              "ds_read_b64_tr_b16 v[156:157], %9 offset:64\n\t"
-              "ds_read_b64_tr_b16 v[158:159], %9 offset:%12\n\t"
-              "ds_read_b64_tr_b16 v[148:149], %8 offset:64\n\t"
-              "ds_read_b64_tr_b16 v[150:151], %8 offset:%13\n\t"
-              "ds_read_b64_tr_b16 v[160:161], %9 offset:128\n\t"
-              "ds_read_b64_tr_b16 v[162:163], %9 offset:%14\n\t"
-              "ds_read_b64_tr_b16 v[164:165], %9 offset:192\n\t"
-              "ds_read_b64_tr_b16 v[166:167], %9 offset:%15\n\t"
-              "s_waitcnt lgkmcnt(8)\n\t"
-              "v_mfma_f32_32x32x16_bf16 %0, v[144:147], v[152:155], %0\n\t"
-              "s_waitcnt lgkmcnt(6)\n\t"
-              "v_mfma_f32_32x32x16_bf16 %1, v[144:147], v[156:159], %1\n\t"
-              "s_waitcnt lgkmcnt(4)\n\t"
-              "v_mfma_f32_32x32x16_bf16 %4, v[148:151], v[152:155], %4\n\t"
-              "v_mfma_f32_32x32x16_bf16 %5, v[148:151], v[156:159], %5\n\t"
-              "s_waitcnt lgkmcnt(2)\n\t"
-              "v_mfma_f32_32x32x16_bf16 %2, v[144:147], v[160:163], %2\n\t"
-              "v_mfma_f32_32x32x16_bf16 %6, v[148:151], v[160:163], %6\n\t"
-              "s_waitcnt lgkmcnt(0)\n\t"
-              "v_mfma_f32_32x32x16_bf16 %3, v[144:147], v[164:167], %3\n\t"
-              "v_mfma_f32_32x32x16_bf16 %7, v[148:151], v[164:167], %7\n\t"
-              : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
-                "+v"(acc[1][2]), "+v"(acc[1][3])
-              : "v"(ap), "v"(bp), "n"(4 * TS_PP), "n"(4 * TS_QP), "n"(4 * TS_QP + 64), "n"(4 * TS_PP + 64), "n"(4 * TS_QP + 128),
-                "n"(4 * TS_QP + 192)
-              : "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157",
-                "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
-        }
+        const unsigned ap = a_lane + slot_c * TS_SLOT, bp = b_lane + slot_c * TS_SLOT;
+        // Two k-steps (16 time rows each) of the wave's 2 x 4 tiles.  Hand-allocated operand registers: a transposed
+        // read returns half an MFMA operand, and letting the compiler pair the halves costs a copy of every fragment
+        // (24 VGPRs this 168-register kernel does not have).  v[144:151] = A fragments of M-tiles 0,1;
+        // v[152:167] = B fragments of N-tiles 0..3.  Tiles beyond the job's valid region are computed too (their
+        // results are never written out).
+#define TS_KSTEP(KO)                                                                                                       \
+        asm volatile(                                                                                                      \
+            "ds_read_b64_tr_b16 v[144:145], %8 offset:%10\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[146:147], %8 offset:%11\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[152:153], %9 offset:%14\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[154:155], %9 offset:%15\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[156:157], %9 offset:%16\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[158:159], %9 offset:%17\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[148:149], %8 offset:%12\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[150:151], %8 offset:%13\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[160:161], %9 offset:%18\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[162:163], %9 offset:%19\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[164:165], %9 offset:%20\n\t"                                                             \
+            "ds_read_b64_tr_b16 v[166:167], %9 offset:%21\n\t"                                                             \
+            "s_waitcnt lgkmcnt(8)\n\t"                                                                                     \
+            "v_mfma_f32_32x32x16_bf16 %0, v[144:147], v[152:155], %0\n\t"                                                  \
+            "s_waitcnt lgkmcnt(6)\n\t"                                                                                     \
+            "v_mfma_f32_32x32x16_bf16 %1, v[144:147], v[156:159], %1\n\t"                                                  \
+            "s_waitcnt lgkmcnt(4)\n\t"                                                                                     \
+            "v_mfma_f32_32x32x16_bf16 %4, v[148:151], v[152:155], %4\n\t"                                                  \
+            "v_mfma_f32_32x32x16_bf16 %5, v[148:151], v[156:159], %5\n\t"                                                  \
+            "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
+            "v_mfma_f32_32x32x16_bf16 %2, v[144:147], v[160:163], %2\n\t"                                                  \
+            "v_mfma_f32_32x32x16_bf16 %6, v[148:151], v[160:163], %6\n\t"                                                  \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+            "v_mfma_f32_32x32x16_bf16 %3, v[144:147], v[164:167], %3\n\t"                                                  \
+            "v_mfma_f32_32x32x16_bf16 %7, v[148:151], v[164:167], %7\n\t"                                                  \
+            : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),        \
+              "+v"(acc[1][2]), "+v"(acc[1][3])                                                                             \
+            : "v"(ap), "v"(bp), "n"((KO) * TS_PP), "n"((KO) * TS_PP + 4 * TS_PP), "n"((KO) * TS_PP + 64),                   \
+              "n"((KO) * TS_PP + 4 * TS_PP + 64), "n"((KO) * TS_QP), "n"((KO) * TS_QP + 4 * TS_QP), "n"((KO) * TS_QP + 64), \
+              "n"((KO) * TS_QP + 4 * TS_QP + 64), "n"((KO) * TS_QP + 128), "n"((KO) * TS_QP + 4 * TS_QP + 128),             \
+              "n"((KO) * TS_QP + 192), "n"((KO) * TS_QP + 4 * TS_QP + 192)                                                  \
+            : "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", \
+              "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167")
+        TS_KSTEP(0);
+        TS_KSTEP(16);
+#undef TS_KSTEP
       }
-      ++k_comp;
-      s_comp = next_useful(s_comp + 1);
+      slot_c = slot_c + 1 == TS_NS ? 0 : slot_c + 1;
+      --ahead;
+      cur_adv(cc);
     }
 
     // the MFMAs above are opaque to the compiler's hazard recogniser: cover the MFMA-result -> VALU-read wait states here
@@ -286,16 +324,19 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
   }
 }
 
-extern "C" int wae_gemm_tn_stream(const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* wg_seg_dev,
-                                  int32_t nwg, int32_t B, int32_t T, void* stream) {
-  WAE_REQUIRE(jobs_dev && segs_dev && wg_seg_dev && nwg > 0 && B > 0 && T > 0, "gemm_tn_stream: bad arguments");
+extern "C" int wae_gemm_tn_stream(const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
+                                  int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, void* stream) {
+  WAE_REQUIRE(jobs_dev && segs_dev && team_seg_dev && nteams > 0 && team_size > 0 && nwg >= nteams * team_size && B > 0 && T > 0,
+              "gemm_tn_stream: bad arguments");
+  WAE_REQUIRE(B <= 64, "gemm_tn_stream: at most 64 clips per launch (one all-ones column per clip)");
   static_assert(sizeof(wae_ts_job) == sizeof(TsJob), "wae_ts_job and TsJob must have the same layout");
   static_assert(sizeof(wae_ts_seg) == sizeof(TsSeg), "wae_ts_seg and TsSeg must have the same layout");
   static_assert(TS_NPP * 1024 == TS_SP && TS_NPQ * 1024 == TS_SQ, "slab images must be whole DMA pieces");
   TsArgs a;
   a.jobs = (const TsJob*)jobs_dev;
   a.segs = (const TsSeg*)segs_dev;
-  a.wg_seg = wg_seg_dev;
+  a.team_seg = team_seg_dev;
+  a.nteams = nteams; a.team_size = team_size;
   a.B = B; a.T = T; a.spc = (T + TS_KT - 1) / TS_KT;
   const size_t lds = (size_t)TS_NS * TS_SLOT;
   static bool attr_done = false;
