@@ -195,29 +195,42 @@ def main():
                 "mfma_frac": achieved_tf / peak_tf,
                 "note": "SURVEY 8(d) forward bytes per layer (2R+2S+Cc)*e x 64000 samples; HIP events around the 24-layer stack"}
     roof = fwd_roof
-    if args.mode == "train" and ev_tn:
-        # dominant kernel of the train step: gemm_tn_kernel (per-layer weight gradients), one launch per layer.
-        # algorithmic bytes per launch = the operands it must read once: dz (G), x (R), c (Cc), dxhat (R), u (H)
-        tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn)
-        tn_bytes = (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) * es * samples
-        tn_flops = 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H) * samples
-        tn_gbs = tn_bytes / (tn_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "gemm_tn_kernel", "achieved": tn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": tn_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": tn_ms, "algorithmic_bytes_per_launch": tn_bytes,
-                "mfma_achieved_tflops": tn_flops / (tn_ms * 1e-3) / 1e12, "mfma_frac": tn_flops / (tn_ms * 1e-3) / 1e12 / peak_tf,
-                "note": "per-layer weight-gradient launch (dW1 taps, dWc, dW_out); operands read once = (G+2R+Cc+H)*e per sample"}
+    extra = {}
+    if args.mode == "train":
+        # The kernel with the largest share of the train step is still glu_fwd_kernel (24 launches); in training it also
+        # saves the pre-activations: SURVEY 8(d) train bytes, forward part = (2R + 2S + Cc) + G per layer and sample.
+        tb = (2 * C2["R"] + 2 * C2["S"] + C2["Cc"] + C2["G"]) * es * samples
+        roof = dict(fwd_roof, achieved=tb / (glu_ms * 1e-3) / 1e9, frac=tb / (glu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    algorithmic_bytes_per_launch=tb,
+                    note="training forward of one layer: SURVEY 8(d) (2R+2S+Cc+G)*e x 64000 samples (z saved for backward); "
+                         "HIP events around the 24-layer stack")
+        if ev_tn:
+            # weight gradients: bf16 = ONE gemm_tn_stream_kernel launch for all layers, fp32 = one gemm_tn_kernel per layer.
+            # algorithmic bytes = the operands each layer must read once: dz (G), x (R), c (Cc), dxhat (R), u (H)
+            nl = geom.layers if len(ev_tn) // args.steps == 1 else 1
+            tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn)
+            tn_bytes = nl * (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) * es * samples
+            tn_flops = nl * 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H) * samples
+            tn_gbs = tn_bytes / (tn_ms * 1e-3) / 1e9
+            extra["roofline_wgrad"] = {
+                "bound": "hbm", "kernel": "gemm_tn_stream_kernel" if nl > 1 else "gemm_tn_kernel", "achieved": tn_gbs,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tn_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": tn_ms,
+                "algorithmic_bytes_per_launch": tn_bytes, "mfma_achieved_tflops": tn_flops / (tn_ms * 1e-3) / 1e12,
+                "mfma_frac": tn_flops / (tn_ms * 1e-3) / 1e12 / peak_tf,
+                "note": "weight gradients of %d layer(s) per launch (dW1 taps, dWc, dW_out); operands read once = "
+                        "(G+2R+Cc+H)*e per sample and layer" % nl}
     fwd_bytes_per_sample = geom.layers * (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es + (C2["S"] + 0) * es + 4 + 1
     value = world * samples * args.steps / dt
 
     # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (profiles/*pmc_traffic.json;
     # bench.py cannot run the profiler on itself).  Only applied when the run matches the profiled configuration.
     try:
-        with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")) as fh:
             pmc = json.load(fh)["kernels"]
         if args.dtype == "bf16" and args.mode == "train":
-            for rf in (roof, fwd_roof):
+            for rf in [roof] + list(extra.values()):
                 for k, v in pmc.items():
-                    if rf["kernel"] in k and ("Li6ELb0" in k or "gemm_tn" in k):
+                    if rf["kernel"] in k:
                         rf["traffic"] = v["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -238,6 +251,7 @@ def main():
             "roofline": roof,
             "roofline_glu_fwd": fwd_roof,
         }
+        res.update(extra)
         if not args.no_cpu and world == 1:
             cb, cpu_loss = cpu_baseline_train(sd) if args.mode == "train" else cpu_baseline(sd)
             res["cpu_baseline"] = cb

@@ -318,7 +318,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         _tm(eng, B, T, g.Hp, 2, 1.0, [(g_next.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
             eng.w_bu.data_ptr() + l * eng.n_bu * es, dz_ptr, dzs, fw["z"][l].data_ptr(), Z2)
         # weight gradients of the dilated conv, the conditioning 1x1 (+ per-clip zb sums) and conv1x1_out: one launch
-        ev = getattr(eng, "_tn_events", None)
+        ev = getattr(eng, "_tn_events", None) if ws["stream"] is None else None
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(eng.device))
