@@ -58,7 +58,9 @@ int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, i
 int wae_pack_gather(const float* src, const int32_t* map, void* dst, int64_t n, int32_t nbatch,
                     int64_t src_stride, int64_t dst_stride, int32_t dtype, void* stream);
 /* inverse (gradients): dst[map[i] + b*dst_stride] += src[s(i) + b*src_stride] (fp32 atomics; several i may share a
- * slot unless unique != 0, which promises one source per slot and uses plain adds); s(i) = i, or with src_cols > 0 the element (i / src_cols, i % src_cols) of a row-major tile of pitch src_ld */
+ * slot unless unique == 1, which promises one source per slot and uses plain adds); s(i) = i, or with src_cols > 0 the
+ * element (i / src_cols, i % src_cols) of a row-major tile of pitch src_ld.  unique == 2: every row of the tile feeds the
+ * one slot map[row * src_cols] (bias gradients from the per-clip ones columns): the row is summed and added once. */
 int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int64_t n, int32_t nbatch,
                            int64_t src_stride, int64_t dst_stride, int32_t src_cols, int64_t src_ld, int32_t unique,
                            void* stream);

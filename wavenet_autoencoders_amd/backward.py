@@ -358,13 +358,13 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     OP = P.ONES_PAD
     scat(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], nb=g.layers, ss=Z2 * sm["ld1"], ds=lay.layer_stride)
     scat(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride)
-    scat(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=0)
+    scat(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=2)
     scat(cs, sm["ws"], g.Sp, g.Ku, sm["lds"])
-    scat(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=0)
+    scat(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=2)
     scat(c3, sm["w3"], g.Op, g.Sp, sm["ldh"])
-    scat(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=0)
+    scat(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2)
     scat(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"])
-    scat(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=0)
+    scat(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)
     scat(ctab, sm["tab"], P._ru(g.O, 128) if False else g.O, g.Rp, g.Rp)
     scat(fb, sm["fb"], 1, g.Rp, g.Rp)
     # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
