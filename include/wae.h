@@ -244,6 +244,22 @@ typedef struct wae_tn_tile {
 int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, int32_t ntiles, int32_t B, int32_t T, int32_t splits,
                       void* stream);
 
+/* ---- backward data path across one layer boundary, fused (csrc/glu_bwd.hip; autograd of modules.py:115-163) ----------
+ *   dx_l-hat = alpha * (dx_{l+1}-hat + sum_tap W1_l,tap^T dz_l[t + (k-1-tap) d])   -> g_out (B,T,Rp), also kept in registers
+ *   dz_{l-1} = gate'(z_{l-1}) * (W_out_{l-1}^T dx_l-hat + W_skip_{l-1}^T dskip)    -> dz_prev (B,T,dz_stride)
+ * = wae_gemm_tm mode 1 for layer l followed by mode 2 for layer l-1, without re-reading dx_l-hat.  dz / dz_prev point at
+ * the layers' 2Hp columns inside the (B,T,dz_stride) buffer; z_prev is (B,T,2Hp); w_x = the mode-1 weights of layer l,
+ * w_uo = W_out_{l-1}^T in accumulator-row k order (packing.py: bwd_uo_map), w_us = the W_skip part of the mode-2 weights.
+ * wae_glu_bwd_fused_supported(Rp, Hp) tells whether an instance exists (else use the two wae_gemm_tm launches). */
+typedef struct wae_glu_bwd_desc {
+  int32_t dtype, B, T, Rp, Hp, Sp, ktaps, dilation;
+  float alpha;
+} wae_glu_bwd_desc;
+int wae_glu_bwd_fused_supported(int32_t Rp, int32_t Hp);
+int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
+                      const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
+                      const void* w_us, void* stream);
+
 /* ---- all weight-gradient contractions of a step in one launch (csrc/gemm_tn_stream.hip; bf16 operands only) ------
  * Same contraction as wae_gemm_tn_tiles, C[m][n] += alpha * sum_{b,t} P[b,t][m] * Q[b,t+shift][n], cut differently:
  * a job is one 384 x 256 output region over the whole batch; the (job, 32-row time slab) list is cut into one

@@ -49,6 +49,15 @@ def test_decoder_backward_fp32(name):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_decoder_backward_fused_boundary_kernel_fp32(name, monkeypatch):
+    """wae_glu_bwd_fused (K_X of layer l + K_U of layer l-1 in one launch; opt-in) against autograd through the oracle."""
+    monkeypatch.setenv("WAE_BWD_FUSED", "1")
+    res = _run(name, "fp32", [1280 if name == "A" else 640, (1280 if name == "A" else 640) - 137])
+    bad = {k: v for k, v in res.items() if v[0] > 1e-3 * max(v[1], 1e-6) + 1e-7}
+    assert not bad, bad
+
+
 def test_decoder_backward_bf16_is_close():
     res = _run("A", "bf16", [1280, 1280])
     # bf16 storage of activations/gradients: compare at 8 % of each tensor's gradient range (dc is a heavily

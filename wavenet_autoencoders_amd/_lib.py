@@ -33,6 +33,10 @@ class TnTile(ctypes.Structure):          # include/wae.h: wae_tn_tile (device ar
                 ("m_valid", c_i32), ("n_valid", c_i32), ("m0", c_i32), ("shift", c_i32), ("ones_col", c_i32), ("alpha", c_f32)]
 
 
+class GluBwdDesc(ctypes.Structure):      # include/wae.h: wae_glu_bwd_desc
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Rp", "Hp", "Sp", "ktaps", "dilation")] + [("alpha", c_f32)]
+
+
 class TsJob(ctypes.Structure):           # include/wae.h: wae_ts_job (device array element)
     _fields_ = [("P", c_vp), ("Q", c_vp), ("C", c_vp), ("p_stride", c_i64), ("q_stride", c_i64), ("ldc", c_i64),
                 ("m_valid", c_i32), ("n_valid", c_i32), ("shift", c_i32), ("ones_col", c_i32), ("alpha", c_f32), ("pad_", c_i32)]
@@ -70,6 +74,8 @@ SIGNATURES = {
     "wae_head_bwd_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_gemm_tm": (c_i32, [ctypes.POINTER(TmDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "wae_gemm_tn_tiles": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "wae_glu_bwd_fused_supported": (c_i32, [c_i32, c_i32]),
+    "wae_glu_bwd_fused": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wae_gemm_tn_stream": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "wae_sum_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),

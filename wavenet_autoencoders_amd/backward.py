@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -34,6 +35,13 @@ def _prepare_bwd(eng):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
+    # Fusing K_X(l) with K_U(l-1) (csrc/glu_bwd.hip) measured SLOWER than the two launches at C2 (118 us vs 60 + 50 us:
+    # the chunk loop is bound by weight/operand movement per chunk, which fusion does not reduce), so it is opt-in.
+    eng.fused_bwd = bool(eng.lib.wae_glu_bwd_fused_supported(g.Rp, g.Hp)) and os.environ.get("WAE_BWD_FUSED", "0") == "1"
+    if eng.fused_bwd:
+        eng.m_buo = up(P.bwd_uo_map(g, lay, eng.dt))
+        eng.n_buo = eng.m_buo.numel()
+        eng.w_buo = torch.zeros(g.layers * eng.n_buo, dtype=eng.tdtype, device=dev)
     eng.m_bc = up(P.bwd_c_map(g, lay, eng.dt)) if g.Ccp else None
     eng.m_hb_w = up(P.head_bwd_map(g, lay, eng.dt))
     eng.n_bu, eng.n_bx = eng.m_bu.numel(), eng.m_bx.numel()
@@ -64,6 +72,9 @@ def pack_bwd_weights(eng):
                                 eng.dt, st), "pack bwd U")
     L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bx), L.ptr(eng.w_bx), eng.n_bx, g.layers, lay.layer_stride, eng.n_bx,
                                 eng.dt, st), "pack bwd X")
+    if eng.fused_bwd:
+        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_buo), L.ptr(eng.w_buo), eng.n_buo, g.layers, lay.layer_stride,
+                                    eng.n_buo, eng.dt, st), "pack bwd UO")
     if g.Ccp:
         L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bc), L.ptr(eng.w_bc), eng.m_bc.numel(), 1, 0, 0, eng.dt, st),
                 "pack bwd C")
@@ -310,27 +321,48 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     dzs = g.layers * Z2
     c1, co = eng.cview["c1"], eng.cview["co"]
     g_next = ws["gzero"]                      # dxhat_{L} = 0: the last layer's x' is dead (wavenet.py:205-207)
-    for l in range(g.layers - 1, -1, -1):
-        d = g.dilations[l]
-        assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % len(ws["gx"])].data_ptr()
-        dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
-        # du -> dz
-        _tm(eng, B, T, g.Hp, 2, 1.0, [(g_next.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
-            eng.w_bu.data_ptr() + l * eng.n_bu * es, dz_ptr, dzs, fw["z"][l].data_ptr(), Z2)
-        # weight gradients of the dilated conv, the conditioning 1x1 (+ per-clip zb sums) and conv1x1_out: one launch
-        ev = getattr(eng, "_tn_events", None) if ws["stream"] is None else None
+    ngx = len(ws["gx"])
+    ck = 64 if eng.dt == L.WAE_BF16 else 32
+    us_off = (g.Rp // ck) * g.NP * 4 * 1024   # bytes: the W_skip chunks follow the W_out chunks in the mode-2 stream
+
+    def k_u(l, gn):                            # du -> dz of layer l
+        _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
+            eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2)
+
+    def k_x(l, gn, gc):                        # dx-hat of layer l
+        srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
+        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp)
+
+    def tn_layer(l):                           # per-layer weight gradients (fp32 path; bf16 takes them all at the end)
+        if ws["stream"] is not None:
+            return
+        ev = getattr(eng, "_tn_events", None)
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(eng.device))
-        if ws["stream"] is None:
-            ws["tt_layer"][l].launch(B, T)
+        ws["tt_layer"][l].launch(B, T)
         if ev is not None:
             e1.record(torch.cuda.current_stream(eng.device))
             ev.append((e0, e1))
-        # dx
-        g_cur = ws["gx"][l % len(ws["gx"])]
-        srcs = [(dz_ptr, dzs, Z2, (g.k - 1 - tap) * d) for tap in range(g.k)]
-        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, g_cur.data_ptr(), g.Rp, g_next.data_ptr(), g.Rp)
+
+    k_u(g.layers - 1, g_next)
+    for l in range(g.layers - 1, -1, -1):
+        assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % ngx].data_ptr()
+        tn_layer(l)                            # needs dz_l and dx_{l+1}-hat
+        g_cur = ws["gx"][l % ngx]
+        if l > 0 and eng.fused_bwd:
+            # K_X of layer l and K_U of layer l-1 in one launch (csrc/glu_bwd.hip)
+            d = L.GluBwdDesc(eng.dt, B, T, g.Rp, g.Hp, g.Sp, g.k, g.dilations[l], RS)
+            L.check(lib.wae_glu_bwd_fused(ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
+                                          L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][l - 1]),
+                                          ctypes.c_void_p(ws["dz"].data_ptr() + (l - 1) * Z2 * es),
+                                          ctypes.c_void_p(eng.w_bx.data_ptr() + l * eng.n_bx * es),
+                                          ctypes.c_void_p(eng.w_buo.data_ptr() + (l - 1) * eng.n_buo * es),
+                                          ctypes.c_void_p(eng.w_bu.data_ptr() + (l - 1) * eng.n_bu * es + us_off), st), "glu_bwd_fused")
+        else:
+            k_x(l, g_next, g_cur)
+            if l > 0:
+                k_u(l - 1, g_cur)
         g_next = g_cur
     if ws["stream"] is not None:          # every layer's dW1 taps, dWc + zb sums, dW_out + bias: one launch
         ev = getattr(eng, "_tn_events", None)

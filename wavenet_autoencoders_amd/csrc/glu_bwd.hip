@@ -1,0 +1,248 @@
+// wae_glu_bwd_fused: the backward data path across one layer boundary in ONE launch (autograd of modules.py:115-163):
+//
+//   dx_l-hat[t]  = sqrt(.5) * ( dx_{l+1}-hat[t] + sum_tap W1_l,tap^T dz_l[t + (k-1-tap) d_l] )        (K_X of layer l)
+//   du_{l-1}[t]  = W_out_{l-1}^T dx_l-hat[t] + W_skip_{l-1}^T dskip[t]                                 (K_U of layer l-1)
+//   dz_{l-1}[t]  = gate'(z_{l-1}[t]) * du_{l-1}[t]
+//
+// ("-hat" = the stored gradient already carries the layer's sqrt(.5).)  The unfused path runs these as two wae_gemm_tm
+// launches (RESIDUAL, then GATE_BWD) and re-reads dx_l-hat from HBM in between.  Here the 32x32 accumulator tiles of the
+// first GEMM (column = time on the lane, rows = residual channels in the registers) are scaled, stored once (the weight
+// gradient of conv1x1_out and the next boundary need them) and converted in place into the B operand of the second GEMM
+// (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand") -- the same chaining as
+// csrc/glu_fwd.hip, run backwards.  Decomposition as in csrc/gemm_tm.hip: 128 time steps per workgroup, one wave per
+// 32 time columns owning all rows, weights in A-fragment order through a double-buffered LDS ring.
+#include "wae_common.hpp"
+
+struct GbArgs {
+  const char* dz;       // (B,T,dz_stride): dz_l columns (2Hp) of layer l
+  const char* g_next;   // (B,T,Rp): dx_{l+1}-hat
+  char* g_out;          // (B,T,Rp): dx_l-hat
+  const char* dskip;    // (B,T,Sp)
+  const char* z_prev;   // (B,T,2Hp): pre-activations of layer l-1
+  char* dz_prev;        // (B,T,dz_stride): dz_{l-1} columns
+  const char* w_x;      // first_gemm_map(Rp, k*2Hp): chunks [q][blk][m]
+  const char* w_uo;     // second_gemm_map(Hp, Rp): [mt][kb] in accumulator-row k order
+  const char* w_us;     // first_gemm_map(Hp, Sp)
+  int64_t dz_stride;
+  float alpha;
+  int B, T, Sp, ktaps, dilation;
+};
+
+template <typename E, int NTX, int NTU>
+__global__ void __launch_bounds__(256, 1) glu_bwd_fused_kernel(GbArgs p) {
+  using T_ = ET<E>;
+  using frag = typename T_::frag;
+  constexpr int ES = sizeof(E);
+  constexpr int KBU = T_::KBU;
+  constexpr int CHX = NTX * 4 * 1024;            // GEMM-A chunk (= ring slot)
+  constexpr int NKB = NTX * KBU;                 // 16-byte k-blocks of GEMM B1 (K = Rp)
+  constexpr int MTB = (CHX / (NKB * 1024) >= 2 && NTU % 2 == 0) ? 2 : 1;   // M-tiles per B1 chunk
+  constexpr int CHB1 = MTB * NKB * 1024;
+  constexpr int CHB2 = NTU * 4 * 1024;
+  static_assert(CHB1 <= CHX && CHB2 <= CHX, "ring slots are sized for the first GEMM's chunks");
+  constexpr int Z2 = 2 * NTU * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int tiles_per_b = (p.T + 127) >> 7;
+  const int b = blockIdx.x / tiles_per_b;
+  const int t0w = (blockIdx.x % tiles_per_b) * 128 + wave * 32;
+  const int t = t0w + n;
+  const bool tvalid = t < p.T;
+  const int rows_valid = min(max(p.T - t0w, 0), 32);
+  char* stg = smem + 2 * CHX + wave * STG_BYTES;
+  const int64_t row0 = (int64_t)b * p.T + t0w;
+
+  const int cpt = Z2 / T_::CK;                 // chunks per tap
+  const int nqa = p.ktaps * cpt;
+  constexpr int nqb1 = NTU / MTB;
+  const int nqb2 = p.Sp / T_::CK;
+  const int nq_total = nqa + nqb1 + nqb2;
+  auto chunk_src = [&](int qi, int& bytes) -> const char* {
+    if (qi < nqa) { bytes = CHX; return p.w_x + (int64_t)qi * CHX; }
+    if (qi < nqa + nqb1) { bytes = CHB1; return p.w_uo + (int64_t)(qi - nqa) * CHB1; }
+    bytes = CHB2;
+    return p.w_us + (int64_t)(qi - nqa - nqb1) * CHB2;
+  };
+  auto dma = [&](int qi) {
+    int bytes;
+    const char* src = chunk_src(qi, bytes);
+    dma_chunk(src, smem + (qi & 1) * CHX, bytes, wave, lane);
+  };
+
+  frag Bn[4], Bc[4];
+  auto load_B = [&](const char* base, int64_t stride_e, int col_chunk, int shift, frag (&Bf)[4]) {
+    const int ts = t + shift;
+    const bool ok = tvalid && ts >= 0 && ts < p.T;
+    const char* src = base + (((int64_t)b * p.T + (ok ? ts : 0)) * stride_e) * ES + col_chunk * 128 + h * 16;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      if (ok) {
+        Bf[blk] = *(const frag*)(src + blk * 32);
+      } else {
+        frag zf = {};
+        Bf[blk] = zf;
+      }
+    }
+  };
+  auto load_B_a = [&](int q, frag (&Bf)[4]) {   // GEMM A: dz_l rows shifted forward in time (transpose of the causal conv)
+    const int tap = q / cpt;
+    load_B(p.dz, p.dz_stride, q - tap * cpt, (p.ktaps - 1 - tap) * p.dilation, Bf);
+  };
+
+  // ---- GEMM A: acc_x = sum_tap W1_tap^T dz_l ----------------------------------------------------------------------
+  f32x16 accx[NTX];
+#pragma unroll
+  for (int m = 0; m < NTX; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[m][r] = 0.f;
+  constexpr int NPX = StagePasses<NTX, E>::N;
+  f32x4 pre_x[NPX][8];   // residual rows dx_{l+1}-hat: fetched now, they arrive under the MFMAs
+  if (rows_valid > 0) stage_fetch_tiles<E, NTX>(pre_x, p.g_next + row0 * NTX * 32 * ES, (int64_t)NTX * 32 * ES, rows_valid, lane);
+  dma(0);
+  load_B_a(0, Bn);
+  for (int q = 0; q < nqa; ++q) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
+    dma(q + 1);                                   // nq_total > nqa: there is always a next chunk
+    if (q + 1 < nqa) load_B_a(q + 1, Bn);
+    gemm_chunk<4 * NTX, NTX, 4>(smem + (q & 1) * CHX + lane * 16, Bc, accx);
+  }
+
+  // ---- epilogue A: dx_l-hat = alpha * (acc + residual); stored once, kept as the operand of GEMM B1 ---------------------
+  frag xf[NKB];
+  {
+    f32x16 res[NTX];
+    if (rows_valid > 0) stage_unpack_tiles<E, NTX>(stg, res, pre_x, lane);
+#pragma unroll
+    for (int m = 0; m < NTX; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[m][r] = p.alpha * (accx[m][r] + (rows_valid > 0 ? res[m][r] : 0.f));
+      frag tmp[KBU];
+      acc_to_frags(accx[m], tmp);
+#pragma unroll
+      for (int s = 0; s < KBU; ++s) xf[m * KBU + s] = tmp[s];
+    }
+    if (rows_valid > 0) stage_store_tiles<E, NTX>(stg, accx, p.g_out + row0 * NTX * 32 * ES, (int64_t)NTX * 32 * ES, rows_valid, lane);
+  }
+
+  // ---- GEMM B: du = W_out^T dx_l-hat (operand from registers) + W_skip^T dskip (operand from memory) -------------------
+  f32x16 accu[NTU];
+#pragma unroll
+  for (int m = 0; m < NTU; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accu[m][r] = 0.f;
+  constexpr int NPU = StagePasses<NTU, E>::N;
+  f32x4 pre_a[NPU][8], pre_b[NPU][8];   // saved pre-activations z_{l-1} (tanh half, sigmoid half)
+  if (rows_valid > 0) {
+    const char* zrow = p.z_prev + row0 * Z2 * ES;
+    stage_fetch_tiles<E, NTU>(pre_a, zrow, (int64_t)Z2 * ES, rows_valid, lane);
+    stage_fetch_tiles<E, NTU>(pre_b, zrow + (int64_t)NTU * 32 * ES, (int64_t)Z2 * ES, rows_valid, lane);
+  }
+#pragma unroll
+  for (int q1 = 0; q1 < nqb1; ++q1) {
+    const int qi = nqa + q1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma(qi + 1);                                  // nqb2 >= 1
+    if (q1 + 1 == nqb1) load_B(p.dskip, p.Sp, 0, 0, Bn);
+    gemm_chunk<MTB * NKB, MTB, NKB, true>(smem + (qi & 1) * CHX + lane * 16, xf, *(f32x16(*)[MTB]) & accu[q1 * MTB]);
+  }
+  for (int q2 = 0; q2 < nqb2; ++q2) {
+    const int qi = nqa + nqb1 + q2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
+    if (qi + 1 < nq_total) {
+      dma(qi + 1);
+      load_B(p.dskip, p.Sp, q2 + 1, 0, Bn);
+    }
+    gemm_chunk<4 * NTU, NTU, 4>(smem + (qi & 1) * CHX + lane * 16, Bc, accu);
+  }
+  if (rows_valid <= 0) return;
+
+  // ---- epilogue B: gate backward (modules.py:154: u = tanh(a) * sigmoid(b)):  da = du s (1 - th^2),  db = du th s (1 - s) ------
+  f32x16 za[NTU], zg[NTU];
+  stage_unpack_tiles<E, NTU>(stg, za, pre_a, lane);
+  stage_unpack_tiles<E, NTU>(stg, zg, pre_b, lane);
+#pragma unroll
+  for (int m = 0; m < NTU; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float th, sg;
+      if constexpr (sizeof(E) == 4) {
+        th = tanhf(za[m][r]);
+        sg = 1.0f / (1.0f + expf(-zg[m][r]));
+      } else {
+        const float ea = __builtin_amdgcn_exp2f(fmaxf(za[m][r], -15.0f) * -2.885390081777927f);
+        th = (1.0f - ea) * fast_rcp(1.0f + ea);
+        sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(zg[m][r] * -1.4426950408889634f));
+      }
+      const float du = accu[m][r];
+      za[m][r] = du * sg * (1.0f - th * th);
+      zg[m][r] = du * th * sg * (1.0f - sg);
+    }
+  }
+  char* orow = p.dz_prev + row0 * p.dz_stride * ES;
+  stage_store_tiles<E, NTU>(stg, za, orow, p.dz_stride * ES, rows_valid, lane);
+  stage_store_tiles<E, NTU>(stg, zg, orow + (int64_t)NTU * 32 * ES, p.dz_stride * ES, rows_valid, lane);
+}
+
+template <typename E, int NTX, int NTU>
+static int launch_gb(const GbArgs& a, hipStream_t st) {
+  constexpr int CHX = NTX * 4 * 1024;
+  const size_t lds = 2 * CHX + 4 * STG_BYTES;
+  static size_t attr_done = 0;
+  if (attr_done < lds) {
+    if (hipFuncSetAttribute((const void*)glu_bwd_fused_kernel<E, NTX, NTU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      wae_set_error("glu_bwd_fused: cannot raise dynamic LDS to %zu", lds);
+      return WAE_EHIP;
+    }
+    attr_done = lds;
+  }
+  const int tiles = (a.T + 127) / 128;
+  hipLaunchKernelGGL((glu_bwd_fused_kernel<E, NTX, NTU>), dim3(a.B * tiles), dim3(256), lds, st, a);
+  return wae_check_launch("glu_bwd_fused");
+}
+
+template <typename E>
+static int dispatch_gb(int ntx, int ntu, const GbArgs& a, hipStream_t st) {
+  // (Rp/32, Hp/32) pairs of the shipped presets and the test configurations
+  if (ntx == 8 && ntu == 6) return launch_gb<E, 8, 6>(a, st);
+  if (ntx == 8 && ntu == 4) return launch_gb<E, 8, 4>(a, st);
+  if (ntx == 4 && ntu == 1) return launch_gb<E, 4, 1>(a, st);
+  if (ntx == 4 && ntu == 2) return launch_gb<E, 4, 2>(a, st);
+  if (ntx == 4 && ntu == 3) return launch_gb<E, 4, 3>(a, st);
+  if (ntx == 4 && ntu == 4) return launch_gb<E, 4, 4>(a, st);
+  wae_set_error("glu_bwd_fused: no instance for Rp=%d, Hp=%d (use the two wae_gemm_tm launches)", ntx * 32, ntu * 32);
+  return WAE_EUNSUPPORTED;
+}
+
+extern "C" int wae_glu_bwd_fused_supported(int32_t Rp, int32_t Hp) {
+  const int x = Rp / 32, u = Hp / 32;
+  return (x == 8 && (u == 6 || u == 4)) || (x == 4 && u >= 1 && u <= 4);
+}
+
+extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
+                                 const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
+                                 const void* w_us, void* stream) {
+  WAE_REQUIRE(d && dz && g_next && g_out && dskip && z_prev && dz_prev && w_x && w_uo && w_us, "glu_bwd_fused: null pointer argument");
+  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "glu_bwd_fused: bad dtype");
+  const int ck = d->dtype == WAE_BF16 ? 64 : 32;
+  WAE_REQUIRE(d->B > 0 && d->T > 0 && d->Rp % 128 == 0 && d->Hp % 32 == 0 && d->Sp % ck == 0 && d->Sp > 0 && d->ktaps >= 1 &&
+                  d->dilation >= 1 && (2 * d->Hp) % ck == 0,
+              "glu_bwd_fused: bad sizes");
+  GbArgs a;
+  a.dz = (const char*)dz; a.g_next = (const char*)g_next; a.g_out = (char*)g_out; a.dskip = (const char*)dskip;
+  a.z_prev = (const char*)z_prev; a.dz_prev = (char*)dz_prev; a.w_x = (const char*)w_x; a.w_uo = (const char*)w_uo;
+  a.w_us = (const char*)w_us; a.dz_stride = dz_stride; a.alpha = d->alpha; a.B = d->B; a.T = d->T; a.Sp = d->Sp;
+  a.ktaps = d->ktaps; a.dilation = d->dilation;
+  hipStream_t st = as_stream(stream);
+  if (d->dtype == WAE_BF16) return dispatch_gb<__bf16>(d->Rp / 32, d->Hp / 32, a, st);
+  return dispatch_gb<float>(d->Rp / 32, d->Hp / 32, a, st);
+}

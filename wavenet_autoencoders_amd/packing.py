@@ -420,6 +420,13 @@ def bwd_u_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     return first_gemm_map(g.Hp, g.Rp + g.Sp, dtype, src)
 
 
+def bwd_uo_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
+    """W_out^T for the fused boundary kernel (csrc/glu_bwd.hip): rows h (Hp), K = Rp in accumulator-row order (the
+    operand is the just-computed dx-hat tile stack)."""
+    o = lay.off("wavenet.conv_layers.0.conv1x1_out.weight_v")
+    return second_gemm_map(g.Hp, g.Rp, dtype, lambda h, r: np.where((r < g.R) & (h < g.H), o + r * g.H + h, -1))
+
+
 def bwd_x_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     """dx = sum_tap W1_tap^T dz[t + (k-1-tap) d]: rows r (Rp), K = k sources of 2Hp gate columns."""
     conv = lay.off("wavenet.conv_layers.0.conv.weight_v")
