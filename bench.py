@@ -45,6 +45,35 @@ def synth_inputs(rank, device):
     return x.to(device), lat.to(device), g.to(device)
 
 
+def ar_leg(device, T_ar=4000):
+    """Second half of BASELINE.json's metric: autoregressive kHz of synthesis.py's incremental_forward on one GPU, one
+    utterance (config C4: hps/vqwae.json decoder, 16 kHz; a 0.25 s prefix of the 10 s clip -- the per-sample cost is
+    constant), categorical sampling as in the reference (wavenet.py:300-338).  Untimed warm-up, then one timed run."""
+    import torch
+    from oracle import wae_oracle as O          # closed-form weights only
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153,
+               upsample_scales=[4, 4, 8, 5], cin_pad=0)
+    out = {}
+    for dt in ("fp32", "bf16"):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dt, device=str(device))
+        eng.load_state_dict(O.make_state_dict(dict(cfg), salt=7, with_encoder=False))
+        gen = torch.Generator(device="cpu").manual_seed(1234)
+        lat = torch.randn(1, 64, T_ar // 640 + 1, generator=gen)[:, :, :max(T_ar // 640, 1)].to(device)
+        Tg = lat.shape[-1] * 640
+        gid = torch.zeros(1, dtype=torch.int64, device=device)
+        eng.incremental_forward(lat, gid, Tg, mode="sample")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.incremental_forward(lat, gid, Tg, mode="sample")
+        torch.cuda.synchronize()
+        out[dt] = Tg / (time.perf_counter() - t0) / 1e3
+    return {"metric": "autoregressive kHz (synthesis.py incremental_forward, 1 utterance, 1 GPU)", "value": max(out.values()),
+            "unit": "kHz", "fp32_khz": out["fp32"], "bf16_khz": out["bf16"], "samples": Tg,
+            "config": "C4: hps/vqwae.json decoder (20 layers, R=G=S=256), categorical sampling, one persistent launch"}
+
+
 def cpu_baseline_train(sd, nclips=8):
     """Oracle train step (autograd through the CPU restatement + its Adam/EMA), bounded sample of the same workload."""
     import numpy as np
@@ -106,6 +135,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-ar", action="store_true", help="skip the autoregressive leg (BASELINE config C4, rank 0 only)")
     args = ap.parse_args()
 
     import torch
@@ -252,6 +282,8 @@ def main():
             "roofline_glu_fwd": fwd_roof,
         }
         res.update(extra)
+        if not args.no_ar and world == 1:
+            res["autoregressive"] = ar_leg(device)
         if not args.no_cpu and world == 1:
             cb, cpu_loss = cpu_baseline_train(sd) if args.mode == "train" else cpu_baseline(sd)
             res["cpu_baseline"] = cb
