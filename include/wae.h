@@ -202,6 +202,19 @@ int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_
                     const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
                     const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits, void* stream);
 
+/* The same decoding with ONE utterance spread over C cooperating workgroups / CUs (csrc/ar_coop.hip): the gate rows of
+ * every layer are split over the members, which exchange the gated activations once per layer through `msg`
+ * ((B, 2, C, NV) 8-byte {sequence, value} granules, NV = wae_ar_coop_msg_values(d, C)); each member keeps its own copy
+ * of the history rings: ring is (B, C, ring_total).  B <= 8, C <= 32.  The caller zeroes msg and *error before the
+ * launch; *error != 0 afterwards means an exchange timed out (the output is then invalid). */
+int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C);
+int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                         int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                         const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                         const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                         const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                         uint64_t* msg, int32_t* error, void* stream);
+
 /* ---- backward data path of the gated stack: C[t][M] = sum_s W_s . X_s[t + shift_s] on time-major operands ----
  * (autograd of modules.py:115-163; see csrc/gemm_tm.hip).  mode 0: out (t, M) = acc.  mode 1 (residual):
  * out = alpha * (acc + aux[t]).  mode 2 (gate backward): acc = du over M = Hp rows, aux = z (t, 2Hp),

@@ -29,3 +29,13 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"AR {dtype} B={B} T={T}: {dt:.3f} s -> {T / dt / 1e3:.2f} kHz per utterance, {B * T / dt / 1e3:.1f} kHz aggregate, "
       f"{dt / T * 1e6:.1f} us/sample")
+prof = getattr(eng, "_ar_profile", None)
+if prof is not None:
+    f = int(prof[1])
+    print("  XCC ids of the members:", prof[20:52].tolist())
+    print(f"  cooperative path: same-XCD exchange = {f & 1}, XCC id of member 0 / last member = {(f >> 4) & 15} / {(f >> 8) & 15}")
+if prof is not None and int(prof[2:].abs().sum()) != 0:
+    import numpy as np
+    pc = prof.cpu().numpy()[2:18].view(np.uint64)
+    names = ["assemble taps", "gate rows GEMV", "publish+gather u", "x'+skip GEMV", "skip exchange", "head", "draw"]
+    print("  s_memtime ticks per sample (member 0):", {n: int(v // T) for n, v in zip(names, pc)})

@@ -1,0 +1,559 @@
+// wae_ar_generate_coop: autoregressive decoding of ONE utterance on C cooperating CUs (same arithmetic and packed
+// weights as csrc/ar_fwd.hip; reference: conv.py:17-62, wavenet.py:218-346).
+//
+// csrc/ar_fwd.hip runs an utterance on one CU: per sample it streams every layer's matrices (1.1 MB fp32 per layer at
+// hps/vqwae.json) through that CU's one L2 port -- 60 GB/s, 2.8 kHz.  Here C workgroups (one per CU, dealt so that they
+// share an XCD and its L2) split the big matrix-vector product of each layer by gate channels:
+//   member m:  z[rows of its channels] = W1[rows] . [x taps ; c] + zb   ->   u[its channels] = tanh(a) * sigmoid(b)
+//   exchange:  every member publishes its slice of u, all members gather the whole u                (1 per layer)
+//   redundantly on every member:  x' = (W_out u + b + x) * sqrt(.5)   (its own copy of the history rings)
+//   member m:  skip[its rows] += W_skip[rows] . u        ->   one exchange per sample, then the head and the draw of the
+//   next input run redundantly (identical code on identical data: every member feeds back the same sample).
+// Exchange protocol (MI355X_MICROARCH.md "inter-workgroup visibility"): one 8-byte agent-scope atomic store per value
+// {sequence number, value} (single-copy atomic: no tearing, no fence needed), polled with 8-byte agent-scope atomic loads
+// (sc1: served by the XCD's L2, never a stale L1 line).  Two message banks alternate, so a member that runs ahead
+// cannot overwrite a bank a slower member still reads (it cannot pass the next exchange before that member publishes).
+// A poll that does not complete within ~1 s raises *error and every member leaves the loop: never a hung device.
+#include "wae_common.hpp"
+
+#define ARC_THREADS 256
+#define ARC_HP 4      // history elements a thread prefetches per layer: (ktaps-1)*R <= ARC_HP * ARC_THREADS is the fast case
+#define ARC_W2P 32    // 16-byte packets of a W2 row a thread requests before it waits for the exchange
+
+struct ArcArgs {
+  int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp, C;
+  float scale;
+  const int32_t* dil;
+  const int64_t* ring_off;
+  float* ring;            // (B, C, ring_total): every member keeps its own history rings
+  int64_t ring_total;
+  const char* w_layers;
+  int64_t layer_stride, w2_off;
+  const float* bias2;
+  const float* zb;
+  const float* first_tab;
+  const float* first_bias;
+  const char* w_head;
+  const float* head_bias;
+  const char* c_up;
+  int c_dtype;
+  const int32_t* inputs;
+  int init_idx;
+  const float* uniforms;
+  int32_t* out_idx;
+  float* out_logits;
+  unsigned long long* msg;   // (B, 2 banks, C, NV) {seq, value} granules
+  int NV;                    // values per member and exchange = max(channels per member, skip rows per member)
+  int* error;
+};
+
+template <typename E>
+__device__ __forceinline__ void arc_load_w(const char* p, float (&w)[ET<E>::EPL]);
+template <>
+__device__ __forceinline__ void arc_load_w<float>(const char* p, float (&w)[4]) {
+  const f32x4 v = *(const f32x4*)p;
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void arc_load_w<__bf16>(const char* p, float (&w)[8]) {
+  const f32x4 raw = *(const f32x4*)p;
+  const unsigned r[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[2 * i] = __uint_as_float(r[i] << 16);
+    w[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+
+// rows [r0, r0+nr) of a blocked matrix ([k/EPL][rows_pad][EPL]) times v (LDS): thread -> (row i = tid % nr, slice tid / nr);
+// partial sums to psum[slice * nr + i]
+template <typename E>
+__device__ __forceinline__ void arc_gemv_rows(const char* __restrict__ W, const float* v, float* psum, int rows_pad, int K, int r0,
+                                              int nr, int ns) {
+  constexpr int EPL = ET<E>::EPL;
+  const int i = threadIdx.x % nr, s = threadIdx.x / nr;
+  if (s >= ns) return;
+  const int nkb = (K + EPL - 1) / EPL;
+  float acc = 0.f;
+  for (int kb = s; kb < nkb; kb += ns) {
+    float w[EPL];
+    arc_load_w<E>(W + ((int64_t)kb * rows_pad + r0 + i) * 16, w);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], v[kb * EPL + j], acc);
+  }
+  psum[s * nr + i] = acc;
+}
+
+template <typename E>
+__device__ __forceinline__ void arc_unpack(const f32x4& raw, float (&w)[ET<E>::EPL]);
+template <>
+__device__ __forceinline__ void arc_unpack<float>(const f32x4& raw, float (&w)[4]) {
+  w[0] = raw.x; w[1] = raw.y; w[2] = raw.z; w[3] = raw.w;
+}
+template <>
+__device__ __forceinline__ void arc_unpack<__bf16>(const f32x4& raw, float (&w)[8]) {
+  // bf16 -> fp32 is a 16-bit shift: even elements sit in the low halves
+  const unsigned r[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[2 * i] = __uint_as_float(r[i] << 16);
+    w[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+
+// sum_{kb = kb0, kb0 + kstep, .. < nkb} W[kb][row] . v[kb]: U packets are requested before the first is used (a loop that
+// waits for every 16-byte packet in turn spends an L2 round trip per packet: 20 us per layer)
+template <typename E, int U>
+__device__ __forceinline__ float arc_dot(const char* __restrict__ wrow, int64_t kb_stride, int kb0, int kstep, int nkb, const float* v) {
+  constexpr int EPL = ET<E>::EPL;
+  float acc = 0.f;
+  int kb = kb0;
+  for (; kb + (U - 1) * kstep < nkb; kb += U * kstep) {
+    float w[U][EPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) arc_load_w<E>(wrow + (int64_t)(kb + u * kstep) * kb_stride, w[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) acc = fmaf(w[u][j], v[(kb + u * kstep) * EPL + j], acc);
+  }
+  for (; kb < nkb; kb += kstep) {
+    float w[EPL];
+    arc_load_w<E>(wrow + (int64_t)kb * kb_stride, w);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], v[kb * EPL + j], acc);
+  }
+  return acc;
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding global load
+// (s_waitcnt vmcnt(0)), which would turn each prefetch below into a wait at the next barrier.
+__device__ __forceinline__ void arc_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ unsigned long long arc_pack(unsigned seq, float v) {
+  return ((unsigned long long)__float_as_uint(v) << 32) | seq;
+}
+
+// Gather one exchange: wave 0 alone spins (lane i on the first granule of member i; 32 workgroups x 256 spinning threads
+// on a handful of L2 lines slowed the publishers to 25 us per layer), the other waves wait at the barrier; then every
+// thread fetches its own granule (already there but for a straggling store: re-checked).  dst[i] = f(value i).
+template <typename F>
+__device__ __forceinline__ bool arc_gather(unsigned long long* bank, int NV, int C, int per_member, int total, unsigned seq, int* error,
+                                           int* abort_flag, F&& sink) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    if (tid < C && tid * per_member < total) {
+      int spins = 0;
+      while ((unsigned)__hip_atomic_load(bank + tid * NV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+        if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          *abort_flag = 1;
+          __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
+  arc_barrier();
+  if (*abort_flag) return false;
+  for (int i = tid; i < total; i += ARC_THREADS) {
+    const int mem = i / per_member, j = i - mem * per_member;
+    unsigned long long v = __hip_atomic_load(bank + mem * NV + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while ((unsigned)v != seq && ++spins < (1 << 20)) v = __hip_atomic_load(bank + mem * NV + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)v != seq) { *abort_flag = 1; __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    sink(i, __uint_as_float((unsigned)(v >> 32)));
+  }
+  arc_barrier();
+  return *abort_flag == 0;
+}
+
+template <typename E>
+__global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int EPL = ET<E>::EPL;
+  const int tid = threadIdx.x;
+  // blocks b and b + 8 share an XCD (round-robin dispatch; speed only): utterance = b % 8, member = b / 8
+  const int b = blockIdx.x & 7, m = blockIdx.x >> 3;
+  if (b >= p.B || m >= p.C) return;
+  const int H = p.G / 2, C = p.C;
+  const int hc = (H + C - 1) / C, ch0 = min(m * hc, H), ch1 = min(ch0 + hc, H), nch = ch1 - ch0;
+  const int sc = (p.S + C - 1) / C, s0 = min(m * sc, p.S), s1 = min(s0 + sc, p.S), nsk = s1 - s0;
+  const int K1 = p.ktaps * p.R + (p.Cc > 0 ? p.Cc : 0);
+  const int K1p = (K1 + EPL - 1) / EPL * EPL;
+  const int Hk = (H + EPL - 1) / EPL * EPL;
+  const int Sk = (p.S + EPL - 1) / EPL * EPL;
+  float* vbuf = sm;                       // K1p
+  float* xbuf = vbuf + K1p;               // R
+  float* ubuf = xbuf + p.R;               // Hk
+  float* skipb = ubuf + Hk;               // Sk   full skip vector after the exchange (also the head's h0)
+  float* hbuf = skipb + Sk;               // Sk
+  float* lbuf = hbuf + Sk;                // O logits, then exp(l - max)
+  float* psum = lbuf + ((p.O + 3) & ~3);  // ARC_THREADS
+  float* myskip = psum + ARC_THREADS;     // sc
+  int* ibuf = (int*)(myskip + ((sc + 3) & ~3));   // [0] = current input id, [1] = abort flag
+
+  float* ring = p.ring + ((int64_t)b * C + m) * p.ring_total;
+  const float* zb_b = p.zb + (int64_t)b * p.L * 2 * p.Hp;
+  unsigned long long* msg_b = p.msg + (int64_t)b * 2 * C * p.NV;
+  const int g_pad = (p.G + 63) & ~63, w_pad = (p.R + p.S + 63) & ~63, s_pad = (p.S + 63) & ~63, o_pad = (p.O + 63) & ~63;
+
+  for (int i = tid; i < K1p; i += ARC_THREADS) vbuf[i] = 0.f;
+  for (int i = tid; i < Hk; i += ARC_THREADS) ubuf[i] = 0.f;
+  for (int i = tid; i < Sk; i += ARC_THREADS) { skipb[i] = 0.f; hbuf[i] = 0.f; }
+  if (tid == 0) { ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
+  arc_barrier();
+
+  unsigned seq = 0;   // exchange counter (same on every member); message bank = seq & 1
+  // Where all members run on ONE XCD (the usual placement: blocks b and b+8 share one), messages go through that XCD's L2:
+  // plain 8-byte stores keep the line there (an agent-scope atomic store writes it through to memory and drops it from
+  // L2, so that every poll becomes a fabric round trip: 3.5 us per exchange instead of ~1.2).  The members compare their
+  // XCC ids once, through the always-valid agent-scope path, and all reach the same verdict.
+  bool fast = false;
+  auto publish = [&](unsigned long long* slot, unsigned long long v) {
+    if (fast) *(volatile unsigned long long*)slot = v;
+    else __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    ++seq;
+    unsigned long long* bank = msg_b + (int64_t)(seq & 1) * C * p.NV;
+    if (tid == 0) publish(bank + m * p.NV, arc_pack(seq, (float)xcc));
+    float* ids = psum;
+    if (!arc_gather(bank, p.NV, C, 1, C, seq, p.error, &ibuf[1], [&](int i, float v) { ids[i] = v; })) return;
+    bool same = true;
+    for (int i = 1; i < C; ++i) same = same && ids[i] == ids[0];
+    if (tid == 0 && m == 0 && b == 0) p.error[1] = 0x1000 | (same ? 1 : 0) | ((int)ids[0] << 4) | ((int)ids[C - 1] << 8);
+#ifdef WAE_ARC_PROFILE
+    if (tid < C && m == 0 && b == 0) p.error[20 + tid] = (int)ids[tid];
+#endif
+    arc_barrier();
+    fast = same;
+  }
+#ifdef WAE_ARC_PROFILE
+  unsigned long long pc[8] = {}, pt = __builtin_amdgcn_s_memtime();
+#define ARC_TICK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc[i] += n_ - pt; pt = n_; } while (0)
+#else
+#define ARC_TICK(i) do { } while (0)
+#endif
+  // history element i (= tap * R + ch, tap < ktaps - 1) of layer l at sample t: zero before the clip starts
+  auto hist_load = [&](int l, int t, int i) -> float {
+    const int tap = i / p.R, ch = i - tap * p.R;
+    const int d = p.dil[l];
+    const int rlen = (p.ktaps - 1) * d + 1;
+    const int tt = t - (p.ktaps - 1 - tap) * d;
+    return tt >= 0 ? ring[p.ring_off[l] + (int64_t)(tt % rlen) * p.R + ch] : 0.f;
+  };
+  float hist[ARC_HP];
+#pragma unroll
+  for (int k = 0; k < ARC_HP; ++k) hist[k] = 0.f;   // layer 0 at t = 0: no history yet
+  for (int t = 0; t < p.T; ++t) {
+    const int cur = ibuf[0];
+    if (tid < p.R) xbuf[tid] = p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
+    for (int cc = tid; cc < p.Cc; cc += ARC_THREADS) {
+      const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
+      vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : ((const float*)p.c_up)[ci];
+    }
+    if (tid < sc) myskip[tid] = 0.f;
+    arc_barrier();
+
+    for (int l = 0; l < p.L; ++l) {
+      const int d = p.dil[l];
+      const int rlen = (p.ktaps - 1) * d + 1;
+      float* rl = ring + p.ring_off[l];
+      // current tap from xbuf (and into the ring); history taps were requested one layer ago (hist[])
+      for (int i = tid, k = 0; i < p.ktaps * p.R; i += ARC_THREADS, ++k) {
+        const int tap = i / p.R, ch = i - tap * p.R;
+        float v;
+        if (tap == p.ktaps - 1) {
+          v = xbuf[ch];
+          rl[(int64_t)(t % rlen) * p.R + ch] = v;
+        } else {
+          v = k < ARC_HP ? hist[k] : hist_load(l, t, i);
+        }
+        vbuf[i] = v;
+      }
+      {   // request the history rows of the next layer (or of layer 0 of the next sample): they do not depend on this one
+        const int ln = l + 1 < p.L ? l + 1 : 0, tn = l + 1 < p.L ? t : t + 1;
+#pragma unroll
+        for (int k = 0; k < ARC_HP; ++k) {
+          const int i = tid + k * ARC_THREADS;
+          hist[k] = i < (p.ktaps - 1) * p.R ? hist_load(ln, tn, i) : 0.f;
+        }
+      }
+      arc_barrier();
+      ARC_TICK(0);
+      const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
+      // ---- this member's gate rows: tanh rows [ch0, ch1), sigmoid rows H + [ch0, ch1) ------------------------------
+      if (nch > 0) {
+        const int ns = ARC_THREADS / (2 * nch);
+        const int i2 = tid % (2 * nch), s = tid / (2 * nch);
+        if (s < ns) {
+          const int row = i2 < nch ? ch0 + i2 : H + ch0 + (i2 - nch);
+          const int nkb = (K1 + EPL - 1) / EPL;
+          psum[s * 2 * nch + i2] = arc_dot<E, 8>(wl + (int64_t)row * 16, (int64_t)g_pad * 16, s, ns, nkb, vbuf);
+        }
+      }
+      arc_barrier();
+      ARC_TICK(1);
+      // gate + publish / gather u: member mem's channel j lands at ubuf[mem * hc + j]
+      const char* w2 = wl + p.w2_off;
+      const int nkb2 = (H + EPL - 1) / EPL;
+      f32x4 w2raw[ARC_W2P];
+      const int SL = ARC_THREADS / sc, sj = tid / SL, ss = tid - sj * SL;   // skip row and k slice of this thread
+      f32x4 skraw[2];
+      {
+        ++seq;
+        unsigned long long* bank = msg_b + (int64_t)(seq & 1) * C * p.NV;
+        if (tid < nch) {
+          const int ns = ARC_THREADS / (2 * nch);
+          const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
+          float a = zbl[ch0 + tid], g = zbl[p.Hp + ch0 + tid];
+          for (int s = 0; s < ns; ++s) { a += psum[s * 2 * nch + tid]; g += psum[s * 2 * nch + nch + tid]; }
+          const float u = tanhf(a) * (1.f / (1.f + expf(-g)));
+          publish(bank + m * p.NV + tid, arc_pack(seq, u));
+        }
+        // this thread's row of W_out: requested now, it travels while the members exchange u
+        if (tid < p.R) {
+#pragma unroll
+          for (int kb = 0; kb < ARC_W2P; ++kb)
+            if (kb < nkb2) w2raw[kb] = *(const volatile f32x4*)(w2 + ((int64_t)kb * w_pad + tid) * 16);
+        }
+        // this member's skip rows: row sj, k-blocks ss, ss + SL, ..: one or two packets per thread
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (sj < nsk && ss + q * SL < nkb2) skraw[q] = *(const volatile f32x4*)(w2 + ((int64_t)(ss + q * SL) * w_pad + p.R + s0 + sj) * 16);
+        if (!arc_gather(bank, p.NV, C, hc, H, seq, p.error, &ibuf[1], [&](int i, float v) { ubuf[i] = v; })) return;
+      }
+      ARC_TICK(2);
+      // ---- x' on every member (rows 0..R-1 of W2), skip rows [s0, s1) on this member ---------------------------------
+      const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
+      if (tid < p.R) {
+        float acc = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < ARC_W2P; ++kb)
+          if (kb < nkb2) {
+            float w[EPL];
+            arc_unpack<E>(w2raw[kb], w);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], ubuf[kb * EPL + j], acc);
+          }
+        if (nkb2 > ARC_W2P) acc += arc_dot<E, 8>(w2 + (int64_t)tid * 16, (int64_t)w_pad * 16, ARC_W2P, 1, nkb2, ubuf);
+        xbuf[tid] = (acc + b2[tid] + xbuf[tid]) * 0.70710678118654752440f;
+      }
+      {
+        float part = 0.f;
+        if (sj < nsk) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (ss + q * SL < nkb2) {
+              float w[EPL];
+              arc_unpack<E>(skraw[q], w);
+#pragma unroll
+              for (int j = 0; j < EPL; ++j) part = fmaf(w[j], ubuf[(ss + q * SL) * EPL + j], part);
+            }
+          for (int kb = ss + 2 * SL; kb < nkb2; kb += SL) {   // wider layers than the two prefetched packets cover
+            float w[EPL];
+            arc_load_w<E>(w2 + ((int64_t)kb * w_pad + p.R + s0 + sj) * 16, w);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) part = fmaf(w[j], ubuf[kb * EPL + j], part);
+          }
+        }
+        if (SL == 32 || SL == 64) {     // a row's slices are the lanes of half a wave / one wave: reduce in registers
+          for (int o = SL >> 1; o > 0; o >>= 1) part += __shfl_down(part, o, SL);
+          if (ss == 0 && sj < nsk) myskip[sj] += part + b2[p.R + s0 + sj];
+        } else {
+          psum[tid] = part;
+        }
+      }
+      if (!(SL == 32 || SL == 64)) {
+        arc_barrier();
+        if (tid < nsk) {
+          float y = b2[p.R + s0 + tid];
+          for (int q = 0; q < SL; ++q) y += psum[tid * SL + q];
+          myskip[tid] += y;
+        }
+      }
+      arc_barrier();
+      ARC_TICK(3);
+    }
+    // ---- gather the skip vector (one exchange per sample), then head + draw on every member ------------------------------
+    {
+      ++seq;
+      unsigned long long* bank = msg_b + (int64_t)(seq & 1) * C * p.NV;
+      if (tid < nsk) publish(bank + m * p.NV + tid, arc_pack(seq, myskip[tid]));
+      const float scale = p.scale;
+      if (!arc_gather(bank, p.NV, C, sc, p.S, seq, p.error, &ibuf[1], [&](int i, float v) { skipb[i] = fmaxf(v * scale, 0.f); })) return;
+    }
+    ARC_TICK(4);
+    {
+      const int nkb = (p.S + EPL - 1) / EPL;
+      for (int r = tid; r < p.S; r += ARC_THREADS) {
+        const float acc = arc_dot<E, 8>(p.w_head + (int64_t)r * 16, (int64_t)s_pad * 16, 0, 1, nkb, skipb);
+        hbuf[r] = fmaxf(acc + p.head_bias[r], 0.f);
+      }
+      arc_barrier();
+      const char* w3 = p.w_head + (int64_t)nkb * s_pad * 16;
+      for (int r = tid; r < p.O; r += ARC_THREADS) {
+        const float y = arc_dot<E, 8>(w3 + (int64_t)r * 16, (int64_t)o_pad * 16, 0, 1, nkb, hbuf) + p.head_bias[p.S + r];
+        lbuf[r] = y;
+        if (p.out_logits && m == 0) p.out_logits[((int64_t)b * p.O + r) * p.T + t] = y;
+      }
+      arc_barrier();
+    }
+    ARC_TICK(5);
+    // ---- next input (wavenet.py:300-338): same arithmetic and summation order as csrc/ar_fwd.hip; the exponentials are
+    //      evaluated by all threads, the order-dependent sums by one ---------------------------------------------------------
+    // argmax with the first maximal index (as the serial scan of csrc/ar_fwd.hip)
+    {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int i = tid; i < p.O; i += ARC_THREADS)
+        if (lbuf[i] > bv) { bv = lbuf[i]; bi = i; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_down(bv, o, 64);
+        const int oi = __shfl_down(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if ((tid & 63) == 0) { psum[2 * (tid >> 6)] = bv; ((int*)psum)[2 * (tid >> 6) + 1] = bi; }
+      arc_barrier();
+      if (tid == 0) {
+        for (int w = 1; w < ARC_THREADS / 64; ++w) {
+          const float ov = psum[2 * w];
+          const int oi = ((int*)psum)[2 * w + 1];
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        psum[16] = bv;
+        ibuf[2] = bi;
+      }
+      arc_barrier();
+    }
+    int produced_par = -1;
+    if (p.mode == 2 && p.O <= ARC_THREADS) {
+      // softmax in fp32 (F.softmax), then inverse CDF over a double cumulative sum (numpy's choice, wavenet.py:331), all in
+      // parallel: block sum for the denominator, block scan for the cumulative sums, block count of the sums below u * total
+      const float mx = psum[16];
+      const float e = tid < p.O ? expf(lbuf[tid] - mx) : 0.f;
+      float sden = e;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sden += __shfl_down(sden, o, 64);
+      if ((tid & 63) == 0) psum[32 + (tid >> 6)] = sden;
+      arc_barrier();
+      float den = 0.f;
+      for (int w = 0; w < ARC_THREADS / 64; ++w) den += psum[32 + w];
+      double c = tid < p.O ? (double)(e / den) : 0.0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(c, o, 64);
+        if ((tid & 63) >= o) c += up;
+      }
+      double* dsum = (double*)(psum + 40);
+      if ((tid & 63) == 63) dsum[tid >> 6] = c;
+      arc_barrier();
+      double base = 0.0, tot = 0.0;
+      for (int w = 0; w < ARC_THREADS / 64; ++w) {
+        if (w < (tid >> 6)) base += dsum[w];
+        tot += dsum[w];
+      }
+      c += base;
+      const double thr = (double)p.uniforms[(int64_t)b * p.T + t] * tot;
+      const unsigned long long below = __ballot(tid < p.O && c < thr);
+      if ((tid & 63) == 0) ((int*)psum)[56 + (tid >> 6)] = __popcll(below);
+      arc_barrier();
+      int cnt = 0;
+      for (int w = 0; w < ARC_THREADS / 64; ++w) cnt += ((int*)psum)[56 + w];
+      produced_par = min(cnt, p.O - 1);
+    } else if (p.mode == 2) {
+      const float mx = psum[16];
+      for (int i = tid; i < p.O; i += ARC_THREADS) lbuf[i] = expf(lbuf[i] - mx);
+      arc_barrier();
+    }
+    if (tid == 0) {
+      int produced = ibuf[2];
+      if (p.mode == 2 && produced_par >= 0) {
+        produced = produced_par;
+      } else if (p.mode == 2) {
+        float den = 0.f;
+        for (int i = 0; i < p.O; ++i) den += lbuf[i];
+        double tot = 0.0;
+        for (int i = 0; i < p.O; ++i) tot += (double)(lbuf[i] / den);
+        const double thr = (double)p.uniforms[(int64_t)b * p.T + t] * tot;
+        double c = 0.0;
+        int cnt = 0;
+        for (int i = 0; i < p.O; ++i) {
+          c += (double)(lbuf[i] / den);
+          if (c < thr) ++cnt;
+        }
+        produced = min(cnt, p.O - 1);
+      }
+      if (m == 0) p.out_idx[(int64_t)b * p.T + t] = produced;
+      ibuf[0] = (p.inputs && t + 1 < p.T) ? p.inputs[(int64_t)b * p.T + t + 1] : produced;
+    }
+    arc_barrier();
+    ARC_TICK(6);
+  }
+#ifdef WAE_ARC_PROFILE
+  if (tid == 0 && b == 0 && m == 0) {
+    unsigned long long* o = (unsigned long long*)(p.error + 2);
+    for (int i = 0; i < 8; ++i) o[i] = pc[i];
+  }
+#endif
+}
+
+extern "C" int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C) {
+  if (!d || C <= 0) return WAE_EINVAL;
+  const int H = d->G / 2;
+  const int hc = (H + C - 1) / C, sc = (d->S + C - 1) / C;
+  return hc > sc ? hc : sc;
+}
+
+extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                                    int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                                    const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                                    const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                                    const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                                    uint64_t* msg, int32_t* error, void* stream) {
+  WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias &&
+                  out_idx && msg && error, "ar_generate_coop: null pointer argument");
+  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate_coop: bad dtype");
+  WAE_REQUIRE(d->B > 0 && d->B <= 8, "ar_generate_coop: 1..8 utterances per launch (one XCD each); use wae_ar_generate for more");
+  WAE_REQUIRE(C >= 1 && C <= 32, "ar_generate_coop: 1..32 cooperating workgroups per utterance");
+  WAE_REQUIRE(d->T > 0 && d->L > 0 && d->R > 0 && d->R <= ARC_THREADS && d->G > 0 && d->G % 2 == 0 && d->S > 0 && d->O > 0,
+              "ar_generate_coop: bad sizes (R <= %d)", ARC_THREADS);
+  WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_coop: Cc > 0 but c_up is null");
+  WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate_coop: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
+  WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate_coop: sample mode needs uniforms");
+  WAE_REQUIRE(d->mode != 0 || inputs, "ar_generate_coop: teacher-forced mode needs inputs");
+  WAE_REQUIRE(!d->scalar_input, "ar_generate_coop: scalar-input (DMoL) decoding is not implemented yet");
+  const int H = d->G / 2;
+  const int hc = (H + C - 1) / C, sc = (d->S + C - 1) / C;
+  WAE_REQUIRE(2 * hc <= ARC_THREADS && sc <= ARC_THREADS, "ar_generate_coop: too few workgroups for G=%d, S=%d", d->G, d->S);
+  ArcArgs a;
+  a.dtype = d->dtype; a.B = d->B; a.T = d->T; a.L = d->L; a.R = d->R; a.G = d->G; a.S = d->S; a.O = d->O; a.Cc = d->Cc;
+  a.Ccp = d->Ccp; a.Hp = d->Hp; a.ktaps = d->ktaps; a.mode = d->mode; a.Rp = d->Rp; a.C = C; a.scale = d->scale; a.dil = dilations;
+  a.ring_off = ring_off; a.ring = ring; a.ring_total = ring_total; a.w_layers = (const char*)w_layers;
+  a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
+  a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
+  a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
+  a.out_logits = out_logits; a.msg = (unsigned long long*)msg; a.NV = hc > sc ? hc : sc; a.error = error;
+  const int epl = d->dtype == WAE_BF16 ? 8 : 4;
+  auto ru = [](int x, int mm) { return (x + mm - 1) / mm * mm; };
+  const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
+                                              2 * ru(d->S, epl) + ru(d->O, 4) + ARC_THREADS + ru(sc, 4) + 8);
+  hipStream_t st = as_stream(stream);
+  // the message banks must start with sequence numbers no exchange will use (0): the caller zeroes msg and error
+  if (d->dtype == WAE_BF16) {
+    (void)hipFuncSetAttribute((const void*)ar_coop_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_coop_kernel<__bf16>, dim3(8 * C), dim3(ARC_THREADS), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)ar_coop_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_coop_kernel<float>, dim3(8 * C), dim3(ARC_THREADS), lds, st, a);
+  }
+  return wae_check_launch("ar_generate_coop");
+}

@@ -47,9 +47,14 @@ __device__ __forceinline__ void load_w<float>(const char* p, float (&w)[4]) {
 }
 template <>
 __device__ __forceinline__ void load_w<__bf16>(const char* p, float (&w)[8]) {
-  const bf16x8 v = *(const bf16x8*)p;
+  // bf16 -> fp32 is a 16-bit shift; even elements sit in the low halves of the four dwords
+  const f32x4 raw = *(const f32x4*)p;
+  const unsigned r[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) w[j] = (float)v[j];
+  for (int i = 0; i < 4; ++i) {
+    w[2 * i] = __uint_as_float(r[i] << 16);
+    w[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
 }
 
 // y[r] = sum_k W[r][k] v[k] for r < rows; W blocked [k/EPL][rows_pad][EPL]; v in LDS (K padded to EPL, zero filled).

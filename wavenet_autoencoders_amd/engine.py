@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -364,7 +365,11 @@ class WaeEngine:
                                   self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
                                   L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
                                   L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
-        ring = torch.empty(B * self.ar_ring_total, dtype=torch.float32, device=dev)
+        # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
+        # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
+        coop = B <= 8 and os.environ.get("WAE_AR_COOP", "1") != "0"
+        C = max(1, min(32, g.H, g.S)) if coop else 1
+        ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
         inputs = test_inputs.to(torch.int32).contiguous() if test_inputs is not None else None
         if m == 2 and uniforms is None:
             uniforms = torch.rand(B, T, device=dev)
@@ -374,11 +379,24 @@ class WaeEngine:
         es = self.ar_w.element_size()
         d = L.ArDesc(self.dt, B, T, g.layers, g.R, g.Rp, g.G, g.Hp, g.S, g.O, max(g.Cc, 0), g.Ccp, g.k, m, int(init_idx), 0,
                      math.sqrt(1.0 / g.layers))
-        L.check(lib.wae_ar_generate(ctypes.byref(d), L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring), self.ar_ring_total,
-                                    L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es, L.ptr(self.ar_b2), L.ptr(zb),
-                                    L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(self.ar_wh), L.ptr(self.ar_hb),
-                                    L.ptr(c_up), self.dt, L.ptr(inputs), L.ptr(uni), L.ptr(out_idx), L.ptr(logits), st),
-                "ar_generate")
+        if coop:
+            nv = lib.wae_ar_coop_msg_values(ctypes.byref(d), C)
+            msg = torch.zeros(B * 2 * C * nv, dtype=torch.int64, device=dev)
+            err = torch.zeros(64, dtype=torch.int32, device=dev)   # [0] = time-out flag; the rest: profile counters of a -DWAE_ARC_PROFILE build
+            L.check(lib.wae_ar_generate_coop(ctypes.byref(d), C, L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring),
+                                             self.ar_ring_total, L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es,
+                                             L.ptr(self.ar_b2), L.ptr(zb), L.ptr(self.first_tab), L.ptr(self.first_bias),
+                                             L.ptr(self.ar_wh), L.ptr(self.ar_hb), L.ptr(c_up), self.dt, L.ptr(inputs), L.ptr(uni),
+                                             L.ptr(out_idx), L.ptr(logits), L.ptr(msg), L.ptr(err), st), "ar_generate_coop")
+            self._ar_profile = err
+            if int(err[0].item()) != 0:  # synchronises: generation is a blocking call for its callers anyway
+                raise L.WaeError("ar_generate_coop: an exchange between the cooperating workgroups timed out")
+        else:
+            L.check(lib.wae_ar_generate(ctypes.byref(d), L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring), self.ar_ring_total,
+                                        L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es, L.ptr(self.ar_b2), L.ptr(zb),
+                                        L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(self.ar_wh), L.ptr(self.ar_hb),
+                                        L.ptr(c_up), self.dt, L.ptr(inputs), L.ptr(uni), L.ptr(out_idx), L.ptr(logits), st),
+                    "ar_generate")
         self._ar_keep = (c_up, zb, ring, inputs, uni, gid32)   # keep device buffers alive until the stream has run
         return dict(idx=out_idx, logits=logits)
 
