@@ -202,18 +202,21 @@ int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_
                     const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
                     const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits, void* stream);
 
-/* The same decoding with ONE utterance spread over C cooperating workgroups / CUs (csrc/ar_coop.hip): the gate rows of
- * every layer are split over the members, which exchange the gated activations once per layer through `msg`
- * ((B, 2, C, NV) 8-byte {sequence, value} granules, NV = wae_ar_coop_msg_values(d, C)); each member keeps its own copy
- * of the history rings: ring is (B, C, ring_total).  B <= 8, C <= 32.  The caller zeroes msg and *error before the
- * launch; *error != 0 afterwards means an exchange timed out (the output is then invalid). */
+/* The same decoding with ONE utterance spread over C cooperating workgroups / CUs (csrc/ar_coop.hip): every layer is
+ * split by gate channels; the members all-reduce their shares of x' once per layer and of the skip vector once per
+ * sample through `acc` (B x wae_ar_coop_acc_floats(d) floats), `msg` ((B, 2, C, NV) 8-byte granules, NV =
+ * wae_ar_coop_msg_values(d, C)) carries the start-up handshake; each member keeps its own copy of the history rings:
+ * ring is (B, C, ring_total).  B <= 8, C <= 32, R and S <= 256.  The caller zeroes msg, acc and error (>= 64 ints) before
+ * the launch; error[0] != 0 afterwards means a wait timed out (the output is then invalid).  Sums are formed by fp32
+ * atomics in arrival order: reproducible to rounding, not bitwise. */
+int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d);
 int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C);
 int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
                          int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
                          const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
                          const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
                          const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
-                         uint64_t* msg, int32_t* error, void* stream);
+                         uint64_t* msg, float* acc, int32_t* error, void* stream);
 
 /* ---- backward data path of the gated stack: C[t][M] = sum_s W_s . X_s[t + shift_s] on time-major operands ----
  * (autograd of modules.py:115-163; see csrc/gemm_tm.hip).  mode 0: out (t, M) = acc.  mode 1 (residual):

@@ -85,8 +85,9 @@ SIGNATURES = {
     "wae_ar_generate": (c_i32, [ctypes.POINTER(ArDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7 + [c_i32]
                         + [c_vp] * 5),
     "wae_ar_coop_msg_values": (c_i32, [ctypes.POINTER(ArDesc), c_i32]),
+    "wae_ar_coop_acc_floats": (c_i64, [ctypes.POINTER(ArDesc)]),
     "wae_ar_generate_coop": (c_i32, [ctypes.POINTER(ArDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7
-                             + [c_i32] + [c_vp] * 7),
+                             + [c_i32] + [c_vp] * 8),
     "wae_masked_mean": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
     "wae_from_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),

@@ -3,22 +3,25 @@
 //
 // csrc/ar_fwd.hip runs an utterance on one CU: per sample it streams every layer's matrices (1.1 MB fp32 per layer at
 // hps/vqwae.json) through that CU's one L2 port -- 60 GB/s, 2.8 kHz.  Here C workgroups (one per CU, dealt so that they
-// share an XCD and its L2) split the big matrix-vector product of each layer by gate channels:
+// share an XCD and its L2) split each layer by gate channels:
 //   member m:  z[rows of its channels] = W1[rows] . [x taps ; c] + zb   ->   u[its channels] = tanh(a) * sigmoid(b)
-//   exchange:  every member publishes its slice of u, all members gather the whole u                (1 per layer)
-//   redundantly on every member:  x' = (W_out u + b + x) * sqrt(.5)   (its own copy of the history rings)
-//   member m:  skip[its rows] += W_skip[rows] . u        ->   one exchange per sample, then the head and the draw of the
-//   next input run redundantly (identical code on identical data: every member feeds back the same sample).
-// Exchange protocol (MI355X_MICROARCH.md "inter-workgroup visibility"): one 8-byte agent-scope atomic store per value
-// {sequence number, value} (single-copy atomic: no tearing, no fence needed), polled with 8-byte agent-scope atomic loads
-// (sc1: served by the XCD's L2, never a stale L1 line).  Two message banks alternate, so a member that runs ahead
-// cannot overwrite a bank a slower member still reads (it cannot pass the next exchange before that member publishes).
-// A poll that does not complete within ~1 s raises *error and every member leaves the loop: never a hung device.
+//   member m:  its share of x' and of the skip row sums:  W_out[:, its channels] u,  W_skip[:, its channels] u
+//   all-reduce of the x' shares (fp32 atomic adds into an L2 accumulator + a counter; 1 per layer), residual on every
+//   member (each keeps its own copy of the history rings); the skip shares are summed over the layers locally (the skip
+//   path is linear) and all-reduced ONCE per sample; the head and the draw of the next input then run redundantly
+//   (identical code on identical data: every member feeds back the same sample).
+// No member ever streams a whole matrix: per layer it reads its 2*hc rows of W1 and 2 x 16-byte column packets per row of
+// W_out / W_skip.  (v1 all-gathered u and computed x' redundantly: 32 CUs pulling the same 128 KB through one L2 cost
+// 7 us per layer.)  The sums are formed by atomics in arrival order: results are reproducible to fp32 rounding, not bitwise.
+// Where all members run on one XCD (checked at start through agent-scope messages), the accumulators stay in that XCD's
+// L2; otherwise every access is an agent-scope atomic.  A wait that does not complete within ~1 s raises *error and every
+// member leaves: never a hung device.
 #include "wae_common.hpp"
 
 #define ARC_THREADS 256
 #define ARC_HP 4      // history elements a thread prefetches per layer: (ktaps-1)*R <= ARC_HP * ARC_THREADS is the fast case
-#define ARC_W2P 32    // 16-byte packets of a W2 row a thread requests before it waits for the exchange
+#define ARC_NB 3       // accumulator banks of the all-reduce (see arc_allreduce)
+#define ARC_ACC_FLOATS(R, S) (ARC_NB * ((R) + (S)) + 2 * ARC_NB + 10)
 
 struct ArcArgs {
   int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp, C;
@@ -44,6 +47,7 @@ struct ArcArgs {
   float* out_logits;
   unsigned long long* msg;   // (B, 2 banks, C, NV) {seq, value} granules
   int NV;                    // values per member and exchange = max(channels per member, skip rows per member)
+  float* acc;                // (B, ARC_ACC_FLOATS(R, S)): 3 banks of R and of S partial-sum accumulators + counters, zeroed
   int* error;
 };
 
@@ -171,6 +175,51 @@ __device__ __forceinline__ bool arc_gather(unsigned long long* bank, int NV, int
   return *abort_flag == 0;
 }
 
+// Sum one value per thread (n <= ARC_THREADS values) over the C members of an utterance: fp32 atomic adds into an L2
+// accumulator bank, a counter that tells when all C members have added, then every member reads the n sums.
+// Use number `use` (0, 1, 2, ..) takes bank use % 3.  Before it adds, a member zeroes ITS share of the NEXT bank; a member
+// that sees the counter complete therefore knows the next bank is clean (every member finished its zero stores before
+// its adds), and the bank being zeroed was last read two uses ago, before its readers published the previous use.
+// fast (all members on one XCD): the adds, stores and counter stay in that XCD's L2 (no cache-control bits);
+// otherwise agent-scope atomics (memory side).  Returns false on time-out.
+__device__ __forceinline__ bool arc_allreduce(float* banks, int* cnt, int n, unsigned use, float mine, float& sum, int C, int m,
+                                              bool fast, int* error, int* abort_flag) {
+  const int tid = threadIdx.x;
+  const int k = use % ARC_NB, kn = (use + 1) % ARC_NB;
+  float* bank = banks + (int64_t)k * n;
+  float* next = banks + (int64_t)kn * n;
+  const int per = (n + C - 1) / C;
+  if (tid < per && m * per + tid < n) {
+    if (fast) *(volatile float*)(next + m * per + tid) = 0.f;
+    else __hip_atomic_store(next + m * per + tid, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero stores are in L2 / memory before anything is added
+  if (tid < n) {
+    if (fast) __hip_atomic_fetch_add(bank + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_add(bank + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's adds have been performed
+  arc_barrier();
+  if (tid == 0) {
+    if (fast) __hip_atomic_fetch_add(cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_add(cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = C * (int)(use / ARC_NB + 1);
+    int spins = 0;
+    while (__hip_atomic_load(cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        *abort_flag = 1;
+        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  arc_barrier();
+  if (*abort_flag) return false;
+  sum = tid < n ? __hip_atomic_load(bank + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  return true;
+}
+
 template <typename E>
 __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -193,8 +242,8 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   float* hbuf = skipb + Sk;               // Sk
   float* lbuf = hbuf + Sk;                // O logits, then exp(l - max)
   float* psum = lbuf + ((p.O + 3) & ~3);  // ARC_THREADS
-  float* myskip = psum + ARC_THREADS;     // sc
-  int* ibuf = (int*)(myskip + ((sc + 3) & ~3));   // [0] = current input id, [1] = abort flag
+  float* myskip = psum + ARC_THREADS;     // this member's gated activations of the layer (hc values)
+  int* ibuf = (int*)(myskip + ((max(sc, hc) + 3) & ~3));   // [0] = current input id, [1] = abort flag, [2] = argmax
 
   float* ring = p.ring + ((int64_t)b * C + m) * p.ring_total;
   const float* zb_b = p.zb + (int64_t)b * p.L * 2 * p.Hp;
@@ -207,6 +256,11 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   if (tid == 0) { ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
   arc_barrier();
 
+  float* xbanks = p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S);
+  float* sbanks = xbanks + ARC_NB * p.R;
+  int* xcnt = (int*)(sbanks + ARC_NB * p.S);
+  int* scnt = xcnt + ARC_NB;
+  unsigned xuse = 0, suse = 0;
   unsigned seq = 0;   // exchange counter (same on every member); message bank = seq & 1
   // Where all members run on ONE XCD (the usual placement: blocks b and b+8 share one), messages go through that XCD's L2:
   // plain 8-byte stores keep the line there (an agent-scope atomic store writes it through to memory and drops it from
@@ -259,7 +313,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
       const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
       vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : ((const float*)p.c_up)[ci];
     }
-    if (tid < sc) myskip[tid] = 0.f;
+    float skip_part = 0.f;   // this member's contribution to skip row tid, summed over the layers (the skip path is linear)
     arc_barrier();
 
     for (int l = 0; l < p.L; ++l) {
@@ -301,94 +355,76 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
       }
       arc_barrier();
       ARC_TICK(1);
-      // gate + publish / gather u: member mem's channel j lands at ubuf[mem * hc + j]
+      // ---- gate: u of this member's channels ----------------------------------------------------------------------------
       const char* w2 = wl + p.w2_off;
-      const int nkb2 = (H + EPL - 1) / EPL;
-      f32x4 w2raw[ARC_W2P];
-      const int SL = ARC_THREADS / sc, sj = tid / SL, ss = tid - sj * SL;   // skip row and k slice of this thread
-      f32x4 skraw[2];
-      {
-        ++seq;
-        unsigned long long* bank = msg_b + (int64_t)(seq & 1) * C * p.NV;
-        if (tid < nch) {
-          const int ns = ARC_THREADS / (2 * nch);
-          const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
-          float a = zbl[ch0 + tid], g = zbl[p.Hp + ch0 + tid];
-          for (int s = 0; s < ns; ++s) { a += psum[s * 2 * nch + tid]; g += psum[s * 2 * nch + nch + tid]; }
-          const float u = tanhf(a) * (1.f / (1.f + expf(-g)));
-          publish(bank + m * p.NV + tid, arc_pack(seq, u));
-        }
-        // this thread's row of W_out: requested now, it travels while the members exchange u
-        if (tid < p.R) {
+      const int kb_a = ch0 / EPL, kb_b = nch > 0 ? (ch1 - 1) / EPL : kb_a - 1;   // W2 packets that hold this member's columns
+      f32x4 wxr[2], wsr[2];   // row tid of W_out / W_skip, those packets: requested now, used after the gate
 #pragma unroll
-          for (int kb = 0; kb < ARC_W2P; ++kb)
-            if (kb < nkb2) w2raw[kb] = *(const volatile f32x4*)(w2 + ((int64_t)kb * w_pad + tid) * 16);
-        }
-        // this member's skip rows: row sj, k-blocks ss, ss + SL, ..: one or two packets per thread
+      for (int q = 0; q < 2; ++q) {
+        if (kb_a + q <= kb_b && tid < p.R) wxr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + tid) * 16);
+        if (kb_a + q <= kb_b && tid < p.S) wsr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + p.R + tid) * 16);
+      }
+      if (tid < nch) {
+        const int ns = ARC_THREADS / (2 * nch);
+        const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
+        float a = zbl[ch0 + tid], g = zbl[p.Hp + ch0 + tid];
+        for (int s = 0; s < ns; ++s) { a += psum[s * 2 * nch + tid]; g += psum[s * 2 * nch + nch + tid]; }
+        myskip[tid] = tanhf(a) * (1.f / (1.f + expf(-g)));
+      }
+      arc_barrier();
+      // ---- this member's share of x' = W_out u and of skip += W_skip u: columns [ch0, ch1) only ----------------------------
+      float px = 0.f;
+      {
+        float ps = 0.f;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          if (sj < nsk && ss + q * SL < nkb2) skraw[q] = *(const volatile f32x4*)(w2 + ((int64_t)(ss + q * SL) * w_pad + p.R + s0 + sj) * 16);
-        if (!arc_gather(bank, p.NV, C, hc, H, seq, p.error, &ibuf[1], [&](int i, float v) { ubuf[i] = v; })) return;
+          if (kb_a + q <= kb_b) {
+            float wx[EPL], ws[EPL];
+            arc_unpack<E>(wxr[q], wx);
+            arc_unpack<E>(wsr[q], ws);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int ch = (kb_a + q) * EPL + e;
+              if (ch >= ch0 && ch < ch1) {
+                const float u = myskip[ch - ch0];
+                px = fmaf(wx[e], u, px);
+                ps = fmaf(ws[e], u, ps);
+              }
+            }
+          }
+        for (int kb = kb_a + 2; kb <= kb_b; ++kb) {   // more than two packets of columns per member (few members, wide layers)
+          float wx[EPL], ws[EPL];
+          if (tid < p.R) arc_load_w<E>(w2 + ((int64_t)kb * w_pad + tid) * 16, wx);
+          if (tid < p.S) arc_load_w<E>(w2 + ((int64_t)kb * w_pad + p.R + tid) * 16, ws);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int ch = kb * EPL + e;
+            if (ch >= ch0 && ch < ch1) {
+              if (tid < p.R) px = fmaf(wx[e], myskip[ch - ch0], px);
+              if (tid < p.S) ps = fmaf(ws[e], myskip[ch - ch0], ps);
+            }
+          }
+        }
+        const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
+        if (tid < p.S) skip_part += ps + (m == 0 ? b2[p.R + tid] : 0.f);   // the bias once: member 0
       }
       ARC_TICK(2);
-      // ---- x' on every member (rows 0..R-1 of W2), skip rows [s0, s1) on this member ---------------------------------
-      const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
-      if (tid < p.R) {
-        float acc = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < ARC_W2P; ++kb)
-          if (kb < nkb2) {
-            float w[EPL];
-            arc_unpack<E>(w2raw[kb], w);
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], ubuf[kb * EPL + j], acc);
-          }
-        if (nkb2 > ARC_W2P) acc += arc_dot<E, 8>(w2 + (int64_t)tid * 16, (int64_t)w_pad * 16, ARC_W2P, 1, nkb2, ubuf);
-        xbuf[tid] = (acc + b2[tid] + xbuf[tid]) * 0.70710678118654752440f;
-      }
+      // ---- all-reduce x' over the members, then residual (modules.py:157-162) -------------------------------------------------
       {
-        float part = 0.f;
-        if (sj < nsk) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            if (ss + q * SL < nkb2) {
-              float w[EPL];
-              arc_unpack<E>(skraw[q], w);
-#pragma unroll
-              for (int j = 0; j < EPL; ++j) part = fmaf(w[j], ubuf[(ss + q * SL) * EPL + j], part);
-            }
-          for (int kb = ss + 2 * SL; kb < nkb2; kb += SL) {   // wider layers than the two prefetched packets cover
-            float w[EPL];
-            arc_load_w<E>(w2 + ((int64_t)kb * w_pad + p.R + s0 + sj) * 16, w);
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) part = fmaf(w[j], ubuf[kb * EPL + j], part);
-          }
-        }
-        if (SL == 32 || SL == 64) {     // a row's slices are the lanes of half a wave / one wave: reduce in registers
-          for (int o = SL >> 1; o > 0; o >>= 1) part += __shfl_down(part, o, SL);
-          if (ss == 0 && sj < nsk) myskip[sj] += part + b2[p.R + s0 + sj];
-        } else {
-          psum[tid] = part;
-        }
-      }
-      if (!(SL == 32 || SL == 64)) {
-        arc_barrier();
-        if (tid < nsk) {
-          float y = b2[p.R + s0 + tid];
-          for (int q = 0; q < SL; ++q) y += psum[tid * SL + q];
-          myskip[tid] += y;
-        }
+        float sum;
+        if (!arc_allreduce(xbanks, xcnt, p.R, xuse++, px, sum, C, m, fast, p.error, &ibuf[1])) return;
+        const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
+        if (tid < p.R) xbuf[tid] = (sum + b2[tid] + xbuf[tid]) * 0.70710678118654752440f;
       }
       arc_barrier();
       ARC_TICK(3);
     }
-    // ---- gather the skip vector (one exchange per sample), then head + draw on every member ------------------------------
+    // ---- all-reduce the skip vector (once per sample), then head + draw on every member ---------------------------------
     {
-      ++seq;
-      unsigned long long* bank = msg_b + (int64_t)(seq & 1) * C * p.NV;
-      if (tid < nsk) publish(bank + m * p.NV + tid, arc_pack(seq, myskip[tid]));
-      const float scale = p.scale;
-      if (!arc_gather(bank, p.NV, C, sc, p.S, seq, p.error, &ibuf[1], [&](int i, float v) { skipb[i] = fmaxf(v * scale, 0.f); })) return;
+      float sum;
+      if (!arc_allreduce(sbanks, scnt, p.S, suse++, skip_part, sum, C, m, fast, p.error, &ibuf[1])) return;
+      if (tid < p.S) skipb[tid] = fmaxf(sum * p.scale, 0.f);
+      arc_barrier();
     }
     ARC_TICK(4);
     {
@@ -506,6 +542,11 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
 #endif
 }
 
+extern "C" int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d) {
+  if (!d) return WAE_EINVAL;
+  return ARC_ACC_FLOATS(d->R, d->S);
+}
+
 extern "C" int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C) {
   if (!d || C <= 0) return WAE_EINVAL;
   const int H = d->G / 2;
@@ -518,14 +559,15 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
                                     const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
                                     const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
                                     const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
-                                    uint64_t* msg, int32_t* error, void* stream) {
+                                    uint64_t* msg, float* acc, int32_t* error, void* stream) {
   WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias &&
-                  out_idx && msg && error, "ar_generate_coop: null pointer argument");
+                  out_idx && msg && acc && error, "ar_generate_coop: null pointer argument");
   WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate_coop: bad dtype");
   WAE_REQUIRE(d->B > 0 && d->B <= 8, "ar_generate_coop: 1..8 utterances per launch (one XCD each); use wae_ar_generate for more");
   WAE_REQUIRE(C >= 1 && C <= 32, "ar_generate_coop: 1..32 cooperating workgroups per utterance");
-  WAE_REQUIRE(d->T > 0 && d->L > 0 && d->R > 0 && d->R <= ARC_THREADS && d->G > 0 && d->G % 2 == 0 && d->S > 0 && d->O > 0,
-              "ar_generate_coop: bad sizes (R <= %d)", ARC_THREADS);
+  WAE_REQUIRE(d->T > 0 && d->L > 0 && d->R > 0 && d->R <= ARC_THREADS && d->G > 0 && d->G % 2 == 0 && d->S > 0 &&
+                  d->S <= ARC_THREADS && d->O > 0,
+              "ar_generate_coop: bad sizes (R, S <= %d)", ARC_THREADS);
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_coop: Cc > 0 but c_up is null");
   WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate_coop: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate_coop: sample mode needs uniforms");
@@ -541,11 +583,11 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
   a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
   a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
-  a.out_logits = out_logits; a.msg = (unsigned long long*)msg; a.NV = hc > sc ? hc : sc; a.error = error;
+  a.out_logits = out_logits; a.msg = (unsigned long long*)msg; a.NV = hc > sc ? hc : sc; a.acc = acc; a.error = error;
   const int epl = d->dtype == WAE_BF16 ? 8 : 4;
   auto ru = [](int x, int mm) { return (x + mm - 1) / mm * mm; };
   const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
-                                              2 * ru(d->S, epl) + ru(d->O, 4) + ARC_THREADS + ru(sc, 4) + 8);
+                                              2 * ru(d->S, epl) + ru(d->O, 4) + ARC_THREADS + ru(hc > sc ? hc : sc, 4) + 8);
   hipStream_t st = as_stream(stream);
   // the message banks must start with sequence numbers no exchange will use (0): the caller zeroes msg and error
   if (d->dtype == WAE_BF16) {

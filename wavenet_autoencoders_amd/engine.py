@@ -367,7 +367,7 @@ class WaeEngine:
                                   L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
         # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
         # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
-        coop = B <= 8 and os.environ.get("WAE_AR_COOP", "1") != "0"
+        coop = B <= 8 and g.R <= 256 and g.S <= 256 and os.environ.get("WAE_AR_COOP", "1") != "0"
         C = max(1, min(32, g.H, g.S)) if coop else 1
         ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
         inputs = test_inputs.to(torch.int32).contiguous() if test_inputs is not None else None
@@ -382,12 +382,14 @@ class WaeEngine:
         if coop:
             nv = lib.wae_ar_coop_msg_values(ctypes.byref(d), C)
             msg = torch.zeros(B * 2 * C * nv, dtype=torch.int64, device=dev)
+            acc = torch.zeros(B * lib.wae_ar_coop_acc_floats(ctypes.byref(d)), dtype=torch.float32, device=dev)
             err = torch.zeros(64, dtype=torch.int32, device=dev)   # [0] = time-out flag; the rest: profile counters of a -DWAE_ARC_PROFILE build
             L.check(lib.wae_ar_generate_coop(ctypes.byref(d), C, L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring),
                                              self.ar_ring_total, L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es,
                                              L.ptr(self.ar_b2), L.ptr(zb), L.ptr(self.first_tab), L.ptr(self.first_bias),
                                              L.ptr(self.ar_wh), L.ptr(self.ar_hb), L.ptr(c_up), self.dt, L.ptr(inputs), L.ptr(uni),
-                                             L.ptr(out_idx), L.ptr(logits), L.ptr(msg), L.ptr(err), st), "ar_generate_coop")
+                                             L.ptr(out_idx), L.ptr(logits), L.ptr(msg), L.ptr(acc), L.ptr(err), st),
+                    "ar_generate_coop")
             self._ar_profile = err
             if int(err[0].item()) != 0:  # synchronises: generation is a blocking call for its callers anyway
                 raise L.WaeError("ar_generate_coop: an exchange between the cooperating workgroups timed out")
