@@ -20,6 +20,7 @@
 
 #define ARC_THREADS 256
 #define ARC_HP 4      // history elements a thread prefetches per layer: (ktaps-1)*R <= ARC_HP * ARC_THREADS is the fast case
+#define ARC_W1P 8      // W1 packets of a gate row slice a thread holds (fp32: K1/4/32 slices = 6.5 at hps/vqwae.json)
 #define ARC_NB 3       // accumulator banks of the all-reduce (see arc_allreduce)
 #define ARC_ACC_FLOATS(R, S) (ARC_NB * ((R) + (S)) + 2 * ARC_NB + 10)
 
@@ -121,11 +122,16 @@ __device__ __forceinline__ float arc_dot(const char* __restrict__ wrow, int64_t 
 #pragma unroll
       for (int j = 0; j < EPL; ++j) acc = fmaf(w[u][j], v[(kb + u * kstep) * EPL + j], acc);
   }
-  for (; kb < nkb; kb += kstep) {
-    float w[EPL];
-    arc_load_w<E>(wrow + (int64_t)kb * kb_stride, w);
+  if (kb < nkb) {   // the last, partial batch: still one round trip
+    float w[U][EPL];
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], v[kb * EPL + j], acc);
+    for (int u = 0; u < U; ++u)
+      if (kb + u * kstep < nkb) arc_load_w<E>(wrow + (int64_t)(kb + u * kstep) * kb_stride, w[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kb + u * kstep < nkb)
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc = fmaf(w[u][j], v[(kb + u * kstep) * EPL + j], acc);
   }
   return acc;
 }
@@ -182,23 +188,21 @@ __device__ __forceinline__ bool arc_gather(unsigned long long* bank, int NV, int
 // its adds), and the bank being zeroed was last read two uses ago, before its readers published the previous use.
 // fast (all members on one XCD): the adds, stores and counter stay in that XCD's L2 (no cache-control bits);
 // otherwise agent-scope atomics (memory side).  Returns false on time-out.
+// `between` runs once this wave's adds have been performed: loads it issues travel while the members wait for each other.
+template <typename F>
 __device__ __forceinline__ bool arc_allreduce(float* banks, int* cnt, int n, unsigned use, float mine, float& sum, int C, int m,
-                                              bool fast, int* error, int* abort_flag) {
+                                              bool fast, int* error, int* abort_flag, F&& between) {
   const int tid = threadIdx.x;
   const int k = use % ARC_NB, kn = (use + 1) % ARC_NB;
   float* bank = banks + (int64_t)k * n;
-  float* next = banks + (int64_t)kn * n;
+  (void)kn;
   const int per = (n + C - 1) / C;
-  if (tid < per && m * per + tid < n) {
-    if (fast) *(volatile float*)(next + m * per + tid) = 0.f;
-    else __hip_atomic_store(next + m * per + tid, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero stores are in L2 / memory before anything is added
   if (tid < n) {
     if (fast) __hip_atomic_fetch_add(bank + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_fetch_add(bank + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's adds have been performed
+  between();
   arc_barrier();
   if (tid == 0) {
     if (fast) __hip_atomic_fetch_add(cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -217,6 +221,14 @@ __device__ __forceinline__ bool arc_allreduce(float* banks, int* cnt, int n, uns
   arc_barrier();
   if (*abort_flag) return false;
   sum = tid < n ? __hip_atomic_load(bank + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  // zero this member's share of the bank of use + 2 (= the bank of use - 1: every member read it before it added for this
+  // use).  The stores complete before this member's next adds are counted (the vmcnt(0) above, next time round), and a
+  // member adds for use + 2 only after the counter of use + 1 is complete.
+  float* clean = banks + (int64_t)((use + 2) % ARC_NB) * n;
+  if (tid < per && m * per + tid < n) {
+    if (fast) *(volatile float*)(clean + m * per + tid) = 0.f;
+    else __hip_atomic_store(clean + m * per + tid, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   return true;
 }
 
@@ -306,6 +318,30 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   float hist[ARC_HP];
 #pragma unroll
   for (int k = 0; k < ARC_HP; ++k) hist[k] = 0.f;   // layer 0 at t = 0: no history yet
+  // The weights a member needs for a layer -- ARC_W1P packets of its slice of one gate row, two packets of W_out row tid
+  // and of W_skip row tid -- depend on nothing computed: they are requested one layer ahead (before the all-reduce of the
+  // previous layer) and wait in registers.
+  const int gns = nch > 0 ? ARC_THREADS / (2 * nch) : 1;          // k slices per gate row
+  const int gi2 = nch > 0 ? tid % (2 * nch) : 0, gs = nch > 0 ? tid / (2 * nch) : gns;
+  const int grow = gi2 < nch ? ch0 + gi2 : H + ch0 + (gi2 - nch);
+  const int nkb1 = (K1 + EPL - 1) / EPL;
+  const int kb_a = ch0 / EPL, kb_b = nch > 0 ? (ch1 - 1) / EPL : kb_a - 1;   // W2 packets that hold this member's columns
+  f32x4 w1n[ARC_W1P], wxr[2], wsr[2];
+  auto prefetch_layer = [&](int l) {
+    const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
+    if (gs < gns) {
+#pragma unroll
+      for (int u = 0; u < ARC_W1P; ++u)
+        if (gs + u * gns < nkb1) w1n[u] = *(const volatile f32x4*)(wl + ((int64_t)(gs + u * gns) * g_pad + grow) * 16);
+    }
+    const char* w2 = wl + p.w2_off;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (kb_a + q <= kb_b && tid < p.R) wxr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + tid) * 16);
+      if (kb_a + q <= kb_b && tid < p.S) wsr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + p.R + tid) * 16);
+    }
+  };
+  prefetch_layer(0);
   for (int t = 0; t < p.T; ++t) {
     const int cur = ibuf[0];
     if (tid < p.R) xbuf[tid] = p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
@@ -344,31 +380,39 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
       ARC_TICK(0);
       const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
       // ---- this member's gate rows: tanh rows [ch0, ch1), sigmoid rows H + [ch0, ch1) ------------------------------
-      if (nch > 0) {
-        const int ns = ARC_THREADS / (2 * nch);
-        const int i2 = tid % (2 * nch), s = tid / (2 * nch);
-        if (s < ns) {
-          const int row = i2 < nch ? ch0 + i2 : H + ch0 + (i2 - nch);
-          const int nkb = (K1 + EPL - 1) / EPL;
-          psum[s * 2 * nch + i2] = arc_dot<E, 8>(wl + (int64_t)row * 16, (int64_t)g_pad * 16, s, ns, nkb, vbuf);
+      if (gs < gns) {
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < ARC_W1P; ++u)
+          if (gs + u * gns < nkb1) {
+            float w[EPL];
+            arc_unpack<E>(w1n[u], w);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], vbuf[(gs + u * gns) * EPL + j], acc);
+          }
+        if (gs + ARC_W1P * gns < nkb1)   // longer rows than the prefetched packets cover
+          acc += arc_dot<E, 8>(wl + (int64_t)grow * 16, (int64_t)g_pad * 16, gs + ARC_W1P * gns, gns, nkb1, vbuf);
+        // slices of one row sit 2*nch lanes apart: fold them inside the wave when that is a power of two (<= 32),
+        // so that only one partial per wave and row goes through LDS
+        const int rw = 2 * nch;
+        if ((rw & (rw - 1)) == 0 && rw <= 32) {
+          for (int o = 32; o >= rw; o >>= 1) acc += __shfl_xor(acc, o, 64);
+          if ((tid & 63) < rw) psum[(tid >> 6) * rw + gi2] = acc;
+        } else {
+          psum[gs * rw + gi2] = acc;
         }
       }
       arc_barrier();
       ARC_TICK(1);
       // ---- gate: u of this member's channels ----------------------------------------------------------------------------
       const char* w2 = wl + p.w2_off;
-      const int kb_a = ch0 / EPL, kb_b = nch > 0 ? (ch1 - 1) / EPL : kb_a - 1;   // W2 packets that hold this member's columns
-      f32x4 wxr[2], wsr[2];   // row tid of W_out / W_skip, those packets: requested now, used after the gate
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (kb_a + q <= kb_b && tid < p.R) wxr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + tid) * 16);
-        if (kb_a + q <= kb_b && tid < p.S) wsr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + p.R + tid) * 16);
-      }
       if (tid < nch) {
-        const int ns = ARC_THREADS / (2 * nch);
+        const int ns = gns;
         const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
         float a = zbl[ch0 + tid], g = zbl[p.Hp + ch0 + tid];
-        for (int s = 0; s < ns; ++s) { a += psum[s * 2 * nch + tid]; g += psum[s * 2 * nch + nch + tid]; }
+        const int rw = 2 * nch;
+        const int nparts = ((rw & (rw - 1)) == 0 && rw <= 32) ? ARC_THREADS / 64 : ns;
+        for (int s = 0; s < nparts; ++s) { a += psum[s * rw + tid]; g += psum[s * rw + nch + tid]; }
         myskip[tid] = tanhf(a) * (1.f / (1.f + expf(-g)));
       }
       arc_barrier();
@@ -412,7 +456,9 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
       // ---- all-reduce x' over the members, then residual (modules.py:157-162) -------------------------------------------------
       {
         float sum;
-        if (!arc_allreduce(xbanks, xcnt, p.R, xuse++, px, sum, C, m, fast, p.error, &ibuf[1])) return;
+        if (!arc_allreduce(xbanks, xcnt, p.R, xuse++, px, sum, C, m, fast, p.error, &ibuf[1],
+                           [&]() { prefetch_layer(l + 1 < p.L ? l + 1 : 0); }))
+          return;
         const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
         if (tid < p.R) xbuf[tid] = (sum + b2[tid] + xbuf[tid]) * 0.70710678118654752440f;
       }
@@ -422,7 +468,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
     // ---- all-reduce the skip vector (once per sample), then head + draw on every member ---------------------------------
     {
       float sum;
-      if (!arc_allreduce(sbanks, scnt, p.S, suse++, skip_part, sum, C, m, fast, p.error, &ibuf[1])) return;
+      if (!arc_allreduce(sbanks, scnt, p.S, suse++, skip_part, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
       if (tid < p.S) skipb[tid] = fmaxf(sum * p.scale, 0.f);
       arc_barrier();
     }
@@ -430,13 +476,13 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
     {
       const int nkb = (p.S + EPL - 1) / EPL;
       for (int r = tid; r < p.S; r += ARC_THREADS) {
-        const float acc = arc_dot<E, 8>(p.w_head + (int64_t)r * 16, (int64_t)s_pad * 16, 0, 1, nkb, skipb);
+        const float acc = arc_dot<E, 32>(p.w_head + (int64_t)r * 16, (int64_t)s_pad * 16, 0, 1, nkb, skipb);
         hbuf[r] = fmaxf(acc + p.head_bias[r], 0.f);
       }
       arc_barrier();
       const char* w3 = p.w_head + (int64_t)nkb * s_pad * 16;
       for (int r = tid; r < p.O; r += ARC_THREADS) {
-        const float y = arc_dot<E, 8>(w3 + (int64_t)r * 16, (int64_t)o_pad * 16, 0, 1, nkb, hbuf) + p.head_bias[p.S + r];
+        const float y = arc_dot<E, 32>(w3 + (int64_t)r * 16, (int64_t)o_pad * 16, 0, 1, nkb, hbuf) + p.head_bias[p.S + r];
         lbuf[r] = y;
         if (p.out_logits && m == 0) p.out_logits[((int64_t)b * p.O + r) * p.T + t] = y;
       }

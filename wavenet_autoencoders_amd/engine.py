@@ -368,7 +368,7 @@ class WaeEngine:
         # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
         # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
         coop = B <= 8 and g.R <= 256 and g.S <= 256 and os.environ.get("WAE_AR_COOP", "1") != "0"
-        C = max(1, min(32, g.H, g.S)) if coop else 1
+        C = max(1, min(int(os.environ.get("WAE_AR_COOP_C", "32")), 32, g.H, g.S)) if coop else 1
         ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
         inputs = test_inputs.to(torch.int32).contiguous() if test_inputs is not None else None
         if m == 2 and uniforms is None:
