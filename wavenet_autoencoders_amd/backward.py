@@ -30,8 +30,6 @@ def _prepare_bwd(eng):
     if getattr(eng, "_bwd_ready", False):
         return
     g, dev, lay = eng.g, eng.device, eng.lay
-    if g.scalar_input:
-        raise NotImplementedError("backward for scalar-input (DMoL) models is not implemented yet")
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
@@ -216,7 +214,9 @@ def bwd_workspace(eng, B, T):
                   dh1=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
                   dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
                   dc=torch.zeros(B, T, max(g.Ccp, 64), dtype=td, device=dev),
-                  ids=torch.zeros(B, T, dtype=torch.int32, device=dev))
+                  ids=torch.zeros(B, T, dtype=torch.int32, device=dev),
+                  # scalar input (first_conv is a 1x1 on one channel): operand [x | 1 | 0 ...] of its weight/bias gradient
+                  xs1=torch.zeros(B, T, 64, dtype=td, device=dev) if g.scalar_input else None)
         _build_tile_tables(eng, ws, eng._ws[(B, T, True)], B, T)
         eng._ws[key] = ws
     return ws
@@ -275,7 +275,10 @@ def _build_tile_tables(eng, ws, fw, B, T):
     ws["tt_head"] = tt.finalize(B)
     tt = TileTable(eng)
     g0 = ws["gx"][0]                                    # dxhat_0 lands in gx[0 % 2]
-    tt.add(g.O, g.Rp, 0, -1, 1.0 / RS, 0, 0, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp, onehot_ptr=ws["ids"].data_ptr())
+    if g.scalar_input:     # rows 0 / 1 of the tile = d weight / d bias:  sum_t [x[t] | 1] (x) dx0[t]
+        tt.add(64, g.Rp, 0, -1, 1.0 / RS, ws["xs1"].data_ptr(), 64, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp)
+    else:
+        tt.add(g.O, g.Rp, 0, -1, 1.0 / RS, 0, 0, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp, onehot_ptr=ws["ids"].data_ptr())
     ws["tt_first"] = tt.finalize(B)
 
 
@@ -300,7 +303,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     else:
         count = int(torch.clamp(lengths.detach().to("cpu", torch.int64).clamp(max=T) - 1, min=0).sum())
     inv_count = loss_scale / max(count, 1)
-    xi = x_ids.to(torch.int32).contiguous()
+    xi = x_ids.to(torch.int32).contiguous() if not g.scalar_input else None
     tg = targets.to(torch.int32).contiguous() if targets is not None else None
     ln = lengths.to(torch.int32).to(eng.device).contiguous() if lengths is not None else None
     keep = [xi, tg, ln]
@@ -379,9 +382,15 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     # ---- first conv: dW[r][class] = sum_t dx0[t][r] onehot(id[t])[class];  dx0 = dxhat_0 / sqrt(.5) -----------------------
     ctab, fb = eng.cview["ctab"], eng.cview["fb"]
     assert g_next.data_ptr() == ws["gx"][0].data_ptr()
-    ws["ids"].copy_(xi)
-    ws["tt_first"].launch(B, T)
-    L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
+    if g.scalar_input:
+        ws["xs1"][:, :, 0] = x_ids.to(ws["xs1"].dtype)
+        ws["xs1"][:, :, 1] = 1.0
+        ws["tt_first"].launch(B, T)
+        fb.copy_(ctab[g.Rp:2 * g.Rp])            # row 1: bias gradient; row 0 (weight) is scattered below
+    else:
+        ws["ids"].copy_(xi)
+        ws["tt_first"].launch(B, T)
+        L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
 
     # ---- scatter the dense tiles into the effective-weight gradient arena ----------------------------------------------
     def scat(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1):
@@ -397,7 +406,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     scat(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2)
     scat(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"])
     scat(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)
-    scat(ctab, sm["tab"], P._ru(g.O, 128) if False else g.O, g.Rp, g.Rp)
+    scat(ctab, sm["tab"], 1 if g.scalar_input else g.O, g.Rp, g.Rp)
     scat(fb, sm["fb"], 1, g.Rp, g.Rp)
     # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
     wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1

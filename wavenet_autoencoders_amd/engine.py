@@ -424,28 +424,62 @@ class WaeEngine:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.opt_step = 0
 
-    def backward(self, x, gid, targets, lengths, gvec=None, loss_scale: float = 1.0):
-        """Gradients of (masked CE [+ vq_loss]) of the last train-mode forward -> self.grads (flat arena)."""
+    def backward(self, x, gid, targets, lengths, gvec=None, loss_scale: float = 1.0, ext_dy=None):
+        """Gradients of (masked CE or, with ext_dy (B,T,Op) = d loss / d logits, any output loss [+ vq_loss]) of the last
+        train-mode forward -> self.grads (flat arena)."""
         from . import backward as BW
-        dc = BW.decoder_backward(self, x, targets, lengths, gid, gvec, loss_scale=loss_scale)
+        dc = BW.decoder_backward(self, x, targets, lengths, gid, gvec, ext_dy=ext_dy, loss_scale=loss_scale)
         if self.g.Ccp and self.g.upsample_scales:
             BW.frontend_backward(self, dc, loss_scale)
         return BW.finish_grads(self)
 
+    def dmol_loss_and_grad(self, y_hat: torch.Tensor, y: torch.Tensor, lengths, num_classes: int = 65536,
+                           log_scale_min: float = -7.0):
+        """DiscretizedMixturelogisticLoss (vqwae_train.py:382-401 with the shift of :766): y_hat (B,3M,T) fp32, y (B,T) fp32
+        -> (masked mean loss, d loss / d y_hat as (B,T,Op) in the compute dtype for decoder_backward's ext_dy)."""
+        g, lib, st = self.g, self.lib, self.stream()
+        B, _, T = y_hat.shape
+        yf = y.contiguous().float()
+        nll = torch.empty(B, T, dtype=torch.float32, device=self.device)
+        dy = torch.empty_like(y_hat)
+        L.check(lib.wae_dmol_loss_fwd(L.ptr(y_hat), L.ptr(yf), L.ptr(nll), L.ptr(dy), B, g.O // 3, T, int(num_classes),
+                                      float(log_scale_min), 1, st), "dmol_loss")
+        tt = torch.arange(T, device=self.device)[None, :]
+        ln = (lengths.to(self.device) if lengths is not None else torch.full((B,), T, device=self.device)).clamp(max=T)
+        mask = (tt < (ln[:, None] - 1)).float()                      # t pairs with target t+1 < length
+        count = mask.sum().clamp(min=1.0)
+        loss = (nll * mask).sum() / count
+        dyt = torch.zeros(B, T, g.Op, dtype=self.tdtype, device=self.device)
+        dy_scaled = (dy * (mask / count)[:, None, :]).contiguous()
+        L.check(lib.wae_to_btc(L.ptr(dy_scaled), L.ptr(dyt), B, g.O, T, g.Op, self.dt, st), "to_btc dy")
+        self._dmol_keep = (yf, nll, dy, dy_scaled)
+        return loss, dyt
+
     def train_step(self, x, c, gid, lengths=None, lr: float = 4e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                   weight_decay: float = 0.0, clip_thresh: float = 100.0, ema_decay: float = 0.9999, grad_hook=None):
+                   weight_decay: float = 0.0, clip_thresh: float = 100.0, ema_decay: float = 0.9999, grad_hook=None,
+                   quantize_channels: int = 65536, log_scale_min: float = -7.0):
         """One optimisation step: forward (teacher forced, targets = x shifted by one), backward, [grad_hook(grads) e.g.
-        the data-parallel all-reduce], clip_grad_norm_ + Adam + EMA.  Returns dict(loss, ce, vq_loss, perp, grad_norm)."""
+        the data-parallel all-reduce], clip_grad_norm_ + Adam + EMA.  Returns dict(loss, ce, vq_loss, perp, grad_norm).
+        Class-id input: masked cross-entropy; scalar input (hparams input_type "raw"): discretized mixture of logistics."""
         if not hasattr(self, "exp_avg"):
             self.init_optimizer()
         self.prepare_weights()
-        if self.g.has_encoder:
+        if self.g.scalar_input:
+            fwd = self.forward if self.g.has_encoder else self.decoder_forward
+            out = fwd(x, c, gid, targets=None, lengths=None, want_logits=True, train=True)
+            if not self.g.has_encoder:
+                self._fe = None
+            loss, dyt = self.dmol_loss_and_grad(out["logits"], x, lengths, quantize_channels, log_scale_min)
+            out["loss"] = loss
+            grads = self.backward(x, gid, None, lengths, ext_dy=dyt)
+        elif self.g.has_encoder:
             out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True)
         else:
             out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
                                        layer_events=getattr(self, "_layer_events", None))
             self._fe = None
-        grads = self.backward(x, gid, x, lengths)
+        if not self.g.scalar_input:
+            grads = self.backward(x, gid, x, lengths)
         if grad_hook is not None:
             grad_hook(grads)
         self.opt_step += 1
