@@ -14,8 +14,7 @@
 #define TM_MAX_SRC 4
 #define TM_PLAIN 0
 #define TM_RESIDUAL 1  // out = alpha * (acc + res[t])
-#define TM_GATE_BWD 2
-#define TM_NS 3        // LDS ring slots for the weight chunks  // acc = du (NT = Hp/32 tiles); out (t, 2Hp) = [da | db] from z (t, 2Hp)
+#define TM_GATE_BWD 2  // acc = du (NT = Hp/32 tiles); out (t, 2Hp) = [da | db] from z (t, 2Hp)
 
 struct TmArgs {
   const char* src[TM_MAX_SRC];
@@ -31,16 +30,6 @@ struct TmArgs {
   float alpha;
   int B, T, mode;
 };
-
-__device__ __forceinline__ void tm_wait_vmcnt(int w) {
-#define TM_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (w < 15 ? w : 15) {
-    TM_VMC(0) TM_VMC(1) TM_VMC(2) TM_VMC(3) TM_VMC(4) TM_VMC(5) TM_VMC(6) TM_VMC(7)
-    TM_VMC(8) TM_VMC(9) TM_VMC(10) TM_VMC(11) TM_VMC(12) TM_VMC(13) TM_VMC(14)
-    default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-  }
-#undef TM_VMC
-}
 
 template <typename E, int NT, int MODE>
 __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
@@ -58,7 +47,7 @@ __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
   const int t = t0w + n;
   const bool tvalid = t < p.T;
   const int rows_valid = min(max(p.T - t0w, 0), 32);
-  char* stg = smem + TM_NS * CHB + wave * STG_BYTES;
+  char* stg = smem + 2 * CHB + wave * STG_BYTES;
 
   // chunk -> (source, column block)
   int qend[TM_MAX_SRC];
@@ -68,36 +57,23 @@ __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
     if (s < p.nsrc) nq += p.src_cols[s] / T_::CK;
     qend[s] = nq;
   }
-  // The operand of chunk q is requested TWO chunks ahead into three statically rotating fragment groups (a move of a
-  // group still in flight would stall on it); loads are always issued (row clamped into the clip) so that the number of
-  // outstanding VMEM ops is known, rows outside the clip are zeroed at use.
-  frag S0[4], S1[4], S2[4];
-  auto src_of = [&](int q, int& s, int& q0) {
-    s = 0; q0 = 0;
+  frag Bn[4], Bc[4];
+  auto load_B = [&](int q, frag (&Bf)[4]) {
+    int s = 0, q0 = 0;
 #pragma unroll
     for (int i = 0; i < TM_MAX_SRC - 1; ++i)
       if (q >= qend[i] && i + 1 < p.nsrc) { s = i + 1; q0 = qend[i]; }
-  };
-  auto load_B = [&](int q, frag (&Bf)[4]) {
-    int s, q0;
-    src_of(q, s, q0);
-    const int ts = min(max(t + p.src_shift[s], 0), p.T - 1);
-    const char* src = p.src[s] + (((int64_t)b * p.T + ts) * p.src_stride[s]) * ES + (q - q0) * 128 + h * 16;
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) Bf[blk] = *(const frag*)(src + blk * 32);
-  };
-  auto fix_B = [&](int q, frag (&Bf)[4]) {
-    int s, q0;
-    src_of(q, s, q0);
     const int ts = t + p.src_shift[s];
     const bool ok = tvalid && ts >= 0 && ts < p.T;
-    if (__any(!ok)) {
+    const char* src = p.src[s] + (((int64_t)b * p.T + (ok ? ts : 0)) * p.src_stride[s]) * ES + (q - q0) * 128 + h * 16;
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-        if (!ok) {
-          frag zf = {};
-          Bf[blk] = zf;
-        }
+    for (int blk = 0; blk < 4; ++blk) {
+      if (ok) {
+        Bf[blk] = *(const frag*)(src + blk * 32);
+      } else {
+        frag zf = {};
+        Bf[blk] = zf;
+      }
     }
   };
 
@@ -112,60 +88,30 @@ __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
   constexpr int NPASS_AUX = StagePasses<NAUX, E>::N;
   f32x4 pre_a[NPASS_AUX][8];
   [[maybe_unused]] f32x4 pre_b[NPASS_AUX][8];
-  // Weight chunks: ring of NS slots, requested NS-1 chunks ahead; waits are counted (vmcnt) and the barrier is a bare
-  // s_barrier (__syncthreads() is fence + barrier and the fence drains every outstanding load).  Issue order inside a
-  // chunk top: [DMA pieces of chunk q+D][operand loads of chunk q+2]; loads retire in order, so "at most (ops issued at the
-  // previous top) outstanding" means the operand of this chunk (last thing issued two tops ago) and its weights (older)
-  // have landed.
-  constexpr int NS = TM_NS, D = NS - 1, PPW = CHB / 4 / 1024;
-  int slot_n = 0;
-  auto dma_next = [&](int q) {
-    dma_chunk(p.w + (int64_t)q * CHB, smem + slot_n * CHB, CHB, wave, lane);
-    slot_n = slot_n + 1 == NS ? 0 : slot_n + 1;
-  };
-  // rows the epilogue needs (residual / saved pre-activations): requested two chunks before the end, as the youngest
-  // VMEM ops of the loop (they do not disturb the counted waits), they arrive under the last MFMAs
-  auto fetch_aux = [&]() {
   if constexpr (MODE == TM_RESIDUAL) {
-      if (rows_valid > 0)
-        stage_fetch_tiles<E, NT>(pre_a, p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES, p.aux_stride * ES, rows_valid, lane);
-    } else if constexpr (MODE == TM_GATE_BWD) {
-      if (rows_valid > 0) {
-        const char* zrow = p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES;
-        stage_fetch_tiles<E, NT>(pre_a, zrow, p.aux_stride * ES, rows_valid, lane);
-        stage_fetch_tiles<E, NT>(pre_b, zrow + (int64_t)NT * 32 * ES, p.aux_stride * ES, rows_valid, lane);
-      }
+    if (rows_valid > 0)
+      stage_fetch_tiles<E, NT>(pre_a, p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES, p.aux_stride * ES, rows_valid, lane);
+  } else if constexpr (MODE == TM_GATE_BWD) {
+    if (rows_valid > 0) {
+      const char* zrow = p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES;
+      stage_fetch_tiles<E, NT>(pre_a, zrow, p.aux_stride * ES, rows_valid, lane);
+      stage_fetch_tiles<E, NT>(pre_b, zrow + (int64_t)NT * 32 * ES, p.aux_stride * ES, rows_valid, lane);
     }
-  
-  };
-  for (int j = 0; j < D && j < nq; ++j) dma_next(j);
-  load_B(0, S0);
-  if (nq > 1) load_B(1, S1);
-  int w_next = nq > 1 ? 4 : 0, slot_c = 0;
-  auto step = [&](int q, frag (&Bcur)[4], frag (&Bload)[4]) {
-    tm_wait_vmcnt(w_next);
-    __builtin_amdgcn_s_barrier();
-    int issued = 0;
-    if (q + D < nq) { dma_next(q + D); issued += PPW; }
-    if (q + 2 < nq) { load_B(q + 2, Bload); issued += 4; }
-    if (q == max(nq - 2, 0)) {   // exactly NT*ES row loads per fetched stack (stage_fetch_tiles), none for an empty wave
-      fetch_aux();
-      if (rows_valid > 0) issued += MODE == TM_RESIDUAL ? NT * ES : (MODE == TM_GATE_BWD ? 2 * NT * ES : 0);
+  }
+
+  dma_chunk(p.w, smem, CHB, wave, lane);
+  load_B(0, Bn);
+  for (int q = 0; q < nq; ++q) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
+    if (q + 1 < nq) {
+      dma_chunk(p.w + (int64_t)(q + 1) * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
+      load_B(q + 1, Bn);
     }
-    w_next = issued;
-    fix_B(q, Bcur);
-    gemm_chunk<4 * NT, NT, 4>(smem + slot_c * CHB + lane * 16, Bcur, acc);
-    slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
-  };
-  {
-    int q = 0;
-    for (; q + 3 <= nq; q += 3) {
-      step(q, S0, S2);
-      step(q + 1, S1, S0);
-      step(q + 2, S2, S1);
-    }
-    if (q < nq) step(q, S0, S2);
-    if (q + 1 < nq) step(q + 1, S1, S0);
+    const char* buf = smem + (q & 1) * CHB + lane * 16;
+    gemm_chunk<4 * NT, NT, 4>(buf, Bc, acc);
   }
   if (rows_valid <= 0) return;
 
@@ -213,7 +159,7 @@ __global__ void __launch_bounds__(256, 1) gemm_tm_kernel(TmArgs p) {
 template <typename E, int NT, int MODE>
 static int launch_tm(const TmArgs& a, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
-  const size_t lds = TM_NS * CHB + 4 * STG_BYTES;
+  const size_t lds = 2 * CHB + 4 * STG_BYTES;
   static size_t attr_done = 0;
   if (attr_done < lds) {
     if (hipFuncSetAttribute((const void*)gemm_tm_kernel<E, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
