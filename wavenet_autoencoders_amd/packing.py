@@ -57,6 +57,7 @@ class Geometry:
     c_in: Optional[int] = None
     encoder_hid: Optional[int] = None
     K: int = 256
+    dilations_override: Optional[List[int]] = None   # standalone layers (wavenet_vocoder.modules.ResidualConv1dGLU)
 
     def __post_init__(self):
         assert self.layers % self.stacks == 0                       # wavenet.py:117
@@ -71,6 +72,9 @@ class Geometry:
         self.Ku = _ru(self.layers * self.Hp, 64)       # columns of the (B,T,Ku) buffer of all layers' gated activations
         per = self.layers // self.stacks
         self.dilations = [2 ** (i % per) for i in range(self.layers)]   # wavenet.py:126
+        if self.dilations_override is not None:
+            assert len(self.dilations_override) == self.layers
+            self.dilations = [int(d) for d in self.dilations_override]
         self.receptive_field = (self.k - 1) * sum(self.dilations) + 1   # wavenet.py:42-60
         self.has_encoder = self.c_in is not None
 
