@@ -193,7 +193,7 @@ typedef struct wae_ar_desc {
   int32_t L, R, Rp, G, Hp, S, O, Cc, Ccp, ktaps;
   int32_t mode;
   int32_t init_idx;
-  int32_t scalar_input; /* must be 0 for now */
+  int32_t scalar_input; /* 0: wae_ar_generate / wae_ar_generate_coop; 1: wae_ar_generate_scalar */
   float scale;          /* sqrt(1/L) */
 } wae_ar_desc;
 int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
@@ -201,6 +201,17 @@ int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_
                     const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
                     const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
                     const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits, void* stream);
+
+/* Scalar-input decoders (first_conv has one input channel; wavenet.py:284-285,325-333): the fed-back quantity is the
+ * float drawn by sample_from_discretized_mix_logistic (mixture.py:118-156) from the step's 3M mixture parameters, on
+ * caller-supplied uniforms u_mix (B,T,M), u_log (B,T) in (1e-5, 1-1e-5).  inputs_f (B,T) teacher-forces the inputs
+ * (step t consumes inputs_f[t]; the start value is 0 without it).  out_samples (B,T) and/or out_params (B,3M,T). */
+int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                           int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                           const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                           const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                           const float* inputs_f, const float* u_mix, const float* u_log, float log_scale_min,
+                           int32_t clamp_log_scale, float* out_samples, float* out_params, void* stream);
 
 /* The same decoding with ONE utterance spread over C cooperating workgroups / CUs (csrc/ar_coop.hip): every layer is
  * split by gate channels; the members all-reduce their shares of x' once per layer and of the skip vector once per

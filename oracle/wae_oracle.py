@@ -320,7 +320,8 @@ def dmol_sample(y: torch.Tensor, u_mix: torch.Tensor, u_log: torch.Tensor, log_s
 def incremental_forward(sd: SD, cfg: dict, c_up: Optional[torch.Tensor], g: Optional[torch.Tensor], T: int,
                         test_inputs: Optional[torch.Tensor] = None, initial_input: Optional[torch.Tensor] = None,
                         mode: str = "logits", uniforms: Optional[torch.Tensor] = None,
-                        prefix: str = "wavenet.") -> torch.Tensor:
+                        prefix: str = "wavenet.", u_mix: Optional[torch.Tensor] = None, u_log: Optional[torch.Tensor] = None,
+                        log_scale_min: float = -7.0) -> torch.Tensor:
     """Sample-by-sample decode with per-layer history, restated with an O(1) ring lookup instead of
     the reference's O(d) buffer shift (conv.py:39) -- same arithmetic: tap j reads x[t-(k-1-j)d]
     (zero before t=0, conv.py:35-36) through the linearized (G, k*R) weight (:51-62).
@@ -330,6 +331,9 @@ def incremental_forward(sd: SD, cfg: dict, c_up: Optional[torch.Tensor], g: Opti
           "argmax"  -> greedy one-hot feedback (deterministic stand-in for OneHotCategorical, :335-338)
           "sample"  -> inverse-CDF categorical draw from ``uniforms`` (B, T)
     x inputs are one-hot (B, O, T) for test_inputs / (B, O, 1) for initial_input.  Returns (B, O, T).
+    Scalar-input models (first_conv has one input channel, wavenet.py:284-285,325-333): test_inputs (B, 1, T), the start
+    value is 0; "logits" returns the mixture parameters (B, 3M, T) under teacher forcing, "sample" draws every step with
+    sample_from_discretized_mix_logistic on the explicit uniforms u_mix (B, T, M), u_log (B, T) and returns (B, 1, T).
     """
     L, stacks = cfg["layers"], cfg["stacks"]
     dil = layer_dilations(L, stacks)
@@ -359,13 +363,14 @@ def incremental_forward(sd: SD, cfg: dict, c_up: Optional[torch.Tensor], g: Opti
     w3 = eff_weight(sd, prefix + "last_conv_layers.3").squeeze(-1)
     b3 = sd[prefix + "last_conv_layers.3.bias"]
     R = wf.shape[0]
+    scalar = wf.shape[1] == 1
     hist = [torch.zeros(B, T, R) for _ in range(L)]   # layer inputs over time
     if initial_input is None:
-        cur = torch.zeros(B, O)
-        if test_inputs is None or test_inputs.shape[-1] < 1:
+        cur = torch.zeros(B, 1 if scalar else O)                   # wavenet.py:284-288
+        if not scalar and (test_inputs is None or test_inputs.shape[-1] < 1):
             cur[:, 127] = 1.0                                      # wavenet.py:288
     else:
-        cur = initial_input.view(B, O)
+        cur = initial_input.view(B, -1)
     outs = []
     for t in range(T):
         if test_inputs is not None and t < test_inputs.shape[-1]:
@@ -393,7 +398,9 @@ def incremental_forward(sd: SD, cfg: dict, c_up: Optional[torch.Tensor], g: Opti
             x = (F.linear(u, w["out"], w["out_b"]) + x) * math.sqrt(0.5)
         skips = skips * math.sqrt(1.0 / L)
         y = F.linear(F.relu(F.linear(F.relu(skips), w1, b1)), w3, b3)
-        if mode == "logits":
+        if scalar and mode != "logits":
+            o = dmol_sample(y.unsqueeze(-1), u_mix[:, t:t + 1], u_log[:, t:t + 1], log_scale_min)   # (B, 1)
+        elif mode == "logits":
             o = y
         else:
             prob = F.softmax(y, dim=1)

@@ -336,6 +336,56 @@ def gen_ar(cfg, sd, model, ins, ocfg):
     save(f"ar_{cfg['name']}", c_up=c_up, tf_logits=tf, greedy=greedy, init=init)
 
 
+def gen_ar_scalar(cfg, sd, model, ins, ocfg):
+    """(8b) incremental_forward of a scalar-input decoder (wavenet.py:284-285,325-333).  The reference draws every step with
+    sample_from_discretized_mix_logistic on torch's RNG; its draw is replaced here by the oracle's explicit-uniform restatement
+    (itself pinned by dmol.npz), so that the reference's own incremental loop yields reproducible vectors: the mixture
+    parameters of every step under teacher forcing, and a free-running roll-out."""
+    import wavenet_vocoder.wavenet as ref_wn_mod
+    c, x, xin, g, T = ins
+    Tar, M = 64, cfg["O"] // 3
+    with torch.no_grad():
+        lat = model.encoder(c)
+        quant = model.vq(lat)[0]
+        c_up = model.wavenet.upsample_net(quant)[:, :, :Tar].contiguous()
+    rng = np.random.default_rng(77)
+    u_mix = torch.from_numpy(rng.uniform(1e-5, 1 - 1e-5, size=(2, Tar, M)).astype(np.float32))
+    u_log = torch.from_numpy(rng.uniform(1e-5, 1 - 1e-5, size=(2, Tar)).astype(np.float32))
+    rec, step = [], [0]
+
+    def patched(y, log_scale_min=-7.0, clamp_log_scale=False):
+        t = step[0]
+        step[0] += 1
+        rec.append(y.clone())
+        return O.dmol_sample(y, u_mix[:, t:t + 1], u_log[:, t:t + 1], log_scale_min, clamp_log_scale)
+
+    orig = ref_wn_mod.sample_from_discretized_mix_logistic
+    ref_wn_mod.sample_from_discretized_mix_logistic = patched
+    try:
+        with torch.no_grad():
+            wn = build_ref_wavenet(cfg).eval()
+            wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items() if k.startswith("wavenet.")})
+            wn.upsample_net = None
+            tf_in = xin[:, :, :Tar].transpose(1, 2).contiguous()                 # (B, T, 1)
+            wn.incremental_forward(None, c=c_up, g=g, T=Tar, test_inputs=tf_in, log_scale_min=-7.0)
+            params_tf = torch.cat(rec, dim=-1)                                   # (B, 3M, Tar)
+            fwd = wn(xin[:, :, :Tar].contiguous(), c_up, g, False)
+            close(params_tf, fwd, what="scalar incremental parameters == forward", tol=1e-5)
+            rec.clear()
+            step[0] = 0
+            # free-running from the zero start value; a one-step test_inputs only tells the reference the batch size
+            roll = wn.incremental_forward(None, c=c_up[:, :, :24].contiguous(), g=g, T=24, test_inputs=torch.zeros(2, 1, 1),
+                                          log_scale_min=-7.0)                    # (B, 1, 24)
+    finally:
+        ref_wn_mod.sample_from_discretized_mix_logistic = orig
+    o_tf = O.incremental_forward(sd, ocfg, c_up, g, Tar, test_inputs=xin[:, :, :Tar], mode="logits")
+    close(o_tf, params_tf, what="oracle scalar AR teacher-forced", tol=1e-5)
+    o_roll = O.incremental_forward(sd, ocfg, c_up[:, :, :24].contiguous(), g, 24, mode="sample", u_mix=u_mix, u_log=u_log,
+                                   log_scale_min=-7.0)
+    close(o_roll, roll, what="oracle scalar AR roll-out", tol=1e-5)
+    save(f"ar_{cfg['name']}", c_up=c_up, params_tf=params_tf, roll=roll, u_mix=u_mix, u_log=u_log)
+
+
 def gen_misc():
     steps = [0, 1, 399999, 400000, 400001, 800000, 1200000]
     lr = [ref_lr.step_learning_rate_decay(4e-4, s, anneal_rate=0.5, anneal_interval=400000) for s in steps]
@@ -405,6 +455,7 @@ def main():
             gen_train_step(cfg, sd, ins, ocfg)
     # scalar-input (DMoL) decoder
     sd, model, ins, ocfg = gen_model(CFG_S, 3)
+    gen_ar_scalar(CFG_S, sd, model, ins, ocfg)
     gen_vqwae_probe()
 
 

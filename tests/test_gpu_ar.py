@@ -64,3 +64,29 @@ def test_sampling_matches_oracle_inverse_cdf():
     # a draw can differ only where u lands within float rounding of a CDF step; require >= 95 % identical prefix-free
     first_diff = np.argmax(got != want, axis=1) if (got != want).any() else None
     assert (got == want).mean() > 0.95 or first_diff is None, (got, want)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+def test_scalar_input_decode_against_reference_vectors(dtype, tol):
+    """Scalar-input decoder (wavenet.py:284-285,325-333): mixture parameters of every step under teacher forcing and a
+    free-running roll-out on explicit uniforms, against the vectors the reference's own incremental loop produced."""
+    from helpers import golden_model, load_npz, rel_err
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, zm, ocfg = golden_model("S")
+    z = load_npz("ar_S")
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+    eng.load_state_dict(sd)
+    c_up = torch.from_numpy(z["c_up"]).cuda()
+    Tar = c_up.shape[-1]
+    x = ins["x"][:, 0, :Tar].contiguous().cuda()
+    g = ins["g"].cuda()
+    out = eng.incremental_forward(c_up, g, Tar, mode="logits", test_inputs=x, c_is_upsampled=True)
+    torch.cuda.synchronize()
+    assert rel_err(out["logits"].cpu(), z["params_tf"]) < tol
+    if dtype == "fp32":
+        roll = eng.incremental_forward(c_up[:, :, :24].contiguous(), g, 24, mode="sample", c_is_upsampled=True,
+                                       u_mix=torch.from_numpy(z["u_mix"])[:, :24].contiguous().cuda(),
+                                       u_log=torch.from_numpy(z["u_log"])[:, :24].contiguous().cuda(), log_scale_min=-7.0)
+        torch.cuda.synchronize()
+        assert float((roll["x"].cpu() - torch.from_numpy(z["roll"])[:, 0]).abs().max()) < 1e-3

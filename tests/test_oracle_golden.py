@@ -97,6 +97,20 @@ def test_incremental_forward(name):
     assert np.array_equal(gr.argmax(1).numpy(), z["greedy"])
 
 
+def test_incremental_forward_scalar_input():
+    """Scalar-input decoder (wavenet.py:284-285,325-333): mixture parameters of every step under teacher forcing and a
+    free-running roll-out on explicit uniforms, against the reference's own incremental loop (tests/golden/make_golden.py)."""
+    cfg, sd, ins, zm, ocfg = golden_model("S")
+    z = load_npz("ar_S")
+    c_up = torch.from_numpy(z["c_up"])
+    Tar = c_up.shape[-1]
+    tf = O.incremental_forward(sd, ocfg, c_up, ins["g"], Tar, test_inputs=ins["xin"][:, :, :Tar], mode="logits")
+    assert rel_err(tf, z["params_tf"]) < TOL
+    roll = O.incremental_forward(sd, ocfg, c_up[:, :, :24].contiguous(), ins["g"], 24, mode="sample",
+                                 u_mix=torch.from_numpy(z["u_mix"]), u_log=torch.from_numpy(z["u_log"]), log_scale_min=-7.0)
+    assert rel_err(roll, z["roll"]) < 1e-5
+
+
 def test_train_step_grads_adam_ema():
     cfg, sd, ins, zm, ocfg = golden_model("A")
     z = load_npz("train_A")

@@ -84,6 +84,8 @@ SIGNATURES = {
     "wae_clip_adam_ema": (c_i32, [c_vp] * 5 + [c_i64, c_vp, c_vp, c_i32] + [ctypes.c_double] * 7 + [c_vp]),
     "wae_ar_generate": (c_i32, [ctypes.POINTER(ArDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7 + [c_i32]
                         + [c_vp] * 5),
+    "wae_ar_generate_scalar": (c_i32, [ctypes.POINTER(ArDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7 + [c_i32]
+                               + [c_vp] * 3 + [c_f32, c_i32, c_vp, c_vp, c_vp]),
     "wae_ar_coop_msg_values": (c_i32, [ctypes.POINTER(ArDesc), c_i32]),
     "wae_ar_coop_acc_floats": (c_i64, [ctypes.POINTER(ArDesc)]),
     "wae_ar_generate_coop": (c_i32, [ctypes.POINTER(ArDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7

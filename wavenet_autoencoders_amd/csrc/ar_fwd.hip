@@ -36,6 +36,14 @@ struct ArArgs {
   const float* uniforms;  // (B, T) or null
   int32_t* out_idx;       // (B, T)
   float* out_logits;      // (B, O, T) or null
+  // scalar-input decoders (wavenet.py:284-285,325-333): the fed-back quantity is a float, drawn from the mixture of logistics
+  int scalar;
+  const float* inputs_f;  // (B, T) teacher-forced samples or null
+  const float* u_mix;     // (B, T, M) uniforms of the mixture pick, or null (then inputs_f must cover every step)
+  const float* u_log;     // (B, T) uniforms of the logistic draw
+  float* out_f;           // (B, T) drawn samples, or null
+  float log_scale_min;
+  int clamp_log_scale;
 };
 
 template <typename E>
@@ -141,13 +149,19 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
   for (int i = tid; i < K1p; i += AR_THREADS) vbuf[i] = 0.f;
   for (int i = tid; i < Hk; i += AR_THREADS) ubuf[i] = 0.f;
   for (int i = tid; i < Sk; i += AR_THREADS) { skipb[i] = 0.f; hbuf[i] = 0.f; }
-  if (tid == 0) ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx;
+  float* fcur = (float*)(ibuf + 1);   // scalar input: the current input value
+  if (tid == 0) {
+    ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx;
+    fcur[0] = p.inputs_f ? p.inputs_f[(int64_t)b * p.T] : 0.f;     // wavenet.py:284-285: the start value is zero
+  }
   __syncthreads();
 
   for (int t = 0; t < p.T; ++t) {
-    // ---- first conv: one-hot input == column gather (wavenet.py:311) -------------------------------------
+    // ---- first conv: one-hot input == column gather (wavenet.py:311); scalar input: w * x + b ----------------
     const int cur = ibuf[0];
-    if (tid < p.R) xbuf[tid] = p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
+    if (tid < p.R)
+      xbuf[tid] = p.scalar ? fmaf(p.first_tab[tid], fcur[0], p.first_bias[tid])
+                           : p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
     if (tid >= p.R && tid < p.R + p.Cc) {   // local conditioning of this step -> tail of the operand vector
       const int cc = tid - p.R;
       const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
@@ -213,7 +227,29 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
     }
     __syncthreads();
     // ---- next input: teacher forcing / greedy / categorical draw (wavenet.py:300-338) -------------------------
-    if (tid == 0) {
+    if (tid == 0 && p.scalar) {
+      // sample_from_discretized_mix_logistic (mixture.py:118-156) on caller-supplied uniforms: Gumbel-max mixture pick,
+      // logistic draw, clamp to [-1, 1] -- the arithmetic of dmol_sample_kernel (csrc/loss.hip)
+      float xs = 0.f;
+      if (p.u_mix) {
+        const int M = p.O / 3;
+        const float* um = p.u_mix + ((int64_t)b * p.T + t) * M;
+        float best = -INFINITY;
+        int arg = 0;
+        for (int i = 0; i < M; ++i) {
+          const float v = lbuf[i] - logf(-logf(um[i]));
+          if (v > best) { best = v; arg = i; }
+        }
+        const float mu = lbuf[M + arg];
+        float ls = lbuf[2 * M + arg];
+        if (p.clamp_log_scale) ls = fmaxf(ls, p.log_scale_min);
+        const float u = p.u_log[(int64_t)b * p.T + t];
+        xs = fminf(fmaxf(mu + expf(ls) * (logf(u) - logf(1.f - u)), -1.f), 1.f);
+        if (p.out_f) p.out_f[(int64_t)b * p.T + t] = xs;
+      }
+      fcur[0] = (p.inputs_f && t + 1 < p.T) ? p.inputs_f[(int64_t)b * p.T + t + 1] : xs;
+    }
+    if (tid == 0 && !p.scalar) {
       int nxt;
       float mx = -INFINITY;
       int am = 0;
@@ -244,6 +280,37 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
   }
 }
 
+static int ar_launch(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring, int64_t ring_total,
+                     const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes, const float* bias2, const float* zb,
+                     const float* first_tab, const float* first_bias, const void* w_head, const float* head_bias, const void* c_up,
+                     int32_t c_dtype, const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                     const float* inputs_f, const float* u_mix, const float* u_log, float* out_f, float log_scale_min,
+                     int clamp_log_scale, void* stream) {
+  ArArgs a;
+  a.dtype = d->dtype; a.B = d->B; a.T = d->T; a.L = d->L; a.R = d->R; a.G = d->G; a.S = d->S; a.O = d->O; a.Cc = d->Cc;
+  a.Ccp = d->Ccp; a.Hp = d->Hp; a.ktaps = d->ktaps; a.mode = d->mode; a.Rp = d->Rp; a.scale = d->scale; a.dil = dilations;
+  a.ring_off = ring_off; a.ring = ring; a.ring_total = ring_total; a.w_layers = (const char*)w_layers;
+  a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
+  a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
+  a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
+  a.out_logits = out_logits; a.scalar = d->scalar_input ? 1 : 0; a.inputs_f = inputs_f; a.u_mix = u_mix; a.u_log = u_log;
+  a.out_f = out_f; a.log_scale_min = log_scale_min; a.clamp_log_scale = clamp_log_scale;
+  const int epl = d->dtype == WAE_BF16 ? 8 : 4;
+  const int H = d->G / 2;
+  auto ru = [](int x, int m) { return (x + m - 1) / m * m; };
+  const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
+                                              2 * ru(d->S, epl) + ru(d->O, 4) + AR_THREADS + 4);
+  hipStream_t st = as_stream(stream);
+  if (d->dtype == WAE_BF16) {
+    (void)hipFuncSetAttribute((const void*)ar_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_kernel<__bf16>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)ar_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_kernel<float>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
+  }
+  return wae_check_launch("ar_generate");
+}
+
 extern "C" int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
                                int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
                                const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
@@ -260,27 +327,30 @@ extern "C" int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, c
   WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate: sample mode needs uniforms");
   WAE_REQUIRE(d->mode != 0 || inputs, "ar_generate: teacher-forced mode needs inputs");
-  WAE_REQUIRE(!d->scalar_input, "ar_generate: scalar-input (DMoL) decoding is not implemented yet");
-  ArArgs a;
-  a.dtype = d->dtype; a.B = d->B; a.T = d->T; a.L = d->L; a.R = d->R; a.G = d->G; a.S = d->S; a.O = d->O; a.Cc = d->Cc;
-  a.Ccp = d->Ccp; a.Hp = d->Hp; a.ktaps = d->ktaps; a.mode = d->mode; a.Rp = d->Rp; a.scale = d->scale; a.dil = dilations;
-  a.ring_off = ring_off; a.ring = ring; a.ring_total = ring_total; a.w_layers = (const char*)w_layers;
-  a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
-  a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
-  a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
-  a.out_logits = out_logits;
-  const int epl = d->dtype == WAE_BF16 ? 8 : 4;
-  const int H = d->G / 2;
-  auto ru = [](int x, int m) { return (x + m - 1) / m * m; };
-  const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
-                                              2 * ru(d->S, epl) + ru(d->O, 4) + AR_THREADS + 4);
-  hipStream_t st = as_stream(stream);
-  if (d->dtype == WAE_BF16) {
-    (void)hipFuncSetAttribute((const void*)ar_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(ar_kernel<__bf16>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)ar_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(ar_kernel<float>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
-  }
-  return wae_check_launch("ar_generate");
+  WAE_REQUIRE(!d->scalar_input, "ar_generate: scalar-input decoders go through wae_ar_generate_scalar");
+  return ar_launch(d, dilations, ring_off, ring, ring_total, w_layers, layer_stride_bytes, w2_off_bytes, bias2, zb, first_tab,
+                   first_bias, w_head, head_bias, c_up, c_dtype, inputs, uniforms, out_idx, out_logits, nullptr, nullptr, nullptr,
+                   nullptr, -7.0f, 0, stream);
+}
+
+extern "C" int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                                      int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                                      const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                                      const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                                      const float* inputs_f, const float* u_mix, const float* u_log, float log_scale_min,
+                                      int32_t clamp_log_scale, float* out_samples, float* out_params, void* stream) {
+  WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias,
+              "ar_generate_scalar: null pointer argument");
+  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate_scalar: bad dtype");
+  WAE_REQUIRE(d->scalar_input && d->O > 0 && d->O % 3 == 0, "ar_generate_scalar: needs a scalar-input decoder with 3M output channels");
+  WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0, "ar_generate_scalar: bad sizes");
+  WAE_REQUIRE(d->R + (d->Cc > 0 ? d->Cc : 0) <= AR_THREADS, "ar_generate_scalar: R+Cc must be <= %d", AR_THREADS);
+  WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_scalar: Cc > 0 but c_up is null");
+  WAE_REQUIRE(inputs_f || (u_mix && u_log), "ar_generate_scalar: needs teacher-forced inputs or the uniforms of the draws");
+  WAE_REQUIRE(!u_mix == !u_log, "ar_generate_scalar: u_mix and u_log come together");
+  WAE_REQUIRE(!out_samples || u_mix, "ar_generate_scalar: samples need the uniforms");
+  WAE_REQUIRE(out_samples || out_params, "ar_generate_scalar: no output requested");
+  return ar_launch(d, dilations, ring_off, ring, ring_total, w_layers, layer_stride_bytes, w2_off_bytes, bias2, zb, first_tab,
+                   first_bias, w_head, head_bias, c_up, c_dtype, nullptr, nullptr, nullptr, out_params, inputs_f, u_mix, u_log,
+                   out_samples, log_scale_min, clamp_log_scale, stream);
 }

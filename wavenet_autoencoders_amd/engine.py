@@ -332,15 +332,17 @@ class WaeEngine:
     def incremental_forward(self, c: Optional[torch.Tensor], gid: Optional[torch.Tensor], T: int, mode: str = "sample",
                             test_inputs: Optional[torch.Tensor] = None, uniforms: Optional[torch.Tensor] = None,
                             init_idx: int = 127, c_is_upsampled: bool = False, want_logits: bool = False,
-                            gvec: Optional[torch.Tensor] = None):
+                            gvec: Optional[torch.Tensor] = None, u_mix: Optional[torch.Tensor] = None,
+                            u_log: Optional[torch.Tensor] = None, log_scale_min: float = -7.0, clamp_log_scale: bool = False):
         """WaveNet.incremental_forward (wavenet.py:218-346) as one persistent launch.
 
         mode "logits": teacher-forced on test_inputs (B,T) class ids (softmax=False, quantize=False) -> logits (B,O,T);
         "argmax": greedy feedback; "sample": categorical draw from `uniforms` (B,T) in [0,1) (torch.rand if None).
-        Returns dict(idx (B,T) int32, logits (B,O,T) | None)."""
+        Returns dict(idx (B,T) int32, logits (B,O,T) | None).
+        Scalar-input decoders: test_inputs (B,T) fp32 teacher-forces the inputs (mode "logits" -> the mixture parameters
+        (B,3M,T) as `logits`); mode "sample" draws every step from the mixture of logistics on the uniforms u_mix (B,T,M),
+        u_log (B,T) (torch.rand in (1e-5, 1-1e-5) if None) -> dict(x (B,T) fp32, logits | None)."""
         g, lib = self.g, self.lib
-        if g.scalar_input:
-            raise NotImplementedError("autoregressive decoding of scalar-input (DMoL) models is not implemented yet")
         if not getattr(self, "_ar_packed", False) or self.weights_dirty:
             self.pack_ar_weights()
         st = self.stream()
@@ -367,9 +369,32 @@ class WaeEngine:
                                   L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
         # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
         # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
-        coop = B <= 8 and g.R <= 256 and g.S <= 256 and os.environ.get("WAE_AR_COOP", "1") != "0"
+        coop = (B <= 8 and g.R <= 256 and g.S <= 256 and not g.scalar_input and os.environ.get("WAE_AR_COOP", "1") != "0")
         C = max(1, min(int(os.environ.get("WAE_AR_COOP_C", "32")), 32, g.H, g.S)) if coop else 1
         ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
+        if g.scalar_input:
+            es = self.ar_w.element_size()
+            M = g.O // 3
+            tf = test_inputs.to(dev, torch.float32).contiguous() if test_inputs is not None else None
+            if m == 2 and u_mix is None:
+                u_mix = torch.rand(B, T, M, device=dev) * (1 - 2e-5) + 1e-5          # mixture.py:138,151
+                u_log = torch.rand(B, T, device=dev) * (1 - 2e-5) + 1e-5
+            um = u_mix.to(dev, torch.float32).contiguous() if u_mix is not None else None
+            ul = u_log.to(dev, torch.float32).contiguous() if u_log is not None else None
+            if m == 0 and tf is None:
+                raise ValueError("mode 'logits' needs test_inputs")
+            xs = torch.empty(B, T, dtype=torch.float32, device=dev) if um is not None else None
+            params = torch.empty(B, g.O, T, dtype=torch.float32, device=dev) if (want_logits or m == 0) else None
+            d = L.ArDesc(self.dt, B, T, g.layers, g.R, g.Rp, g.G, g.Hp, g.S, g.O, max(g.Cc, 0), g.Ccp, g.k, m, 0, 1,
+                         math.sqrt(1.0 / g.layers))
+            L.check(lib.wae_ar_generate_scalar(ctypes.byref(d), L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring),
+                                               self.ar_ring_total, L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es,
+                                               L.ptr(self.ar_b2), L.ptr(zb), L.ptr(self.first_tab), L.ptr(self.first_bias),
+                                               L.ptr(self.ar_wh), L.ptr(self.ar_hb), L.ptr(c_up), self.dt,
+                                               L.ptr(tf) if m == 0 else None, L.ptr(um), L.ptr(ul), float(log_scale_min),
+                                               int(bool(clamp_log_scale)), L.ptr(xs), L.ptr(params), st), "ar_generate_scalar")
+            self._ar_keep = (c_up, zb, ring, tf, um, ul, gid32)
+            return dict(x=xs, logits=params)
         inputs = test_inputs.to(torch.int32).contiguous() if test_inputs is not None else None
         if m == 2 and uniforms is None:
             uniforms = torch.rand(B, T, device=dev)

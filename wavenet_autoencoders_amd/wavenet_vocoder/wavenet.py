@@ -117,9 +117,29 @@ class WaveNet(ArenaModel):
         (B, C, T); teacher forcing (test_inputs, quantize=False) -> logits / softmax (B, C, T)."""
         if self.training:
             raise RuntimeError("incremental_forward only supports eval mode")          # conv.py:19-20
-        if self.scalar_input:
-            raise NotImplementedError("autoregressive decoding of scalar-input models is not implemented yet")
         eng = self.engine()
+        if self.scalar_input:
+            # wavenet.py:284-285,325-333: every step draws from the mixture of logistics; the samples are returned (B, 1, T)
+            gid = g.reshape(-1) if (g is not None and g.dtype in (torch.int32, torch.int64)) else None
+            gvec = None if (g is None or gid is not None) else g.reshape(g.shape[0], -1).float().contiguous()
+            tf = None
+            if test_inputs is not None:
+                tf = test_inputs
+                if tf.dim() == 3:
+                    tf = tf.reshape(tf.shape[0], -1)                                     # (B,1,T) or (B,T,1) -> (B,T)
+                if tf.shape[1] < int(T or 0):
+                    raise NotImplementedError("partial teacher forcing followed by sampling is not implemented")
+                T = tf.shape[1]
+            c_is_up = c is not None and (not self.geom.upsample_scales or c.shape[-1] == int(T))
+            B = c.shape[0] if c is not None else (tf.shape[0] if tf is not None else 1)
+            dev = next(self.parameters()).device
+            M = self.out_channels // 3
+            with torch.no_grad():
+                out = eng.incremental_forward(c, gid, int(T), mode="logits" if tf is not None else "sample", test_inputs=tf,
+                                              c_is_upsampled=c_is_up, gvec=gvec, log_scale_min=log_scale_min,
+                                              u_mix=torch.rand(B, int(T), M, device=dev) * (1 - 2e-5) + 1e-5,
+                                              u_log=torch.rand(B, int(T), device=dev) * (1 - 2e-5) + 1e-5)
+            return out["x"].unsqueeze(1)
         tf = None
         if test_inputs is not None:
             tf = _ids_from_input(test_inputs, self.out_channels, False)
