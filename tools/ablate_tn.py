@@ -6,6 +6,8 @@ import sys
 
 import torch
 
+os.environ["WAE_TN_STREAM"] = "0"   # this tool times the per-layer 128x128-tile launches (the fp32 path)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import wae_oracle as O
 from wavenet_autoencoders_amd import Geometry, backward as BW  # noqa: E402

@@ -1,5 +1,8 @@
+"""Probe: does a C5-like wide configuration (R = G = S = 512) run?  (residual/skip widths above 256 are
+not supported yet -- this prints the error each dtype raises.)"""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import wae_oracle as O
 from wavenet_autoencoders_amd import Geometry
 from wavenet_autoencoders_amd.engine import WaeEngine
