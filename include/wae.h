@@ -78,6 +78,26 @@ int wae_enc_conv_fwd(const float* x, const float* w, const float* bias, float* y
 int wae_vq_nearest(const float* lat, const float* emb, int64_t* idx, float* quant, float* stats, int32_t* hist,
                    int32_t B, int32_t D, int32_t Tq, int32_t K, float beta, void* stream);
 
+/* ---- section 8(f) rank 3: the sliced / EMA quantizers (vector_quantization.py:51-128, :132-235, :239-306) -----------
+ * wae_vq_slice: the search above on channels [d0, d0+D) of a (B,Dtot,Tq) tensor against that slice's own codebook
+ * emb (K,D); quant is the (B,Dtot,Tq) output (only the slice is written).  mode 0: search + gather (:84-110),
+ * 1: search only (idx, hist, stats[1]), 2: gather with the idx given (the EMA classes gather from the codebook AFTER
+ * its update, :217-218,:292).  stats[0] = c_loss * mean((q-x)^2) over the slice, stats[1] = slice perplexity
+ * (the sliced classes ADD the slice perplexities, :125-127).  hist: (K+1) int32 scratch; its K counts feed
+ * wae_vq_ema_update.
+ * wae_vq_ema_update (training branch, :190-215 / :275-290): cluster_size = decay*cluster_size + (1-decay)*counts,
+ * Laplace smoothing (+1e-5, K*1e-5), ema_w = decay*ema_w + (1-decay)*sum of the latents assigned to each code,
+ * emb = ema_w / cluster_size.  All three buffers are updated in place.
+ * wae_vq_slice_bwd: dlat = dquant + c_lat*(x-q); demb[idx] += c_emb*(q-x) (demb NULL for EMA codebooks). */
+int wae_vq_slice(const float* lat, const float* emb, int64_t* idx, float* quant, float* stats, int32_t* hist, int32_t B,
+                 int32_t Dtot, int32_t d0, int32_t D, int32_t Tq, int32_t K, float c_loss, int32_t mode, void* stream);
+int wae_vq_ema_update(const float* lat, const int64_t* idx, const int32_t* hist, float* ema_cluster_size, float* ema_w,
+                      float* emb, int32_t B, int32_t Dtot, int32_t d0, int32_t D, int32_t Tq, int32_t K, float decay,
+                      void* stream);
+int wae_vq_slice_bwd(const float* lat, const float* quant, const int64_t* idx, const float* dquant, float* dlat,
+                     float* demb, int32_t B, int32_t Dtot, int32_t d0, int32_t D, int32_t Tq, float c_lat, float c_emb,
+                     void* stream);
+
 /* ---- a3 one upsample stage (upsample.py:19-21 stretch + :39-46 FIR) ------------------------------------
  * in (B,C,Tin) fp32 -> nearest-stretch by s, FIR w[2s+1] zero-padded.  If out_btc != 0 the result is written
  * time-major (B,Tin*s,Cp) in `dtype` (pad channels zeroed), else (B,C,Tin*s) fp32. */

@@ -97,6 +97,89 @@ def vq_forward(emb: torch.Tensor, lat: torch.Tensor, beta: float = 0.25):
     return q_st.permute(0, 2, 1).contiguous(), vq_loss, perp, idx
 
 
+def _vq_assign(emb: torch.Tensor, flat: torch.Tensor):
+    """The per-slice search shared by every quantizer class (vector_quantization.py:84-97, :163-176, :262-270):
+    argmax(-dis) == first minimum of ||e||^2 + ||x||^2 - 2 x.e."""
+    dis = torch.addmm((emb ** 2).sum(1) + (flat ** 2).sum(1, keepdim=True), flat, emb.t(), alpha=-2.0, beta=1.0)
+    return torch.argmax(-1.0 * dis, dim=1)
+
+
+def _perplexity(idx: torch.Tensor, K: int, dtype) -> torch.Tensor:
+    avg = torch.bincount(idx, minlength=K).to(dtype) / idx.numel()
+    return torch.exp(-(avg * torch.log(avg + 1e-10)).sum())
+
+
+def sliced_vq_forward(emb1: torch.Tensor, emb2: torch.Tensor, lat: torch.Tensor, beta: float = 0.25):
+    """SlicedVectorQuantize.forward (vector_quantization.py:75-128): two channel halves, one codebook each (K and K1 codes).
+    NB the loss wiring differs from VectorQuantize: the encoder-side term has weight 1 and the codebook-side term
+    weight beta (:113-118); perplexity is the SUM of the two slice perplexities (:125-127).
+    -> (quant (B,D,T) straight-through, vq_loss, perp, (idx1, idx2))."""
+    x = lat.permute(0, 2, 1).contiguous()
+    B, T, D = x.shape
+    sub = emb1.shape[1]
+    flat = x.view(-1, D)
+    i1, i2 = _vq_assign(emb1, flat[:, :sub]), _vq_assign(emb2, flat[:, sub:])
+    q = torch.cat([emb1[i1].view(B, T, sub), emb2[i2].view(B, T, D - sub)], dim=2)
+    vq_loss = ((q.detach() - x) ** 2).mean() + beta * ((q - x.detach()) ** 2).mean()
+    q_st = x + (q - x).detach()
+    perp = _perplexity(i1, emb1.shape[0], x.dtype) + _perplexity(i2, emb2.shape[0], x.dtype)
+    return q_st.permute(0, 2, 1), vq_loss, perp, (i1, i2)
+
+
+def _ema_update(emb, ema_n, ema_w, flat, idx, decay):
+    """Training branch of the EMA classes (vector_quantization.py:190-215, :275-290); returns the new (emb, ema_n, ema_w)."""
+    K = emb.shape[0]
+    counts = torch.bincount(idx, minlength=K).to(flat.dtype)
+    ema_n = ema_n * decay + (1.0 - decay) * counts
+    n = ema_n.sum()
+    ema_n = (ema_n + 1e-5) / (n + K * 1e-5) * n
+    dw = torch.zeros_like(ema_w).index_add_(0, idx, flat)
+    ema_w = ema_w * decay + (1 - decay) * dw
+    return ema_w / ema_n.unsqueeze(1), ema_n, ema_w
+
+
+def vq_ema_forward(state: dict, lat: torch.Tensor, beta: float = 0.25, decay: float = 0.99, training: bool = True):
+    """VectorQuantizeEMA.forward (vector_quantization.py:255-306).  state: embedding (K,D), ema_cluster_size (K), ema_w (K,D);
+    returns (quant, vq_loss, perp, idx, new_state).  The codes are gathered from the UPDATED codebook (:290-292) with the
+    assignments made against the old one; vq_loss = beta * mse(sg[q], x) only (:294)."""
+    x = lat.permute(0, 2, 1).contiguous()
+    B, T, D = x.shape
+    flat = x.view(-1, D)
+    emb = state["embedding"]
+    idx = _vq_assign(emb, flat)
+    new = dict(state)
+    if training:
+        emb, n, w = _ema_update(emb, state["ema_cluster_size"], state["ema_w"], flat.detach(), idx, decay)
+        new.update(embedding=emb, ema_cluster_size=n, ema_w=w)
+    q = emb[idx].view(B, T, D)
+    vq_loss = beta * ((q.detach() - x) ** 2).mean()
+    q_st = x + (q - x).detach()
+    return q_st.permute(0, 2, 1), vq_loss, _perplexity(idx, emb.shape[0], x.dtype), idx, new
+
+
+def sliced_vq_ema_forward(state: dict, lat: torch.Tensor, beta: float = 0.25, decay: float = 0.99, training: bool = True):
+    """SlicedVectorQuantizeEMA.forward (vector_quantization.py:157-235).  state: embedding1/2, ema_cluster_size1/2, ema_w1/2."""
+    x = lat.permute(0, 2, 1).contiguous()
+    B, T, D = x.shape
+    sub = state["embedding1"].shape[1]
+    flat = x.view(-1, D)
+    parts = (flat[:, :sub], flat[:, sub:])
+    new, qs, idxs, perp = dict(state), [], [], 0.0
+    for s, f in zip(("1", "2"), parts):
+        emb = state["embedding" + s]
+        idx = _vq_assign(emb, f)
+        if training:
+            emb, n, w = _ema_update(emb, state["ema_cluster_size" + s], state["ema_w" + s], f.detach(), idx, decay)
+            new.update({"embedding" + s: emb, "ema_cluster_size" + s: n, "ema_w" + s: w})
+        qs.append(emb[idx].view(B, T, -1))
+        idxs.append(idx)
+        perp = perp + _perplexity(idx, emb.shape[0], x.dtype)
+    q = torch.cat(qs, dim=2)
+    vq_loss = beta * ((q.detach() - x) ** 2).mean()
+    q_st = x + (q - x).detach()
+    return q_st.permute(0, 2, 1), vq_loss, perp, tuple(idxs), new
+
+
 def vq_distances(emb: torch.Tensor, lat: torch.Tensor) -> torch.Tensor:
     """(N, K) distance matrix in the reference's formulation; used for top-2 margins."""
     flat = lat.permute(0, 2, 1).reshape(-1, lat.shape[1])

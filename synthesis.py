@@ -6,7 +6,7 @@ usage: synthesis.py [options] <dump_root> <checkpoint> <dst_dir> <syn_list> <spe
 options:
     --hparams=<parmas>       Hyper parameters [default: ].
     --preset=<json>          Path of preset parameters (json).
-    --length=<T>             Steps to generate (default: computed from the conditioning features).
+    --length=<T>             Accepted and, as in the reference (synthesis.py:327-329), overridden by frames * up_factor.
     --initial-value=<n>      Initial mu-law class id (default: mulaw_quantize(0) = 127).
     --dtype=<fp32|bf16>      Compute precision [default: fp32].
 """
@@ -76,16 +76,26 @@ def main(argv=None):
     with open(args.syn_list) as f:
         pairs = [ln.split() for ln in f if ln.strip()][int(args.start_ind):]
     from scipy.io import wavfile
+    out_dir = f"{args.dst_dir}2019/{args.lan}/test/"                                          # synthesis.py:521-522 (string concat)
+    os.makedirs(out_dir, exist_ok=True)
     for src, tar in pairs:
-        c = np.load(os.path.join(args.dump_root, src, "mfcc.norm.npy"))
-        mult = max(1, 100 // int(args.frame_rate))
-        if len(c) % (4 * mult):                                                               # pad frames (:483-490)
-            c = np.pad(c, ((0, 4 * mult - len(c) % (4 * mult)), (0, 0)), mode="edge")
-        length = args.length or (len(c) // 4) * up * 1                                        # latent frames * up_factor
+        if args.lan == "surprise":
+            src = "test/" + src                                                               # :475-476
+        fid = src.split("_")[1]                                                               # :478
+        path = f"{args.dump_root}/{src}/mfcc.norm.npy"
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"cant find con file in {path}")
+        c = np.load(path)
+        div = 100 // int(args.frame_rate)                                                     # zero-pad to whole latent frames (:482-486)
+        if c.shape[0] % div != 0:
+            c = np.pad(c, [[0, div - c.shape[0] % div], [0, 0]], mode="constant", constant_values=0.0)
+        if tar not in sp2ind:
+            raise KeyError(f"cant find sp {tar} in sp2ind {args.speaker2ind}")
+        length = c.shape[0] * up                                                              # overrides --length (:327-329)
         y = wavegen(eng, length, c, sp2ind[tar], args.initial_value)
-        out = os.path.join(args.dst_dir, f"{tar}_{os.path.basename(src)}.wav")
+        out = f"{out_dir}{tar}_{fid}.wav"
         wavfile.write(out, hparams.sample_rate, y)
-        print("wrote", out)
+        print("Finished! Check out {} for generated audio samples.".format(out), flush=True)
     return 0
 
 

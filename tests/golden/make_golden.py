@@ -443,7 +443,84 @@ def gen_vqwae_probe():
          keys=json.dumps({k: list(v.shape) for k, v in sd.items()}))
 
 
+def gen_quantizers():
+    """Section 8(f) rank 3: SlicedVectorQuantize, SlicedVectorQuantizeEMA, VectorQuantizeEMA (vector_quantization.py:51-306)
+    run on this CPU host.  The two EMA classes test the function object `torch.cuda.is_available` (:183, :277), which is
+    always truthy, and then call .cuda(); Tensor.cuda is made the identity for the duration (reference files untouched).
+    Two training steps then one eval step each; gradients of sum(quant * w) + vq_loss."""
+    B, D, T, K, K1 = 3, 16, 37, 24, 20
+    gen = torch.Generator().manual_seed(11)
+    lats = [torch.randn(B, D, T, generator=gen) * 0.3 for _ in range(3)]
+    w = torch.randn(B, D, T, generator=gen)
+    e1 = (torch.rand(K, D // 2, generator=gen) - 0.5) * 0.8
+    e2 = (torch.rand(K1, D // 2, generator=gen) - 0.5) * 0.8
+    e2k = (torch.rand(K, D // 2, generator=gen) - 0.5) * 0.8
+    ef = (torch.rand(K, D, generator=gen) - 0.5) * 0.8
+    out = dict(lats=torch.stack(lats), w=w, e1=e1, e2=e2, e2k=e2k, ef=ef)
+    keep = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        # --- SlicedVectorQuantize (K codes / K1 codes)
+        m = ref_vq.SlicedVectorQuantize(K, D, beta=0.25, K1=K1)
+        m.embedding1.weight.data.copy_(e1)
+        m.embedding2.weight.data.copy_(e2)
+        x = lats[0].clone().requires_grad_(True)
+        q, loss, perp = m(x)
+        (q * w).sum().add(loss).backward()
+        oq, ol, op, (i1, i2) = O.sliced_vq_forward(e1, e2, lats[0], 0.25)
+        close(oq, q, what="oracle sliced quant", tol=1e-6)
+        close(ol, loss, what="oracle sliced loss", tol=1e-6)
+        close(op, perp, what="oracle sliced perp", tol=1e-5)
+        out.update(s_quant=q, s_loss=loss, s_perp=perp, s_dlat=x.grad, s_demb1=m.embedding1.weight.grad,
+                   s_demb2=m.embedding2.weight.grad, s_idx1=i1, s_idx2=i2)
+        # --- VectorQuantizeEMA
+        m = ref_vq.VectorQuantizeEMA(K, D, beta=0.25, decay=0.9)
+        m.embedding.weight.data.copy_(ef)
+        st = dict(embedding=ef.clone(), ema_cluster_size=torch.zeros(K), ema_w=torch.zeros(K, D))
+        for step in range(3):
+            m.train(step < 2)
+            x = lats[step].clone().requires_grad_(True)
+            q, loss, perp = m(x)
+            (q * w).sum().add(loss).backward()
+            oq, ol, op, idx, st = O.vq_ema_forward(st, lats[step], 0.25, 0.9, training=step < 2)
+            close(oq, q, what=f"oracle ema quant {step}", tol=1e-5)
+            close(ol, loss, what=f"oracle ema loss {step}", tol=1e-5)
+            close(st["embedding"], m.embedding.weight.data, what=f"oracle ema codebook {step}", tol=1e-5)
+            close(st["ema_cluster_size"], m.ema_cluster_size, what=f"oracle ema sizes {step}", tol=1e-5)
+            out.update({f"e{step}_quant": q, f"e{step}_loss": loss, f"e{step}_perp": perp, f"e{step}_dlat": x.grad,
+                        f"e{step}_idx": idx, f"e{step}_emb": m.embedding.weight.data.clone(),
+                        f"e{step}_n": m.ema_cluster_size.clone(), f"e{step}_w": m.ema_w.clone()})
+        assert m.embedding.weight.grad is None or float(m.embedding.weight.grad.abs().sum()) == 0.0
+        # --- SlicedVectorQuantizeEMA
+        m = ref_vq.SlicedVectorQuantizeEMA(K, D, beta=0.25, decay=0.9)
+        m.embedding1.weight.data.copy_(e1)
+        m.embedding2.weight.data.copy_(e2k)
+        st = dict(embedding1=e1.clone(), embedding2=e2k.clone(), ema_cluster_size1=torch.zeros(K), ema_cluster_size2=torch.zeros(K),
+                  ema_w1=torch.zeros(K, D // 2), ema_w2=torch.zeros(K, D // 2))
+        for step in range(3):
+            m.train(step < 2)
+            x = lats[step].clone().requires_grad_(True)
+            q, loss, perp = m(x)
+            (q * w).sum().add(loss).backward()
+            oq, ol, op, idxs, st = O.sliced_vq_ema_forward(st, lats[step], 0.25, 0.9, training=step < 2)
+            close(oq, q, what=f"oracle sliced ema quant {step}", tol=1e-5)
+            close(ol, loss, what=f"oracle sliced ema loss {step}", tol=1e-5)
+            close(op, perp, what=f"oracle sliced ema perp {step}", tol=1e-5)
+            close(st["embedding2"], m.embedding2.weight.data, what=f"oracle sliced ema codebook {step}", tol=1e-5)
+            out.update({f"se{step}_quant": q, f"se{step}_loss": loss, f"se{step}_perp": perp, f"se{step}_dlat": x.grad,
+                        f"se{step}_idx1": idxs[0], f"se{step}_idx2": idxs[1], f"se{step}_emb1": m.embedding1.weight.data.clone(),
+                        f"se{step}_emb2": m.embedding2.weight.data.clone(), f"se{step}_n1": m.ema_cluster_size1.clone(),
+                        f"se{step}_n2": m.ema_cluster_size2.clone(), f"se{step}_w1": m.ema_w1.clone(),
+                        f"se{step}_w2": m.ema_w2.clone()})
+    finally:
+        torch.Tensor.cuda = keep
+    save("quantizers", **out)
+
+
 def main():
+    if sys.argv[1:] == ["quantizers"]:
+        return gen_quantizers()
+    gen_quantizers()
     gen_misc()
     gen_dmol()
     for cfg, salt in ((CFG_A, 1), (CFG_B, 2)):

@@ -157,3 +157,11 @@ def test_engine_refuses_to_run_without_gpu():
     from wavenet_autoencoders_amd._lib import WaeError
     with pytest.raises(WaeError):
         WaeEngine(P.Geometry.from_cfg(CFG))
+
+
+def test_feature_export_output_path_follows_reference_layout():
+    """inference_2019.py:226-230: <dst>2019/<lan>/test/<utterance>.txt from a six-part base_dir."""
+    import inference_2019 as I
+    assert I.output_path("db/x/english/test/utt9/", "out/") == "out/2019/english/test/utt9.txt"
+    with pytest.raises(AssertionError):
+        I.output_path("/abs/db/x/english/test/utt9/", "out/")

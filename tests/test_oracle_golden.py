@@ -181,3 +181,30 @@ def test_mulaw_hand_values():
     assert q.tolist() == [15, 98, 156, 239]   # e.g. (1-ln(128.5)/ln(256))/2*255 = 15.84 -> 15
     back = O.inv_mulaw_quantize(q, 255)
     assert np.all(np.abs(back - x) < 0.03)
+
+
+def test_sliced_and_ema_quantizers_against_reference_vectors():
+    """vector_quantization.py:51-306 (reference classes run on CPU by make_golden.gen_quantizers)."""
+    z = load_npz("quantizers")
+    t = {k: torch.from_numpy(np.asarray(v)) for k, v in z.items()}
+    q, loss, perp, (i1, i2) = O.sliced_vq_forward(t["e1"], t["e2"], t["lats"][0], 0.25)
+    assert torch.equal(i1, t["s_idx1"]) and torch.equal(i2, t["s_idx2"])
+    assert rel_err(q, t["s_quant"]) < 1e-6 and abs(float(loss) - float(t["s_loss"])) < 1e-6
+    assert abs(float(perp) - float(t["s_perp"])) < 1e-4
+    K, D = t["ef"].shape
+    st = dict(embedding=t["ef"].clone(), ema_cluster_size=torch.zeros(K), ema_w=torch.zeros(K, D))
+    for step in range(3):
+        q, loss, perp, idx, st = O.vq_ema_forward(st, t["lats"][step], 0.25, 0.9, training=step < 2)
+        assert torch.equal(idx, t[f"e{step}_idx"])
+        assert rel_err(q, t[f"e{step}_quant"]) < 1e-5 and abs(float(loss) - float(t[f"e{step}_loss"])) < 1e-6
+        assert rel_err(st["embedding"], t[f"e{step}_emb"]) < 1e-5 and rel_err(st["ema_cluster_size"], t[f"e{step}_n"]) < 1e-5
+        assert rel_err(st["ema_w"], t[f"e{step}_w"]) < 1e-5
+    st = dict(embedding1=t["e1"].clone(), embedding2=t["e2k"].clone(), ema_cluster_size1=torch.zeros(K),
+              ema_cluster_size2=torch.zeros(K), ema_w1=torch.zeros(K, D // 2), ema_w2=torch.zeros(K, D // 2))
+    for step in range(3):
+        q, loss, perp, idxs, st = O.sliced_vq_ema_forward(st, t["lats"][step], 0.25, 0.9, training=step < 2)
+        assert torch.equal(idxs[0], t[f"se{step}_idx1"]) and torch.equal(idxs[1], t[f"se{step}_idx2"])
+        assert rel_err(q, t[f"se{step}_quant"]) < 1e-5 and abs(float(perp) - float(t[f"se{step}_perp"])) < 1e-4
+        for s in "12":
+            assert rel_err(st["embedding" + s], t[f"se{step}_emb{s}"]) < 1e-5
+            assert rel_err(st["ema_cluster_size" + s], t[f"se{step}_n{s}"]) < 1e-5

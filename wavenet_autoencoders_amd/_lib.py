@@ -66,6 +66,9 @@ SIGNATURES = {
     "wae_upsample_stage_bwd": (c_i32, [c_vp] * 5 + [c_i32] * 4 + [c_vp]),
     "wae_enc_conv_bwd": (c_i32, [c_vp] * 7 + [c_i32] * 9 + [c_vp]),
     "wae_vq_bwd": (c_i32, [c_vp] * 6 + [c_i32] * 3 + [c_f32, c_f32, c_vp]),
+    "wae_vq_slice": (c_i32, [c_vp] * 6 + [c_i32] * 6 + [c_f32, c_i32, c_vp]),
+    "wae_vq_ema_update": (c_i32, [c_vp] * 6 + [c_i32] * 6 + [c_f32, c_vp]),
+    "wae_vq_slice_bwd": (c_i32, [c_vp] * 6 + [c_i32] * 5 + [c_f32, c_f32, c_vp]),
     "wae_first_conv_fwd": (c_i32, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_i32, c_vp]),
     "wae_glu_layer_fwd": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "wae_glu_packed_bytes": (c_i64, [ctypes.POINTER(GluDesc)]),

@@ -151,26 +151,35 @@ extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, 
 }
 
 // ---- VQ backward: straight-through + both halves of vq_loss (vector_quantization.py:41-45) ---------------------------------
-// dlat = dquant + loss_scale * 2*beta*(x - q)/N ;  demb[idx] += loss_scale * 2*(q - x)/N ,  N = B*Tq*D
+// dlat = dquant + c_x*(x - q) ;  demb[idx] += c_e*(q - x)  over channels [d0, d0+D) of (B, Dtot, Tq) tensors; demb (K, D) of
+// the slice's own codebook, or NULL (EMA codebooks get no gradient, vector_quantization.py:217,:292).
 __global__ void __launch_bounds__(256) vq_bwd_kernel(const float* __restrict__ lat, const float* __restrict__ quant,
                                                      const int64_t* __restrict__ idx, const float* __restrict__ dquant,
-                                                     float* __restrict__ dlat, float* __restrict__ demb, int D, int Tq, float c_x,
-                                                     float c_e, int64_t total) {
+                                                     float* __restrict__ dlat, float* __restrict__ demb, int Dtot, int d0, int D,
+                                                     int Tq, float c_x, float c_e, int64_t total) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int t = (int)(e % Tq);
   const int dch = (int)((e / Tq) % D);
   const int b = (int)(e / ((int64_t)Tq * D));
-  const float diff = lat[e] - quant[e];
-  dlat[e] = (dquant ? dquant[e] : 0.f) + c_x * diff;
-  atomicAdd(demb + idx[(int64_t)b * Tq + t] * D + dch, -c_e * diff);
+  const int64_t at = ((int64_t)b * Dtot + d0 + dch) * Tq + t;
+  const float diff = lat[at] - quant[at];
+  dlat[at] = (dquant ? dquant[at] : 0.f) + c_x * diff;
+  if (demb) atomicAdd(demb + idx[(int64_t)b * Tq + t] * D + dch, -c_e * diff);
+}
+extern "C" int wae_vq_slice_bwd(const float* lat, const float* quant, const int64_t* idx, const float* dquant, float* dlat,
+                                float* demb, int32_t B, int32_t Dtot, int32_t d0, int32_t D, int32_t Tq, float c_lat, float c_emb,
+                                void* stream) {
+  WAE_REQUIRE(lat && quant && idx && dlat && B > 0 && D > 0 && Tq > 0 && d0 >= 0 && d0 + D <= Dtot, "vq_slice_bwd: bad arguments");
+  const int64_t total = (int64_t)B * D * Tq;
+  hipLaunchKernelGGL(vq_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), lat, quant, idx, dquant,
+                     dlat, demb, Dtot, d0, D, Tq, c_lat, c_emb, total);
+  return wae_check_launch("vq_slice_bwd");
 }
 extern "C" int wae_vq_bwd(const float* lat, const float* quant, const int64_t* idx, const float* dquant, float* dlat, float* demb,
                           int32_t B, int32_t D, int32_t Tq, float beta, float loss_scale, void* stream) {
-  WAE_REQUIRE(lat && quant && idx && dlat && demb && B > 0 && D > 0 && Tq > 0, "vq_bwd: bad arguments");
-  const int64_t total = (int64_t)B * D * Tq;
-  const float n = (float)total;
-  hipLaunchKernelGGL(vq_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), lat, quant, idx, dquant,
-                     dlat, demb, D, Tq, loss_scale * 2.f * beta / n, loss_scale * 2.f / n, total);
-  return wae_check_launch("vq_bwd");
+  WAE_REQUIRE(demb, "vq_bwd: bad arguments");
+  const float n = (float)((int64_t)B * D * Tq);
+  return wae_vq_slice_bwd(lat, quant, idx, dquant, dlat, demb, B, D, 0, D, Tq, loss_scale * 2.f * beta / n, loss_scale * 2.f / n,
+                          stream);
 }

@@ -237,99 +237,166 @@ extern "C" int wae_enc_conv_fwd(const float* x, const float* w, const float* bia
 }
 
 // ---------------------------------------------------------------------------------------------------
-// VQ nearest (vector_quantization.py:21-49).  One workgroup per latent vector; thread k scores code k with the
-// reference's formulation ||e||^2 + ||x||^2 - 2 x.e, all fp32; first minimum wins (torch.argmin tie-break).
+// VQ nearest (vector_quantization.py:21-49; the sliced/EMA classes of the same file score each slice the same way,
+// :84-97, :163-176, :262-270).  One workgroup per latent vector; thread k scores code k with the reference's
+// formulation ||e||^2 + ||x||^2 - 2 x.e, all fp32; first minimum wins (torch.argmin / argmax(-d) tie-break).
+// The kernel works on channels [d0, d0+D) of a (B, Dtot, Tq) tensor.  mode 0: search + gather, 1: search only,
+// 2: gather with the indices given (after an EMA update moved the codebook).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) vq_nearest_kernel(const float* __restrict__ lat, const float* __restrict__ emb,
                                                          int64_t* __restrict__ idx, float* __restrict__ quant,
-                                                         float* __restrict__ sqerr, int32_t* __restrict__ hist, int D,
-                                                         int Tq, int K) {
+                                                         float* __restrict__ sqerr, int32_t* __restrict__ hist, int Dtot,
+                                                         int d0, int D, int Tq, int K, int mode) {
   extern __shared__ float sh[];
   float* xs = sh;                      // D
   float* best_d = sh + D;              // 256
   int* best_i = (int*)(best_d + 256);  // 256
   const int row = blockIdx.x;          // b*Tq + t
   const int b = row / Tq, t = row % Tq;
-  for (int i = threadIdx.x; i < D; i += 256) xs[i] = lat[((int64_t)b * D + i) * Tq + t];
+  const int64_t base = ((int64_t)b * Dtot + d0) * Tq + t;
+  for (int i = threadIdx.x; i < D; i += 256) xs[i] = lat[base + (int64_t)i * Tq];
   __syncthreads();
-  float in_sqr = 0.f;
-  for (int i = 0; i < D; ++i) in_sqr += xs[i] * xs[i];
-  float bd = INFINITY;
-  int bi = 0x7fffffff;
-  for (int kk = threadIdx.x; kk < K; kk += 256) {
-    const float* e = emb + (int64_t)kk * D;
-    float es = 0.f, dot = 0.f;
-    for (int i = 0; i < D; ++i) {
-      es += e[i] * e[i];
-      dot += xs[i] * e[i];
-    }
-    const float d = (es + in_sqr) - 2.0f * dot;
-    if (d < bd) { bd = d; bi = kk; }
-  }
-  best_d[threadIdx.x] = bd;
-  best_i[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float od = best_d[threadIdx.x + s];
-      const int oi = best_i[threadIdx.x + s];
-      if (od < best_d[threadIdx.x] || (od == best_d[threadIdx.x] && oi < best_i[threadIdx.x])) {
-        best_d[threadIdx.x] = od;
-        best_i[threadIdx.x] = oi;
+  int win;
+  if (mode != 2) {
+    float in_sqr = 0.f;
+    for (int i = 0; i < D; ++i) in_sqr += xs[i] * xs[i];
+    float bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int kk = threadIdx.x; kk < K; kk += 256) {
+      const float* e = emb + (int64_t)kk * D;
+      float es = 0.f, dot = 0.f;
+      for (int i = 0; i < D; ++i) {
+        es += e[i] * e[i];
+        dot += xs[i] * e[i];
       }
+      const float d = (es + in_sqr) - 2.0f * dot;
+      if (d < bd) { bd = d; bi = kk; }
     }
+    best_d[threadIdx.x] = bd;
+    best_i[threadIdx.x] = bi;
     __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        const float od = best_d[threadIdx.x + s];
+        const int oi = best_i[threadIdx.x + s];
+        if (od < best_d[threadIdx.x] || (od == best_d[threadIdx.x] && oi < best_i[threadIdx.x])) {
+          best_d[threadIdx.x] = od;
+          best_i[threadIdx.x] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    win = best_i[0];
+    if (threadIdx.x == 0) {
+      idx[row] = win;
+      atomicAdd(hist + win, 1);
+    }
+  } else {
+    win = (int)idx[row];
   }
-  const int win = best_i[0];
+  if (mode == 1) return;
   float se = 0.f;
   for (int i = threadIdx.x; i < D; i += 256) {
     const float q = emb[(int64_t)win * D + i];
-    quant[((int64_t)b * D + i) * Tq + t] = q;
+    quant[base + (int64_t)i * Tq] = q;
     const float df = q - xs[i];
     se += df * df;
   }
   se = wave_sum(se);
   if ((threadIdx.x & 63) == 0 && se != 0.f) atomicAdd(sqerr, se);
-  if (threadIdx.x == 0) {
-    idx[row] = win;
-    atomicAdd(hist + win, 1);
-  }
 }
 
+// stats[0] = c_loss * mean((q-x)^2) over the slice (mode != 1); stats[1] = perplexity of the slice (mode != 2)
 __global__ void __launch_bounds__(256) vq_stats_kernel(const float* __restrict__ sqerr, const int32_t* __restrict__ hist,
-                                                       float* __restrict__ stats, int K, int N, int D, float beta) {
+                                                       float* __restrict__ stats, int K, int N, int D, float c_loss, int mode) {
   __shared__ float part[4];
   float s = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) {
-    const float pk = (float)hist[k] / (float)N;
-    s += pk * logf(pk + 1e-10f);
-  }
+  if (mode != 2)
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float pk = (float)hist[k] / (float)N;
+      s += pk * logf(pk + 1e-10f);
+    }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
     const float tot = part[0] + part[1] + part[2] + part[3];
     const float mse = sqerr[0] / ((float)N * (float)D);
-    stats[0] = beta * mse + mse;  // vector_quantization.py:41-43 (forward values of both terms are equal)
-    stats[1] = expf(-tot);
+    if (mode != 1) stats[0] = c_loss * mse;
+    if (mode != 2) stats[1] = expf(-tot);
   }
+}
+
+extern "C" int wae_vq_slice(const float* lat, const float* emb, int64_t* idx, float* quant, float* stats, int32_t* hist,
+                            int32_t B, int32_t Dtot, int32_t d0, int32_t D, int32_t Tq, int32_t K, float c_loss, int32_t mode,
+                            void* stream) {
+  WAE_REQUIRE(lat && emb && idx && stats && hist && (quant || mode == 1), "vq_slice: null pointer");
+  WAE_REQUIRE(B > 0 && D > 0 && Tq > 0 && K > 0 && d0 >= 0 && d0 + D <= Dtot && mode >= 0 && mode <= 2, "vq_slice: bad sizes");
+  hipStream_t st = as_stream(stream);
+  // scratch: hist[K] counts, then one float (sum of squared errors) stored after it; mode 2 keeps the counts
+  float* sqerr = (float*)(hist + K);
+  const hipError_t e = mode == 2 ? hipMemsetAsync(sqerr, 0, sizeof(float), st)
+                                 : hipMemsetAsync(hist, 0, (size_t)(K + 1) * sizeof(int32_t), st);
+  if (e != hipSuccess) {
+    wae_set_error("vq_slice: memset failed");
+    return WAE_EHIP;
+  }
+  const size_t lds = (size_t)(D + 512) * sizeof(float);
+  hipLaunchKernelGGL(vq_nearest_kernel, dim3(B * Tq), dim3(256), lds, st, lat, emb, idx, quant, sqerr, hist, Dtot, d0, D, Tq, K,
+                     mode);
+  hipLaunchKernelGGL(vq_stats_kernel, dim3(1), dim3(256), 0, st, sqerr, hist, stats, K, B * Tq, D, c_loss, mode);
+  return wae_check_launch("vq_slice");
 }
 
 extern "C" int wae_vq_nearest(const float* lat, const float* emb, int64_t* idx, float* quant, float* stats, int32_t* hist,
                               int32_t B, int32_t D, int32_t Tq, int32_t K, float beta, void* stream) {
-  WAE_REQUIRE(lat && emb && idx && quant && stats && hist, "vq_nearest: null pointer");
-  WAE_REQUIRE(B > 0 && D > 0 && Tq > 0 && K > 0, "vq_nearest: bad sizes");
-  hipStream_t st = as_stream(stream);
-  // scratch: hist[K] counts, then one float (sum of squared errors) stored after it
-  if (hipMemsetAsync(hist, 0, (size_t)(K + 1) * sizeof(int32_t), st) != hipSuccess) {
-    wae_set_error("vq_nearest: memset failed");
-    return WAE_EHIP;
+  // vector_quantization.py:41-43: the forward values of the two loss terms are equal, so vq_loss = (beta + 1) * mse
+  return wae_vq_slice(lat, emb, idx, quant, stats, hist, B, D, 0, D, Tq, K, beta + 1.0f, 0, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// EMA codebook update (vector_quantization.py:190-215 per slice, :275-287): cluster sizes with Laplace smoothing in one
+// workgroup, then one workgroup per code sums its latents in row order (no atomics: the update is reproducible).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vq_ema_sizes_kernel(const int32_t* __restrict__ hist, float* __restrict__ ema_n, int K,
+                                                           float decay) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float v = ema_n[k] * decay + (1.0f - decay) * (float)hist[k];
+    ema_n[k] = v;
+    s += v;
   }
-  float* sqerr = (float*)(hist + K);
-  const size_t lds = (size_t)(D + 512) * sizeof(float);
-  hipLaunchKernelGGL(vq_nearest_kernel, dim3(B * Tq), dim3(256), lds, st, lat, emb, idx, quant, sqerr, hist, D, Tq, K);
-  hipLaunchKernelGGL(vq_stats_kernel, dim3(1), dim3(256), 0, st, sqerr, hist, stats, K, B * Tq, D, beta);
-  return wae_check_launch("vq_nearest");
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float n = part[0] + part[1] + part[2] + part[3];
+  for (int k = threadIdx.x; k < K; k += 256) ema_n[k] = (ema_n[k] + 1e-5f) / (n + (float)K * 1e-5f) * n;
+}
+__global__ void __launch_bounds__(64) vq_ema_codes_kernel(const float* __restrict__ lat, const int64_t* __restrict__ idx,
+                                                          const float* __restrict__ ema_n, float* __restrict__ ema_w,
+                                                          float* __restrict__ emb, int Dtot, int d0, int D, int Tq, int N,
+                                                          float decay) {
+  const int k = blockIdx.x;
+  for (int i = threadIdx.x; i < D; i += 64) {
+    float dw = 0.f;
+    for (int row = 0; row < N; ++row)
+      if (idx[row] == k) dw += lat[((int64_t)(row / Tq) * Dtot + d0 + i) * Tq + row % Tq];
+    const float w = ema_w[(int64_t)k * D + i] * decay + (1.0f - decay) * dw;
+    ema_w[(int64_t)k * D + i] = w;
+    emb[(int64_t)k * D + i] = w / ema_n[k];
+  }
+}
+extern "C" int wae_vq_ema_update(const float* lat, const int64_t* idx, const int32_t* hist, float* ema_cluster_size, float* ema_w,
+                                 float* emb, int32_t B, int32_t Dtot, int32_t d0, int32_t D, int32_t Tq, int32_t K, float decay,
+                                 void* stream) {
+  WAE_REQUIRE(lat && idx && hist && ema_cluster_size && ema_w && emb, "vq_ema_update: null pointer");
+  WAE_REQUIRE(B > 0 && D > 0 && Tq > 0 && K > 0 && d0 >= 0 && d0 + D <= Dtot, "vq_ema_update: bad sizes");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(vq_ema_sizes_kernel, dim3(1), dim3(256), 0, st, hist, ema_cluster_size, K, decay);
+  hipLaunchKernelGGL(vq_ema_codes_kernel, dim3(K), dim3(64), 0, st, lat, idx, ema_cluster_size, ema_w, emb, Dtot, d0, D, Tq,
+                     B * Tq, decay);
+  return wae_check_launch("vq_ema_update");
 }
 
 // ---------------------------------------------------------------------------------------------------
