@@ -422,6 +422,25 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     return ws["dc"]
 
 
+def _debug_kernels(eng, B, T, l):
+    """(du/dz launch, dx launch) of layer l as closures over the workspaces of the last train step (tools/ablate_tm.py)."""
+    g, ws, fw = eng.g, eng._ws[("bwd", B, T)], eng._ws[(B, T, True)]
+    es = eng.w_glu.element_size()
+    Z2 = 2 * g.Hp
+    dzs = g.layers * Z2
+    ngx = len(ws["gx"])
+    gn, gc = ws["gx"][(l + 1) % ngx], ws["gx"][l % ngx]
+
+    def k_u():
+        _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
+            eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2)
+
+    def k_x():
+        srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
+        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp)
+    return k_u, k_x
+
+
 def finish_grads(eng):
     """d_eff (gradient wrt effective weights) -> grads (wrt weight_g / weight_v and plain parameters)."""
     lay = eng.lay

@@ -322,17 +322,19 @@ __device__ __forceinline__ void stage_fetch_pass(f32x4 (&r)[8], const char* gin,
     r[i] = *(const f32x4*)(gin + row * row_stride + ck * 16);
   }
 }
-template <typename EO, int NTP>
+template <typename EO, int NTP, int PITCH = 256>
 __device__ __forceinline__ void stage_unpack_pass(char* stg, f32x16* y, const f32x4 (&r)[8], int lane) {
   using vec4 = typename ET<EO>::vec4;
   constexpr int SEG = NTP * 32 * sizeof(EO);
+  static_assert(SEG <= PITCH, "a staging pass covers at most PITCH bytes per row");
   constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 32 / RPI;
+  constexpr int KEY = PITCH / 16 - 1;
   const int n = lane & 31, h = lane >> 5;
   const int rr = lane / LPR, ck = lane % LPR;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int row = i * RPI + rr;
-    *(f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4)) = r[i];
+    *(f32x4*)(stg + row * PITCH + ((ck ^ (row & KEY)) << 4)) = r[i];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -341,7 +343,7 @@ __device__ __forceinline__ void stage_unpack_pass(char* stg, f32x16* y, const f3
     for (int g = 0; g < 4; ++g) {
       int c16, sub;
       if constexpr (sizeof(EO) == 2) { c16 = 4 * mt + g; sub = 8 * h; } else { c16 = 8 * mt + 2 * g + h; sub = 0; }
-      const f32x4 v = to_f32x4(*(const vec4*)(stg + n * 256 + ((c16 ^ (n & 15)) << 4) + sub));
+      const f32x4 v = to_f32x4(*(const vec4*)(stg + n * PITCH + ((c16 ^ (n & KEY)) << 4) + sub));
       y[mt][4 * g] = v.x; y[mt][4 * g + 1] = v.y; y[mt][4 * g + 2] = v.z; y[mt][4 * g + 3] = v.w;
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
