@@ -21,10 +21,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c: continue
             agg.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
-    with open("$OUT/pmc_%s_per_kernel_mean_kb.csv" % c, "w") as fh:
-        fh.write("kernel,launches,mean_kb\n")
+    with open("$OUT/pmc_%s_per_kernel_mean_kb.csv" % c, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "launches", "mean_kb"])
         for k, v in agg.items():
-            fh.write("%s,%d,%.1f\n" % (k, len(v), sum(v) / len(v)))
+            w.writerow([k, len(v), "%.1f" % (sum(v) / len(v))])
             res.setdefault(k, {})[c] = sum(v) / len(v)
 out = {k: {"fetch_kb_raw": v.get("FETCH_SIZE", 0.0), "write_kb": v.get("WRITE_SIZE", 0.0),
            "hbm_bytes_per_launch": (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024} for k, v in res.items()}
