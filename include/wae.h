@@ -259,7 +259,8 @@ int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilatio
 typedef struct wae_tm_desc {
   int32_t dtype;
   int32_t B, T;
-  int32_t M;    /* output rows, multiple of 32, M/32 in {1,2,3,4,6,8} */
+  int32_t M;    /* output rows, multiple of 32: M/32 in {1,2,3,4,6,8}, or (modes 0/1/3/4) any multiple of 128: the output is then
+                   cut into equal slices of 8, 6 or 4 tiles and w_packed is [slice][chunk] (packing.py: first_gemm_map) */
   int32_t nsrc;
   int32_t mode;
   float alpha;
@@ -267,6 +268,28 @@ typedef struct wae_tm_desc {
 int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
                 const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,
                 int64_t out_stride, const void* aux, int64_t aux_stride, void* stream);
+
+/* Wide decoder head: skip / head widths above 256 (BASELINE config C5: R = S = 512) do not fit the register-chained
+ * wae_head_fwd / wae_head_bwd; the same arithmetic (wavenet.py:204-214, vqwae_train.py:363-379 with the shift of :764)
+ * then runs as launches of the kernel above with epilogues, h0 / h1 / dy / dh1 passing through HBM:
+ *   mode 3: out = relu(alpha * (bias[m] + acc)), aux = fp32 bias (M floats, aux_stride ignored)
+ *   mode 4: out = aux[t][m] > 0 ? alpha * acc : 0, aux = the saved activation (t, M) in the compute dtype
+ *   mode 5 (wae_gemm_tm_ce): acc = bias + W3 h1 over M = Op in {128, 256} padded classes; ce->logits (B,O,T) fp32 and / or
+ *           ce->nll[b,t] = lse - y[target[t+1]] (0 at t = T-1), ce->lse optional; `out` unused
+ *   mode 6 (wae_gemm_tm_ce): out (t, Op) = (exp(bias + acc - ce->lse[t]) - onehot(target[t+1])) * w[t],
+ *           w[t] = ce->inv_count if t + 1 < min(lengths[b], T) else 0 (lengths == NULL: T) */
+typedef struct wae_tm_ce {
+  float* logits;
+  const int32_t* target;
+  float* nll;
+  float* lse;
+  const int32_t* lengths;
+  float inv_count;
+  int32_t O;
+} wae_tm_ce;
+int wae_gemm_tm_ce(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
+                   const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,
+                   int64_t out_stride, const float* bias, const wae_tm_ce* ce, void* stream);
 
 /* ---- weight gradients: C[m][n] += alpha * sum_{b,t} P[b,t][m] * Q[b,t+shift][n]  (csrc/gemm_tn.hip) ----------
  * The work is described as an array of 128x128 output tiles in DEVICE memory; one launch processes them all (the

@@ -1,0 +1,131 @@
+"""GPU parity of the wide configuration (BASELINE config C5: residual / gate / skip widths of 512) against the CPU oracle.
+
+Widths above 256 take different launches than the C1-C4 presets: wae_gemm_tm cuts outputs wider than 256 rows into
+slices, and the head runs as separate GEMM launches with epilogues (wae_gemm_tm modes 3-6) instead of the register-chained
+head kernels.  The same head path is also forced onto the narrow golden models (WAE_HEAD_WIDE=1), where the fused kernels
+provide a second reference."""
+import pytest
+import torch
+
+from helpers import golden_model, rel_err
+from oracle import wae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# C5 dims (R = G = S = 512, Cc = 64, Cg = 32) on a short stack / short clips so that the oracle finishes in seconds
+WIDE = dict(layers=4, stacks=2, R=512, G=512, S=512, O=256, Cc=64, Cg=32, k=3, n_speakers=8, upsample_scales=None, cin_pad=0)
+
+
+def _wide_inputs(B=2, T=777):
+    sd = O.make_state_dict(dict(WIDE), salt=5, with_encoder=False)
+    x = ((O.hash_fill((B, T), 21) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    c = O.hash_fill((B, WIDE["Cc"], T), 22, 1.3)
+    g = torch.tensor([1, 6])[:B]
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    return sd, x, xin, c, g
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_wide_forward_logits_and_loss(dtype, tol):
+    """decoder logits within 1e-3 relative (fp32; bf16: 5e-2 of the logit range) and the fused shifted CE of the wide head"""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    sd, x, xin, c, g = _wide_inputs()
+    B, T = x.shape
+    lengths = torch.tensor([T, T - 201])
+    with torch.no_grad():
+        y_ref = O.wavenet_forward(sd, dict(layers=4, stacks=2, upsample_scales=None, cin_pad=0), xin, c, g)
+        loss_ref = O.masked_ce_loss(y_ref, x.unsqueeze(-1), lengths)
+    eng = WaeEngine(Geometry.from_cfg(WIDE), dtype=dtype)
+    assert eng.wide_head
+    eng.load_state_dict(sd)
+    out = eng.decoder_forward(x.cuda(), c.cuda(), g.cuda(), targets=x.cuda(), lengths=lengths.cuda(), c_is_upsampled=True)
+    torch.cuda.synchronize()
+    assert rel_err(out["logits"].cpu(), y_ref) < tol
+    assert abs(float(out["loss"]) - float(loss_ref)) < (1e-4 if dtype == "fp32" else 3e-2)
+
+
+def _grad_check(eng, cfg, sd, x, xin, c_up, g, lengths, ocfg, ref_dtype=torch.float32):
+    """ref_dtype float64: at 512 channels the fp32 oracle itself sits on ReLU knife edges (a head pre-activation within
+    1e-6 of zero flips between the oracle in fp32 and in fp64 and moves db1 by 1 %): the reference is then the fp64 oracle."""
+    from wavenet_autoencoders_amd import backward as BW
+    psd = {k: v.clone().to(ref_dtype).requires_grad_(True) for k, v in sd.items()
+           if k.startswith("wavenet.") and "upsample_net" not in k}
+    cl = c_up.clone().to(ref_dtype).requires_grad_(True)
+    y = O.wavenet_forward(psd, dict(ocfg, upsample_scales=None), xin.to(ref_dtype), cl, g)
+    loss = O.masked_ce_loss(y, x.unsqueeze(-1), lengths)
+    loss.backward()
+    out = eng.decoder_forward(x.cuda(), c_up.cuda(), g.cuda(), targets=x.cuda(), lengths=lengths.cuda(), train=True,
+                              c_is_upsampled=True, want_logits=False)
+    dc = BW.decoder_backward(eng, x.cuda(), x.cuda(), lengths, g.cuda())
+    grads = BW.finish_grads(eng)
+    torch.cuda.synchronize()
+    res = {"loss": (abs(float(out["loss"]) - float(loss)), abs(float(loss)))}
+    for k, v in psd.items():
+        gref = (v.grad if v.grad is not None else torch.zeros_like(v)).float()
+        got = grads[eng.lay.off(k):eng.lay.off(k) + eng.lay.numel(k)].view(eng.lay.shapes[k]).cpu()
+        res[k] = (float((got - gref).abs().max()), float(gref.abs().max()))
+    dc_ref = cl.grad.transpose(1, 2).float()
+    res["dc"] = (float((dc[:, :, :cfg["Cc"]].float().cpu() - dc_ref).abs().max()), float(dc_ref.abs().max()))
+    return res
+
+
+def test_wide_backward_fp32():
+    """parameter gradients of the masked CE at R = G = S = 512 against autograd through the oracle (sliced wae_gemm_tm
+    outputs, wide-head backward launches, 512-wide weight-gradient tiles)"""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    sd, x, xin, c, g = _wide_inputs(T=640)
+    T = x.shape[1]
+    eng = WaeEngine(Geometry.from_cfg(WIDE), dtype="fp32")
+    eng.load_state_dict(sd)
+    res = _grad_check(eng, WIDE, sd, x, xin, c, g, torch.tensor([T, T - 137]), dict(layers=4, stacks=2, cin_pad=0),
+                      ref_dtype=torch.float64)
+    bad = {k: v for k, v in res.items() if v[0] > 1e-3 * max(v[1], 1e-6) + 1e-7}
+    assert not bad, bad
+
+
+def test_wide_train_step_bf16_matches_fp32_engine():
+    """bf16 (stream-K weight gradients over 512-wide regions) against the fp32 engine on the same step: loss and the
+    gradient norm agree to bf16 accuracy, and a repeated batch learns"""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    sd, x, xin, c, g = _wide_inputs(T=1280)
+    got = {}
+    for dtype in ("fp32", "bf16"):
+        eng = WaeEngine(Geometry.from_cfg(WIDE), dtype=dtype)
+        eng.load_state_dict(sd)
+        losses = []
+        for _ in range(4):
+            r = eng.train_step(x.cuda(), c.cuda(), g.cuda(), lr=1e-3)
+            losses.append(float(r["loss"]))
+            if len(losses) == 1:
+                gn = float(r["grad_norm"])
+        torch.cuda.synchronize()
+        got[dtype] = (losses, gn)
+        assert bool(torch.isfinite(eng.params).all())
+        assert losses[-1] < losses[0], losses
+    assert abs(got["bf16"][0][0] - got["fp32"][0][0]) < 3e-2
+    assert abs(got["bf16"][1] - got["fp32"][1]) < 0.1 * got["fp32"][1], got
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_wide_head_path_on_golden_models_fp32(name, monkeypatch):
+    """the separate-launch head (forced by WAE_HEAD_WIDE=1) on the golden models: logits against the reference's own
+    vectors, gradients against autograd through the oracle"""
+    monkeypatch.setenv("WAE_HEAD_WIDE", "1")
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model(name)
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype="fp32")
+    assert eng.wide_head
+    eng.load_state_dict(sd)
+    x, g = ins["x"], ins["g"]
+    T = x.shape[1]
+    c_up = torch.from_numpy(z["c_up"])
+    out = eng.decoder_forward(x.cuda(), c_up.cuda(), g.cuda(), c_is_upsampled=True)
+    torch.cuda.synchronize()
+    assert rel_err(out["logits"].cpu(), torch.from_numpy(z["y_hat"])) < 1e-3
+    res = _grad_check(eng, cfg, sd, x, ins["xin"], c_up, g, torch.tensor([T, T - 137]), ocfg)
+    bad = {k: v for k, v in res.items() if v[0] > 1e-3 * max(v[1], 1e-6) + 1e-7}
+    assert not bad, bad

@@ -28,6 +28,11 @@ class TmDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "M", "nsrc", "mode")] + [("alpha", c_f32)]
 
 
+class TmCe(ctypes.Structure):            # include/wae.h: wae_tm_ce (modes 5 / 6 of the wide head)
+    _fields_ = [("logits", c_vp), ("target", c_vp), ("nll", c_vp), ("lse", c_vp), ("lengths", c_vp), ("inv_count", c_f32),
+                ("O", c_i32)]
+
+
 class TnTile(ctypes.Structure):          # include/wae.h: wae_tn_tile (device array element)
     _fields_ = [("P", c_vp), ("Q", c_vp), ("onehot", c_vp), ("C", c_vp), ("p_stride", c_i64), ("q_stride", c_i64), ("ldc", c_i64),
                 ("m_valid", c_i32), ("n_valid", c_i32), ("m0", c_i32), ("shift", c_i32), ("ones_col", c_i32), ("alpha", c_f32)]
@@ -76,6 +81,7 @@ SIGNATURES = {
     "wae_head_bwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 7 + [c_f32] + [c_vp] * 5),
     "wae_head_bwd_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_gemm_tm": (c_i32, [ctypes.POINTER(TmDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "wae_gemm_tm_ce": (c_i32, [ctypes.POINTER(TmDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(TmCe), c_vp]),
     "wae_gemm_tn_tiles": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "wae_glu_bwd_fused_supported": (c_i32, [c_i32, c_i32]),
     "wae_glu_bwd_fused": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

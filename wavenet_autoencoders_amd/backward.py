@@ -41,7 +41,7 @@ def _prepare_bwd(eng):
         eng.n_buo = eng.m_buo.numel()
         eng.w_buo = torch.zeros(g.layers * eng.n_buo, dtype=eng.tdtype, device=dev)
     eng.m_bc = up(P.bwd_c_map(g, lay, eng.dt)) if g.Ccp else None
-    eng.m_hb_w = up(P.head_bwd_map(g, lay, eng.dt))
+    eng.m_hb_w = up(P.head_bwd_map(g, lay, eng.dt)) if not eng.wide_head else torch.zeros(0, dtype=torch.int32, device=dev)
     eng.n_bu, eng.n_bx = eng.m_bu.numel(), eng.m_bx.numel()
     eng.w_bu = torch.zeros(g.layers * eng.n_bu, dtype=eng.tdtype, device=dev)
     eng.w_bx = torch.zeros(g.layers * eng.n_bx, dtype=eng.tdtype, device=dev)
@@ -76,8 +76,13 @@ def pack_bwd_weights(eng):
     if g.Ccp:
         L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bc), L.ptr(eng.w_bc), eng.m_bc.numel(), 1, 0, 0, eng.dt, st),
                 "pack bwd C")
-    L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_hb_w), L.ptr(eng.w_hb), eng.m_hb_w.numel(), 1, 0, 0, eng.dt, st),
-            "pack head bwd")
+    if eng.wide_head:
+        for k in ("w3t", "w1t"):
+            L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_hwide[k]), L.ptr(eng.w_hwide[k]), eng.m_hwide[k].numel(), 1, 0, 0,
+                                        eng.dt, st), "pack wide head " + k)
+    else:
+        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_hb_w), L.ptr(eng.w_hb), eng.m_hb_w.numel(), 1, 0, 0, eng.dt, st),
+                "pack head bwd")
 
 
 def _arr(ctype, vals):
@@ -93,6 +98,18 @@ def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=Non
     shifts = _arr(ctypes.c_int32, [s[3] for s in srcs])
     L.check(eng.lib.wae_gemm_tm(ctypes.byref(d), ptrs, strides, cols, shifts, ctypes.c_void_p(w_ptr), ctypes.c_void_p(out_ptr),
                                 out_stride, ctypes.c_void_p(aux_ptr) if aux_ptr else None, aux_stride, eng.stream()), "gemm_tm")
+
+
+def _tm_ce(eng, B, T, M, mode, srcs, w_ptr, out_ptr, out_stride, bias_ptr, ce):
+    """wae_gemm_tm_ce (modes 5 / 6 of the wide head): ce is an L.TmCe"""
+    d = L.TmDesc(eng.dt, B, T, M, len(srcs), mode, 1.0)
+    ptrs = _arr(ctypes.c_void_p, [s[0] for s in srcs])
+    strides = _arr(ctypes.c_int64, [s[1] for s in srcs])
+    cols = _arr(ctypes.c_int32, [s[2] for s in srcs])
+    shifts = _arr(ctypes.c_int32, [s[3] for s in srcs])
+    L.check(eng.lib.wae_gemm_tm_ce(ctypes.byref(d), ptrs, strides, cols, shifts, ctypes.c_void_p(w_ptr),
+                                   ctypes.c_void_p(out_ptr) if out_ptr else None, out_stride, ctypes.c_void_p(bias_ptr),
+                                   ctypes.byref(ce), eng.stream()), "gemm_tm_ce")
 
 
 class TileTable:
@@ -311,11 +328,24 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     # ---- head --------------------------------------------------------------------------------------------------
     hd = L.HeadDesc(eng.dt, B, T, g.Ku, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
     b3 = ctypes.c_void_p(eng.b_head.data_ptr() + 2 * g.Sp * 4)
-    L.check(lib.wae_head_bwd(ctypes.byref(hd), L.ptr(fw["h0"]), L.ptr(fw["h1"]), L.ptr(eng.w_hb), b3, L.ptr(fw["lse"]), L.ptr(tg),
-                             L.ptr(ln), inv_count, L.ptr(ext_dy), L.ptr(ws["dy"]), L.ptr(ws["dh1"]), L.ptr(ws["dskip"]), st),
-            "head_bwd")
-    if ext_dy is not None:
-        ws["dy"].copy_(ext_dy)                # the tile table points at ws["dy"]
+    if eng.wide_head:
+        # the same three steps as csrc/head_bwd.hip, one wae_gemm_tm launch each (dy, dh1, dskip through HBM)
+        if ext_dy is not None:
+            ws["dy"].copy_(ext_dy)
+        else:
+            ce = L.TmCe(None, tg.data_ptr(), None, fw["lse"].data_ptr(), ln.data_ptr() if ln is not None else None, inv_count, g.O)
+            _tm_ce(eng, B, T, g.Op, 6, [(fw["h1"].data_ptr(), g.Sp, g.Sp, 0)], eng.w_hwide["w3"].data_ptr(), ws["dy"].data_ptr(),
+                   g.Op, b3.value, ce)
+        _tm(eng, B, T, g.Sp, 4, 1.0, [(ws["dy"].data_ptr(), g.Op, g.Op, 0)], eng.w_hwide["w3t"].data_ptr(), ws["dh1"].data_ptr(),
+            g.Sp, fw["h1"].data_ptr(), g.Sp)
+        _tm(eng, B, T, g.Sp, 4, math.sqrt(1.0 / g.layers), [(ws["dh1"].data_ptr(), g.Sp, g.Sp, 0)], eng.w_hwide["w1t"].data_ptr(),
+            ws["dskip"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp)
+    else:
+        L.check(lib.wae_head_bwd(ctypes.byref(hd), L.ptr(fw["h0"]), L.ptr(fw["h1"]), L.ptr(eng.w_hb), b3, L.ptr(fw["lse"]), L.ptr(tg),
+                                 L.ptr(ln), inv_count, L.ptr(ext_dy), L.ptr(ws["dy"]), L.ptr(ws["dh1"]), L.ptr(ws["dskip"]), st),
+                "head_bwd")
+        if ext_dy is not None:
+            ws["dy"].copy_(ext_dy)                # the tile table points at ws["dy"]
     c3, c1h, cs = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"]
     ws["tt_head"].launch(B, T)
 

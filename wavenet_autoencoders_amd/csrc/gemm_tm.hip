@@ -21,6 +21,22 @@
 #define TM_PLAIN 0
 #define TM_RESIDUAL 1  // out = alpha * (acc + res[t])
 #define TM_GATE_BWD 2  // acc = du (NT = Hp/32 tiles); out (t, 2Hp) = [da | db] from z (t, 2Hp)
+// The wide decoder head (skip / head widths above 256: the fused csrc/head_fwd.hip / head_bwd.hip keep every tile of a time
+// column in one wave) runs as separate launches of this kernel, intermediate activations through HBM:
+#define TM_BIAS_RELU 3  // out = relu(alpha * (bias[m] + acc)), aux = fp32 bias (M)             (wavenet.py:208-213)
+#define TM_RELU_BWD 4   // out = aux[t][m] > 0 ? alpha * acc : 0, aux = the saved activation      (autograd of the ReLUs)
+#define TM_CE 5         // acc = bias + logits (M = Op): optional (B,O,T) store, nll / lse of the shifted targets
+#define TM_CE_BWD 6     // out = (softmax(bias + acc) - onehot(target[t+1])) * w[t]  from the saved lse
+
+struct TmCe {           // modes 5 / 6 (vqwae_train.py:363-379 with the shift of :764)
+  float* logits;
+  const int32_t* target;
+  float* nll;
+  float* lse;
+  const int32_t* lengths;
+  float inv_count;
+  int O;
+};
 
 struct TmArgs {
   const char* src[TM_MAX_SRC];
@@ -35,6 +51,7 @@ struct TmArgs {
   int64_t aux_stride;
   float alpha;
   int B, T, mode;
+  TmCe ce;
 };
 
 template <typename E, int NT, int MODE, int OCC>
@@ -53,9 +70,14 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
   const int t = t0w + n;
   const bool tvalid = t < p.T;
   const int rows_valid = min(max(p.T - t0w, 0), 32);
+  // M above 256 rows: blockIdx.y picks a slice of NT tiles; the weight stream is [slice][chunk], out / aux columns follow
+  const int slice = blockIdx.y;
+  const int64_t col0 = (int64_t)slice * NT * 32;
+  constexpr bool RES_LIKE = MODE == TM_RESIDUAL || MODE == TM_RELU_BWD;
+  constexpr bool BIASED = MODE == TM_BIAS_RELU || MODE == TM_CE || MODE == TM_CE_BWD;
   // PAIRED: two workgroups per CU; the gate-backward epilogue then walks the tiles two at a time (fetch of the next
   // pair under the math of this one) so that it fits 256 registers, and stages through 4 KiB per wave
-  constexpr bool PAIRED = OCC == 2 && MODE != TM_PLAIN && NT % 2 == 0 && sizeof(E) == 2;
+  constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD) && NT % 2 == 0 && sizeof(E) == 2;
   constexpr int STGB = PAIRED ? 4096 : STG_BYTES;
   // PAIRED stages through the (then idle) weight ring after the chunk loop: 2 x (2 CHB) <= 128 KiB of LDS per CU
   char* stg = PAIRED ? smem + wave * STGB : smem + 2 * CHB + wave * STGB;
@@ -88,24 +110,30 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
     }
   };
 
+  const char* wbase = p.w + (int64_t)slice * nq * CHB;
   f32x16 acc[NT];
 #pragma unroll
-  for (int m = 0; m < NT; ++m)
+  for (int m = 0; m < NT; ++m) {
+    if constexpr (BIASED) {
+      init_rows(acc[m], (const float*)p.aux + col0 + 32 * m, h);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    }
+  }
 
   // rows the epilogue needs (residual, or the saved pre-activations z): fetched now, they arrive under the MFMAs
-  constexpr int NAUX = PAIRED ? 1 : (MODE == TM_GATE_BWD ? 2 * NT : (MODE == TM_RESIDUAL ? NT : 1));
+  constexpr int NAUX = PAIRED ? 1 : (MODE == TM_GATE_BWD ? 2 * NT : (RES_LIKE ? NT : 1));
   constexpr int NPASS_AUX = StagePasses<NAUX, E>::N;
   [[maybe_unused]] f32x4 fa[8], fb[8];
   f32x4 pre_a[NPASS_AUX][8];
   [[maybe_unused]] f32x4 pre_b[NPASS_AUX][8];
-  if constexpr (PAIRED && MODE == TM_RESIDUAL) {
+  if constexpr (PAIRED && RES_LIKE) {
     if (rows_valid > 0 && !TM_ABL(8))
-      stage_fetch_pass<E, 2>(fa, p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES, p.aux_stride * ES, rows_valid, lane);
-  } else if constexpr (MODE == TM_RESIDUAL) {
+      stage_fetch_pass<E, 2>(fa, p.aux + (((int64_t)b * p.T + t0w) * p.aux_stride + col0) * ES, p.aux_stride * ES, rows_valid, lane);
+  } else if constexpr (RES_LIKE) {
     if (rows_valid > 0 && !TM_ABL(8))
-      stage_fetch_tiles<E, NT>(pre_a, p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES, p.aux_stride * ES, rows_valid, lane);
+      stage_fetch_tiles<E, NT>(pre_a, p.aux + (((int64_t)b * p.T + t0w) * p.aux_stride + col0) * ES, p.aux_stride * ES, rows_valid, lane);
   } else if constexpr (PAIRED) {
     if (rows_valid > 0 && !TM_ABL(8)) {
       const char* zrow = p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES;
@@ -120,7 +148,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
     }
   }
 
-  if (!TM_ABL(2)) dma_chunk(p.w, smem, CHB, wave, lane);
+  if (!TM_ABL(2)) dma_chunk(wbase, smem, CHB, wave, lane);
   load_B(0, Bn);
   for (int q = 0; q < nq; ++q) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -128,7 +156,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
     if (q + 1 < nq) {
-      if (!TM_ABL(2)) dma_chunk(p.w + (int64_t)(q + 1) * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
+      if (!TM_ABL(2)) dma_chunk(wbase + (int64_t)(q + 1) * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
       load_B(q + 1, Bn);
     }
     const char* buf = smem + (q & 1) * CHB + lane * 16;
@@ -145,12 +173,89 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
     return;
   }
 
+  [[maybe_unused]] auto combine = [&](float a, float r) -> float {
+    if constexpr (MODE == TM_RELU_BWD) return r > 0.f ? p.alpha * a : 0.f;
+    else return p.alpha * (a + r);
+  };
   if constexpr (MODE == TM_PLAIN) {
+    char* orow = p.out + (((int64_t)b * p.T + t0w) * p.out_stride + col0) * ES;
+    stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
+  } else if constexpr (MODE == TM_BIAS_RELU) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = fmaxf(acc[m][r] * p.alpha, 0.f);
+    char* orow = p.out + (((int64_t)b * p.T + t0w) * p.out_stride + col0) * ES;
+    stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
+  } else if constexpr (MODE == TM_CE) {
+    // logits (B,O,T) and / or the shifted cross-entropy: same arithmetic as csrc/head_fwd.hip, all O tiles at once
+    const TmCe& c = p.ce;
+    const bool want_ce = c.target != nullptr && c.nll != nullptr;
+    int tgt = -1;
+    if (want_ce && tvalid && t + 1 < p.T) tgt = c.target[(int64_t)b * p.T + t + 1];
+    float run_m = -INFINITY, run_s = 0.f, picked = 0.f;
+    if (tvalid) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        float tile_m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cls = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (cls < c.O) {
+            if (c.logits) c.logits[((int64_t)b * c.O + cls) * p.T + t] = acc[m][r];
+            tile_m = fmaxf(tile_m, acc[m][r]);
+            if (cls == tgt) picked = acc[m][r];
+          }
+        }
+        if (want_ce && tile_m > -INFINITY) {
+          const float nm = fmaxf(run_m, tile_m);
+          float s = run_s * __expf(run_m - nm);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cls = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (cls < c.O) s += __expf(acc[m][r] - nm);
+          }
+          run_m = nm;
+          run_s = s;
+        }
+      }
+    }
+    if (want_ce) {
+      const float om = __shfl_xor(run_m, 32), os = __shfl_xor(run_s, 32), op = __shfl_xor(picked, 32);
+      const float nm = fmaxf(run_m, om);
+      float s = 0.f;
+      if (run_m > -INFINITY) s += run_s * __expf(run_m - nm);
+      if (om > -INFINITY) s += os * __expf(om - nm);
+      if (tvalid && h == 0) {
+        float v = 0.f;
+        if (tgt >= 0) v = (nm + __logf(s)) - (picked + op);
+        c.nll[(int64_t)b * p.T + t] = v;
+        if (c.lse) c.lse[(int64_t)b * p.T + t] = nm + __logf(s);
+      }
+    }
+  } else if constexpr (MODE == TM_CE_BWD) {
+    const TmCe& c = p.ce;
+    const float lse = tvalid ? c.lse[(int64_t)b * p.T + t] : 0.f;
+    int tgt = -1;
+    float wt = 0.f;
+    if (tvalid && t + 1 < p.T) {
+      const int len = c.lengths ? min(c.lengths[b], p.T) : p.T;
+      if (t < len - 1) { wt = c.inv_count; tgt = c.target[(int64_t)b * p.T + t + 1]; }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cls = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float g = 0.f;
+        if (cls < c.O) g = (expf(acc[m][r] - lse) - (cls == tgt ? 1.f : 0.f)) * wt;
+        acc[m][r] = g;
+      }
     char* orow = p.out + ((int64_t)b * p.T + t0w) * p.out_stride * ES;
     stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
-  } else if constexpr (MODE == TM_RESIDUAL && PAIRED) {
-    const char* arow = p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES;
-    char* orow = p.out + ((int64_t)b * p.T + t0w) * p.out_stride * ES;
+  } else if constexpr (RES_LIKE && PAIRED) {
+    const char* arow = p.aux + (((int64_t)b * p.T + t0w) * p.aux_stride + col0) * ES;
+    char* orow = p.out + (((int64_t)b * p.T + t0w) * p.out_stride + col0) * ES;
 #pragma unroll
     for (int pr = 0; pr < NT / 2; ++pr) {
       f32x16 res[2];
@@ -159,17 +264,17 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[2 * pr + i][r] = p.alpha * (acc[2 * pr + i][r] + res[i][r]);
+        for (int r = 0; r < 16; ++r) acc[2 * pr + i][r] = combine(acc[2 * pr + i][r], res[i][r]);
       stage_store_pass<E, 2, 128>(stg, &acc[2 * pr], orow + pr * 64 * ES, p.out_stride * ES, rows_valid, lane);
     }
-  } else if constexpr (MODE == TM_RESIDUAL) {
+  } else if constexpr (RES_LIKE) {
     f32x16 res[NT];
     stage_unpack_tiles<E, NT>(stg, res, pre_a, lane);
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = p.alpha * (acc[m][r] + res[m][r]);
-    char* orow = p.out + ((int64_t)b * p.T + t0w) * p.out_stride * ES;
+      for (int r = 0; r < 16; ++r) acc[m][r] = combine(acc[m][r], res[m][r]);
+    char* orow = p.out + (((int64_t)b * p.T + t0w) * p.out_stride + col0) * ES;
     stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
   } else {
     // gate backward (modules.py:154: u = tanh(a) * sigmoid(b)):  da = du * s * (1 - th^2),  db = du * th * s * (1 - s)
@@ -223,9 +328,9 @@ static int g_tm_occ = 2 | 4;   // bit 1: gate-backward launches, bit 2: residual
 extern "C" void wae_debug_set_tm_occ(int occ) { g_tm_occ = occ; }
 
 template <typename E, int NT, int MODE, int OCC>
-static int launch_tm_occ(const TmArgs& a, hipStream_t st) {
+static int launch_tm_occ(const TmArgs& a, int nslices, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
-  constexpr bool PAIRED = OCC == 2 && MODE != TM_PLAIN && NT % 2 == 0 && sizeof(E) == 2;
+  constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD) && NT % 2 == 0 && sizeof(E) == 2;
   const size_t lds = PAIRED ? 2 * CHB : 2 * CHB + 4 * STG_BYTES;
   static size_t attr_done = 0;
   if (attr_done < lds) {
@@ -237,41 +342,82 @@ static int launch_tm_occ(const TmArgs& a, hipStream_t st) {
     attr_done = lds;
   }
   const int tiles = (a.T + 127) / 128;
-  hipLaunchKernelGGL((gemm_tm_kernel<E, NT, MODE, OCC>), dim3(a.B * tiles), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_tm_kernel<E, NT, MODE, OCC>), dim3(a.B * tiles, nslices), dim3(256), lds, st, a);
   return wae_check_launch("gemm_tm");
 }
 template <typename E, int NT, int MODE>
-static int launch_tm(const TmArgs& a, hipStream_t st) {
-  if constexpr (sizeof(E) == 2 && NT % 2 == 0 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL)) {
-    if (g_tm_occ & (MODE == TM_GATE_BWD ? 2 : 4)) return launch_tm_occ<E, NT, MODE, 2>(a, st);
+static int launch_tm(const TmArgs& a, int nslices, hipStream_t st) {
+  if constexpr (sizeof(E) == 2 && NT % 2 == 0 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD)) {
+    if (g_tm_occ & (MODE == TM_GATE_BWD ? 2 : 4)) return launch_tm_occ<E, NT, MODE, 2>(a, nslices, st);
   }
-  return launch_tm_occ<E, NT, MODE, 1>(a, st);
+  return launch_tm_occ<E, NT, MODE, 1>(a, nslices, st);
+}
+
+// M/32 tiles -> (tiles per slice, slices): up to 8 tiles in one slice, wider outputs in equal slices of 8, 6 or 4 tiles
+static bool tm_slicing(int nt, int* nts, int* nslices) {
+  if (nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 6 || nt == 8) { *nts = nt; *nslices = 1; return true; }
+  for (int c : {8, 6, 4})
+    if (nt % c == 0) { *nts = c; *nslices = nt / c; return true; }
+  return false;
 }
 
 template <typename E, int MODE>
 static int dispatch_nt(int nt, const TmArgs& a, hipStream_t st) {
-  switch (nt) {
-    case 1: return launch_tm<E, 1, MODE>(a, st);
-    case 2: return launch_tm<E, 2, MODE>(a, st);
-    case 3: return launch_tm<E, 3, MODE>(a, st);
-    case 4: return launch_tm<E, 4, MODE>(a, st);
-    case 6: return launch_tm<E, 6, MODE>(a, st);
-    case 8: return launch_tm<E, 8, MODE>(a, st);
-    default:
-      wae_set_error("gemm_tm: unsupported M=%d (M/32 must be 1,2,3,4,6 or 8)", nt * 32);
-      return WAE_EUNSUPPORTED;
+  int nts = 0, nsl = 0;
+  if (!tm_slicing(nt, &nts, &nsl) || (nsl > 1 && (MODE == TM_GATE_BWD || MODE == TM_CE || MODE == TM_CE_BWD))) {
+    wae_set_error("gemm_tm: unsupported M=%d for mode %d (M/32 must be 1,2,3,4,6,8 or, modes 0/1/3/4, a multiple of 4)", nt * 32, MODE);
+    return WAE_EUNSUPPORTED;
+  }
+  if constexpr (MODE == TM_CE || MODE == TM_CE_BWD) {   // M = Op: 128 or 256 classes (padded)
+    if (nts == 4) return launch_tm<E, 4, MODE>(a, nsl, st);
+    if (nts == 8) return launch_tm<E, 8, MODE>(a, nsl, st);
+    wae_set_error("gemm_tm: modes 5/6 need M = 128 or 256 (got %d)", nt * 32);
+    return WAE_EUNSUPPORTED;
+  } else if constexpr (MODE == TM_BIAS_RELU || MODE == TM_RELU_BWD) {
+    switch (nts) {
+      case 4: return launch_tm<E, 4, MODE>(a, nsl, st);
+      case 6: return launch_tm<E, 6, MODE>(a, nsl, st);
+      case 8: return launch_tm<E, 8, MODE>(a, nsl, st);
+      default:
+        wae_set_error("gemm_tm: modes 3/4 need M a multiple of 128 or 192 (got %d)", nt * 32);
+        return WAE_EUNSUPPORTED;
+    }
+  } else {
+    switch (nts) {
+      case 1: return launch_tm<E, 1, MODE>(a, nsl, st);
+      case 2: return launch_tm<E, 2, MODE>(a, nsl, st);
+      case 3: return launch_tm<E, 3, MODE>(a, nsl, st);
+      case 4: return launch_tm<E, 4, MODE>(a, nsl, st);
+      case 6: return launch_tm<E, 6, MODE>(a, nsl, st);
+      default: return launch_tm<E, 8, MODE>(a, nsl, st);
+    }
   }
 }
 
-extern "C" int wae_gemm_tm(const wae_tm_desc* d, const void* const* src, const int64_t* src_stride, const int32_t* src_cols,
-                           const int32_t* src_shift, const void* w_packed, void* out, int64_t out_stride, const void* aux,
-                           int64_t aux_stride, void* stream) {
-  WAE_REQUIRE(d && src && src_stride && src_cols && src_shift && w_packed && out, "gemm_tm: null pointer argument");
+template <typename E>
+static int dispatch_mode(int mode, int nt, const TmArgs& a, hipStream_t st) {
+  switch (mode) {
+    case TM_PLAIN: return dispatch_nt<E, TM_PLAIN>(nt, a, st);
+    case TM_RESIDUAL: return dispatch_nt<E, TM_RESIDUAL>(nt, a, st);
+    case TM_GATE_BWD: return dispatch_nt<E, TM_GATE_BWD>(nt, a, st);
+    case TM_BIAS_RELU: return dispatch_nt<E, TM_BIAS_RELU>(nt, a, st);
+    case TM_RELU_BWD: return dispatch_nt<E, TM_RELU_BWD>(nt, a, st);
+    case TM_CE: return dispatch_nt<E, TM_CE>(nt, a, st);
+    default: return dispatch_nt<E, TM_CE_BWD>(nt, a, st);
+  }
+}
+
+static int tm_run(const wae_tm_desc* d, const void* const* src, const int64_t* src_stride, const int32_t* src_cols,
+                  const int32_t* src_shift, const void* w_packed, void* out, int64_t out_stride, const void* aux,
+                  int64_t aux_stride, const wae_tm_ce* ce, void* stream) {
+  WAE_REQUIRE(d && src && src_stride && src_cols && src_shift && w_packed, "gemm_tm: null pointer argument");
   WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "gemm_tm: bad dtype");
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->M > 0 && d->M % 32 == 0, "gemm_tm: bad sizes");
   WAE_REQUIRE(d->nsrc >= 1 && d->nsrc <= TM_MAX_SRC, "gemm_tm: 1..%d sources", TM_MAX_SRC);
-  WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "gemm_tm: bad mode");
+  WAE_REQUIRE(d->mode >= 0 && d->mode <= TM_CE_BWD, "gemm_tm: bad mode");
   WAE_REQUIRE(d->mode == TM_PLAIN || aux, "gemm_tm: this mode needs aux");
+  WAE_REQUIRE(d->mode == TM_CE || out, "gemm_tm: null output");
+  WAE_REQUIRE((d->mode != TM_CE && d->mode != TM_CE_BWD) || ce, "gemm_tm: modes 5/6 go through wae_gemm_tm_ce");
   const int ck = d->dtype == WAE_BF16 ? 64 : 32;
   TmArgs a;
   for (int s = 0; s < TM_MAX_SRC; ++s) {
@@ -284,14 +430,28 @@ extern "C" int wae_gemm_tm(const wae_tm_desc* d, const void* const* src, const i
   }
   a.nsrc = d->nsrc; a.w = (const char*)w_packed; a.out = (char*)out; a.out_stride = out_stride; a.aux = (const char*)aux;
   a.aux_stride = aux_stride; a.alpha = d->alpha; a.B = d->B; a.T = d->T; a.mode = d->mode;
+  a.ce = TmCe{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  if (ce) {
+    WAE_REQUIRE(ce->O > 0 && ce->O <= d->M, "gemm_tm: 0 < O <= M");
+    if (d->mode == TM_CE) WAE_REQUIRE(ce->logits || (ce->target && ce->nll), "gemm_tm: mode 5 produces logits and / or nll");
+    if (d->mode == TM_CE_BWD) WAE_REQUIRE(ce->lse && ce->target, "gemm_tm: mode 6 needs lse and target");
+    a.ce = TmCe{ce->logits, ce->target, ce->nll, ce->lse, ce->lengths, ce->inv_count, ce->O};
+  }
   hipStream_t st = as_stream(stream);
   const int nt = d->M / 32;
-  if (d->dtype == WAE_BF16) {
-    if (d->mode == TM_PLAIN) return dispatch_nt<__bf16, TM_PLAIN>(nt, a, st);
-    if (d->mode == TM_RESIDUAL) return dispatch_nt<__bf16, TM_RESIDUAL>(nt, a, st);
-    return dispatch_nt<__bf16, TM_GATE_BWD>(nt, a, st);
-  }
-  if (d->mode == TM_PLAIN) return dispatch_nt<float, TM_PLAIN>(nt, a, st);
-  if (d->mode == TM_RESIDUAL) return dispatch_nt<float, TM_RESIDUAL>(nt, a, st);
-  return dispatch_nt<float, TM_GATE_BWD>(nt, a, st);
+  if (d->dtype == WAE_BF16) return dispatch_mode<__bf16>(d->mode, nt, a, st);
+  return dispatch_mode<float>(d->mode, nt, a, st);
+}
+
+extern "C" int wae_gemm_tm(const wae_tm_desc* d, const void* const* src, const int64_t* src_stride, const int32_t* src_cols,
+                           const int32_t* src_shift, const void* w_packed, void* out, int64_t out_stride, const void* aux,
+                           int64_t aux_stride, void* stream) {
+  return tm_run(d, src, src_stride, src_cols, src_shift, w_packed, out, out_stride, aux, aux_stride, nullptr, stream);
+}
+
+extern "C" int wae_gemm_tm_ce(const wae_tm_desc* d, const void* const* src, const int64_t* src_stride, const int32_t* src_cols,
+                              const int32_t* src_shift, const void* w_packed, void* out, int64_t out_stride, const float* bias,
+                              const wae_tm_ce* ce, void* stream) {
+  WAE_REQUIRE(d && (d->mode == TM_CE || d->mode == TM_CE_BWD) && ce && bias, "gemm_tm_ce: mode 5 or 6 with ce and bias");
+  return tm_run(d, src, src_stride, src_cols, src_shift, w_packed, out, out_stride, bias, 0, ce, stream);
 }

@@ -51,7 +51,15 @@ class WaeEngine:
         self.m_b2 = up(P.glu_bias2_map(g, self.lay))
         tab, fb = P.first_conv_maps(g, self.lay)
         self.m_tab, self.m_fb = up(tab), up(fb)
-        self.m_hw = up(P.head_w_map(g, self.lay, self.dt))
+        # head: register-chained kernels up to 256 skip channels; wider heads as separate GEMM launches (csrc/gemm_tm.hip)
+        self.wide_head = P.head_is_wide(g)
+        if self.wide_head:
+            hm = P.head_wide_maps(g, self.lay, self.dt)
+            self.m_hwide = {k: up(v) for k, v in hm.items()}
+            self.w_hwide = {k: torch.zeros(v.numel(), dtype=self.tdtype, device=dev) for k, v in self.m_hwide.items()}
+            self.m_hw = torch.zeros(0, dtype=torch.int32, device=dev)
+        else:
+            self.m_hw = up(P.head_w_map(g, self.lay, self.dt))
         self.m_hb = up(P.head_bias_map(g, self.lay))
         self.n_w1 = self.m_w1.numel()
         self.n_w2 = self.m_w2.numel()
@@ -109,8 +117,13 @@ class WaeEngine:
                                     L.WAE_F32, st), "pack first table")
         L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_fb), L.ptr(self.first_bias), g.Rp, 1, 0, 0, L.WAE_F32, st),
                 "pack first bias")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hw), L.ptr(self.w_head), self.m_hw.numel(), 1, 0, 0,
-                                    self.dt, st), "pack head W")
+        if self.wide_head:
+            for k in ("skip", "w1", "w3"):
+                L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hwide[k]), L.ptr(self.w_hwide[k]), self.m_hwide[k].numel(),
+                                            1, 0, 0, self.dt, st), "pack wide head " + k)
+        else:
+            L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hw), L.ptr(self.w_head), self.m_hw.numel(), 1, 0, 0,
+                                        self.dt, st), "pack head W")
         L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hb), ctypes.c_void_p(self.b_head.data_ptr() + g.Sp * 4),
                                     g.Sp + g.Op, 1, 0, 0, L.WAE_F32, st), "pack head bias")
         L.check(lib.wae_sum_rows(L.ptr(self.eff), lay.off("wavenet.conv_layers.0.conv1x1_skip.bias"), lay.layer_stride,
@@ -134,6 +147,7 @@ class WaeEngine:
             if train:
                 ws["z"] = [torch.empty(B, T, 2 * g.Hp, dtype=td, device=dev) for _ in range(g.layers)]
                 ws["lse"] = torch.zeros(B, T, dtype=torch.float32, device=dev)
+            if train or self.wide_head:       # the wide head passes h0 / h1 through HBM in inference too
                 ws["h0"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
                 ws["h1"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
             self._ws[key] = ws
@@ -279,10 +293,13 @@ class WaeEngine:
         hd = L.HeadDesc(self.dt, B, T, g.Ku, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
         logits = torch.empty(B, g.O, T, dtype=torch.float32, device=self.device) if want_logits else None
         tg = targets.to(torch.int32).contiguous() if targets is not None else None
-        L.check(lib.wae_head_fwd(ctypes.byref(hd), L.ptr(ws["u"]), L.ptr(self.w_head), L.ptr(self.b_head), L.ptr(logits),
-                                 L.ptr(tg), L.ptr(ws["nll"]) if tg is not None else None,
-                                 L.ptr(ws["lse"]) if (train and tg is not None) else None,
-                                 L.ptr(ws["h0"]) if train else None, L.ptr(ws["h1"]) if train else None, st), "head")
+        if self.wide_head:
+            self._head_fwd_wide(ws, B, T, logits, tg, train)
+        else:
+            L.check(lib.wae_head_fwd(ctypes.byref(hd), L.ptr(ws["u"]), L.ptr(self.w_head), L.ptr(self.b_head), L.ptr(logits),
+                                     L.ptr(tg), L.ptr(ws["nll"]) if tg is not None else None,
+                                     L.ptr(ws["lse"]) if (train and tg is not None) else None,
+                                     L.ptr(ws["h0"]) if train else None, L.ptr(ws["h1"]) if train else None, st), "head")
         out = dict(logits=logits, nll=None, loss=None)
         if tg is not None:
             ln = lengths.to(self.device, torch.int32).contiguous() if lengths is not None else None
@@ -290,6 +307,23 @@ class WaeEngine:
             out["nll"] = ws["nll"]
             out["loss"] = ws["loss"][0]
         return out
+
+    def _head_fwd_wide(self, ws, B, T, logits, tg, train):
+        """wavenet.py:204-214 (+ the shifted CE of vqwae_train.py:363-379,:764) for skip widths above 256: three launches of
+        wae_gemm_tm -- h0 = relu(sqrt(1/L) (sum_l b_skip_l + W_skip u)), h1 = relu(b1 + W1 h0), logits / nll from b3 + W3 h1."""
+        from . import backward as BW
+        g = self.g
+        bh = self.b_head.data_ptr()
+        BW._tm(self, B, T, g.Sp, 3, math.sqrt(1.0 / g.layers), [(ws["u"].data_ptr(), g.Ku, g.Ku, 0)],
+               self.w_hwide["skip"].data_ptr(), ws["h0"].data_ptr(), g.Sp, bh, 0)
+        BW._tm(self, B, T, g.Sp, 3, 1.0, [(ws["h0"].data_ptr(), g.Sp, g.Sp, 0)], self.w_hwide["w1"].data_ptr(),
+               ws["h1"].data_ptr(), g.Sp, bh + g.Sp * 4, 0)
+        ce = L.TmCe(logits.data_ptr() if logits is not None else None, tg.data_ptr() if tg is not None else None,
+                    ws["nll"].data_ptr() if tg is not None else None,
+                    ws["lse"].data_ptr() if (train and tg is not None) else None, None, 0.0, g.O)
+        BW._tm_ce(self, B, T, g.Op, 5, [(ws["h1"].data_ptr(), g.Sp, g.Sp, 0)], self.w_hwide["w3"].data_ptr(), None, 0,
+                  bh + 2 * g.Sp * 4, ce)
+        self._ce_keep = (logits, tg)
 
     # ------------------------------------------------------------------ autoregressive synthesis
     def _prepare_ar(self):

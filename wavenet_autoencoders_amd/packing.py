@@ -382,14 +382,27 @@ def ar_ring_offsets(g: Geometry) -> np.ndarray:
 # backward: transposed weight streams (csrc/gemm_tm.hip, csrc/head_bwd.hip) and the scatter maps that
 # bring the dense weight-gradient tiles of csrc/gemm_tn.hip back into the flat gradient arena
 # ---------------------------------------------------------------------------------------------------
+def tm_slicing(Mp: int) -> Tuple[int, int]:
+    """(tiles per slice, slices) of an Mp-row output of wae_gemm_tm (csrc/gemm_tm.hip: tm_slicing must agree)."""
+    nt = Mp // 32
+    if nt in (1, 2, 3, 4, 6, 8):
+        return nt, 1
+    for c in (8, 6, 4):
+        if nt % c == 0:
+            return c, nt // c
+    raise ValueError(f"wae_gemm_tm: unsupported output width {Mp}")
+
+
 def first_gemm_map(Mp: int, Kp: int, dtype: int, src_fn) -> np.ndarray:
-    """[q][blk][m][lane][j] stream of an (Mp x Kp) matrix; src_fn(row, kk) -> arena offset or -1 (vectorised)."""
+    """[slice][q][blk][m][lane][j] stream of an (Mp x Kp) matrix; src_fn(row, kk) -> arena offset or -1 (vectorised).
+    Outputs wider than 256 rows are cut into slices of tm_slicing(Mp) tiles, each with its own chunk stream."""
     t = _traits(dtype)
     EPL, CK = t["EPL"], t["CK"]
     assert Mp % 32 == 0 and Kp % CK == 0, (Mp, Kp)
-    q, blk, m, lane, j = np.meshgrid(np.arange(Kp // CK), np.arange(4), np.arange(Mp // 32), np.arange(64), np.arange(EPL),
-                                     indexing="ij")
-    row = 32 * m + (lane & 31)
+    nts, nsl = tm_slicing(Mp)
+    sl, q, blk, m, lane, j = np.meshgrid(np.arange(nsl), np.arange(Kp // CK), np.arange(4), np.arange(nts), np.arange(64),
+                                         np.arange(EPL), indexing="ij")
+    row = 32 * (sl * nts + m) + (lane & 31)
     kk = q * CK + blk * 2 * EPL + (lane >> 5) * EPL + j
     return src_fn(row, kk).astype(np.int32).reshape(-1)
 
@@ -460,6 +473,33 @@ def head_bwd_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     b = second_gemm_map(g.Sp, g.Op, dtype, lambda s, kk: np.where((s < g.S) & (kk < g.O), w3 + kk * g.S + s, -1))
     c = second_gemm_map(g.Sp, g.Sp, dtype, lambda s, kk: np.where((s < g.S) & (kk < g.S), w1 + kk * g.S + s, -1))
     return np.concatenate([a, b, c]).astype(np.int32)
+
+
+def head_wide_maps(g: Geometry, lay: ParamLayout, dtype: int) -> Dict[str, np.ndarray]:
+    """Weight streams of the wide head (Sp > 256; wae_gemm_tm modes 3-6), all in first-GEMM order:
+    skip = all layers' conv1x1_skip over K = Ku (layer, gated channel); w1 / w3 = last_conv_layers.1 / .3;
+    w3t / w1t = their transposes for the backward data path."""
+    ws = lay.off("wavenet.conv_layers.0.conv1x1_skip.weight_v")
+    w1 = lay.off("wavenet.last_conv_layers.1.weight_v")
+    w3 = lay.off("wavenet.last_conv_layers.3.weight_v")
+
+    def skip_src(row, kk):
+        layer, ch = kk // g.Hp, kk % g.Hp
+        return np.where((row < g.S) & (layer < g.layers) & (ch < g.H), ws + layer * lay.layer_stride + row * g.H + ch, -1)
+    return dict(
+        skip=first_gemm_map(g.Sp, g.Ku, dtype, skip_src),
+        w1=first_gemm_map(g.Sp, g.Sp, dtype, lambda r, kk: np.where((r < g.S) & (kk < g.S), w1 + r * g.S + kk, -1)),
+        w3=first_gemm_map(g.Op, g.Sp, dtype, lambda o, kk: np.where((o < g.O) & (kk < g.S), w3 + o * g.S + kk, -1)),
+        w3t=first_gemm_map(g.Sp, g.Op, dtype, lambda s_, kk: np.where((s_ < g.S) & (kk < g.O), w3 + kk * g.S + s_, -1)),
+        w1t=first_gemm_map(g.Sp, g.Sp, dtype, lambda s_, kk: np.where((s_ < g.S) & (kk < g.S), w1 + kk * g.S + s_, -1)),
+    )
+
+
+def head_is_wide(g: Geometry) -> bool:
+    """The register-chained head kernels hold Sp/32 <= 8 accumulator tiles per wave; wider heads (or WAE_HEAD_WIDE=1, for
+    tests) run as separate wae_gemm_tm launches."""
+    import os
+    return g.Sp > 256 or os.environ.get("WAE_HEAD_WIDE", "0") == "1"
 
 
 ONES_PAD = 128   # spare C columns that receive the per-clip "ones column" sums (B <= 128)
