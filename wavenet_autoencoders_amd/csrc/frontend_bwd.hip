@@ -12,52 +12,94 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 
 // ---- upsample stage: out[t] = sum_j w[j] * in[(t + j - s) / s]  (0 <= t + j - s < Tin*s) ---------------------------------
+// din[i] = sum_{u in [is, is+s)} sum_j w[j] dout[u - j + s]: every dout[t], t = is + d with d in [-s, 2s), enters with the
+// sum of the taps that reach it, coef[d + s] = sum_{j = max(0, s-d)}^{min(2s, 2s-1-d)} w[j] (formed once per block):
+// 3s loads per frame instead of s(2s+1).
+#define UPW_MAXTAPS 33
 __global__ void __launch_bounds__(256) upsample_stage_bwd_in_kernel(const float* __restrict__ dout, const float* __restrict__ w,
                                                                    float* __restrict__ din, int C, int Tin, int s) {
+  __shared__ float coef[3 * (UPW_MAXTAPS / 2)];
+  if (threadIdx.x < 3 * s) {
+    const int d = (int)threadIdx.x - s;
+    float a = 0.f;
+    for (int j = max(0, s - d); j <= min(2 * s, 2 * s - 1 - d); ++j) a += w[j];
+    coef[threadIdx.x] = a;
+  }
+  __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y, b = blockIdx.z;
   if (i >= Tin) return;
   const int Tout = Tin * s;
   const float* dr = dout + ((int64_t)b * C + c) * Tout;
   float acc = 0.f;
-  for (int u = i * s; u < (i + 1) * s; ++u)
-    for (int j = 0; j <= 2 * s; ++j) {
-      const int t = u - j + s;
-      if (t >= 0 && t < Tout) acc = fmaf(w[j], dr[t], acc);
-    }
+  const int tb = i * s - s;
+  for (int k = 0; k < 3 * s; ++k) {
+    const int t = tb + k;
+    if (t >= 0 && t < Tout) acc = fmaf(coef[k], dr[t], acc);
+  }
   din[((int64_t)b * C + c) * Tin + i] = acc;
 }
 // dw[j] = sum_{row,t} dout[row][t] * in[row][(t + j - s) / s]  for 0 <= t + j - s < Tout   (autograd of upsample.py:51-66).
-// One block = 1024 consecutive t of one (clip, channel) row: dout is read once, coalesced, and feeds all 2s+1 taps from
-// registers; (t + j - s) / s = t / s - 1 + (t % s + j) / s needs one division per element instead of one 64-bit division
-// per element AND tap (the previous form took 0.17 ms per step).
-#define UPW_MAXTAPS 33
+// With t = q s + rem the input index is q - 1 + (rem + j) / s, and (rem + j) / s in {0, 1, 2} does not depend on q: the
+// 2s+1 tap sums are regroupings of the 3s correlations A[rem][o] = sum_q dout[q s + rem] in[q - 1 + o] (in[-1] = in[Tin] = 0
+// reproduce the zero padding), dw[j] = sum_rem A[rem][(rem + j) / s].  A thread walks frames q: s contiguous dout loads,
+// three in loads, 3s FMAs (the tap-by-tap form needed s(2s+1) selects + FMAs and took 0.1 ms per step).  A block walks
+// whole (clip, channel) rows; at most 256 blocks leave their 2s+1 sums as atomics.  S = 0: any s <= 16, tap-by-tap.
+template <int S>
 __global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* __restrict__ dout, const float* __restrict__ in,
-                                                                  float* __restrict__ dw, int BC, int Tin, int s) {
-  const int row = blockIdx.y;
+                                                                  float* __restrict__ dw, int BC, int Tin, int s_rt) {
+  const int s = S > 0 ? S : s_rt;
+  constexpr int NTAP = S > 0 ? 2 * S + 1 : UPW_MAXTAPS;
   const int Tout = Tin * s, ntap = 2 * s + 1;
-  const float* drow = dout + (int64_t)row * Tout;
-  const float* irow = in + (int64_t)row * Tin;
-  float acc[UPW_MAXTAPS];
+  float acc[NTAP];
 #pragma unroll
-  for (int j = 0; j < UPW_MAXTAPS; ++j) acc[j] = 0.f;
-  for (int t = blockIdx.x * 1024 + threadIdx.x; t < min(Tout, (blockIdx.x + 1) * 1024); t += 256) {
-    const float g = drow[t];
-    const int q = t / s, rem = t - q * s;
-    // the three input samples a tap can land on
-    const float i0 = q >= 1 ? irow[q - 1] : 0.f, i1 = irow[q], i2 = q + 1 < Tin ? irow[q + 1] : 0.f;
+  for (int j = 0; j < NTAP; ++j) acc[j] = 0.f;
+  if constexpr (S > 0) {
+    float A[S][3];
 #pragma unroll
-    for (int j = 0; j < UPW_MAXTAPS; ++j)
-      if (j < ntap) {
-        const int k = rem + j;                       // (t + j - s) / s = q - 1 + k / s,  k / s in {0, 1, 2}
-        const int u = t + j - s;
-        const float v = k < s ? i0 : (k < 2 * s ? i1 : i2);
-        if (u >= 0 && u < Tout) acc[j] = fmaf(g, v, acc[j]);
+    for (int r = 0; r < S; ++r) A[r][0] = A[r][1] = A[r][2] = 0.f;
+    for (int row = blockIdx.x; row < BC; row += gridDim.x) {
+      const float* drow = dout + (int64_t)row * Tout;
+      const float* irow = in + (int64_t)row * Tin;
+      for (int q = threadIdx.x; q < Tin; q += 256) {
+        float g[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) g[r] = drow[q * S + r];
+        const float i0 = q >= 1 ? irow[q - 1] : 0.f, i1 = irow[q], i2 = q + 1 < Tin ? irow[q + 1] : 0.f;
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+          A[r][0] = fmaf(g[r], i0, A[r][0]);
+          A[r][1] = fmaf(g[r], i1, A[r][1]);
+          A[r][2] = fmaf(g[r], i2, A[r][2]);
+        }
       }
+    }
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+      for (int r = 0; r < S; ++r) acc[j] += A[r][(r + j) / S];
+  } else {
+    for (int row = blockIdx.x; row < BC; row += gridDim.x) {
+      const float* drow = dout + (int64_t)row * Tout;
+      const float* irow = in + (int64_t)row * Tin;
+      for (int t = threadIdx.x; t < Tout; t += 256) {
+        const float g = drow[t];
+        const int q = t / s, rem = t - q * s;
+        const float i0 = q >= 1 ? irow[q - 1] : 0.f, i1 = irow[q], i2 = q + 1 < Tin ? irow[q + 1] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j)
+          if (j < ntap) {
+            const int k = rem + j;                       // (t + j - s) / s = q - 1 + k / s,  k / s in {0, 1, 2}
+            const int u = t + j - s;
+            const float v = k < s ? i0 : (k < 2 * s ? i1 : i2);
+            if (u >= 0 && u < Tout) acc[j] = fmaf(g, v, acc[j]);
+          }
+      }
+    }
   }
   __shared__ float part[4][UPW_MAXTAPS];
 #pragma unroll
-  for (int j = 0; j < UPW_MAXTAPS; ++j)
+  for (int j = 0; j < NTAP; ++j)
     if (j < ntap) {
       const float v = wave_sum_f(acc[j]);
       if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][j] = v;
@@ -68,10 +110,14 @@ __global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* 
 extern "C" int wae_upsample_stage_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, int32_t B,
                                       int32_t C, int32_t Tin, int32_t s, void* stream) {
   WAE_REQUIRE(dout && in && w && din && dw && B > 0 && C > 0 && Tin > 0 && s > 0, "upsample_stage_bwd: bad arguments");
+  WAE_REQUIRE(2 * s + 1 <= UPW_MAXTAPS, "upsample_stage_bwd: scale %d > %d is not supported", s, (UPW_MAXTAPS - 1) / 2);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(upsample_stage_bwd_in_kernel, dim3((Tin + 255) / 256, C, B), dim3(256), 0, st, dout, w, din, C, Tin, s);
-  WAE_REQUIRE(2 * s + 1 <= UPW_MAXTAPS, "upsample_stage_bwd: scale %d > %d is not supported", s, (UPW_MAXTAPS - 1) / 2);
-  hipLaunchKernelGGL(upsample_stage_bwd_w_kernel, dim3((Tin * s + 1023) / 1024, B * C), dim3(256), 0, st, dout, in, dw, B * C, Tin, s);
+  const int rows = B * C, nb = rows < 256 ? rows : 256;
+  if (s == 4) hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<4>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
+  else if (s == 5) hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<5>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
+  else if (s == 8) hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<8>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
+  else hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<0>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
   return wae_check_launch("upsample_stage_bwd");
 }
 

@@ -115,8 +115,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
   const int n = lane & 31, h = lane >> 5;
   constexpr int TW = NW * 32;
   const int tiles_per_b = (p.T + TW - 1) / TW;
-  const int b = blockIdx.x / tiles_per_b;
-  const int t0w = (blockIdx.x % tiles_per_b) * TW + wave * 32;
+  const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int b = tile_id / tiles_per_b;
+  const int t0w = (tile_id % tiles_per_b) * TW + wave * 32;
   const int t = t0w + n;
   const bool tvalid = t < p.T;
   const int rows_valid = min(max(p.T - t0w, 0), 32);

@@ -40,8 +40,9 @@ __global__ void __launch_bounds__(256, 1) head_bwd_kernel(HeadBwdArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 31, h = lane >> 5;
   const int tiles_per_b = (p.T + 127) >> 7;
-  const int b = blockIdx.x / tiles_per_b;
-  const int t0w = (blockIdx.x % tiles_per_b) * 128 + wave * 32;
+  const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int b = tile_id / tiles_per_b;
+  const int t0w = (tile_id % tiles_per_b) * 128 + wave * 32;
   const int t = t0w + n;
   const bool tvalid = t < p.T;
   const int rows_valid = min(max(p.T - t0w, 0), 32);

@@ -436,6 +436,40 @@ __global__ void __launch_bounds__(256) upsample_stage_kernel(const float* __rest
   }
 }
 
+// Last stage (time-major output, audio rate): a block = UPT output steps of one clip.  The input frames those steps touch
+// ((UPT + 2s)/s + 2 per channel) are staged in LDS with reads that run along time, then thread (c, t) walks its 2s+1 taps
+// with an incremental (u / s, u % s) -- same fmaf chain, same order as the direct form above (bit-identical), but the
+// direct form's loads were one cache line per lane (64 channel rows apart) and took 0.1 ms per step at C2.
+#define UPT 64
+template <typename E>
+__global__ void __launch_bounds__(256) upsample_last_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                            void* __restrict__ out, int C, int Tin, int s, int Cp, int nfp) {
+  extern __shared__ float sm[];              // [Cp][nfp] input frames, then [2s+1] taps
+  const int b = blockIdx.y, t0 = blockIdx.x * UPT, Tout = Tin * s;
+  const int fl = max(t0 - s, 0) / s, fh = min(t0 + UPT - 1 + s, Tout - 1) / s, nf = fh - fl + 1;
+  float* taps = sm + Cp * nfp;
+  for (int i = threadIdx.x; i < Cp * nf; i += 256) {
+    const int c = i / nf, f = i - c * nf;
+    sm[c * nfp + f] = c < C ? in[((int64_t)b * C + c) * Tin + fl + f] : 0.f;
+  }
+  if (threadIdx.x <= 2 * s) taps[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const int c = threadIdx.x % Cp, tl = threadIdx.x / Cp, tstep = 256 / Cp;
+  const float* r = sm + c * nfp - fl;
+  for (int t = t0 + tl; t < min(t0 + UPT, Tout); t += tstep) {
+    float acc = 0.f;
+    if (c < C) {
+      int j0 = max(0, s - t), u = t + j0 - s;      // first tap with u >= 0
+      int q = u / s, rem = u - q * s;
+      for (int j = j0; j <= 2 * s && u < Tout; ++j, ++u) {
+        acc = fmaf(taps[j], r[q], acc);
+        if (++rem == s) { rem = 0; ++q; }
+      }
+    }
+    store_e<E>(out, ((int64_t)b * Tout + t) * Cp + c, acc);
+  }
+}
+
 extern "C" int wae_upsample_stage_fwd(const float* in, const float* w, void* out, int32_t B, int32_t C, int32_t Tin,
                                       int32_t s, int32_t out_btc, int32_t Cp, int32_t dtype, void* stream) {
   WAE_REQUIRE(in && w && out && B > 0 && C > 0 && Tin > 0 && s > 0, "upsample_stage: bad arguments");
@@ -446,6 +480,16 @@ extern "C" int wae_upsample_stage_fwd(const float* in, const float* w, void* out
                        s, 0, C);
   } else {
     WAE_REQUIRE(Cp >= C, "upsample_stage: Cp < C");
+    if (Cp <= 256 && 256 % Cp == 0) {
+      const int nfp = UPT / s + 5;           // frames per channel row (+1: odd pitch against bank conflicts)
+      const size_t lds = ((size_t)Cp * (nfp | 1) + 2 * s + 1) * sizeof(float);
+      dim3 g2((Tout + UPT - 1) / UPT, B);
+      if (dtype == WAE_BF16)
+        hipLaunchKernelGGL(upsample_last_kernel<__bf16>, g2, dim3(256), lds, st, in, w, out, C, Tin, s, Cp, nfp | 1);
+      else
+        hipLaunchKernelGGL(upsample_last_kernel<float>, g2, dim3(256), lds, st, in, w, out, C, Tin, s, Cp, nfp | 1);
+      return wae_check_launch("upsample_stage_fwd");
+    }
     const int64_t n = (int64_t)Tout * Cp;
     dim3 grid((unsigned)((n + 255) / 256), 1, B);
     if (dtype == WAE_BF16)
@@ -551,19 +595,27 @@ extern "C" int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int
 }
 
 // sum of the per-layer skip biases (the head's GEMM 0 starts from it)
-__global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__ src, int64_t off, int64_t stride, int L, int n,
+__global__ void __launch_bounds__(1024) sum_rows_kernel(const float* __restrict__ src, int64_t off, int64_t stride, int L, int n,
                                                        int n_pad, float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_pad) return;
+  // block = 64 columns x 16 row groups (the serial form walked up to 256 dependent loads per thread: 35-70 us per call)
+  __shared__ float part[16][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   float s = 0.f;
-  if (i < n)
-    for (int l = 0; l < L; ++l) s += src[off + (int64_t)l * stride + i];
-  out[i] = s;
+  if (col < n)
+    for (int l = grp; l < L; l += 16) s += src[off + (int64_t)l * stride + col];
+  part[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && col < n_pad) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
+    out[col] = col < n ? t : 0.f;
+  }
 }
 extern "C" int wae_sum_rows(const float* src, int64_t off, int64_t stride, int32_t L, int32_t n, int32_t n_pad, float* out,
                             void* stream) {
   WAE_REQUIRE(src && out && L > 0 && n > 0 && n_pad >= n, "sum_rows: bad arguments");
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, as_stream(stream), src, off, stride, L, n,
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((n_pad + 63) / 64), dim3(1024), 0, as_stream(stream), src, off, stride, L, n,
                      n_pad, out);
   return wae_check_launch("sum_rows");
 }
@@ -575,23 +627,42 @@ template <typename E>
 __global__ void __launch_bounds__(256) first_conv_kernel(const int32_t* __restrict__ idx, const float* __restrict__ xs,
                                                          const float* __restrict__ table, const float* __restrict__ bias,
                                                          void* __restrict__ x0, int64_t BT, int Rp) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t bt = e / Rp;
-  const int r = (int)(e % Rp);
-  if (bt >= BT) return;
-  float v;
-  if (idx)
-    v = table[(int64_t)idx[bt] * Rp + r] + bias[r];
-  else
-    v = fmaf(table[r], xs[bt], bias[r]);
-  store_e<E>(x0, e, v);
+  // thread = 8 consecutive residual channels of one sample (Rp is a multiple of 128): 16-byte table / bias loads, one
+  // 16-byte bf16 store; a block covers 16 samples
+  const int tpr = Rp >> 3;
+  for (int i = threadIdx.x; i < 16 * tpr; i += 256) {
+    const int row = i / tpr, r = (i - row * tpr) * 8;
+    const int64_t bt = (int64_t)blockIdx.x * 16 + row;
+    if (bt >= BT) return;
+    f32x4 v0, v1;
+    const f32x4 b0 = *(const f32x4*)(bias + r), b1 = *(const f32x4*)(bias + r + 4);
+    if (idx) {
+      const float* tr = table + (int64_t)idx[bt] * Rp + r;
+      v0 = *(const f32x4*)tr + b0;
+      v1 = *(const f32x4*)(tr + 4) + b1;
+    } else {
+      const float x = xs[bt];
+      const f32x4 t0 = *(const f32x4*)(table + r), t1 = *(const f32x4*)(table + r + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v0[k] = fmaf(t0[k], x, b0[k]); v1[k] = fmaf(t1[k], x, b1[k]); }
+    }
+    if constexpr (sizeof(E) == 2) {
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { o[k] = (__bf16)v0[k]; o[4 + k] = (__bf16)v1[k]; }
+      *(bf16x8*)((__bf16*)x0 + bt * Rp + r) = o;
+    } else {
+      *(f32x4*)((float*)x0 + bt * Rp + r) = v0;
+      *(f32x4*)((float*)x0 + bt * Rp + r + 4) = v1;
+    }
+  }
 }
 
 extern "C" int wae_first_conv_fwd(const int32_t* idx, const float* xs, const float* table, const float* bias, void* x0,
                                   int64_t BT, int32_t Rp, int32_t O, int32_t dtype, void* stream) {
-  WAE_REQUIRE((idx || xs) && table && bias && x0 && BT > 0 && Rp > 0, "first_conv: bad arguments");
+  WAE_REQUIRE((idx || xs) && table && bias && x0 && BT > 0 && Rp > 0 && Rp % 8 == 0, "first_conv: bad arguments");
   (void)O;
-  dim3 grid((unsigned)((BT * Rp + 255) / 256));
+  dim3 grid((unsigned)((BT + 15) / 16));
   if (dtype == WAE_BF16)
     hipLaunchKernelGGL(first_conv_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp);
   else
@@ -667,7 +738,13 @@ __global__ void __launch_bounds__(1024) masked_mean_kernel(const float* __restri
   for (int b = 0; b < B; ++b) {
     const int len = lengths ? min(lengths[b], T) : T;
     const float* r = nll + (int64_t)b * T;
-    for (int t = threadIdx.x; t < len - 1; t += 1024) s += (double)r[t];
+    // four independent loads in flight per thread (one dependent fp64 chain per load took 26 us per step)
+    int t = threadIdx.x;
+    for (; t + 3072 < len - 1; t += 4096) {
+      const float a0 = r[t], a1 = r[t + 1024], a2 = r[t + 2048], a3 = r[t + 3072];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; t < len - 1; t += 1024) s += (double)r[t];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);

@@ -393,6 +393,15 @@ __device__ __forceinline__ f32x4 residual_piece(const bf16x8 (&res)[N], int mt, 
   return r;
 }
 
+// XCD-aware tile order.  The dispatcher deals workgroups round-robin over the 8 XCDs (flat id mod 8) and every XCD has its
+// own 4 MiB L2.  Time tiles that are neighbours -- they share the dilated taps x[t - d], x[t - 2d] and the halo rows --
+// must therefore NOT get consecutive flat ids: XCD k takes the k-th contiguous eighth of the tile list instead, so the
+// rows a tile's taps reach were (or are being) fetched into the same L2 by the tiles running next to it.  Bijective for any n.
+__device__ __forceinline__ int xcd_contiguous_tile(int bid, int n) {
+  const int k = bid & 7, q = n >> 3, r = n & 7;
+  return k * q + min(k, r) + (bid >> 3);
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
