@@ -264,7 +264,12 @@ typedef struct wae_tm_desc {
   int32_t nsrc;
   int32_t mode;
   float alpha;
+  int32_t flags; /* WAE_TM_INTERLEAVE: the chunk stream visits the (equally wide) sources round-robin per 128-byte column
+                    block -- [block 0 of source 0, of source 1, ..., block 1 of source 0, ...] -- instead of source by source:
+                    the dilated taps of one column block are then read back to back, while the tiles d and 2d rows away
+                    fetch the same rows into the same L2 (w_packed follows the same order) */
 } wae_tm_desc;
+#define WAE_TM_INTERLEAVE 1
 int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
                 const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,
                 int64_t out_stride, const void* aux, int64_t aux_stride, void* stream);

@@ -25,7 +25,7 @@ class ArDesc(ctypes.Structure):
 
 
 class TmDesc(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "M", "nsrc", "mode")] + [("alpha", c_f32)]
+    _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "M", "nsrc", "mode")] + [("alpha", c_f32), ("flags", c_i32)]
 
 
 class TmCe(ctypes.Structure):            # include/wae.h: wae_tm_ce (modes 5 / 6 of the wide head)

@@ -40,6 +40,8 @@ def _prepare_bwd(eng):
         eng.m_buo = up(P.bwd_uo_map(g, lay, eng.dt))
         eng.n_buo = eng.m_buo.numel()
         eng.w_buo = torch.zeros(g.layers * eng.n_buo, dtype=eng.tdtype, device=dev)
+        eng.m_bxf = up(P.bwd_x_map(g, lay, eng.dt, interleave=False))     # the fused kernel walks the taps one by one
+        eng.w_bxf = torch.zeros(g.layers * eng.m_bxf.numel(), dtype=eng.tdtype, device=dev)
     eng.m_bc = up(P.bwd_c_map(g, lay, eng.dt)) if g.Ccp else None
     eng.m_hb_w = up(P.head_bwd_map(g, lay, eng.dt)) if not eng.wide_head else torch.zeros(0, dtype=torch.int32, device=dev)
     eng.n_bu, eng.n_bx = eng.m_bu.numel(), eng.m_bx.numel()
@@ -73,6 +75,8 @@ def pack_bwd_weights(eng):
     if eng.fused_bwd:
         L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_buo), L.ptr(eng.w_buo), eng.n_buo, g.layers, lay.layer_stride,
                                     eng.n_buo, eng.dt, st), "pack bwd UO")
+        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bxf), L.ptr(eng.w_bxf), eng.n_bx, g.layers, lay.layer_stride,
+                                    eng.n_bx, eng.dt, st), "pack bwd X (tap by tap)")
     if g.Ccp:
         L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bc), L.ptr(eng.w_bc), eng.m_bc.numel(), 1, 0, 0, eng.dt, st),
                 "pack bwd C")
@@ -89,9 +93,9 @@ def _arr(ctype, vals):
     return (ctype * len(vals))(*vals)
 
 
-def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=None, aux_stride=0):
+def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=None, aux_stride=0, flags=0):
     """srcs: list of (device ptr int, row stride elems, cols, shift)"""
-    d = L.TmDesc(eng.dt, B, T, M, len(srcs), mode, alpha)
+    d = L.TmDesc(eng.dt, B, T, M, len(srcs), mode, alpha, flags)
     ptrs = _arr(ctypes.c_void_p, [s[0] for s in srcs])
     strides = _arr(ctypes.c_int64, [s[1] for s in srcs])
     cols = _arr(ctypes.c_int32, [s[2] for s in srcs])
@@ -102,7 +106,7 @@ def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=Non
 
 def _tm_ce(eng, B, T, M, mode, srcs, w_ptr, out_ptr, out_stride, bias_ptr, ce):
     """wae_gemm_tm_ce (modes 5 / 6 of the wide head): ce is an L.TmCe"""
-    d = L.TmDesc(eng.dt, B, T, M, len(srcs), mode, 1.0)
+    d = L.TmDesc(eng.dt, B, T, M, len(srcs), mode, 1.0, 0)
     ptrs = _arr(ctypes.c_void_p, [s[0] for s in srcs])
     strides = _arr(ctypes.c_int64, [s[1] for s in srcs])
     cols = _arr(ctypes.c_int32, [s[2] for s in srcs])
@@ -364,7 +368,8 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
 
     def k_x(l, gn, gc):                        # dx-hat of layer l
         srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
-        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp)
+        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp,
+            flags=P.TM_INTERLEAVE)
 
     def tn_layer(l):                           # per-layer weight gradients (fp32 path; bf16 takes them all at the end)
         if ws["stream"] is not None:
@@ -389,7 +394,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             L.check(lib.wae_glu_bwd_fused(ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
                                           L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][l - 1]),
                                           ctypes.c_void_p(ws["dz"].data_ptr() + (l - 1) * Z2 * es),
-                                          ctypes.c_void_p(eng.w_bx.data_ptr() + l * eng.n_bx * es),
+                                          ctypes.c_void_p(eng.w_bxf.data_ptr() + l * eng.n_bx * es),
                                           ctypes.c_void_p(eng.w_buo.data_ptr() + (l - 1) * eng.n_buo * es),
                                           ctypes.c_void_p(eng.w_bu.data_ptr() + (l - 1) * eng.n_bu * es + us_off), st), "glu_bwd_fused")
         else:
@@ -467,7 +472,8 @@ def _debug_kernels(eng, B, T, l):
 
     def k_x():
         srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
-        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp)
+        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp,
+            flags=P.TM_INTERLEAVE)
     return k_u, k_x
 
 

@@ -51,6 +51,7 @@ struct TmArgs {
   int64_t aux_stride;
   float alpha;
   int B, T, mode;
+  int interleave;  // chunk q -> source q % nsrc, column block q / nsrc (all sources equally wide)
   TmCe ce;
 };
 
@@ -94,9 +95,14 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
   frag Bn[4], Bc[4];
   auto load_B = [&](int q, frag (&Bf)[4]) {
     int s = 0, q0 = 0;
+    if (p.interleave) {
+      s = q % p.nsrc;
+      q0 = q - q / p.nsrc;       // q - q0 = column block q / nsrc
+    } else {
 #pragma unroll
-    for (int i = 0; i < TM_MAX_SRC - 1; ++i)
-      if (q >= qend[i] && i + 1 < p.nsrc) { s = i + 1; q0 = qend[i]; }
+      for (int i = 0; i < TM_MAX_SRC - 1; ++i)
+        if (q >= qend[i] && i + 1 < p.nsrc) { s = i + 1; q0 = qend[i]; }
+    }
     const int ts = t + p.src_shift[s];
     const bool ok = tvalid && ts >= 0 && ts < p.T;
     const char* src = p.src[s] + (((int64_t)b * p.T + (ok ? ts : 0)) * p.src_stride[s]) * ES + (q - q0) * 128 + h * 16;
@@ -431,6 +437,9 @@ static int tm_run(const wae_tm_desc* d, const void* const* src, const int64_t* s
   }
   a.nsrc = d->nsrc; a.w = (const char*)w_packed; a.out = (char*)out; a.out_stride = out_stride; a.aux = (const char*)aux;
   a.aux_stride = aux_stride; a.alpha = d->alpha; a.B = d->B; a.T = d->T; a.mode = d->mode;
+  a.interleave = (d->flags & WAE_TM_INTERLEAVE) ? 1 : 0;
+  if (a.interleave)
+    for (int s = 1; s < d->nsrc; ++s) WAE_REQUIRE(src_cols[s] == src_cols[0], "gemm_tm: interleaved sources must be equally wide");
   a.ce = TmCe{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
   if (ce) {
     WAE_REQUIRE(ce->O > 0 && ce->O <= d->M, "gemm_tm: 0 < O <= M");

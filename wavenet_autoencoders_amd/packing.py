@@ -444,12 +444,21 @@ def bwd_uo_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     return second_gemm_map(g.Hp, g.Rp, dtype, lambda h, r: np.where((r < g.R) & (h < g.H), o + r * g.H + h, -1))
 
 
-def bwd_x_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
-    """dx = sum_tap W1_tap^T dz[t + (k-1-tap) d]: rows r (Rp), K = k sources of 2Hp gate columns."""
+TM_INTERLEAVE = 1    # include/wae.h: WAE_TM_INTERLEAVE
+
+
+def bwd_x_map(g: Geometry, lay: ParamLayout, dtype: int, interleave: bool = True) -> np.ndarray:
+    """dx = sum_tap W1_tap^T dz[t + (k-1-tap) d]: rows r (Rp), K = k sources of 2Hp gate columns, visited round-robin per
+    128-byte column block (WAE_TM_INTERLEAVE): chunk q = cblk * k + tap; interleave=False: tap by tap (csrc/glu_bwd.hip)."""
     conv = lay.off("wavenet.conv_layers.0.conv.weight_v")
+    CK = _traits(dtype)["CK"]
 
     def src(r, kk):
-        tap, c2 = kk // (2 * g.Hp), kk % (2 * g.Hp)
+        q, within = kk // CK, kk % CK
+        if interleave:
+            tap, c2 = q % g.k, (q // g.k) * CK + within
+        else:
+            tap, c2 = kk // (2 * g.Hp), kk % (2 * g.Hp)
         row, ok = _gate_row(g, c2)
         return np.where(ok & (r < g.R), conv + (row * g.R + r) * g.k + tap, -1)
     return first_gemm_map(g.Rp, g.k * 2 * g.Hp, dtype, src)
