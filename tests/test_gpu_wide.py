@@ -129,3 +129,18 @@ def test_wide_head_path_on_golden_models_fp32(name, monkeypatch):
     res = _grad_check(eng, cfg, sd, x, ins["xin"], c_up, g, torch.tensor([T, T - 137]), ocfg)
     bad = {k: v for k, v in res.items() if v[0] > 1e-3 * max(v[1], 1e-6) + 1e-7}
     assert not bad, bad
+
+
+def test_wide_incremental_forward_matches_teacher_forced_fp32():
+    """WaveNet.incremental_forward (wavenet.py:218-346) at R = S = 512 (1024 rows in the second matrix-vector product, more
+    rows than threads): teacher-forced incremental logits against the oracle's parallel forward on the same inputs"""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    sd, x, xin, c, g = _wide_inputs(B=2, T=96)
+    with torch.no_grad():
+        y_ref = O.wavenet_forward(sd, dict(layers=4, stacks=2, upsample_scales=None, cin_pad=0), xin, c, g)
+    eng = WaeEngine(Geometry.from_cfg(WIDE), dtype="fp32")
+    eng.load_state_dict(sd)
+    out = eng.incremental_forward(c.cuda(), g.cuda(), T=x.shape[1], mode="logits", test_inputs=x.cuda(), c_is_upsampled=True)
+    torch.cuda.synchronize()
+    assert rel_err(out["logits"].cpu(), y_ref) < 1e-3

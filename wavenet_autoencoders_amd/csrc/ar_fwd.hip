@@ -44,6 +44,7 @@ struct ArArgs {
   float* out_f;           // (B, T) drawn samples, or null
   float log_scale_min;
   int clamp_log_scale;
+  int psum_floats;        // max over the matrix-vector products of slices x padded rows (>= AR_THREADS)
 };
 
 template <typename E>
@@ -66,16 +67,18 @@ __device__ __forceinline__ void load_w<__bf16>(const char* p, float (&w)[8]) {
 }
 
 // y[r] = sum_k W[r][k] v[k] for r < rows; W blocked [k/EPL][rows_pad][EPL]; v in LDS (K padded to EPL, zero filled).
-// Threads are laid out as (row = tid % RW, slice = tid / RW); partials go to psum[slice][row]; caller barriers and sums.
+// Threads are laid out as (row = tid % RW, slice = tid / RW); partials go to psum[slice][row] (row pitch rows_pad); caller
+// barriers and sums.  More rows than threads (R + S = 1024 at C5): NS = 1 and a thread walks rows tid, tid + RW, ...
 template <typename E>
 __device__ __forceinline__ void gemv_partial(const char* __restrict__ W, const float* v, float* psum, int rows_pad, int K, int RW,
                                              int NS) {
   constexpr int EPL = ET<E>::EPL;
-  const int r = threadIdx.x % RW, s = threadIdx.x / RW;
-  if (s >= NS || r >= rows_pad) return;
+  const int r0 = threadIdx.x % RW, s = threadIdx.x / RW;
+  if (s >= NS) return;
   const int nkb = (K + EPL - 1) / EPL;
   const int per = (nkb + NS - 1) / NS;
   const int kb0 = s * per, kb1 = min(nkb, kb0 + per);
+  for (int r = r0; r < rows_pad; r += RW) {
   float acc = 0.f;
   const char* wp = W + ((int64_t)kb0 * rows_pad + r) * 16;
   const int64_t step = (int64_t)rows_pad * 16;
@@ -101,12 +104,13 @@ __device__ __forceinline__ void gemv_partial(const char* __restrict__ W, const f
 #pragma unroll
     for (int j = 0; j < EPL; ++j) acc = fmaf(w0[j], v[kb * EPL + j], acc);
   }
-  psum[s * RW + r] = acc;
+  psum[s * rows_pad + r] = acc;
+  }
 }
 
-__device__ __forceinline__ float psum_total(const float* psum, int r, int RW, int NS) {
+__device__ __forceinline__ float psum_total(const float* psum, int r, int rows_pad, int NS) {
   float a = 0.f;
-  for (int s = 0; s < NS; ++s) a += psum[s * RW + r];
+  for (int s = 0; s < NS; ++s) a += psum[s * rows_pad + r];
   return a;
 }
 
@@ -135,8 +139,8 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
   float* skipb = ubuf + Hk;               // Sk   (also the head's h0)
   float* hbuf = skipb + Sk;               // Sk   (h1)
   float* lbuf = hbuf + Sk;                // O    logits
-  float* psum = lbuf + ((p.O + 3) & ~3);  // 1024
-  int* ibuf = (int*)(psum + AR_THREADS);        // [0] = current input id
+  float* psum = lbuf + ((p.O + 3) & ~3);  // p.psum_floats
+  int* ibuf = (int*)(psum + p.psum_floats);     // [0] = current input id
 
   float* ring = p.ring + (int64_t)b * p.ring_total;
   const float* zb_b = p.zb + (int64_t)b * p.L * 2 * p.Hp;
@@ -159,11 +163,10 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
   for (int t = 0; t < p.T; ++t) {
     // ---- first conv: one-hot input == column gather (wavenet.py:311); scalar input: w * x + b ----------------
     const int cur = ibuf[0];
-    if (tid < p.R)
-      xbuf[tid] = p.scalar ? fmaf(p.first_tab[tid], fcur[0], p.first_bias[tid])
-                           : p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
-    if (tid >= p.R && tid < p.R + p.Cc) {   // local conditioning of this step -> tail of the operand vector
-      const int cc = tid - p.R;
+    for (int r = tid; r < p.R; r += AR_THREADS)
+      xbuf[r] = p.scalar ? fmaf(p.first_tab[r], fcur[0], p.first_bias[r])
+                         : p.first_tab[(int64_t)cur * p.Rp + r] + p.first_bias[r];
+    for (int cc = AR_THREADS - 1 - tid; cc < p.Cc; cc += AR_THREADS) {   // local conditioning of this step -> tail of the operand vector
       const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
       vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : ((const float*)p.c_up)[ci];
     }
@@ -193,11 +196,11 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
       gemv_partial<E>(wl, vbuf, psum, gp, K1, gRW, gNS);
       __syncthreads();
       // ---- gate (modules.py:138-154): thread h owns channel h ------------------------------------------------
-      if (tid < H) {
+      for (int hh = tid; hh < H; hh += AR_THREADS) {
         const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
-        const float a = psum_total(psum, tid, gRW, gNS) + zbl[tid];
-        const float g = psum_total(psum, H + tid, gRW, gNS) + zbl[p.Hp + tid];
-        ubuf[tid] = tanhf(a) * (1.f / (1.f + expf(-g)));
+        const float a = psum_total(psum, hh, gp, gNS) + zbl[hh];
+        const float g = psum_total(psum, H + hh, gp, gNS) + zbl[p.Hp + hh];
+        ubuf[hh] = tanhf(a) * (1.f / (1.f + expf(-g)));
       }
       __syncthreads();
       gemv_partial<E>(wl + p.w2_off, ubuf, psum, wp_, H, wRW, wNS);
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
       // ---- residual + skip (modules.py:157-162, wavenet.py:315) ------------------------------------------------
       const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
       for (int i = tid; i < p.R + p.S; i += AR_THREADS) {
-        const float y = psum_total(psum, i, wRW, wNS) + b2[i];
+        const float y = psum_total(psum, i, wp_, wNS) + b2[i];
         if (i < p.R) xbuf[i] = (y + xbuf[i]) * 0.70710678118654752440f;
         else skipb[i - p.R] += y;
       }
@@ -216,12 +219,12 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
     __syncthreads();
     gemv_partial<E>(p.w_head, skipb, psum, sp_, p.S, sRW, sNS);
     __syncthreads();
-    for (int i = tid; i < p.S; i += AR_THREADS) hbuf[i] = fmaxf(psum_total(psum, i, sRW, sNS) + p.head_bias[i], 0.f);
+    for (int i = tid; i < p.S; i += AR_THREADS) hbuf[i] = fmaxf(psum_total(psum, i, sp_, sNS) + p.head_bias[i], 0.f);
     __syncthreads();
     gemv_partial<E>(p.w_head + (int64_t)((p.S + EPL - 1) / EPL) * sp_ * 16, hbuf, psum, op_, p.S, oRW, oNS);
     __syncthreads();
     for (int i = tid; i < p.O; i += AR_THREADS) {
-      const float y = psum_total(psum, i, oRW, oNS) + p.head_bias[p.S + i];
+      const float y = psum_total(psum, i, op_, oNS) + p.head_bias[p.S + i];
       lbuf[i] = y;
       if (p.out_logits) p.out_logits[((int64_t)b * p.O + i) * p.T + t] = y;
     }
@@ -298,8 +301,11 @@ static int ar_launch(const wae_ar_desc* d, const int32_t* dilations, const int64
   const int epl = d->dtype == WAE_BF16 ? 8 : 4;
   const int H = d->G / 2;
   auto ru = [](int x, int m) { return (x + m - 1) / m * m; };
+  int psz = AR_THREADS;
+  for (int rows : {d->G, d->R + d->S, d->S, d->O}) psz = psz > ru(rows, 64) ? psz : ru(rows, 64);
+  a.psum_floats = psz;
   const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
-                                              2 * ru(d->S, epl) + ru(d->O, 4) + AR_THREADS + 4);
+                                              2 * ru(d->S, epl) + ru(d->O, 4) + psz + 4);
   hipStream_t st = as_stream(stream);
   if (d->dtype == WAE_BF16) {
     (void)hipFuncSetAttribute((const void*)ar_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -322,7 +328,6 @@ extern "C" int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, c
   WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate: bad dtype");
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0 && d->O > 0,
               "ar_generate: bad sizes");
-  WAE_REQUIRE(d->R + (d->Cc > 0 ? d->Cc : 0) <= AR_THREADS, "ar_generate: R+Cc must be <= %d", AR_THREADS);
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate: Cc > 0 but c_up is null");
   WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate: sample mode needs uniforms");
@@ -344,7 +349,6 @@ extern "C" int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilat
   WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate_scalar: bad dtype");
   WAE_REQUIRE(d->scalar_input && d->O > 0 && d->O % 3 == 0, "ar_generate_scalar: needs a scalar-input decoder with 3M output channels");
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0, "ar_generate_scalar: bad sizes");
-  WAE_REQUIRE(d->R + (d->Cc > 0 ? d->Cc : 0) <= AR_THREADS, "ar_generate_scalar: R+Cc must be <= %d", AR_THREADS);
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_scalar: Cc > 0 but c_up is null");
   WAE_REQUIRE(inputs_f || (u_mix && u_log), "ar_generate_scalar: needs teacher-forced inputs or the uniforms of the draws");
   WAE_REQUIRE(!u_mix == !u_log, "ar_generate_scalar: u_mix and u_log come together");
