@@ -53,40 +53,69 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   const int nq2 = (p.Op >> 5) / MT2;
   const int nq_total = nq0 + NQ1 + nq2;
   const char* urow = p.u + ((int64_t)b * p.T + (tvalid ? t : 0)) * p.Ku * ES + h * 16;
-  char* stg = smem + 2 * CHB + wave * STG_BYTES;
-  float* bias_lds = (float*)(smem + 2 * CHB + 4 * STG_BYTES);
-
-  frag Bn[4], Bc[4];
-  auto load_B = [&](int q, frag (&Bf)[4]) {
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
-      if (tvalid) {
-        Bf[blk] = *(const frag*)(urow + q * 128 + blk * 32);
-      } else {
-        frag zf = {};
-        Bf[blk] = zf;
-      }
-    }
-  };
+  char* stg = smem + 3 * CHB + wave * STG_BYTES;
+  float* bias_lds = (float*)(smem + 3 * CHB + 4 * STG_BYTES);
 
   // biases -> LDS once (accumulator inits then never touch vmcnt)
   for (int i = threadIdx.x * 4; i < 2 * p.Sp + p.Op; i += 1024) *(f32x4*)(bias_lds + i) = *(const f32x4*)(p.bias + i);
-  dma_chunk(p.w, smem, CHB, wave, lane);
-  load_B(0, Bn);
 
   // ---- GEMM 0: skip contraction over all layers' u --------------------------------------------------------
+  // K = Ku is long (72 chunks at C2) and its operand comes from HBM: with the operand one chunk ahead and one workgroup
+  // per CU every chunk waited a full memory round trip (3.3 us against 0.43 us of MFMAs: 0.29 ms per launch).  Now the
+  // operand fragments of chunk q live in group q % 4, requested THREE chunks ahead by inline-asm loads, the weight chunks
+  // go through a 3-slot ring two chunks ahead, the VMEM issue of a chunk is spread over its MFMAs, and the wait at the top
+  // of chunk q is counted: it leaves B(q+2) and DMA(q+1) in flight.
   f32x16 acc[NT];
 #pragma unroll
   for (int m = 0; m < NT; ++m) init_rows(acc[m], p.bias + 32 * m, h);
-  for (int q = 0; q < nq0; ++q) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  {
+    constexpr int PPW = NT;                      // 1-KiB DMA pieces per wave and chunk
+    frag G0[4], G1[4], G2[4], G3[4], Bc[4];
+    auto request_B = [&](int q, frag (&G)[4]) {
+      const char* s0 = urow + (int64_t)q * 128;
+      gload_async<0>(G[0], s0); gload_async<32>(G[1], s0); gload_async<64>(G[2], s0); gload_async<96>(G[3], s0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bias / init loads retired: from here on VMEM ops are counted by hand
+    request_B(0, G0);
+    request_B(min(1, nq0 - 1), G1);
+    dma_chunk(p.w, smem, CHB, wave, lane);
+    request_B(min(2, nq0 - 1), G2);
+    dma_chunk(p.w + (int64_t)min(1, nq0 - 1) * CHB, smem + CHB, CHB, wave, lane);
+    int slot = 0;
+    auto step = [&](int q, frag (&Gc)[4], frag (&Gl)[4]) {
+      wait_vmcnt_frags<4 + PPW>(Gc);
+      __builtin_amdgcn_s_barrier();   // chunk q visible; every wave is past its reads of chunk q-1, whose slot is refilled now
+      {
+        const frag z = {};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Bc[i] = Bn[i];
-    if (q + 1 < nq_total) dma_chunk(p.w + (int64_t)(q + 1) * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
-    if (q + 1 < nq0) load_B(q + 1, Bn);
-    const char* buf = smem + (q & 1) * CHB + lane * 16;
-    gemm_chunk<4 * NT, NT, 4>(buf, Bc, acc);
+        for (int i = 0; i < 4; ++i) Bc[i] = tvalid ? Gc[i] : z;
+      }
+      // past the end the last chunk is requested again (into a group / slot nobody reads): the issue pattern never changes
+      const char* s0 = urow + (int64_t)min(q + 3, nq0 - 1) * 128;
+      int slot_d = slot + 2; if (slot_d >= 3) slot_d -= 3;
+      const char* dsrc = p.w + (int64_t)min(q + 2, nq0 - 1) * CHB + wave * (CHB / 4) + lane * 16;
+      char* ddst = smem + slot_d * CHB + wave * (CHB / 4);
+      auto filler = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int SP = (4 * NT) / (4 + PPW);
+        if constexpr (I % SP == 0 && I / SP < 4 + PPW) {
+          constexpr int k = I / SP;
+          if constexpr (k < 4) gload_async<k * 32>(Gl[k], s0);
+          else dma_piece(dsrc + (k - 4) * 1024, ddst + (k - 4) * 1024);
+        }
+      };
+      gemm_chunk_fill<4 * NT, NT, 4>(smem + slot * CHB + lane * 16, Bc, acc, filler);
+      slot = slot + 1 == 3 ? 0 : slot + 1;
+    };
+    for (int q = 0; q < nq0; q += 4) {
+      step(q, G0, G3);
+      if (q + 1 < nq0) step(q + 1, G1, G0);
+      if (q + 2 < nq0) step(q + 2, G2, G1);
+      if (q + 3 < nq0) step(q + 3, G3, G2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                  // every wave is done with the ring: the remaining chunks alternate between its first two slots
+    dma_chunk(p.w + (int64_t)nq0 * CHB, smem, CHB, wave, lane);
   }
 
   // ---- h0 = relu(skips * scale) -> operand fragments (+ optional save) ------------------------------------
@@ -110,8 +139,8 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
     if (q1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi + 1) & 1) * CHB, CHB, wave, lane);
-    const char* buf = smem + (qi & 1) * CHB + lane * 16;
+    if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi - nq0 + 1) & 1) * CHB, CHB, wave, lane);
+    const char* buf = smem + ((qi - nq0) & 1) * CHB + lane * 16;
     f32x16(&y)[MT2] = *reinterpret_cast<f32x16(*)[MT2]>(&acc[q1 * MT2]);
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], bias_lds + p.Sp + 32 * (q1 * MT2 + mt), h);
@@ -139,8 +168,8 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
     const int qi = nq0 + NQ1 + q2;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi + 1) & 1) * CHB, CHB, wave, lane);
-    const char* buf = smem + (qi & 1) * CHB + lane * 16;
+    if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi - nq0 + 1) & 1) * CHB, CHB, wave, lane);
+    const char* buf = smem + ((qi - nq0) & 1) * CHB + lane * 16;
     f32x16 y[MT2];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], b3 + 32 * (q2 * MT2 + mt), h);
@@ -192,7 +221,7 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
 template <typename E, int NT>
 static int launch_head(const HeadArgs& a, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
-  const size_t lds = 2 * CHB + 4 * STG_BYTES + (size_t)(2 * a.Sp + a.Op) * 4;
+  const size_t lds = 3 * CHB + 4 * STG_BYTES + (size_t)(2 * a.Sp + a.Op) * 4;
   static size_t attr_done = 0;
   if (attr_done < lds) {
     if (hipFuncSetAttribute((const void*)head_fwd_kernel<E, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

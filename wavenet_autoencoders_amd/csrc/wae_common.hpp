@@ -185,6 +185,19 @@ __device__ __forceinline__ void gemm_chunk(const char* buf, const frag (&B)[NB],
   gemm_chunk_fill<N, NM, NB, KMAJOR, PDMAX>(buf, B, acc, nf);
 }
 
+// Operand fragments requested by inline asm and retired by a counted wait that carries the destinations ("+v": every use
+// comes after it).  hipcc's own bookkeeping puts s_waitcnt vmcnt(0) in front of the first use of a loop-carried plain load,
+// which drains the LDS-DMA requests of the NEXT chunks that were issued after it (vmcnt retires in order).
+template <int OFF, typename F>
+__device__ __forceinline__ void gload_async(F& dst, const char* ptr) {
+  static_assert(sizeof(F) == 16, "one 16-byte fragment");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF));
+}
+template <int CNT, typename F>
+__device__ __forceinline__ void wait_vmcnt_frags(F (&a)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(CNT));
+}
+
 // one 1-KiB LDS-DMA piece: lane l copies 16 bytes from g (per-lane address) to lds_base (wave-uniform) + 16 l
 __device__ __forceinline__ void dma_piece(const char* g, char* lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
