@@ -183,3 +183,42 @@ def test_vqwae_fullsize_probe_fp32():
     y = out["logits"].cpu()
     assert rel_err(y[0][:, torch.from_numpy(z["probe_t"])], z["y_probe"]) < FP32_TOL
     assert abs(float(y.double().sum()) - float(z["y_sum"])) < 1e-3 * float(z["y_abs_sum"])
+
+
+def test_c2_full_size_properties():
+    """BASELINE config C2 at full size (24 layers, R256 G368 S256, 8 x 8000 samples; too large for the oracle): properties that
+    do not depend on size -- (1) causality: logits at t < t* do not change when the inputs from t* on change (the receptive
+    field looks backwards only, wavenet.py:42-60); (2) clips are independent: clip 0 alone gives the logits it gives inside the
+    batch, bit for bit (the forward has no cross-clip arithmetic and no atomics); (3) the bf16 engine's teacher-forced loss agrees
+    with the fp32 engine's within 2e-2; (4) a repeated forward is bitwise reproducible."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153, upsample_scales=[4, 4, 4, 5],
+               cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+    B, T = 8, 8000
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.randint(0, 256, (B, T), generator=gen)
+    lat = torch.randn(B, 64, T // 320, generator=gen)
+    g = torch.randint(0, 153, (B,), generator=gen)
+    losses = {}
+    for dtype in ("fp32", "bf16"):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        out = eng.decoder_forward(x.cuda(), lat.cuda(), g.cuda(), targets=x.cuda())
+        y = out["logits"].clone()
+        losses[dtype] = float(out["loss"])
+        out2 = eng.decoder_forward(x.cuda(), lat.cuda(), g.cuda(), targets=x.cuda())
+        assert torch.equal(out2["logits"], y), "forward is not reproducible"
+        if dtype == "fp32":
+            ts = 5000
+            x2 = x.clone()
+            x2[:, ts:] = (x2[:, ts:] + 37) % 256
+            y2 = eng.decoder_forward(x2.cuda(), lat.cuda(), g.cuda())["logits"]
+            assert torch.equal(y2[:, :, :ts], y[:, :, :ts]), "a future input changed a past output"
+            assert not torch.equal(y2[:, :, ts:], y[:, :, ts:])
+            y1 = eng.decoder_forward(x[:1].cuda(), lat[:1].cuda(), g[:1].cuda())["logits"]
+            assert torch.equal(y1[0], y[0]), "clip 0 depends on its batch neighbours"
+        del eng
+        torch.cuda.empty_cache()
+    assert abs(losses["bf16"] - losses["fp32"]) < 2e-2, losses
