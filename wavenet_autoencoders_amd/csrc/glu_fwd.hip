@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
     int64_t rp;
     int ts = t;
     if (q < nq_conv) {
-      const int tap = q / cpr, cblk = q - tap * cpr;
+      // column block by column block, the taps of one block back to back: a tile reads x[t - d] right after x[t] while the
+      // tile d rows earlier reads the same rows as its last tap -- they meet in L2 (packing.py: glu_w1_map, same order)
+      const int cblk = q / p.ktaps, tap = q - cblk * p.ktaps;
       ts = t - (p.ktaps - 1 - tap) * p.dilation;
       base = xb + cblk * 128 + h * 16;
       rp = row_x;
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
     for (int blk = 0; blk < 4; ++blk) Bf[blk] = *(const frag*)(src + blk * 32);
   };
   auto fix_B = [&](int q, frag (&Bf)[4]) {
-    const int shift = q < nq_conv ? (p.ktaps - 1 - q / cpr) * p.dilation : 0;
+    const int shift = q < nq_conv ? (p.ktaps - 1 - q % p.ktaps) * p.dilation : 0;
     const bool ok = tvalid && t - shift >= 0 && !ABL(p.flags, DBG_NO_BLOAD);
     if (__any(!ok)) {
 #pragma unroll

@@ -10,7 +10,7 @@ holds, for output row ``32*m + i`` of M-tile m, EPL consecutive-in-k elements (E
 
 GEMM 1 stream ``[pass][q][blk][m][lane][j]`` (chunk q = one 128-byte slice of an activation row; pass p covers the
 gate channels [p*NPH*32, (p+1)*NPH*32), NPH = glu_pass_tiles(NP); m < NPH: tanh rows, m >= NPH: sigmoid rows):
-    q <  k*(Rp/CK): tap = q // (Rp/CK), cblk = q % (Rp/CK)   -> conv weight (G, R, k)
+    q <  k*(Rp/CK): cblk = q // k, tap = q % k               -> conv weight (G, R, k)  (taps of a column block back to back)
     q >=          : c chunk                                   -> conv1x1c weight (G, Cc)
     channel = cblk*CK + blk*2*EPL + h*EPL + j          (CK = 64 bf16 / 32 f32 channels per chunk)
     gate-a row = 32*(p*NPH + m) + i, gate-b row = H + 32*(p*NPH + m - NPH) + i (reference row = half*H + i)
@@ -209,8 +209,8 @@ def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     ig = 32 * (ps * NPH + m - half * NPH) + i
     row = half * g.H + ig
     is_conv = q < nq_conv
-    tap = np.where(is_conv, q // cpr, 0)
-    cblk = np.where(is_conv, q % cpr, q - nq_conv)
+    tap = np.where(is_conv, q % g.k, 0)               # taps of one column block back to back (csrc/glu_fwd.hip: b_src)
+    cblk = np.where(is_conv, q // g.k, q - nq_conv)
     ch = cblk * CK + blk * 2 * EPL + h * EPL + j
     conv_off = lay.off("wavenet.conv_layers.0.conv.weight_v")
     src_conv = conv_off + (row * g.R + ch) * g.k + tap
