@@ -618,6 +618,8 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate_coop: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate_coop: sample mode needs uniforms");
   WAE_REQUIRE(d->mode != 0 || inputs, "ar_generate_coop: teacher-forced mode needs inputs");
+  WAE_REQUIRE(inputs || (d->init_idx >= 0 && d->init_idx < d->O), "ar_generate_coop: init_idx %d is not a class (O = %d)", d->init_idx,
+              d->O);
   WAE_REQUIRE(!d->scalar_input, "ar_generate_coop: scalar-input (DMoL) decoding is not implemented yet");
   const int H = d->G / 2;
   const int hc = (H + C - 1) / C, sc = (d->S + C - 1) / C;

@@ -333,6 +333,8 @@ extern "C" int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, c
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate: sample mode needs uniforms");
   WAE_REQUIRE(d->mode != 0 || inputs, "ar_generate: teacher-forced mode needs inputs");
   WAE_REQUIRE(!d->scalar_input, "ar_generate: scalar-input decoders go through wae_ar_generate_scalar");
+  // the start class indexes the first-conv table: wavenet.py:288 sets class 127, an IndexError there when O <= 127
+  WAE_REQUIRE(inputs || (d->init_idx >= 0 && d->init_idx < d->O), "ar_generate: init_idx %d is not a class (O = %d)", d->init_idx, d->O);
   return ar_launch(d, dilations, ring_off, ring, ring_total, w_layers, layer_stride_bytes, w2_off_bytes, bias2, zb, first_tab,
                    first_bias, w_head, head_bias, c_up, c_dtype, inputs, uniforms, out_idx, out_logits, nullptr, nullptr, nullptr,
                    nullptr, -7.0f, 0, stream);

@@ -430,6 +430,9 @@ class WaeEngine:
             self._ar_keep = (c_up, zb, ring, tf, um, ul, gid32)
             return dict(x=xs, logits=params)
         inputs = test_inputs.to(torch.int32).contiguous() if test_inputs is not None else None
+        if inputs is None and not 0 <= int(init_idx) < g.O:
+            # wavenet.py:288 writes a one at class 127 of the start vector: the same IndexError when there are fewer classes
+            raise IndexError(f"index {int(init_idx)} is out of bounds for dimension 2 with size {g.O}")
         if m == 2 and uniforms is None:
             uniforms = torch.rand(B, T, device=dev)
         uni = uniforms.float().contiguous() if uniforms is not None else None
