@@ -85,7 +85,7 @@ def test_fragment_maps_reproduce_the_layer(dtype):
     for q in range(w1.shape[0]):
         for n in range(T):
             if q < g.k * cpr:
-                tap, cblk = divmod(q, cpr)
+                cblk, tap = divmod(q, g.k)          # taps of one column block back to back (csrc/glu_fwd.hip: b_src)
                 ts = n - (g.k - 1 - tap) * d
                 row = xp[ts] if ts >= 0 else np.zeros(g.Rp)
             else:
