@@ -222,3 +222,26 @@ def test_c2_full_size_properties():
         del eng
         torch.cuda.empty_cache()
     assert abs(losses["bf16"] - losses["fp32"]) < 2e-2, losses
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_glu_workgroup_shapes_agree(dtype):
+    """the fused layer kernel's two workgroup shapes (8 waves x 256 steps, the default; 4 waves x 128 steps) contract in the same
+    order: identical logits on a model with ragged T"""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("B")
+    c_up = torch.from_numpy(z["c_up"])
+    T = 515
+    outs = []
+    for nw in (8, 4):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.lib.wae_debug_set_glu_waves(nw)
+        try:
+            eng.load_state_dict(sd)
+            out = eng.decoder_forward(ins["x"][:, :T].cuda(), c_up[:, :, :T].cuda(), ins["g"].cuda(), c_is_upsampled=True)
+            torch.cuda.synchronize()
+            outs.append(out["logits"].cpu())
+        finally:
+            eng.lib.wae_debug_set_glu_waves(8)
+    assert torch.equal(outs[0], outs[1])

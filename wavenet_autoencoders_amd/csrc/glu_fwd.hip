@@ -425,7 +425,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
 #endif
 }
 
-static int g_glu_nw = 4;  // waves per workgroup: 4 (two workgroups per CU) or 8 (one 256-step workgroup per CU)
+// waves per workgroup: 8 (one 256-step workgroup per CU) or 4 (two workgroups per CU).  With the XCD-contiguous tile order and
+// the tap-interleaved chunk stream the 8-wave shape measures 2-5 % faster at C2 (59.8 vs 61.2 us inference, 67.4 vs 71.1 us
+// with z saved; A/B on one box, WAE_GLU_WAVES=4|8); before those two changes the 4-wave shape was the faster one.
+static int g_glu_nw = 8;
 extern "C" void wae_debug_set_glu_waves(int nw) { g_glu_nw = nw == 8 ? 8 : 4; }
 
 static int g_glu_slots = 0;  // 0 = as many ring slots as fit (<= 6)

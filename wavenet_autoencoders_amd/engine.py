@@ -33,6 +33,8 @@ class WaeEngine:
         if not torch.cuda.is_available():
             raise L.WaeError("WaeEngine needs a ROCm GPU: the hot path has no CPU implementation")
         self.lib = L.lib()
+        if os.environ.get("WAE_GLU_WAVES"):      # A/B switch of the fused layer kernel's workgroup shape (4 or 8 waves)
+            self.lib.wae_debug_set_glu_waves(int(os.environ["WAE_GLU_WAVES"]))
         self.g = geom
         self.dt = _dt(dtype)
         self.tdtype = torch.bfloat16 if self.dt == L.WAE_BF16 else torch.float32
