@@ -31,6 +31,8 @@ def _prepare_bwd(eng):
         return
     g, dev, lay = eng.g, eng.device, eng.lay
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    if os.environ.get("WAE_TM_OCC"):     # A/B switch: bit 1 gate-backward, bit 2 residual launches with two workgroups per CU
+        eng.lib.wae_debug_set_tm_occ(int(os.environ["WAE_TM_OCC"]))
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
     # Fusing K_X(l) with K_U(l-1) (csrc/glu_bwd.hip) measured SLOWER than the two launches at C2 (118 us vs 60 + 50 us:
