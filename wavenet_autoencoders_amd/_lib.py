@@ -126,6 +126,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise WaeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the hot path)")
+        # torch first: its wheel carries its own libamdhip64, and libwae_hip.so must bind to THAT runtime -- loaded the other
+        # way round, /opt/rocm's copy comes in as a second HIP runtime that does not know torch's allocations
+        # (hipMemcpyAsync on a torch tensor then fails with "invalid value")
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
