@@ -65,9 +65,12 @@ class GradBucketer:
         self.handles = []
         self.comm_stream = torch.cuda.Stream(grads.device) if grads.is_cuda else None
 
-    def _launch(self, i: int):
-        lo, hi = self.bounds[i]
-        self.launched[i] = True
+    def _launch(self, i: int, j: Optional[int] = None):
+        """all-reduce buckets i..j (contiguous) as ONE collective"""
+        j = i if j is None else j
+        lo, hi = self.bounds[i][0], self.bounds[j][1]
+        for k in range(i, j + 1):
+            self.launched[k] = True
         if self.world == 1:
             return
         view = self.grads[lo:hi]
@@ -87,9 +90,19 @@ class GradBucketer:
                 self._launch(i)
 
     def finish(self):
-        for i in range(len(self.bounds) - 1, -1, -1):
-            if not self.launched[i]:
-                self._launch(i)
+        # what backward did not hand over early goes out in as few collectives as possible: every run of adjacent buckets is
+        # one all-reduce (the whole arena when nothing was launched early -- a ring all-reduce over xGMI is per-link bound and
+        # reaches its bandwidth only on large messages; six 8-MiB calls pay six launch latencies for nothing)
+        i = len(self.bounds) - 1
+        while i >= 0:
+            if self.launched[i]:
+                i -= 1
+                continue
+            j = i
+            while i - 1 >= 0 and not self.launched[i - 1]:
+                i -= 1
+            self._launch(i, j)
+            i -= 1
         for h in self.handles:
             h.wait()
         if self.comm_stream is not None:
