@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counter passes over one python script (run on the GPU box).  Usage: tools/pmc_run.sh <out_dir> <kernel substring> <script> [args...]
+# Counter passes over one python script (run on the GPU box).  Usage: tools/pmc_run.sh <out_dir> <kernel substring[,substring...]> <script> [args...]
 # Each pass is its own rocprofv3 run under `timeout` (a TA_* pass once hung a box until gpurun's limit: never list those).
 OUT=$1; KSUB=$2; shift 2
 ROOT=$(pwd)
@@ -17,14 +17,17 @@ done
 cd $ROOT
 python3 - <<PY
 import csv, glob, collections
-agg = collections.OrderedDict()
+subs = "$KSUB".split(",")
+agg = collections.OrderedDict((s_, collections.OrderedDict()) for s_ in subs)
 for f in sorted(glob.glob("$OUT/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "$KSUB" not in r["Kernel_Name"]:
-            continue
-        agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for s_ in subs:
+            if s_ in r["Kernel_Name"]:
+                agg[s_].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as fh:
-    for k, v in agg.items():
-        line = f"{k:34s} mean/launch {sum(v)/len(v):18.1f}  (n={len(v)})"
-        print(line); fh.write(line + "\n")
+    for s_ in subs:
+        fh.write("== kernels matching %r\n" % s_); print("==", s_)
+        for k, v in agg[s_].items():
+            line = f"{k:34s} mean/launch {sum(v)/len(v):18.1f}  (n={len(v)})"
+            print(line); fh.write(line + "\n")
 PY
