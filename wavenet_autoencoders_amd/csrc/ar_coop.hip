@@ -22,7 +22,7 @@
 #define ARC_HP 4      // history elements a thread prefetches per layer: (ktaps-1)*R <= ARC_HP * ARC_THREADS is the fast case
 #define ARC_W1P 8      // W1 packets of a gate row slice a thread holds (fp32: K1/4/32 slices = 6.5 at hps/vqwae.json)
 #define ARC_NB 3       // accumulator banks of the all-reduce (see arc_allreduce)
-#define ARC_ACC_FLOATS(R, S) (ARC_NB * ((R) + (S)) + 2 * ARC_NB + 10)
+#define ARC_ACC_FLOATS(R, S) (2 * ARC_NB * ((R) + (S)) + 32)   // {sum, count} granules: 3 banks of R and of S
 
 struct ArcArgs {
   int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp, C;
@@ -48,7 +48,7 @@ struct ArcArgs {
   float* out_logits;
   unsigned long long* msg;   // (B, 2 banks, C, NV) {seq, value} granules
   int NV;                    // values per member and exchange = max(channels per member, skip rows per member)
-  float* acc;                // (B, ARC_ACC_FLOATS(R, S)): 3 banks of R and of S partial-sum accumulators + counters, zeroed
+  float* acc;                // (B, ARC_ACC_FLOATS(R, S)): 3 banks of R and of S {sum, count} granules, zeroed
   int* error;
 };
 
@@ -181,55 +181,64 @@ __device__ __forceinline__ bool arc_gather(unsigned long long* bank, int NV, int
   return *abort_flag == 0;
 }
 
-// Sum one value per thread (n <= ARC_THREADS values) over the C members of an utterance: fp32 atomic adds into an L2
-// accumulator bank, a counter that tells when all C members have added, then every member reads the n sums.
-// Use number `use` (0, 1, 2, ..) takes bank use % 3.  Before it adds, a member zeroes ITS share of the NEXT bank; a member
-// that sees the counter complete therefore knows the next bank is clean (every member finished its zero stores before
-// its adds), and the bank being zeroed was last read two uses ago, before its readers published the previous use.
-// fast (all members on one XCD): the adds, stores and counter stay in that XCD's L2 (no cache-control bits);
-// otherwise agent-scope atomics (memory side).  Returns false on time-out.
-// `between` runs once this wave's adds have been performed: loads it issues travel while the members wait for each other.
+// Sum one value per thread (n <= ARC_THREADS values) over the C members of an utterance.  Value j lives in an 8-byte granule
+// {fp32 sum, int32 count} of an L2-resident bank; use number `use` (0, 1, 2, ..) takes bank use % 3.  Thread j of every member
+//   1. adds its share to the sum, then 1 to the count (two no-return atomics of one lane to one granule: the L2 channel
+//      performs them in program order),
+//   2. polls its granule with ONE 8-byte load until count = C x (uses of this bank so far): a single-copy-atomic snapshot, so
+//      a complete count comes with the complete sum,
+//   3. (thread j of member j % C only) zeroes the sum of granule j in the bank of use + 2.
+// One L2 round trip after the last member's adds arrive -- the previous scheme (adds, wait for them, a counter, a barrier,
+// then the sums) was three dependent round trips, 5.5 of the 8.4 us per layer.  Everything is per index j: thread j sees
+// count(use) complete => every member's thread j has added for `use` => their reads of the bank of use - 1 (= use + 2) have
+// returned => the owner may zero it; and the owner's zero store is performed before its own adds of use + 1 (the vmcnt(0)
+// in front of them, long satisfied by then), hence before anybody sees count(use + 1) complete and adds for use + 2.
+// fast (all members on one XCD): the atomics stay in that XCD's L2; otherwise agent-scope atomics (memory side).
+// `between` runs once the adds are issued: loads it issues travel while the members wait for each other.
 template <typename F>
-__device__ __forceinline__ bool arc_allreduce(float* banks, int* cnt, int n, unsigned use, float mine, float& sum, int C, int m,
-                                              bool fast, int* error, int* abort_flag, F&& between) {
+__device__ __forceinline__ bool arc_allreduce(float* banks, int n, unsigned use, float mine, float& sum, int C, int m, bool fast,
+                                              int* error, int* abort_flag, F&& between) {
   const int tid = threadIdx.x;
-  const int k = use % ARC_NB, kn = (use + 1) % ARC_NB;
-  float* bank = banks + (int64_t)k * n;
-  (void)kn;
-  const int per = (n + C - 1) / C;
+  float* gran = banks + ((int64_t)(use % ARC_NB) * n + tid) * 2;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's zero store of two uses ago has been performed
   if (tid < n) {
-    if (fast) __hip_atomic_fetch_add(bank + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_fetch_add(bank + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fast) {
+      __hip_atomic_fetch_add(gran, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add((int*)gran + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      __hip_atomic_fetch_add(gran, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add((int*)gran + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's adds have been performed
   between();
-  arc_barrier();
-  if (tid == 0) {
-    if (fast) __hip_atomic_fetch_add(cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_fetch_add(cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int target = C * (int)(use / ARC_NB + 1);
+  sum = 0.f;
+  bool bad = false;
+  if (tid < n) {
+    const unsigned target = (unsigned)C * (use / ARC_NB + 1);
     int spins = 0;
-    while (__hip_atomic_load(cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    unsigned long long v;
+    for (;;) {
+      v = __hip_atomic_load((unsigned long long*)gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(v >> 32) >= target) break;
       if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        *abort_flag = 1;
-        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = true;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
+    sum = __uint_as_float((unsigned)v);
+    if (!bad && tid % C == m) {      // the owner of granule tid clears the bank of use + 2 (= the bank of use - 1)
+      float* clean = banks + ((int64_t)((use + 2) % ARC_NB) * n + tid) * 2;
+      if (fast) *(volatile float*)clean = 0.f;
+      else __hip_atomic_store(clean, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (bad) {
+    *abort_flag = 1;
+    __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   arc_barrier();
-  if (*abort_flag) return false;
-  sum = tid < n ? __hip_atomic_load(bank + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-  // zero this member's share of the bank of use + 2 (= the bank of use - 1: every member read it before it added for this
-  // use).  The stores complete before this member's next adds are counted (the vmcnt(0) above, next time round), and a
-  // member adds for use + 2 only after the counter of use + 1 is complete.
-  float* clean = banks + (int64_t)((use + 2) % ARC_NB) * n;
-  if (tid < per && m * per + tid < n) {
-    if (fast) *(volatile float*)(clean + m * per + tid) = 0.f;
-    else __hip_atomic_store(clean + m * per + tid, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return true;
+  return *abort_flag == 0;
 }
 
 template <typename E>
@@ -269,9 +278,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   arc_barrier();
 
   float* xbanks = p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S);
-  float* sbanks = xbanks + ARC_NB * p.R;
-  int* xcnt = (int*)(sbanks + ARC_NB * p.S);
-  int* scnt = xcnt + ARC_NB;
+  float* sbanks = xbanks + 2 * ARC_NB * p.R;
   unsigned xuse = 0, suse = 0;
   unsigned seq = 0;   // exchange counter (same on every member); message bank = seq & 1
   // Where all members run on ONE XCD (the usual placement: blocks b and b+8 share one), messages go through that XCD's L2:
@@ -456,7 +463,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
       // ---- all-reduce x' over the members, then residual (modules.py:157-162) -------------------------------------------------
       {
         float sum;
-        if (!arc_allreduce(xbanks, xcnt, p.R, xuse++, px, sum, C, m, fast, p.error, &ibuf[1],
+        if (!arc_allreduce(xbanks, p.R, xuse++, px, sum, C, m, fast, p.error, &ibuf[1],
                            [&]() { prefetch_layer(l + 1 < p.L ? l + 1 : 0); }))
           return;
         const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
@@ -468,7 +475,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
     // ---- all-reduce the skip vector (once per sample), then head + draw on every member ---------------------------------
     {
       float sum;
-      if (!arc_allreduce(sbanks, scnt, p.S, suse++, skip_part, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
+      if (!arc_allreduce(sbanks, p.S, suse++, skip_part, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
       if (tid < p.S) skipb[tid] = fmaxf(sum * p.scale, 0.f);
       arc_barrier();
     }
