@@ -22,7 +22,7 @@
 #define ARC_HP 4      // history elements a thread prefetches per layer: (ktaps-1)*R <= ARC_HP * ARC_THREADS is the fast case
 #define ARC_W1P 8      // W1 packets of a gate row slice a thread holds (fp32: K1/4/32 slices = 6.5 at hps/vqwae.json)
 #define ARC_NB 3       // accumulator banks of the all-reduce (see arc_allreduce)
-#define ARC_ACC_FLOATS(R, S) (2 * ARC_NB * ((R) + (S)) + 32)   // {sum, count} granules: 3 banks of R and of S
+#define ARC_ACC_FLOATS(R, S, O) (2 * ARC_NB * ((R) + 2 * (S) + (O)) + 32)   // {sum, count} granules: 3 banks each of R, S, S, O
 
 struct ArcArgs {
   int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp, C;
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   if (b >= p.B || m >= p.C) return;
   const int H = p.G / 2, C = p.C;
   const int hc = (H + C - 1) / C, ch0 = min(m * hc, H), ch1 = min(ch0 + hc, H), nch = ch1 - ch0;
-  const int sc = (p.S + C - 1) / C, s0 = min(m * sc, p.S), s1 = min(s0 + sc, p.S), nsk = s1 - s0;
+  const int sc = (p.S + C - 1) / C, s0 = min(m * sc, p.S), s1 = min(s0 + sc, p.S), nsk = s1 - s0;   // head rows of this member
   const int K1 = p.ktaps * p.R + (p.Cc > 0 ? p.Cc : 0);
   const int K1p = (K1 + EPL - 1) / EPL * EPL;
   const int Hk = (H + EPL - 1) / EPL * EPL;
@@ -277,9 +277,11 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   if (tid == 0) { ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
   arc_barrier();
 
-  float* xbanks = p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S);
+  float* xbanks = p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S, p.O);
   float* sbanks = xbanks + 2 * ARC_NB * p.R;
-  unsigned xuse = 0, suse = 0;
+  float* hbanks = sbanks + 2 * ARC_NB * p.S;       // all-gather of h1 (head rows are split over the members)
+  float* ybanks = hbanks + 2 * ARC_NB * p.S;       // all-gather of the logits
+  unsigned xuse = 0, suse = 0, huse = 0, yuse = 0;
   unsigned seq = 0;   // exchange counter (same on every member); message bank = seq & 1
   // Where all members run on ONE XCD (the usual placement: blocks b and b+8 share one), messages go through that XCD's L2:
   // plain 8-byte stores keep the line there (an agent-scope atomic store writes it through to memory and drops it from
@@ -480,18 +482,43 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
       arc_barrier();
     }
     ARC_TICK(4);
+    // ---- head (wavenet.py:209-214), its rows split over the members: member m computes rows [s0, s1) of h1 and [o0, o1) of
+    //      the logits (every member streaming both matrices -- 256 KB per sample through one L2 -- took 24 us per sample), the
+    //      vectors are all-gathered through the all-reduce (the other members add zeros: exact), the draw runs on every member
     {
       const int nkb = (p.S + EPL - 1) / EPL;
-      for (int r = tid; r < p.S; r += ARC_THREADS) {
-        const float acc = arc_dot<E, 32>(p.w_head + (int64_t)r * 16, (int64_t)s_pad * 16, 0, 1, nkb, skipb);
-        hbuf[r] = fmaxf(acc + p.head_bias[r], 0.f);
-      }
+      // nr rows from r0 of a blocked matrix times v: thread -> (row tid / SL, k slice tid % SL); the slices of a row are SL
+      // adjacent lanes of one wave and fold by shuffles; rowres[i] = dot of row r0 + i
+      auto rows_dot = [&](const char* W, int rows_pad, int r0, int nr, const float* v, float* rowres) {
+        int SL = 64;
+        while (SL > 1 && SL * nr > ARC_THREADS) SL >>= 1;
+        const int i = tid / SL, sl = tid - i * SL;
+        float acc = 0.f;
+        if (i < nr)
+          for (int kb = sl; kb < nkb; kb += SL) {
+            float w[EPL];
+            arc_load_w<E>(W + ((int64_t)kb * rows_pad + r0 + i) * 16, w);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], v[kb * EPL + j], acc);
+          }
+        for (int o = SL >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (i < nr && sl == 0) rowres[i] = acc;
+      };
+      const int oc = (p.O + C - 1) / C, o0 = min(m * oc, p.O), o1 = min(o0 + oc, p.O);
+      float sum;
+      rows_dot(p.w_head, s_pad, s0, nsk, skipb, psum);
       arc_barrier();
-      const char* w3 = p.w_head + (int64_t)nkb * s_pad * 16;
-      for (int r = tid; r < p.O; r += ARC_THREADS) {
-        const float y = arc_dot<E, 32>(w3 + (int64_t)r * 16, (int64_t)o_pad * 16, 0, 1, nkb, hbuf) + p.head_bias[p.S + r];
-        lbuf[r] = y;
-        if (p.out_logits && m == 0) p.out_logits[((int64_t)b * p.O + r) * p.T + t] = y;
+      const float mine_h = (tid >= s0 && tid < s1) ? fmaxf(psum[tid - s0] + p.head_bias[tid], 0.f) : 0.f;
+      if (!arc_allreduce(hbanks, p.S, huse++, mine_h, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
+      if (tid < p.S) hbuf[tid] = sum;
+      arc_barrier();
+      rows_dot(p.w_head + (int64_t)nkb * s_pad * 16, o_pad, o0, o1 - o0, hbuf, psum);
+      arc_barrier();
+      const float mine_y = (tid >= o0 && tid < o1) ? psum[tid - o0] + p.head_bias[p.S + tid] : 0.f;
+      if (!arc_allreduce(ybanks, p.O, yuse++, mine_y, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
+      if (tid < p.O) {
+        lbuf[tid] = sum;
+        if (p.out_logits && m == 0) p.out_logits[((int64_t)b * p.O + tid) * p.T + t] = sum;
       }
       arc_barrier();
     }
@@ -597,7 +624,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
 
 extern "C" int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d) {
   if (!d) return WAE_EINVAL;
-  return ARC_ACC_FLOATS(d->R, d->S);
+  return ARC_ACC_FLOATS(d->R, d->S, d->O);
 }
 
 extern "C" int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C) {
@@ -619,8 +646,8 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   WAE_REQUIRE(d->B > 0 && d->B <= 8, "ar_generate_coop: 1..8 utterances per launch (one XCD each); use wae_ar_generate for more");
   WAE_REQUIRE(C >= 1 && C <= 32, "ar_generate_coop: 1..32 cooperating workgroups per utterance");
   WAE_REQUIRE(d->T > 0 && d->L > 0 && d->R > 0 && d->R <= ARC_THREADS && d->G > 0 && d->G % 2 == 0 && d->S > 0 &&
-                  d->S <= ARC_THREADS && d->O > 0,
-              "ar_generate_coop: bad sizes (R, S <= %d)", ARC_THREADS);
+                  d->S <= ARC_THREADS && d->O > 0 && d->O <= ARC_THREADS,
+              "ar_generate_coop: bad sizes (R, S, O <= %d)", ARC_THREADS);
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_coop: Cc > 0 but c_up is null");
   WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate_coop: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate_coop: sample mode needs uniforms");

@@ -405,7 +405,7 @@ class WaeEngine:
                                   L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
         # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
         # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
-        coop = (B <= 8 and g.R <= 256 and g.S <= 256 and not g.scalar_input and os.environ.get("WAE_AR_COOP", "1") != "0")
+        coop = (B <= 8 and g.R <= 256 and g.S <= 256 and g.O <= 256 and not g.scalar_input and os.environ.get("WAE_AR_COOP", "1") != "0")
         C = max(1, min(int(os.environ.get("WAE_AR_COOP_C", "32")), 32, g.H, g.S)) if coop else 1
         ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
         if g.scalar_input:
