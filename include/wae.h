@@ -237,7 +237,7 @@ int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilations, const
  * split by gate channels; the members all-reduce their shares of x' once per layer and of the skip vector once per
  * sample through `acc` (B x wae_ar_coop_acc_floats(d) floats), `msg` ((B, 2, C, NV) 8-byte granules, NV =
  * wae_ar_coop_msg_values(d, C)) carries the start-up handshake; each member keeps its own copy of the history rings:
- * ring is (B, C, ring_total).  B <= 8, C <= 32, R and S <= 256.  The caller zeroes msg, acc and error (>= 64 ints) before
+ * ring is (B, C, ring_total).  B <= 8, C <= 32, R, S and O <= 256.  The caller zeroes msg, acc and error (>= 64 ints) before
  * the launch; error[0] != 0 afterwards means a wait timed out (the output is then invalid).  Sums are formed by fp32
  * atomics in arrival order: reproducible to rounding, not bitwise. */
 int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d);
