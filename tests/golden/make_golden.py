@@ -443,6 +443,34 @@ def gen_vqwae_probe():
          keys=json.dumps({k: list(v.shape) for k, v in sd.items()}))
 
 
+def gen_wide_probe():
+    """BASELINE config C5's widths (R = G = S = 512, Cc = 64, Cg = 32) on a short stack: the reference's own WaveNet on
+    audio-rate conditioning -> sparse logits probe + sums; inputs are the closed-form fills of tests/test_gpu_wide.py."""
+    cfg = dict(name="wide", layers=4, stacks=2, R=512, G=512, S=512, O=256, Cc=64, Cg=32, k=3, n_speakers=8,
+               upsample_scales=None, cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+    B, T = 2, 777
+    x = ((O.hash_fill((B, T), 21) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    c = O.hash_fill((B, cfg["Cc"], T), 22, 1.3)
+    g = torch.tensor([1, 6])
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    model = RefWaveNet(out_channels=256, layers=4, stacks=2, residual_channels=512, gate_channels=512, skip_out_channels=512,
+                       kernel_size=3, dropout=0.0, cin_channels=64, gin_channels=32, n_speakers=8,
+                       upsample_conditional_features=False, scalar_input=False, use_speaker_embedding=True,
+                       output_distribution="Logistic", cin_pad=0)
+    missing = model.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.eval()
+    with torch.no_grad():
+        y_hat = model(xin, c, g, False)
+        oy = O.wavenet_forward(sd, dict(layers=4, stacks=2, upsample_scales=None, cin_pad=0), xin, c, g)
+    e = close(oy, y_hat, what="wide logits", tol=5e-5)
+    print(f"  wide (512 channels): T={T}, max|oracle-ref| = {e:.2e}")
+    ti = torch.arange(0, T, 13)
+    save("model_wide_probe", cfg=json.dumps(cfg), salt=5, x_salt=21, c_salt=22, g=g, T=T, probe_t=ti, y_probe=y_hat[:, :, ti],
+         y_sum=y_hat.double().sum(), y_abs_sum=y_hat.double().abs().sum())
+
+
 def gen_quantizers():
     """Section 8(f) rank 3: SlicedVectorQuantize, SlicedVectorQuantizeEMA, VectorQuantizeEMA (vector_quantization.py:51-306)
     run on this CPU host.  The two EMA classes test the function object `torch.cuda.is_available` (:183, :277), which is
@@ -520,6 +548,8 @@ def gen_quantizers():
 def main():
     if sys.argv[1:] == ["quantizers"]:
         return gen_quantizers()
+    if sys.argv[1:] == ["wide"]:
+        return gen_wide_probe()
     gen_quantizers()
     gen_misc()
     gen_dmol()
@@ -534,6 +564,7 @@ def main():
     sd, model, ins, ocfg = gen_model(CFG_S, 3)
     gen_ar_scalar(CFG_S, sd, model, ins, ocfg)
     gen_vqwae_probe()
+    gen_wide_probe()
 
 
 if __name__ == "__main__":

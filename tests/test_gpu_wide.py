@@ -42,6 +42,11 @@ def test_wide_forward_logits_and_loss(dtype, tol):
     out = eng.decoder_forward(x.cuda(), c.cuda(), g.cuda(), targets=x.cuda(), lengths=lengths.cuda(), c_is_upsampled=True)
     torch.cuda.synchronize()
     assert rel_err(out["logits"].cpu(), y_ref) < tol
+    # and against the reference's own WaveNet on the same inputs (tests/golden/model_wide_probe.npz)
+    from helpers import load_npz
+    z = load_npz("model_wide_probe")
+    assert int(z["T"]) == T and int(z["x_salt"]) == 21 and int(z["c_salt"]) == 22 and z["g"].tolist() == g.tolist()
+    assert rel_err(out["logits"].cpu()[:, :, torch.from_numpy(z["probe_t"])], z["y_probe"]) < tol
     assert abs(float(out["loss"]) - float(loss_ref)) < (1e-4 if dtype == "fp32" else 3e-2)
 
 

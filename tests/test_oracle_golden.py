@@ -208,3 +208,20 @@ def test_sliced_and_ema_quantizers_against_reference_vectors():
         for s in "12":
             assert rel_err(st["embedding" + s], t[f"se{step}_emb{s}"]) < 1e-5
             assert rel_err(st["ema_cluster_size" + s], t[f"se{step}_n{s}"]) < 1e-5
+
+
+def test_wide_probe():
+    """BASELINE config C5's widths (R = G = S = 512) on a short stack: the oracle against the reference's own WaveNet
+    (tests/golden/model_wide_probe.npz; inputs are closed-form fills regenerated here from their salts)."""
+    z = load_npz("model_wide_probe")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]), with_encoder=False)
+    B, T = 2, int(z["T"])
+    x = ((O.hash_fill((B, T), int(z["x_salt"])) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    c = O.hash_fill((B, cfg["Cc"], T), int(z["c_salt"]), 1.3)
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    with torch.no_grad():
+        y = O.wavenet_forward(sd, dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=None, cin_pad=0), xin, c,
+                              torch.from_numpy(z["g"]))
+    assert rel_err(y[:, :, torch.from_numpy(z["probe_t"])], z["y_probe"]) < TOL
+    assert abs(float(y.double().sum()) - float(z["y_sum"])) < 1e-4 * float(z["y_abs_sum"])
