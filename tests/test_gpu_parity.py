@@ -245,3 +245,37 @@ def test_glu_workgroup_shapes_agree(dtype):
         finally:
             eng.lib.wae_debug_set_glu_waves(8)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B,T", [(1, 2), (1, 33), (3, 130), (2, 257), (1, 1025)])
+def test_odd_shapes_forward_and_backward(B, T):
+    """clips shorter than a tile / a wave / the receptive field, odd batch sizes: logits and loss against the oracle (fp32), and a
+    backward pass whose gradients match autograd through the oracle"""
+    from wavenet_autoencoders_amd import Geometry, backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("B")
+    x = ((O.hash_fill((B, T), 91) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+    c = O.hash_fill((B, cfg["Cc"], T), 92, 1.1)
+    g = torch.arange(B) % cfg["n_speakers"]
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    lengths = torch.tensor([T] + [max(2, T - 1 - 7 * i) for i in range(1, B)])
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("wavenet.") and "upsample_net" not in k}
+    y_ref = O.wavenet_forward(psd, dict(ocfg, upsample_scales=None), xin, c, g)
+    loss_ref = O.masked_ce_loss(y_ref, x.unsqueeze(-1), lengths)
+    loss_ref.backward()
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype="fp32")
+    eng.load_state_dict(sd)
+    out = eng.decoder_forward(x.cuda(), c.cuda(), g.cuda(), targets=x.cuda(), lengths=lengths.cuda(), train=True, c_is_upsampled=True)
+    BW.decoder_backward(eng, x.cuda(), x.cuda(), lengths, g.cuda())
+    grads = BW.finish_grads(eng)
+    torch.cuda.synchronize()
+    assert rel_err(out["logits"].cpu(), y_ref.detach()) < FP32_TOL
+    assert abs(float(out["loss"]) - float(loss_ref.detach())) < 1e-4 * max(1.0, abs(float(loss_ref.detach())))
+    bad = {}
+    for k, v in psd.items():
+        gref = v.grad if v.grad is not None else torch.zeros_like(v)
+        got = grads[eng.lay.off(k):eng.lay.off(k) + eng.lay.numel(k)].view(eng.lay.shapes[k]).cpu()
+        err, ref = float((got - gref).abs().max()), float(gref.abs().max())
+        if err > 1e-3 * max(ref, 1e-6) + 1e-7:
+            bad[k] = (err, ref)
+    assert not bad, bad
