@@ -183,3 +183,57 @@ def test_full_train_step_against_golden():
         assert rel_err(view(eng.grads), z["grad:" + key]) < 2e-3, key
         assert rel_err(view(eng.params), z["new:" + key]) < 5e-5, key   # first Adam step ~ lr*sign(g): tiny-|g| elements are eps-sensitive
         assert rel_err(view(eng.shadow), z["ema:" + key]) < 1e-6, key
+
+
+def test_c2_full_size_backward_properties(monkeypatch):
+    """BASELINE config C2 at full size (24 layers, 8 x 8000 samples; too large for the oracle), backward: (1) the bf16 stream-K weight
+    gradients (one launch, every layer, dilations up to 2048) agree with the per-layer tile kernel on the same operands to 2e-4 of
+    each tensor's range; (2) the bf16 gradient arena agrees with the fp32 engine's to 5e-2 of its norm; (3) clip 0's contribution is
+    independent of its batch neighbours: gradients of a batch whose other clips are masked out (lengths 0) equal those of clip 0
+    alone in fp32 (atomics: to rounding)."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153, upsample_scales=[4, 4, 4, 5],
+               cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+    B, T = 8, 8000
+    gen = torch.Generator().manual_seed(4321)
+    x = torch.randint(0, 256, (B, T), generator=gen).cuda()
+    lat = torch.randn(B, 64, T // 320, generator=gen).cuda()
+    g = torch.randint(0, 153, (B,), generator=gen).cuda()
+
+    def grads_of(dtype, stream, xs, lats, gs, lengths):
+        monkeypatch.setenv("WAE_TN_STREAM", stream)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        eng.decoder_forward(xs, lats, gs, targets=xs, lengths=lengths.cuda() if lengths is not None else None, train=True,
+                            want_logits=False)
+        dc = BW.decoder_backward(eng, xs, xs, lengths, gs)
+        BW.frontend_backward(eng, dc)
+        out = BW.finish_grads(eng).clone()
+        torch.cuda.synchronize()
+        lay = eng.lay
+        del eng
+        torch.cuda.empty_cache()
+        return out, lay
+
+    g_stream, lay = grads_of("bf16", "1", x, lat, g, None)
+    g_tiles, _ = grads_of("bf16", "0", x, lat, g, None)
+    bad = {}
+    for k in lay.offsets:
+        if k.startswith("wavenet.conv_layers."):
+            a, b_ = g_tiles[lay.off(k):lay.off(k) + lay.numel(k)], g_stream[lay.off(k):lay.off(k) + lay.numel(k)]
+            err, ref = float((a - b_).abs().max()), float(a.abs().max())
+            if err > 2e-4 * max(ref, 1e-6) + 1e-7:
+                bad[k] = (err, ref)
+    assert not bad, bad
+    g32, _ = grads_of("fp32", "0", x, lat, g, None)
+    rel = float((g_stream - g32).double().norm() / g32.double().norm())
+    assert rel < 5e-2, rel
+    # (3) masked-out neighbours contribute nothing
+    lens = torch.tensor([T] + [0] * (B - 1))
+    g_masked, _ = grads_of("fp32", "0", x, lat, g, lens)
+    g_alone, _ = grads_of("fp32", "0", x[:1], lat[:1], g[:1], torch.tensor([T]))
+    rel = float((g_masked - g_alone).double().norm() / g_alone.double().norm())
+    assert rel < 1e-5, rel
