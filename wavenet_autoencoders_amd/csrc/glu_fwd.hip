@@ -156,11 +156,22 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
     }
     return base + (int64_t)min(max(ts, 0), p.T - 1) * rp;
   };
+  // bf16 only: the fp32 (parity) instantiations spill a few registers, and a fragment group spilled between its request and
+  // the counted wait would be saved before it has landed -- they keep plain loads and the compiler's own waits.
+  constexpr bool ASM_B = sizeof(E) == 2;
+  // Requests go out as inline-asm loads (gload_async) and are retired by the counted waits of chunk_top alone.  As plain
+  // loads they made hipcc put s_waitcnt vmcnt(0) in front of the first use of every loop-carried fragment group (the zero
+  // fill in fix_B, right after the barrier of each chunk) -- which drained the DMA pieces and operand requests of the NEXT
+  // chunks: the ring and the two-chunks-ahead requests bought nothing, every variant of this kernel measured 60 +- 2 us.
   auto load_B = [&](int q, frag (&Bf)[4]) {
     if (ABL(p.flags, DBG_NO_BLOAD)) return;
     const char* src = b_src(q);
+    if constexpr (ASM_B) {
+      gload_async<0>(Bf[0], src); gload_async<32>(Bf[1], src); gload_async<64>(Bf[2], src); gload_async<96>(Bf[3], src);
+    } else {
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) Bf[blk] = *(const frag*)(src + blk * 32);
+      for (int blk = 0; blk < 4; ++blk) Bf[blk] = *(const frag*)(src + blk * 32);
+    }
   };
   auto fix_B = [&](int q, frag (&Bf)[4]) {
     const int shift = q < nq_conv ? (p.ktaps - 1 - q % p.ktaps) * p.dilation : 0;
@@ -277,6 +288,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
     {
       auto step = [&](int q, frag (&Bcur)[4], frag (&Bload)[4]) {
         chunk_top(ps * nq1 + q, q + 2 < nq1 ? q + 2 : -1);
+        // the fragments of this chunk have landed (counted wait in chunk_top): every use comes after this point
+        if constexpr (ASM_B) asm volatile("" : "+v"(Bcur[0]), "+v"(Bcur[1]), "+v"(Bcur[2]), "+v"(Bcur[3]));
         fix_B(q, Bcur);
         const char* buf = smem + slot_c * CHB + lane * 16;
         auto filler = [&](auto ic) {
@@ -286,7 +299,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
             if constexpr (k < PPW) {
               if (dsrc) dma_piece(dsrc + k * 1024, ddst + k * 1024);
             } else {
-              if (bsrc) Bload[k - PPW] = *(const frag*)(bsrc + (k - PPW) * 32);
+              if (bsrc) {
+                if constexpr (ASM_B) gload_async<(k - PPW) * 32>(Bload[k - PPW], bsrc);
+                else Bload[k - PPW] = *(const frag*)(bsrc + (k - PPW) * 32);
+              }
             }
           }
         };
