@@ -16,6 +16,9 @@
 #define WAE_TM_ABLATE 0
 #endif
 #define TM_ABL(bit) ((WAE_TM_ABLATE & (bit)) != 0)
+#ifndef TM_ASM_B
+#define TM_ASM_B 1     // bf16: inline-asm operand requests two chunks ahead (0: the plain-load loop, one chunk ahead)
+#endif
 
 #define TM_MAX_SRC 4
 #define TM_PLAIN 0
@@ -155,6 +158,59 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
     }
   }
 
+  if constexpr (sizeof(E) == 2 && TM_ASM_B) {
+    // bf16: operand fragments of chunk q live in group q % 3, requested TWO chunks ahead by inline-asm loads (clamped address,
+    // zero fill at use) and retired by a counted wait that leaves the youngest request in flight.  With plain loads hipcc
+    // guards the first use of a loop-carried fragment with s_waitcnt vmcnt(0), i.e. every chunk waited for everything it had
+    // just requested (an earlier attempt at a deeper pipeline "measured the same" for that reason).  VMEM order per chunk q:
+    // [DMA(q+1): the weight ring has two slots][B(q+2)]; at the top of chunk q only B(q+1) may be outstanding.
+    auto b_addr = [&](int q, bool& ok) -> const char* {
+      int s_ = 0, q0 = 0;
+      if (p.interleave) {
+        s_ = q % p.nsrc;
+        q0 = q - q / p.nsrc;
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM_MAX_SRC - 1; ++i)
+          if (q >= qend[i] && i + 1 < p.nsrc) { s_ = i + 1; q0 = qend[i]; }
+      }
+      const int ts = t + p.src_shift[s_];
+      ok = tvalid && ts >= 0 && ts < p.T;
+      return p.src[s_] + (((int64_t)b * p.T + (ok ? ts : 0)) * p.src_stride[s_]) * ES + (q - q0) * 128 + h * 16;
+    };
+    frag G0[4], G1[4], G2[4];
+    bool k0, k1, k2;
+    auto request_B = [&](int q, frag (&G)[4], bool& ok) {
+      const char* src = b_addr(q, ok);
+      if (!TM_ABL(1)) { gload_async<0>(G[0], src); gload_async<32>(G[1], src); gload_async<64>(G[2], src); gload_async<96>(G[3], src); }
+    };
+    if (!TM_ABL(2)) dma_chunk(wbase, smem, CHB, wave, lane);
+    request_B(0, G0, k0);
+    request_B(min(1, nq - 1), G1, k1);
+    auto step = [&](int q, frag (&Gc)[4], bool kc, frag (&Gl)[4], bool& kl) {
+      if (TM_ABL(1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else wait_vmcnt_frags<4>(Gc);
+      __builtin_amdgcn_s_barrier();     // chunk q visible; every wave is past its reads of chunk q-1, whose slot is refilled now
+      {
+        const frag z = {};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Gc[i] = (kc && !TM_ABL(1)) ? Gc[i] : z;
+      }
+      // past the end the last chunk is requested again (into the slot / group nobody reads): the wait count never changes
+      const int qd = min(q + 1, nq - 1);
+      if (!TM_ABL(2)) dma_chunk(wbase + (int64_t)qd * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
+      request_B(min(q + 2, nq - 1), Gl, kl);
+      const char* buf = smem + (q & 1) * CHB + lane * 16;
+      if (!TM_ABL(4)) gemm_chunk<4 * NT, NT, 4>(buf, Gc, acc);
+      else asm volatile("" : "+v"(Gc[0]), "+v"(Gc[1]), "+v"(Gc[2]), "+v"(Gc[3]));
+    };
+    for (int q = 0; q < nq; q += 3) {
+      step(q, G0, k0, G2, k2);
+      if (q + 1 < nq) step(q + 1, G1, k1, G0, k0);
+      if (q + 2 < nq) step(q + 2, G2, k2, G1, k1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail requests must not outlive the ring
+    __syncthreads();
+  } else {
   if (!TM_ABL(2)) dma_chunk(wbase, smem, CHB, wave, lane);
   load_B(0, Bn);
   for (int q = 0; q < nq; ++q) {
@@ -169,6 +225,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
     const char* buf = smem + (q & 1) * CHB + lane * 16;
     if (!TM_ABL(4)) gemm_chunk<4 * NT, NT, 4>(buf, Bc, acc);
     else asm volatile("" : "+v"(Bc[0]), "+v"(Bc[1]), "+v"(Bc[2]), "+v"(Bc[3]));
+  }
   }
   if constexpr (PAIRED) __syncthreads();   // every wave is done with the weight ring: it becomes the staging area
   if (rows_valid <= 0) return;
