@@ -255,7 +255,7 @@ def main():
     # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (profiles/*pmc_traffic.json;
     # bench.py cannot run the profiler on itself).  Only applied when the run matches the profiled configuration.
     try:
-        with open(os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")) as fh:
             pmc = json.load(fh)["kernels"]
         if args.dtype == "bf16" and args.mode == "train":
             for rf in [roof] + list(extra.values()):
