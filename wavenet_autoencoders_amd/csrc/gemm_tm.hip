@@ -16,6 +16,9 @@
 #define WAE_TM_ABLATE 0
 #endif
 #define TM_ABL(bit) ((WAE_TM_ABLATE & (bit)) != 0)
+#ifdef WAE_GLU_PLAIN_LOADS
+#define TM_ASM_B 0
+#endif
 #ifndef TM_ASM_B
 #define TM_ASM_B 1     // bf16: inline-asm operand requests two chunks ahead (0: the plain-load loop, one chunk ahead)
 #endif

@@ -158,7 +158,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
   };
   // bf16 only: the fp32 (parity) instantiations spill a few registers, and a fragment group spilled between its request and
   // the counted wait would be saved before it has landed -- they keep plain loads and the compiler's own waits.
+#ifdef WAE_GLU_PLAIN_LOADS   // tools/check_asm_loads.py: the same kernel with compiler-managed loads, for a bitwise comparison
+  constexpr bool ASM_B = false;
+#else
   constexpr bool ASM_B = sizeof(E) == 2;
+#endif
   // Requests go out as inline-asm loads (gload_async) and are retired by the counted waits of chunk_top alone.  As plain
   // loads they made hipcc put s_waitcnt vmcnt(0) in front of the first use of every loop-carried fragment group (the zero
   // fill in fix_B, right after the barrier of each chunk) -- which drained the DMA pieces and operand requests of the NEXT
