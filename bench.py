@@ -282,6 +282,32 @@ def main():
             "roofline_glu_fwd": fwd_roof,
         }
         res.update(extra)
+        if args.mode == "train" and world == 1:
+            # the same stack in inference (no z saved, no backward): the north star states its roofline target on this launch
+            ev_f = []
+            nf = max(3, min(10, args.steps))
+            for i in range(2 + nf):
+                eng.prepare_weights()
+                eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False, layer_events=ev_f if i >= 2 else None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(nf):
+                eng.prepare_weights()
+                eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False)
+            e1.record()
+            torch.cuda.synchronize()
+            f_ms = sum(a.elapsed_time(b) for a, b in ev_f) / len(ev_f) / geom.layers
+            f_step = e0.elapsed_time(e1) / nf
+            res["forward_inference"] = {
+                "metric": "teacher-forced audio samples/sec (24-layer decoder), forward + CE", "value": samples / (f_step * 1e-3),
+                "unit": "samples/s", "ms_per_step": f_step, "steps": nf,
+                "roofline": {"bound": "hbm", "kernel": "glu_fwd_kernel", "achieved": bytes_per_launch / (f_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "avg_launch_ms": f_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                             "mfma_frac": flops_per_launch / (f_ms * 1e-3) / 1e12 / peak_tf,
+                             "note": "inference launch (no z saved): SURVEY 8(d) forward bytes (2R+2S+Cc)*e x 64000 samples; HIP "
+                                     "events around the 24-layer stack"}}
         if not args.no_ar and world == 1:
             res["autoregressive"] = ar_leg(device)
         if not args.no_cpu and world == 1:
