@@ -53,6 +53,12 @@ int wae_weight_norm_fwd(const float* params, float* eff, int64_t n_params, const
 int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, int64_t n_params,
                         const int64_t* v_off, const int64_t* g_off, const int32_t* cols, int32_t nrows,
                         void* stream);
+/* the same over the arena slice [lo, hi) and the weight-normed rows [row_lo, row_hi) that lie inside it: data-parallel
+ * training hands the decoder layers' gradients to the all-reduce while the front end's backward is still running
+ * (replaces the one-shot gather / reduce of vqwae_train.py:698-706) */
+int wae_weight_norm_bwd_range(const float* params, const float* d_eff, float* grads, int64_t lo, int64_t hi,
+                              const int64_t* v_off, const int64_t* g_off, const int32_t* cols, int32_t row_lo,
+                              int32_t row_hi, void* stream);
 
 /* dst[i + b*dst_stride] = (dtype) (map[i] < 0 ? 0 : src[map[i] + b*src_stride]),  i < n, b < nbatch */
 int wae_pack_gather(const float* src, const int32_t* map, void* dst, int64_t n, int32_t nbatch,
@@ -202,6 +208,9 @@ int wae_clip_adam_ema(float* params, const float* grads, float* exp_avg, float* 
  * WaveNet.incremental_forward (wavenet.py:218-346) as ONE persistent launch, one workgroup per utterance ------
  * mode 0: teacher-forced (the reference's test_inputs, softmax=False, quantize=False): logits out, inputs consumed
  * mode 1: greedy, the argmax class is fed back          mode 2: categorical draw by inverse CDF from uniforms[b,t]
+ * mode 3 / 4 (wae_ar_generate only; quantize=False, wavenet.py:335-338 skipped): the softmax probabilities / the raw logits
+ *   of step t are the dense decoder input of step t+1 (first_conv on a (1, O) row) and the step's row of out_logits
+ * Partial teacher forcing (test_inputs shorter than T, wavenet.py:300-305): desc.n_forced.
  * Weights are blocked [k/EPL][rows padded to 64][EPL] (EPL = 8 bf16 / 4 fp32), per layer [W1 (G x (k*R+Cc)) | W2
  * ((R+S) x H)] with layer_stride_bytes between layers; head = [S x S | O x S].  ring: B x ring_total floats of
  * per-layer history, ring_off[l] = float offset of layer l ((k-1)*d_l+1 rows of R).  zb as in wae_gproj_fwd.
@@ -215,6 +224,8 @@ typedef struct wae_ar_desc {
   int32_t init_idx;
   int32_t scalar_input; /* 0: wae_ar_generate / wae_ar_generate_coop; 1: wae_ar_generate_scalar */
   float scale;          /* sqrt(1/L) */
+  int32_t n_forced;     /* with inputs: steps t < n_forced consume inputs[t], later steps the fed-back output
+                           (test_inputs shorter than T, wavenet.py:300-305); <= 0 or >= T: every step is forced */
 } wae_ar_desc;
 int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
                     int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
@@ -375,6 +386,11 @@ int wae_vq_bwd(const float* lat, const float* quant, const int64_t* idx, const f
 
 /* layout helpers: (B,C,T) fp32 <-> (B,T,Cp) dtype */
 int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);
+/* the same with the shifted loss mask and weight of vqwae_train.py:374-379,764-766 applied on the way: row t is multiplied by
+ * `scale` while t + 1 < min(lengths[b], T) (lengths == NULL: T) and zeroed otherwise -- d loss / d y_hat of the masked mean
+ * of a per-step loss (the discretized mixture of logistics, mixture.py:26-106) in the layout wae_head_bwd takes as ext_dy */
+int wae_to_btc_masked(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
+                      const int32_t* lengths, float scale, void* stream);
 int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);
 
 #ifdef __cplusplus

@@ -410,7 +410,9 @@ def incremental_forward(sd: SD, cfg: dict, c_up: Optional[torch.Tensor], g: Opti
     (zero before t=0, conv.py:35-36) through the linearized (G, k*R) weight (:51-62).
 
     c_up: (B, Cc, T) ALREADY upsampled (wavenet.py:276-280 upsamples everything up-front).
-    mode: "logits"  -> teacher-forced/raw outputs (softmax=False, quantize=False; needs test_inputs)
+    mode: "logits"  -> raw outputs (softmax=False, quantize=False): teacher-forced while t < test_inputs' length, then the
+                       output vector of step t-1 is the input of step t (wavenet.py:299-305)
+          "probs"   -> the same with softmax=True, quantize=False: the probability vector is fed back
           "argmax"  -> greedy one-hot feedback (deterministic stand-in for OneHotCategorical, :335-338)
           "sample"  -> inverse-CDF categorical draw from ``uniforms`` (B, T)
     x inputs are one-hot (B, O, T) for test_inputs / (B, O, 1) for initial_input.  Returns (B, O, T).
@@ -485,6 +487,8 @@ def incremental_forward(sd: SD, cfg: dict, c_up: Optional[torch.Tensor], g: Opti
             o = dmol_sample(y.unsqueeze(-1), u_mix[:, t:t + 1], u_log[:, t:t + 1], log_scale_min)   # (B, 1)
         elif mode == "logits":
             o = y
+        elif mode == "probs":
+            o = F.softmax(y, dim=1)
         else:
             prob = F.softmax(y, dim=1)
             if mode == "argmax":

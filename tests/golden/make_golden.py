@@ -333,7 +333,21 @@ def gen_ar(cfg, sd, model, ins, ocfg):
         greedy = torch.stack(seq, dim=1)
     o_g = O.incremental_forward(sd, ocfg, c_up[:, :, :24].contiguous(), g, 24, initial_input=init, mode="argmax")
     assert torch.equal(o_g.argmax(1), greedy), "greedy roll-out differs"
-    save(f"ar_{cfg['name']}", c_up=c_up, tf_logits=tf, greedy=greedy, init=init)
+    # dense feedback (wavenet.py:299-305,335-338 with quantize=False): the softmax probabilities, or the raw logits, of step t
+    # are the decoder input of step t+1; and partial teacher forcing (test_inputs shorter than T: forced, then free-running)
+    Ts, nf = 40, 9
+    with torch.no_grad():
+        c40 = c_up[:, :, :Ts].contiguous()
+        # (the reference takes the batch size from test_inputs, wavenet.py:256: the start vector goes in as a one-step test_inputs)
+        soft = wn2.incremental_forward(init, c=c40, g=g, T=Ts, test_inputs=init, softmax=True, quantize=False)
+        raw = wn2.incremental_forward(init, c=c40, g=g, T=Ts, test_inputs=init, softmax=False, quantize=False)
+        part = wn2.incremental_forward(init, c=c40, g=g, T=Ts, test_inputs=xin[:, :, :nf].contiguous(), softmax=True,
+                                       quantize=False)
+    close(O.incremental_forward(sd, ocfg, c40, g, Ts, initial_input=init, mode="probs"), soft, what="oracle soft feedback", tol=1e-5)
+    close(O.incremental_forward(sd, ocfg, c40, g, Ts, initial_input=init, mode="logits"), raw, what="oracle raw feedback", tol=1e-5)
+    close(O.incremental_forward(sd, ocfg, c40, g, Ts, initial_input=init, test_inputs=xin[:, :, :nf], mode="probs"), part,
+          what="oracle partial teacher forcing", tol=1e-5)
+    save(f"ar_{cfg['name']}", c_up=c_up, tf_logits=tf, greedy=greedy, init=init, soft=soft, raw=raw, part=part, part_forced=nf)
 
 
 def gen_ar_scalar(cfg, sd, model, ins, ocfg):
@@ -545,7 +559,191 @@ def gen_quantizers():
     save("quantizers", **out)
 
 
+CFG_VQWAE = dict(name="vqwae", layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153,
+                 upsample_scales=[4, 4, 8, 5], encoder_hid=256, c_in=39, K=256, cin_pad=0)
+CFG_C5 = dict(name="c5", layers=48, stacks=4, R=512, G=512, S=512, O=256, Cc=64, Cg=32, k=3, n_speakers=153,
+              upsample_scales=[4, 4, 8, 5], cin_pad=0)
+
+
+class _Pick:
+    """Stands in for torch.distributions.OneHotCategorical inside the reference's own incremental loop (wavenet.py:335-338):
+    the draw becomes reproducible -- argmax, or the inverse CDF on explicit uniforms (the oracle's and the engine's form) --
+    and every step's probability vector is recorded."""
+    mode, uniforms, rec, step = "argmax", None, [], 0
+
+    def __init__(self, probs):
+        self.p = probs
+
+    def sample(self):
+        p, t = self.p, _Pick.step
+        _Pick.step += 1
+        _Pick.rec.append(p.clone())
+        if _Pick.mode == "argmax":
+            idx = p.argmax(1)
+        else:
+            cdf = p.double().cumsum(1)
+            idx = (cdf < _Pick.uniforms[:, t:t + 1].double() * cdf[:, -1:]).sum(1).clamp(max=p.shape[1] - 1)
+        return torch.nn.functional.one_hot(idx, p.shape[1]).float()
+
+    @classmethod
+    def start(cls, mode, uniforms=None):
+        cls.mode, cls.uniforms, cls.rec, cls.step = mode, uniforms, [], 0
+
+
+def gen_ar_c4():
+    """BASELINE config C4: the synthesis decoder of hps/vqwae.json (20 layers, R = G = S = 256, dilations to 512) over T = 2560
+    samples -- long enough that every layer's history ring wraps (2 * 512 + 1 entries) at least twice.  The reference's own
+    incremental_forward: teacher-forced logits, a greedy roll-out, an inverse-CDF sampled roll-out and partial teacher forcing."""
+    cfg = CFG_VQWAE
+    sd = O.make_state_dict(dict(cfg), salt=7, with_encoder=False)
+    T, O_ = 2560, cfg["O"]
+    lat = O.hash_fill((1, cfg["Cc"], T // 640), 401, 1.2)
+    x = ((O.hash_fill((1, T), 402) * 0.5 + 0.5) * O_).long().clamp(0, O_ - 1)
+    xin = torch.nn.functional.one_hot(x, O_).float().transpose(1, 2).contiguous()
+    g = torch.tensor([17])
+    u = O.hash_fill((1, T), 403) * 0.5 + 0.5
+    wn = build_ref_wavenet(cfg).eval()
+    wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items()})
+    wn.make_generation_fast_()
+    import time
+    keep = torch.distributions.OneHotCategorical
+    out = {}
+    try:
+        torch.distributions.OneHotCategorical = _Pick
+        with torch.no_grad():
+            t0 = time.time()
+            tf = wn.incremental_forward(None, c=lat, g=g, T=T, test_inputs=xin, softmax=False, quantize=False)
+            print(f"  C4 teacher-forced: {T / (time.time() - t0):.0f} samples/s on the reference")
+            fwd = wn(xin, lat, g, False)
+            close(tf, fwd, what="C4 incremental == forward", tol=2e-5)
+            _Pick.start("argmax")
+            gr = wn.incremental_forward(None, c=lat, g=g, T=T, softmax=True, quantize=True)
+            p_gr = torch.stack(_Pick.rec, dim=-1)                     # (1, O, T)
+            _Pick.start("cdf", u)
+            sm = wn.incremental_forward(None, c=lat, g=g, T=T, softmax=True, quantize=True)
+            p_sm = torch.stack(_Pick.rec, dim=-1)
+            nf, Tp = 700, 1280                                        # forced up to the middle of the d = 512 ring's 2nd lap, then free
+            _Pick.start("argmax")
+            pt = wn.incremental_forward(None, c=lat[:, :, :Tp // 640].contiguous(), g=g, T=Tp, softmax=True, quantize=True,
+                                        test_inputs=xin[:, :, :nf].contiguous())
+            p_pt = torch.stack(_Pick.rec, dim=-1)
+    finally:
+        torch.distributions.OneHotCategorical = keep
+    greedy = gr.argmax(1)
+    top2 = p_gr[:, :, :].topk(2, dim=1)[0].clamp_min(1e-30).log()
+    margin = (top2[:, 0] - top2[:, 1])                                # logit gap between the two best classes, (1, T)
+    sampled = sm.argmax(1)
+    partial = pt.argmax(1)
+    top2p = p_pt.topk(2, dim=1)[0].clamp_min(1e-30).log()
+    partial_margin = top2p[:, 0] - top2p[:, 1]
+    cdf = p_sm.double().cumsum(1)
+    cdf_gap = (cdf / cdf[:, -1:] - u[:, None, :].double()).abs().min(1)[0]   # distance of the uniform from the nearest CDF step
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    # the oracle on a prefix (its loop is the slow part of this generator)
+    Tq = 640
+    c_up = O.upsample_forward(sd, lat, cfg["upsample_scales"])
+    o_tf = O.incremental_forward(sd, ocfg, c_up[:, :, :Tq].contiguous(), g, Tq, test_inputs=xin[:, :, :Tq], mode="logits")
+    close(o_tf, tf[:, :, :Tq], what="oracle C4 teacher-forced prefix", tol=2e-5)
+    probe_t = torch.unique(torch.cat([torch.arange(0, T, 13), torch.arange(1016, 1040), torch.arange(2040, 2064),
+                                      torch.arange(T - 8, T)]))
+    save("ar_c4", cfg=json.dumps(cfg), salt=7, lat=lat, x=x.to(torch.uint8), g=g, probe_t=probe_t, tf_probe=tf[0][:, probe_t],
+         tf_argmax=tf.argmax(1).to(torch.uint8), tf_lse=torch.logsumexp(tf, 1), greedy=greedy.to(torch.uint8),
+         greedy_margin=margin, sampled=sampled.to(torch.uint8), cdf_gap=cdf_gap.float(), u_salt=403,
+         partial=partial.to(torch.uint8), partial_margin=partial_margin, partial_forced=nf)
+    print(f"  C4: min greedy logit margin {margin.min().item():.3e}, min cdf gap {cdf_gap.min().item():.3e}")
+
+
+def _probe_index(n, m=24):
+    """m reproducible positions of a flat tensor of n values: the first 4 and a stride walk"""
+    idx = np.unique(np.concatenate([np.arange(min(4, n)), (np.arange(m, dtype=np.int64) * 2654435761 + 12345) % n]))
+    return torch.from_numpy(idx)
+
+
+def gen_train_vqwae():
+    """BASELINE configs C1 / C3 geometry: hps/vqwae.json in full (302 tensors, 7 555 218 values), B = 2 clips x 5120 samples,
+    one complete reference train step (vqwae_train.py:709-798): loss terms, every parameter's gradient (squared norm + probe
+    values), clip norm, post-Adam parameters and EMA shadow at the probes."""
+    cfg = CFG_VQWAE
+    sd = O.make_state_dict(dict(cfg), 7)
+    c, x, xin, g, T = inputs_for(cfg, 2, 32, 310)
+    assert T == 5120
+    lengths = torch.tensor([T, T - 777])
+    y = x.unsqueeze(-1)
+    model = build_ref_vqvae(cfg, {k: v.clone() for k, v in sd.items()}).train()
+    opt = torch.optim.Adam(model.parameters(), lr=4e-4, eps=1e-8, weight_decay=0.0)
+    shadow = {n: p.data.clone() for n, p in model.named_parameters()}
+    mask = O.sequence_mask(lengths, T).unsqueeze(-1)[:, 1:, :]
+    opt.zero_grad()
+    y_hat, vq_loss, perp = model(xin, c, g, False)
+    crit = torch.nn.CrossEntropyLoss(reduction="none")
+    ce = ((crit(y_hat[:, :, :-1].unsqueeze(-1), y[:, 1:, :]) * mask).sum()) / mask.sum()
+    loss = ce + vq_loss.mean()
+    loss.backward()
+    grads = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 100.0)
+    opt.step()
+    for n, p in model.named_parameters():
+        shadow[n] -= (1.0 - 0.9999) * (shadow[n] - p.data)
+    new = {n: p.data for n, p in model.named_parameters()}
+    # fp64 oracle of the same step: the tight yardstick for the engine's fp32 gradients
+    psd = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    oy, ovq, operp, aux = O.vqvae_forward(psd, ocfg, xin.double(), c.double(), g)
+    oloss = O.masked_ce_loss(oy, y, lengths) + ovq
+    oloss.backward()
+    close(oloss, loss, what="vqwae train loss", tol=1e-5)
+    ograds = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in psd.items()}
+    worst = 0.0
+    for k in grads:
+        e = (ograds[k].float() - grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-20)
+        worst = max(worst, e)
+        assert e < 5e-3, (k, e)
+    print(f"  vqwae.json train step: loss {loss.item():.5f}, |g| {float(gn):.4f}, worst fp32-reference vs fp64-oracle gradient "
+          f"deviation {worst:.2e} of a tensor's max")
+    names = list(grads.keys())
+    pidx = {k: _probe_index(grads[k].numel()) for k in names}
+    cat = lambda d, dt: torch.cat([d[k].reshape(-1)[pidx[k]].to(dt) for k in names])   # noqa: E731
+    save("train_vqwae", cfg=json.dumps(cfg), salt=7, in_salt=310, lengths=lengths, loss=loss.detach(), ce=ce.detach(),
+         vq_loss=vq_loss.detach(), perp=perp.detach(), grad_norm=gn, vq_idx=aux["idx"],
+         names=json.dumps(names), probe_counts=np.array([len(pidx[k]) for k in names]),
+         grad_probe=cat(grads, torch.float32), grad64_probe=cat(ograds, torch.float64), new_probe=cat(new, torch.float32),
+         ema_probe=cat(shadow, torch.float32),
+         grad_sq=np.array([float((grads[k].double() ** 2).sum()) for k in names]),
+         grad64_sq=np.array([float((ograds[k] ** 2).sum()) for k in names]),
+         grad_max=np.array([float(grads[k].abs().max()) for k in names]))
+
+
+def gen_c5_probe():
+    """BASELINE config C5 at FULL depth: 48 layers in 4 stacks (dilations to 2048, receptive field 32 761), R = G = S = 512,
+    one clip of 5120 samples through the reference's WaveNet with its upsampling network: sparse logits probe + sums.
+    (T = 5120 > 2 * 2048: both history taps of the widest layers reach real samples.)"""
+    cfg = CFG_C5
+    sd = O.make_state_dict(dict(cfg), salt=9, with_encoder=False)
+    T = 5120
+    lat = O.hash_fill((1, cfg["Cc"], T // 640), 501, 1.2)
+    x = ((O.hash_fill((1, T), 502) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    g = torch.tensor([41])
+    wn = build_ref_wavenet(cfg).eval()
+    wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items()})
+    with torch.no_grad():
+        y = wn(xin, lat, g, False)
+        ocfg = dict(layers=48, stacks=4, upsample_scales=cfg["upsample_scales"], cin_pad=0)
+        oy = O.wavenet_forward(sd, ocfg, xin, lat, g)
+    e = close(oy, y, what="C5 logits", tol=5e-5)
+    print(f"  C5 full depth: T={T}, max|oracle-ref| = {e:.2e}, |y|max {y.abs().max().item():.3f}")
+    ti = torch.unique(torch.cat([torch.arange(0, T, 37), torch.arange(4090, 4110), torch.arange(T - 4, T)]))
+    save("model_c5_probe", cfg=json.dumps(cfg), salt=9, lat_salt=501, x_salt=502, g=g, T=T, probe_t=ti, y_probe=y[0][:, ti],
+         y_lse=torch.logsumexp(y, 1), y_sum=y.double().sum(), y_abs_sum=y.double().abs().sum())
+
+
 def main():
+    if sys.argv[1:] == ["c4"]:
+        return gen_ar_c4()
+    if sys.argv[1:] == ["train_vqwae"]:
+        return gen_train_vqwae()
+    if sys.argv[1:] == ["c5"]:
+        return gen_c5_probe()
     if sys.argv[1:] == ["quantizers"]:
         return gen_quantizers()
     if sys.argv[1:] == ["wide"]:
@@ -565,6 +763,9 @@ def main():
     gen_ar_scalar(CFG_S, sd, model, ins, ocfg)
     gen_vqwae_probe()
     gen_wide_probe()
+    gen_ar_c4()
+    gen_train_vqwae()
+    gen_c5_probe()
 
 
 if __name__ == "__main__":

@@ -90,3 +90,28 @@ def test_scalar_input_decode_against_reference_vectors(dtype, tol):
                                        u_log=torch.from_numpy(z["u_log"])[:, :24].contiguous().cuda(), log_scale_min=-7.0)
         torch.cuda.synchronize()
         assert float((roll["x"].cpu() - torch.from_numpy(z["roll"])[:, 0]).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_dense_feedback_and_partial_teacher_forcing(name, dtype, tol):
+    """quantize=False free-running (wavenet.py:303-305 with :335-338 skipped): the softmax probabilities, or the raw logits, of
+    step t are the dense input of step t+1; and test_inputs shorter than T (forced, then free) -- against the rows the
+    reference's own incremental_forward returned."""
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    z = load_npz("ar_" + name)
+    eng = _engine(cfg, sd, dtype)
+    Ts = z["soft"].shape[-1]
+    c_up = torch.from_numpy(z["c_up"])[:, :, :Ts].contiguous().cuda()
+    g = ins["g"].cuda()
+    init = cfg["O"] // 2 - 1
+    soft = eng.incremental_forward(c_up, g, Ts, mode="probs", init_idx=init, c_is_upsampled=True)["logits"]
+    raw = eng.incremental_forward(c_up, g, Ts, mode="raw", init_idx=init, c_is_upsampled=True)["logits"]
+    nf = int(z["part_forced"])
+    part = eng.incremental_forward(c_up, g, Ts, mode="probs", test_inputs=ins["x"][:, :nf].cuda(), init_idx=init,
+                                   c_is_upsampled=True)["logits"]
+    torch.cuda.synchronize()
+    assert rel_err(soft.cpu(), z["soft"]) < tol
+    assert rel_err(raw.cpu(), z["raw"]) < tol
+    assert rel_err(part.cpu(), z["part"]) < tol
+    assert abs(float(soft[:, :, -1].sum()) - soft.shape[0]) < 1e-3        # rows are probabilities

@@ -1,0 +1,256 @@
+"""GPU parity of the configurations bench.py times (BASELINE.json configs C1/C3, C4, C5) at their FULL geometry, against
+vectors the reference itself produced (tests/golden/make_golden.py: ar_c4, train_vqwae, model_c5_probe).
+
+C4  hps/vqwae.json synthesis decoder (20 layers, R = G = S = 256, dilations to 512), T = 2560: the per-layer history rings
+    (2 * 512 + 1 rows) wrap twice; 32-CU cooperative kernel and one-CU kernel, fp32 and bf16.
+C1/C3  hps/vqwae.json in full (302 tensors), 2 x 5120 samples: one train step, every parameter gradient.
+C5  48 layers / 4 stacks (dilations to 2048), R = G = S = 512: logits of one 5120-sample clip; causality and clip independence
+    of the 16 x 5120 shard.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz, rel_err
+from oracle import wae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cfg, sd, dtype):
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+    eng.load_state_dict(sd)
+    return eng
+
+
+# ------------------------------------------------------------------------------------------------------------------ C4
+@pytest.fixture(scope="module")
+def c4():
+    z = load_npz("ar_c4")
+    cfg = {k: v for k, v in json.loads(str(z["cfg"])).items() if k not in ("encoder_hid", "c_in", "K")}   # decoder only
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]), with_encoder=False)
+    return cfg, sd, z
+
+
+@pytest.mark.parametrize("coop", ["1", "0"])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_c4_teacher_forced_logits(c4, dtype, tol, coop, monkeypatch):
+    """Teacher-forced incremental decode over 2560 samples == the reference's incremental_forward(test_inputs) at the probe
+    steps (every 13th + the steps around both wraps of the d = 512 rings), and the log-sum-exp of EVERY step."""
+    cfg, sd, z = c4
+    monkeypatch.setenv("WAE_AR_COOP", coop)
+    eng = _engine(cfg, sd, dtype)
+    T = z["x"].shape[1]
+    x = torch.from_numpy(z["x"].astype(np.int64)).cuda()
+    out = eng.incremental_forward(torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda(), T, mode="logits",
+                                  test_inputs=x)
+    torch.cuda.synchronize()
+    y = out["logits"].cpu()[0]                                     # (O, T)
+    pt = torch.from_numpy(z["probe_t"]).long()
+    assert rel_err(y[:, pt], z["tf_probe"]) < tol                  # norm-wise: max|a-b| / max|b|
+    lse = torch.logsumexp(y, 0)
+    assert float((lse - torch.from_numpy(z["tf_lse"])[0]).abs().max()) < tol * float(np.abs(z["tf_probe"]).max())
+    if dtype == "fp32":
+        # the most likely class of every step, except where the reference's own two best logits are closer than 1e-3
+        am = y.argmax(0).numpy()
+        top2 = torch.from_numpy(z["tf_probe"]).topk(2, dim=0)[0]
+        clear = ((top2[0] - top2[1]) > 1e-3).numpy()
+        assert (am[pt.numpy()] == z["tf_argmax"][0][pt.numpy()])[clear].all()
+
+
+def _check_rollout(got, want, margin, thresh, what):
+    """free-running sequences can only part where the reference's own decision was within rounding (margin < thresh);
+    everything before the first such step must be identical"""
+    diff = np.nonzero(got != want)[0]
+    if diff.size == 0:
+        return len(want)
+    first = int(diff[0])
+    assert margin[first] < thresh, f"{what}: first difference at step {first} where the reference's margin is {margin[first]:.3e}"
+    return first
+
+
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_c4_greedy_rollout_fp32(c4, coop, monkeypatch):
+    cfg, sd, z = c4
+    monkeypatch.setenv("WAE_AR_COOP", coop)
+    eng = _engine(cfg, sd, "fp32")
+    T = z["x"].shape[1]
+    lat, g = torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda()
+    out = eng.incremental_forward(lat, g, T, mode="argmax", init_idx=127)
+    torch.cuda.synchronize()
+    n = _check_rollout(out["idx"].cpu().numpy()[0], z["greedy"][0], z["greedy_margin"][0], 1e-3, "greedy")
+    assert n >= 300, f"greedy roll-out left the reference's after {n} steps"
+    # whatever happened after a near-tie: teacher-forced on the reference's own sequence, the engine picks the reference's next
+    # sample at every step whose margin is clear
+    seq = torch.from_numpy(np.concatenate([[127], z["greedy"][0][:-1]]).astype(np.int64))[None].cuda()
+    tf = eng.incremental_forward(lat, g, T, mode="logits", test_inputs=seq)
+    torch.cuda.synchronize()
+    am = tf["logits"].cpu()[0].argmax(0).numpy()
+    clear = z["greedy_margin"][0] > 1e-3
+    assert (am == z["greedy"][0])[clear].all()
+    assert clear.mean() > 0.95
+
+
+def test_c4_sampled_rollout_and_partial_forcing_fp32(c4):
+    cfg, sd, z = c4
+    eng = _engine(cfg, sd, "fp32")
+    T = z["x"].shape[1]
+    lat, g = torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda()
+    u = (O.hash_fill((1, T), int(z["u_salt"])) * 0.5 + 0.5).cuda()
+    out = eng.incremental_forward(lat, g, T, mode="sample", uniforms=u, init_idx=127)
+    torch.cuda.synchronize()
+    n = _check_rollout(out["idx"].cpu().numpy()[0], z["sampled"][0], z["cdf_gap"][0], 1e-5, "inverse-CDF draw")
+    assert n >= 400, f"sampled roll-out left the reference's after {n} steps"
+    # test_inputs shorter than T (wavenet.py:300-305): 700 forced steps, then greedy feedback
+    nf, Tp = int(z["partial_forced"]), z["partial"].shape[1]
+    x = torch.from_numpy(z["x"].astype(np.int64))[:, :nf].cuda()
+    out = eng.incremental_forward(lat[:, :, :Tp // 640].contiguous(), g, Tp, mode="argmax", test_inputs=x, n_forced=nf)
+    torch.cuda.synchronize()
+    got, want, mg = out["idx"].cpu().numpy()[0], z["partial"][0], z["partial_margin"][0]
+    assert (got[:nf] == want[:nf])[mg[:nf] > 1e-3].all()             # forced steps: independent decisions
+    n = _check_rollout(got[nf:], want[nf:], mg[nf:], 1e-3, "free-running tail")
+    assert n >= 100
+
+
+def test_c4_bf16_follows_the_reference_sequence(c4):
+    """bf16 storage cannot reproduce a 2560-step greedy path bit for bit; teacher-forced on the reference's path it must make
+    the reference's decision wherever the two best logits are 0.25 apart (5 % of the logit range is the stated bf16 bound)."""
+    cfg, sd, z = c4
+    eng = _engine(cfg, sd, "bf16")
+    T = z["x"].shape[1]
+    lat, g = torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda()
+    seq = torch.from_numpy(np.concatenate([[127], z["greedy"][0][:-1]]).astype(np.int64))[None].cuda()
+    tf = eng.incremental_forward(lat, g, T, mode="logits", test_inputs=seq)
+    torch.cuda.synchronize()
+    am = tf["logits"].cpu()[0].argmax(0).numpy()
+    clear = z["greedy_margin"][0] > 0.25
+    assert clear.sum() > 50 and (am == z["greedy"][0])[clear].all()
+
+
+# --------------------------------------------------------------------------------------------------------------- C1 / C3
+def test_vqwae_full_geometry_train_step_fp32():
+    """hps/vqwae.json, 2 clips x 5120 samples, ragged lengths: loss terms, VQ indices (bit-exact), every one of the 302
+    parameter gradients at its probes and by its norm, the clip norm, post-Adam parameters and the EMA shadow -- against
+    the reference's own step (fp32) and the fp64 oracle of the same step."""
+    z = load_npz("train_vqwae")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]))
+    eng = _engine(cfg, sd, "fp32")
+    B, F = 2, 32
+    s = int(z["in_salt"])
+    c = O.hash_fill((B, cfg["c_in"], F), s + 1, 1.7)
+    T = 5120
+    x = ((O.hash_fill((B, T), s + 2) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+    g = ((O.hash_fill((B,), s + 3) * 0.5 + 0.5) * cfg["n_speakers"]).long().clamp(0, cfg["n_speakers"] - 1)
+    lengths = torch.from_numpy(z["lengths"])
+    eng.init_optimizer()
+    grads_seen = {}
+
+    def hook(grads):
+        grads_seen["g"] = grads.clone()
+
+    res = eng.train_step(x.cuda(), c.cuda(), g.cuda(), lengths=lengths.cuda(), lr=4e-4, clip_thresh=100.0, ema_decay=0.9999,
+                         grad_hook=hook)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng._fe["idx"].cpu().numpy(), z["vq_idx"])
+    assert abs(float(res["ce"]) - float(z["ce"])) < 1e-4 * float(z["ce"])
+    assert abs(float(res["vq_loss"]) - float(z["vq_loss"])) < 1e-5 * max(1.0, float(z["vq_loss"]))
+    assert abs(float(res["perp"]) - float(z["perp"])) < 1e-3
+    assert abs(float(res["grad_norm"]) - float(z["grad_norm"])) < 1e-3 * float(z["grad_norm"])
+    names = json.loads(str(z["names"]))
+    counts = z["probe_counts"]
+    grads = grads_seen["g"].cpu()
+    params, shadow = eng.params.cpu(), eng.shadow.cpu()
+    off, bad = 0, {}
+    for i, k in enumerate(names):
+        n = eng.lay.numel(k)
+        idx = np.unique(np.concatenate([np.arange(min(4, n)), (np.arange(24, dtype=np.int64) * 2654435761 + 12345) % n]))
+        assert len(idx) == counts[i]
+        sl = slice(off, off + len(idx))
+        off += len(idx)
+        o = eng.lay.off(k)
+        gk = grads[o:o + n]
+        gmax = float(z["grad_max"][i])
+        e64 = float((gk[idx].double() - torch.from_numpy(z["grad64_probe"][sl])).abs().max())
+        e32 = float((gk[idx] - torch.from_numpy(z["grad_probe"][sl])).abs().max())
+        sq = float((gk.double() ** 2).sum())
+        # 5e-4 of the tensor's largest gradient against fp64 (the reference's own fp32 step is within 2.2e-4 of it: the
+        # upsampling FIR and weight_g gradients are long cancelling sums), norms to 2e-3
+        # (weight_g gradients are cancelling sums -- largest ~1e-5 where weight_v's are ~1e-3 -- hence the absolute floor)
+        if e64 > 5e-4 * gmax + 2e-8 or e32 > 1e-3 * gmax + 2e-8 or abs(sq - z["grad64_sq"][i]) > 2e-3 * z["grad64_sq"][i] + 1e-12:
+            bad[k] = (e64, e32, gmax, sq, float(z["grad64_sq"][i]))
+        # the first Adam step moves every weight by lr * g / (|g| + eps): where |g| is not far above eps = 1e-8 (weight_g
+        # rows whose gradient cancels to ~0) the step inherits the gradient's relative error, at most lr itself
+        pk, sk = params[o:o + n], shadow[o:o + n]
+        gr = torch.from_numpy(z["grad_probe"][sl])
+        tol = 4e-4 * torch.clamp(4 * (gk[idx] - gr).abs() / (gr.abs() + 1e-8), max=1.0) + 2e-6
+        assert bool(((pk[idx] - torch.from_numpy(z["new_probe"][sl])).abs() <= tol).all()), k
+        assert bool(((sk[idx] - torch.from_numpy(z["ema_probe"][sl])).abs() <= 1e-4 * tol + 1e-6).all()), k
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------------------------ C5
+@pytest.fixture(scope="module")
+def c5():
+    z = load_npz("model_c5_probe")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]), with_encoder=False)
+    return cfg, sd, z
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_c5_full_depth_logits(c5, dtype, tol):
+    cfg, sd, z = c5
+    eng = _engine(cfg, sd, dtype)
+    T = int(z["T"])
+    lat = O.hash_fill((1, cfg["Cc"], T // 640), int(z["lat_salt"]), 1.2)
+    x = ((O.hash_fill((1, T), int(z["x_salt"])) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    out = eng.decoder_forward(x.cuda(), lat.cuda(), torch.from_numpy(z["g"]).cuda())
+    torch.cuda.synchronize()
+    y = out["logits"].cpu()[0]
+    pt = torch.from_numpy(z["probe_t"]).long()
+    assert rel_err(y[:, pt], z["y_probe"]) < tol
+    scale = float(np.abs(z["y_probe"]).max())
+    assert float((torch.logsumexp(y, 0) - torch.from_numpy(z["y_lse"])[0]).abs().max()) < tol * scale
+    if dtype == "fp32":
+        assert abs(float(y.double().sum()) - float(z["y_sum"])) < 1e-4 * float(z["y_abs_sum"])
+
+
+def test_c5_shard_properties_bf16(c5):
+    """The per-GPU shard of C5 (16 clips x 5120 samples, bf16): causality through all 48 layers (a change at t0 leaves every
+    earlier step bit-identical), independence of the clips, and the bf16 loss against the fp32 engine."""
+    cfg, sd, z = c5
+    B, T = 16, 5120
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, T))).cuda()
+    lat = torch.from_numpy(rng.standard_normal((B, cfg["Cc"], T // 640)).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.integers(0, cfg["n_speakers"], size=(B,))).cuda()
+    eng = _engine(cfg, sd, "bf16")
+    base = eng.decoder_forward(x, lat, g, targets=x)
+    y0, l0 = base["logits"].clone(), float(base["loss"])
+    t0 = 4097
+    x2 = x.clone()
+    x2[3, t0:] = (x2[3, t0:] + 101) % 256                          # clip 3 changes from t0 on
+    y1 = eng.decoder_forward(x2, lat, g)["logits"]
+    torch.cuda.synchronize()
+    assert torch.equal(y1[3, :, :t0], y0[3, :, :t0]), "a later input changed an earlier output"
+    assert not torch.equal(y1[3, :, t0 + 1:], y0[3, :, t0 + 1:])
+    others = [b for b in range(B) if b != 3]
+    assert torch.equal(y1[others], y0[others]), "clips are not independent"
+    # the same clips alone (B = 2) give the same rows as inside the shard
+    y2 = eng.decoder_forward(x[5:7].contiguous(), lat[5:7].contiguous(), g[5:7].contiguous())["logits"]
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y0[5:7])
+    del eng
+    e32 = _engine(cfg, sd, "fp32")
+    l32 = float(e32.decoder_forward(x[:4].contiguous(), lat[:4].contiguous(), g[:4].contiguous(), targets=x[:4].contiguous(),
+                                    want_logits=False)["loss"])
+    eb = _engine(cfg, sd, "bf16")
+    lb = float(eb.decoder_forward(x[:4].contiguous(), lat[:4].contiguous(), g[:4].contiguous(), targets=x[:4].contiguous(),
+                                  want_logits=False)["loss"])
+    assert abs(lb - l32) < 2e-2 * l32, (lb, l32)
+    assert np.isfinite(l0)

@@ -225,3 +225,88 @@ def test_wide_probe():
                               torch.from_numpy(z["g"]))
     assert rel_err(y[:, :, torch.from_numpy(z["probe_t"])], z["y_probe"]) < TOL
     assert abs(float(y.double().sum()) - float(z["y_sum"])) < 1e-4 * float(z["y_abs_sum"])
+
+
+# ---- full-geometry configurations (BASELINE.json C4, C1/C3, C5): the oracle against the reference's own vectors ------------
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_dense_feedback_and_partial_forcing(name):
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    z = load_npz("ar_" + name)
+    Ts = z["soft"].shape[-1]
+    c_up = torch.from_numpy(z["c_up"])[:, :, :Ts].contiguous()
+    init = torch.from_numpy(z["init"])
+    nf = int(z["part_forced"])
+    assert rel_err(O.incremental_forward(sd, ocfg, c_up, ins["g"], Ts, initial_input=init, mode="probs"), z["soft"]) < TOL
+    assert rel_err(O.incremental_forward(sd, ocfg, c_up, ins["g"], Ts, initial_input=init, mode="logits"), z["raw"]) < TOL
+    assert rel_err(O.incremental_forward(sd, ocfg, c_up, ins["g"], Ts, initial_input=init, test_inputs=ins["xin"][:, :, :nf],
+                                         mode="probs"), z["part"]) < TOL
+
+
+def test_c4_incremental_prefix():
+    """hps/vqwae.json synthesis decoder: the oracle's incremental loop over the first 160 samples of ar_c4.npz (teacher-forced
+    logits at the probe steps, then the reference's greedy decisions where its margin is clear)."""
+    z = load_npz("ar_c4")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]), with_encoder=False)
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    Tq = 160
+    c_up = O.upsample_forward(sd, torch.from_numpy(z["lat"]), cfg["upsample_scales"])[:, :, :Tq].contiguous()
+    x = torch.from_numpy(z["x"].astype(np.int64))[:, :Tq]
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    g = torch.from_numpy(z["g"])
+    with torch.no_grad():
+        y = O.incremental_forward(sd, ocfg, c_up, g, Tq, test_inputs=xin, mode="logits")
+        pt = z["probe_t"][z["probe_t"] < Tq]
+        assert rel_err(y[0][:, pt], z["tf_probe"][:, :len(pt)]) < TOL
+        assert rel_err(torch.logsumexp(y, 1), z["tf_lse"][:, :Tq]) < TOL
+        gr = O.incremental_forward(sd, ocfg, c_up[:, :, :64].contiguous(), g, 64, mode="argmax").argmax(1).numpy()[0]
+    clear = z["greedy_margin"][0][:64] > 1e-3
+    first_unclear = int(np.argmin(clear)) if not clear.all() else 64
+    assert np.array_equal(gr[:first_unclear], z["greedy"][0][:first_unclear])
+
+
+def test_c5_full_depth_probe():
+    z = load_npz("model_c5_probe")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]), with_encoder=False)
+    T = 1920                                   # a prefix: causal, so the first 1920 steps do not depend on the rest
+    lat = O.hash_fill((1, cfg["Cc"], int(z["T"]) // 640), int(z["lat_salt"]), 1.2)[:, :, :T // 640].contiguous()
+    x = ((O.hash_fill((1, int(z["T"])), int(z["x_salt"])) * 0.5 + 0.5) * 256).long().clamp(0, 255)[:, :T]
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    with torch.no_grad():
+        y = O.wavenet_forward(sd, dict(layers=48, stacks=4, upsample_scales=cfg["upsample_scales"], cin_pad=0), xin, lat,
+                              torch.from_numpy(z["g"]))
+    # the four smoothing FIRs together look 640 + 160 + 40 + 5 samples ahead: compare away from the cut
+    pt = z["probe_t"][z["probe_t"] < T - 900]
+    assert rel_err(y[0][:, pt], z["y_probe"][:, :len(pt)]) < TOL
+
+
+def test_vqwae_full_geometry_train_step():
+    """hps/vqwae.json in full, 2 x 5120 samples: loss terms and every parameter's gradient (probes + squared norm) of the
+    oracle's autograd against the reference's own train step."""
+    z = load_npz("train_vqwae")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]))
+    s, B, T = int(z["in_salt"]), 2, 5120
+    c = O.hash_fill((B, cfg["c_in"], 32), s + 1, 1.7)
+    x = ((O.hash_fill((B, T), s + 2) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    g = ((O.hash_fill((B,), s + 3) * 0.5 + 0.5) * cfg["n_speakers"]).long().clamp(0, cfg["n_speakers"] - 1)
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    y, vq, perp, aux = O.vqvae_forward(psd, ocfg, xin, c, g)
+    ce = O.masked_ce_loss(y, x.unsqueeze(-1), torch.from_numpy(z["lengths"]))
+    (ce + vq).backward()
+    assert np.array_equal(aux["idx"].numpy(), z["vq_idx"])
+    assert abs(float(ce) - float(z["ce"])) < 1e-5 * float(z["ce"])
+    assert abs(float(vq) - float(z["vq_loss"])) < 1e-6 * max(1.0, float(z["vq_loss"]))
+    names = json.loads(str(z["names"]))
+    off = 0
+    for i, k in enumerate(names):
+        gk = psd[k].grad.reshape(-1) if psd[k].grad is not None else torch.zeros(psd[k].numel())
+        n = gk.numel()
+        idx = np.unique(np.concatenate([np.arange(min(4, n)), (np.arange(24, dtype=np.int64) * 2654435761 + 12345) % n]))
+        sl = slice(off, off + len(idx))
+        off += len(idx)
+        assert float((gk[idx] - torch.from_numpy(z["grad_probe"][sl])).abs().max()) < 1e-3 * float(z["grad_max"][i]) + 1e-8, k   # weight_g gradients are cancelling sums (largest ~1e-5 where weight_v's are ~1e-3): absolute floor
+        assert abs(float((gk.double() ** 2).sum()) - z["grad_sq"][i]) < 1e-3 * z["grad_sq"][i] + 1e-14, k

@@ -21,7 +21,7 @@ class GluDesc(ctypes.Structure):
 
 class ArDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "L", "R", "Rp", "G", "Hp", "S", "O", "Cc", "Ccp", "ktaps", "mode",
-                                     "init_idx", "scalar_input")] + [("scale", c_f32)]
+                                     "init_idx", "scalar_input")] + [("scale", c_f32), ("n_forced", c_i32)]
 
 
 class TmDesc(ctypes.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "wae_last_error": (ctypes.c_char_p, []),
     "wae_weight_norm_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "wae_weight_norm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "wae_weight_norm_bwd_range": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_pack_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "wae_unpack_scatter_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i64, c_i32, c_vp]),
     "wae_enc_conv_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp]),
@@ -101,6 +102,7 @@ SIGNATURES = {
                              + [c_i32] + [c_vp] * 8),
     "wae_masked_mean": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
+    "wae_to_btc_masked": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp, c_f32, c_vp]),
     "wae_from_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
 }
 

@@ -305,12 +305,34 @@ def _build_tile_tables(eng, ws, fw, B, T):
     ws["tt_first"] = tt.finalize(B)
 
 
+def layer_segment(eng):
+    """[lo, hi) of the flat arena that holds the gated layers and the head -- ~95 % of the parameters, and final as soon as the
+    weight-gradient launches and gproj_bwd have run (first_conv sits in front of it, the speaker embedding, the upsampling
+    network, the encoder and the codebook behind it)."""
+    lay = eng.lay
+    keys = list(lay.offsets)
+    last = keys.index("wavenet.last_conv_layers.3.weight_v")
+    hi = lay.offsets[keys[last + 1]] if last + 1 < len(keys) else lay.total
+    return lay.off("wavenet.conv_layers.0.conv.bias"), hi
+
+
+def _wn_bwd_range(eng, lo, hi):
+    """weight-norm backward (d_eff -> grads) of the arena slice [lo, hi)"""
+    lay = eng.lay
+    r0, r1 = int(np.searchsorted(lay.wn_v_off, lo)), int(np.searchsorted(lay.wn_v_off, hi))
+    L.check(eng.lib.wae_weight_norm_bwd_range(L.ptr(eng.params), L.ptr(eng.d_eff), L.ptr(eng.grads), lo, hi, L.ptr(eng.wn_v),
+                                              L.ptr(eng.wn_g), L.ptr(eng.wn_c), r0, r1, eng.stream()), "weight_norm_bwd")
+
+
 def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: Optional[torch.Tensor],
                      gid: Optional[torch.Tensor], gvec: Optional[torch.Tensor] = None, ext_dy: Optional[torch.Tensor] = None,
-                     loss_scale: float = 1.0):
+                     loss_scale: float = 1.0, grad_sync=None):
     """Backward of the last ``decoder_forward(..., train=True)`` with the same (B, T).  Fills ``eng.grads`` (flat arena,
     reference parameter layout incl. weight_g / weight_v) for every decoder parameter and returns dc (B,T,Ccp): the
-    gradient wrt the upsampled local conditioning.  ``ext_dy`` (B,T,Op): external d loss / d logits (DMoL)."""
+    gradient wrt the upsampled local conditioning.  ``ext_dy`` (B,T,Op): external d loss / d logits (DMoL).
+    ``grad_sync`` (distributed.GradSync): the layers' + head's slice of the gradient arena is finished (weight-norm backward
+    of that slice) and handed to the all-reduce BEFORE the conditioning / first-conv / front-end gradients are computed, so
+    the collective runs under them."""
     _prepare_bwd(eng)
     g, lib, lay, st = eng.g, eng.lib, eng.lay, eng.stream()
     B, T = x_ids.shape
@@ -413,6 +435,38 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         if ev is not None:
             e1.record(torch.cuda.current_stream(eng.device))
             ev.append((e0, e1))
+    # ---- scatter the dense tiles of the layers and the head into the effective-weight gradient arena -----------------------
+    def scat(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1):
+        L.check(lib.wae_unpack_scatter_add(ctypes.c_void_p(src.data_ptr() + off * 4), L.ptr(mp), L.ptr(eng.d_eff), rows * cols, nb,
+                                           ss, ds, cols, ld, unique, st), "scatter")
+    OP = P.ONES_PAD
+    scat(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], nb=g.layers, ss=Z2 * sm["ld1"], ds=lay.layer_stride)
+    scat(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride)
+    scat(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=2)
+    scat(cs, sm["ws"], g.Sp, g.Ku, sm["lds"])
+    scat(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=2)
+    scat(c3, sm["w3"], g.Op, g.Sp, sm["ldh"])
+    scat(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2)
+    scat(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"])
+    scat(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)
+    # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
+    wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
+    emb_off = lay.offsets.get("wavenet.embed_speakers.weight", 0)
+    use_gid = gid is not None and "wavenet.embed_speakers.weight" in lay.offsets
+    gid32 = gid.to(torch.int32).contiguous() if gid is not None else None
+    keep.append(gid32)
+    L.check(lib.wae_gproj_bwd(L.ptr(eng.eff), L.ptr(eng.d_eff), wg_off, lay.off("wavenet.conv_layers.0.conv.bias"),
+                              lay.layer_stride, L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec), L.ptr(c1),
+                              Z2 * sm["ld1"], sm["ld1"], g.k * g.Rp + g.Ccp, B, g.layers, g.G, g.Hp, max(g.Cg, 0), st),
+            "gproj_bwd")
+    # ---- data parallel: the layers' + head's gradients are final -> weight-norm backward of that slice, then the all-reduce
+    #      starts on its side stream while the launches below (and the front end's backward) still run ------------------------
+    eng._grads_done = None
+    if grad_sync is not None:
+        lo, hi = layer_segment(eng)
+        _wn_bwd_range(eng, lo, hi)
+        eng._grads_done = (lo, hi)
+        grad_sync.ready_range(lo, hi)
     # ---- local-conditioning gradient over all layers at once ---------------------------------------------------------
     if g.Ccp:
         _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), dzs, dzs, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
@@ -428,33 +482,8 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         ws["ids"].copy_(xi)
         ws["tt_first"].launch(B, T)
         L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
-
-    # ---- scatter the dense tiles into the effective-weight gradient arena ----------------------------------------------
-    def scat(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1):
-        L.check(lib.wae_unpack_scatter_add(ctypes.c_void_p(src.data_ptr() + off * 4), L.ptr(mp), L.ptr(eng.d_eff), rows * cols, nb,
-                                           ss, ds, cols, ld, unique, st), "scatter")
-    OP = P.ONES_PAD
-    scat(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], nb=g.layers, ss=Z2 * sm["ld1"], ds=lay.layer_stride)
-    scat(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride)
-    scat(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=2)
-    scat(cs, sm["ws"], g.Sp, g.Ku, sm["lds"])
-    scat(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=2)
-    scat(c3, sm["w3"], g.Op, g.Sp, sm["ldh"])
-    scat(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2)
-    scat(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"])
-    scat(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)
     scat(ctab, sm["tab"], 1 if g.scalar_input else g.O, g.Rp, g.Rp)
     scat(fb, sm["fb"], 1, g.Rp, g.Rp)
-    # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
-    wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
-    emb_off = lay.offsets.get("wavenet.embed_speakers.weight", 0)
-    use_gid = gid is not None and "wavenet.embed_speakers.weight" in lay.offsets
-    gid32 = gid.to(torch.int32).contiguous() if gid is not None else None
-    keep.append(gid32)
-    L.check(lib.wae_gproj_bwd(L.ptr(eng.eff), L.ptr(eng.d_eff), wg_off, lay.off("wavenet.conv_layers.0.conv.bias"),
-                              lay.layer_stride, L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec), L.ptr(c1),
-                              Z2 * sm["ld1"], sm["ld1"], g.k * g.Rp + g.Ccp, B, g.layers, g.G, g.Hp, max(g.Cg, 0), st),
-            "gproj_bwd")
     eng._bwd_keep = keep
     return ws["dc"]
 
@@ -480,10 +509,18 @@ def _debug_kernels(eng, B, T, l):
 
 
 def finish_grads(eng):
-    """d_eff (gradient wrt effective weights) -> grads (wrt weight_g / weight_v and plain parameters)."""
+    """d_eff (gradient wrt effective weights) -> grads (wrt weight_g / weight_v and plain parameters); the slice that
+    decoder_backward already finished for the all-reduce (eng._grads_done) is left alone."""
     lay = eng.lay
-    L.check(eng.lib.wae_weight_norm_bwd(L.ptr(eng.params), L.ptr(eng.d_eff), L.ptr(eng.grads), lay.total, L.ptr(eng.wn_v),
-                                        L.ptr(eng.wn_g), L.ptr(eng.wn_c), len(lay.wn_cols), eng.stream()), "weight_norm_bwd")
+    done = getattr(eng, "_grads_done", None)
+    if done is None:
+        _wn_bwd_range(eng, 0, lay.total)
+    else:
+        if done[0] > 0:
+            _wn_bwd_range(eng, 0, done[0])
+        if done[1] < lay.total:
+            _wn_bwd_range(eng, done[1], lay.total)
+        eng._grads_done = None
     return eng.grads
 
 

@@ -42,6 +42,7 @@ struct ArcArgs {
   const char* c_up;
   int c_dtype;
   const int32_t* inputs;
+  int n_forced;           // steps t < n_forced consume inputs[t] (wavenet.py:300-305); 0 without inputs
   int init_idx;
   const float* uniforms;
   int32_t* out_idx;
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   for (int i = tid; i < K1p; i += ARC_THREADS) vbuf[i] = 0.f;
   for (int i = tid; i < Hk; i += ARC_THREADS) ubuf[i] = 0.f;
   for (int i = tid; i < Sk; i += ARC_THREADS) { skipb[i] = 0.f; hbuf[i] = 0.f; }
-  if (tid == 0) { ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
+  if (tid == 0) { ibuf[0] = p.n_forced > 0 ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
   arc_barrier();
 
   float* xbanks = p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S, p.O);
@@ -609,7 +610,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
         produced = min(cnt, p.O - 1);
       }
       if (m == 0) p.out_idx[(int64_t)b * p.T + t] = produced;
-      ibuf[0] = (p.inputs && t + 1 < p.T) ? p.inputs[(int64_t)b * p.T + t + 1] : produced;
+      ibuf[0] = t + 1 < p.n_forced ? p.inputs[(int64_t)b * p.T + t + 1] : produced;
     }
     arc_barrier();
     ARC_TICK(6);
@@ -651,7 +652,7 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_coop: Cc > 0 but c_up is null");
   WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate_coop: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate_coop: sample mode needs uniforms");
-  WAE_REQUIRE(d->mode != 0 || inputs, "ar_generate_coop: teacher-forced mode needs inputs");
+  WAE_REQUIRE(d->mode != 0 || (inputs && (d->n_forced <= 0 || d->n_forced >= d->T)), "ar_generate_coop: mode 0 needs inputs for every step");
   WAE_REQUIRE(inputs || (d->init_idx >= 0 && d->init_idx < d->O), "ar_generate_coop: init_idx %d is not a class (O = %d)", d->init_idx,
               d->O);
   WAE_REQUIRE(!d->scalar_input, "ar_generate_coop: scalar-input (DMoL) decoding is not implemented yet");
@@ -665,6 +666,7 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
   a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
   a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
+  a.n_forced = inputs ? (d->n_forced > 0 && d->n_forced < d->T ? d->n_forced : d->T) : 0;
   a.out_logits = out_logits; a.msg = (unsigned long long*)msg; a.NV = hc > sc ? hc : sc; a.acc = acc; a.error = error;
   const int epl = d->dtype == WAE_BF16 ? 8 : 4;
   auto ru = [](int x, int mm) { return (x + mm - 1) / mm * mm; };

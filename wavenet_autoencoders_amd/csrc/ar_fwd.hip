@@ -32,6 +32,7 @@ struct ArArgs {
   const char* c_up;         // (B, T, Ccp) dtype_c
   int c_dtype;
   const int32_t* inputs;  // (B, T) teacher-forced class ids or null
+  int n_forced;           // steps t < n_forced consume inputs[t] / inputs_f[t] (wavenet.py:300-305); 0 without inputs
   int init_idx;
   const float* uniforms;  // (B, T) or null
   int32_t* out_idx;       // (B, T)
@@ -155,17 +156,27 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
   for (int i = tid; i < Sk; i += AR_THREADS) { skipb[i] = 0.f; hbuf[i] = 0.f; }
   float* fcur = (float*)(ibuf + 1);   // scalar input: the current input value
   if (tid == 0) {
-    ibuf[0] = p.inputs ? p.inputs[(int64_t)b * p.T] : p.init_idx;
-    fcur[0] = p.inputs_f ? p.inputs_f[(int64_t)b * p.T] : 0.f;     // wavenet.py:284-285: the start value is zero
+    ibuf[0] = (p.inputs && p.n_forced > 0) ? p.inputs[(int64_t)b * p.T] : p.init_idx;
+    fcur[0] = (p.inputs_f && p.n_forced > 0) ? p.inputs_f[(int64_t)b * p.T] : 0.f;     // wavenet.py:284-285: the start value is zero
   }
   __syncthreads();
 
   for (int t = 0; t < p.T; ++t) {
     // ---- first conv: one-hot input == column gather (wavenet.py:311); scalar input: w * x + b ----------------
     const int cur = ibuf[0];
-    for (int r = tid; r < p.R; r += AR_THREADS)
-      xbuf[r] = p.scalar ? fmaf(p.first_tab[r], fcur[0], p.first_bias[r])
-                         : p.first_tab[(int64_t)cur * p.Rp + r] + p.first_bias[r];
+    if (cur < 0) {
+      // dense feedback (quantize=False, wavenet.py:335-338 skipped): the previous step's probability / logit vector, still in
+      // lbuf, is the decoder input -- first_conv on a dense (1, O) row (wavenet.py:311)
+      for (int r = tid; r < p.R; r += AR_THREADS) {
+        float acc = p.first_bias[r];
+        for (int o = 0; o < p.O; ++o) acc = fmaf(p.first_tab[(int64_t)o * p.Rp + r], lbuf[o], acc);
+        xbuf[r] = acc;
+      }
+    } else {
+      for (int r = tid; r < p.R; r += AR_THREADS)
+        xbuf[r] = p.scalar ? fmaf(p.first_tab[r], fcur[0], p.first_bias[r])
+                           : p.first_tab[(int64_t)cur * p.Rp + r] + p.first_bias[r];
+    }
     for (int cc = AR_THREADS - 1 - tid; cc < p.Cc; cc += AR_THREADS) {   // local conditioning of this step -> tail of the operand vector
       const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
       vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : ((const float*)p.c_up)[ci];
@@ -226,9 +237,22 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
     for (int i = tid; i < p.O; i += AR_THREADS) {
       const float y = psum_total(psum, i, op_, oNS) + p.head_bias[p.S + i];
       lbuf[i] = y;
-      if (p.out_logits) p.out_logits[((int64_t)b * p.O + i) * p.T + t] = y;
+      if (p.out_logits && p.mode != 3) p.out_logits[((int64_t)b * p.O + i) * p.T + t] = y;
     }
     __syncthreads();
+    if (p.mode == 3) {
+      // softmax=True, quantize=False: the probability vector is the step's output and the next step's input
+      float mx = -INFINITY, den = 0.f;
+      for (int i = 0; i < p.O; ++i) mx = fmaxf(mx, lbuf[i]);
+      for (int i = 0; i < p.O; ++i) den += expf(lbuf[i] - mx);
+      __syncthreads();
+      for (int i = tid; i < p.O; i += AR_THREADS) {
+        const float pr = expf(lbuf[i] - mx) / den;
+        lbuf[i] = pr;
+        if (p.out_logits) p.out_logits[((int64_t)b * p.O + i) * p.T + t] = pr;
+      }
+      __syncthreads();
+    }
     // ---- next input: teacher forcing / greedy / categorical draw (wavenet.py:300-338) -------------------------
     if (tid == 0 && p.scalar) {
       // sample_from_discretized_mix_logistic (mixture.py:118-156) on caller-supplied uniforms: Gumbel-max mixture pick,
@@ -250,7 +274,7 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
         xs = fminf(fmaxf(mu + expf(ls) * (logf(u) - logf(1.f - u)), -1.f), 1.f);
         if (p.out_f) p.out_f[(int64_t)b * p.T + t] = xs;
       }
-      fcur[0] = (p.inputs_f && t + 1 < p.T) ? p.inputs_f[(int64_t)b * p.T + t + 1] : xs;
+      fcur[0] = (p.inputs_f && t + 1 < p.n_forced) ? p.inputs_f[(int64_t)b * p.T + t + 1] : xs;
     }
     if (tid == 0 && !p.scalar) {
       int nxt;
@@ -275,8 +299,8 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
         produced = min(cnt, p.O - 1);
       }
       p.out_idx[(int64_t)b * p.T + t] = produced;
-      if (p.inputs && t + 1 < p.T) nxt = p.inputs[(int64_t)b * p.T + t + 1];
-      else nxt = produced;
+      if (p.inputs && t + 1 < p.n_forced) nxt = p.inputs[(int64_t)b * p.T + t + 1];
+      else nxt = p.mode >= 3 ? -1 : produced;
       ibuf[0] = nxt;
     }
     __syncthreads();
@@ -295,7 +319,8 @@ static int ar_launch(const wae_ar_desc* d, const int32_t* dilations, const int64
   a.ring_off = ring_off; a.ring = ring; a.ring_total = ring_total; a.w_layers = (const char*)w_layers;
   a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
   a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
-  a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
+  a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx;
+  a.n_forced = (inputs || inputs_f) ? (d->n_forced > 0 && d->n_forced < d->T ? d->n_forced : d->T) : 0; a.uniforms = uniforms; a.out_idx = out_idx;
   a.out_logits = out_logits; a.scalar = d->scalar_input ? 1 : 0; a.inputs_f = inputs_f; a.u_mix = u_mix; a.u_log = u_log;
   a.out_f = out_f; a.log_scale_min = log_scale_min; a.clamp_log_scale = clamp_log_scale;
   const int epl = d->dtype == WAE_BF16 ? 8 : 4;
@@ -329,9 +354,11 @@ extern "C" int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, c
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0 && d->O > 0,
               "ar_generate: bad sizes");
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate: Cc > 0 but c_up is null");
-  WAE_REQUIRE(d->mode >= 0 && d->mode <= 2, "ar_generate: mode must be 0 (logits), 1 (argmax) or 2 (sample)");
+  WAE_REQUIRE(d->mode >= 0 && d->mode <= 4,
+              "ar_generate: mode must be 0 (logits), 1 (argmax), 2 (sample), 3 (feed probabilities back) or 4 (feed logits back)");
   WAE_REQUIRE(d->mode != 2 || uniforms, "ar_generate: sample mode needs uniforms");
-  WAE_REQUIRE(d->mode != 0 || inputs, "ar_generate: teacher-forced mode needs inputs");
+  WAE_REQUIRE(d->mode != 0 || (inputs && (d->n_forced <= 0 || d->n_forced >= d->T)), "ar_generate: mode 0 needs inputs for every step");
+  WAE_REQUIRE(d->mode < 3 || out_logits, "ar_generate: modes 3 / 4 return their vectors through out_logits");
   WAE_REQUIRE(!d->scalar_input, "ar_generate: scalar-input decoders go through wae_ar_generate_scalar");
   // the start class indexes the first-conv table: wavenet.py:288 sets class 127, an IndexError there when O <= 127
   WAE_REQUIRE(inputs || (d->init_idx >= 0 && d->init_idx < d->O), "ar_generate: init_idx %d is not a class (O = %d)", d->init_idx, d->O);
@@ -352,7 +379,8 @@ extern "C" int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilat
   WAE_REQUIRE(d->scalar_input && d->O > 0 && d->O % 3 == 0, "ar_generate_scalar: needs a scalar-input decoder with 3M output channels");
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0, "ar_generate_scalar: bad sizes");
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_scalar: Cc > 0 but c_up is null");
-  WAE_REQUIRE(inputs_f || (u_mix && u_log), "ar_generate_scalar: needs teacher-forced inputs or the uniforms of the draws");
+  WAE_REQUIRE((inputs_f && (d->n_forced <= 0 || d->n_forced >= d->T)) || (u_mix && u_log),
+              "ar_generate_scalar: needs teacher-forced inputs for every step or the uniforms of the draws");
   WAE_REQUIRE(!u_mix == !u_log, "ar_generate_scalar: u_mix and u_log come together");
   WAE_REQUIRE(!out_samples || u_mix, "ar_generate_scalar: samples need the uniforms");
   WAE_REQUIRE(out_samples || out_params, "ar_generate_scalar: no output requested");

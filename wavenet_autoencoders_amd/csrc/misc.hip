@@ -102,19 +102,27 @@ __global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __res
   if (lane == 0) grads[g_off[row]] = dv * inv;
 }
 
-extern "C" int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, int64_t n_params,
-                                   const int64_t* v_off, const int64_t* g_off, const int32_t* cols, int32_t nrows,
-                                   void* stream) {
-  WAE_REQUIRE(params && d_eff && grads && n_params > 0, "weight_norm_bwd: null arena");
+extern "C" int wae_weight_norm_bwd_range(const float* params, const float* d_eff, float* grads, int64_t lo, int64_t hi,
+                                         const int64_t* v_off, const int64_t* g_off, const int32_t* cols, int32_t row_lo,
+                                         int32_t row_hi, void* stream) {
+  WAE_REQUIRE(params && d_eff && grads && lo >= 0 && hi > lo, "weight_norm_bwd: bad arena range");
+  WAE_REQUIRE(row_lo >= 0 && row_hi >= row_lo, "weight_norm_bwd: bad row range");
   hipStream_t st = as_stream(stream);
-  if (hipMemcpyAsync(grads, d_eff, n_params * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+  if (hipMemcpyAsync(grads + lo, d_eff + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
     wae_set_error("weight_norm_bwd: arena copy failed");
     return WAE_EHIP;
   }
+  const int nrows = row_hi - row_lo;
   if (nrows > 0)
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, params, d_eff, grads, v_off,
-                       g_off, cols, nrows);
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, params, d_eff, grads, v_off + row_lo,
+                       g_off + row_lo, cols + row_lo, nrows);
   return wae_check_launch("weight_norm_bwd");
+}
+
+extern "C" int wae_weight_norm_bwd(const float* params, const float* d_eff, float* grads, int64_t n_params,
+                                   const int64_t* v_off, const int64_t* g_off, const int32_t* cols, int32_t nrows,
+                                   void* stream) {
+  return wae_weight_norm_bwd_range(params, d_eff, grads, 0, n_params, v_off, g_off, cols, 0, nrows, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -675,7 +683,7 @@ extern "C" int wae_first_conv_fwd(const int32_t* idx, const float* xs, const flo
 // ---------------------------------------------------------------------------------------------------
 template <typename E>
 __global__ void __launch_bounds__(256) to_btc_kernel(const float* __restrict__ in, void* __restrict__ out, int C, int T,
-                                                     int Cp) {
+                                                     int Cp, const int32_t* __restrict__ lengths, float scale, int masked) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
@@ -684,9 +692,15 @@ __global__ void __launch_bounds__(256) to_btc_kernel(const float* __restrict__ i
     tile[i][lx] = (c < C && t < T) ? in[((int64_t)b * C + c) * T + t] : 0.f;
   }
   __syncthreads();
+  // masked: row t carries the loss of target t + 1 (vqwae_train.py:764-766) -- weight `scale` while t + 1 < length, else 0
+  const int len = masked ? (lengths ? min(lengths[b], T) : T) : 0;
   for (int i = ly; i < 64; i += 4) {
     const int t = t0 + i, c = c0 + lx;
-    if (t < T && c < Cp) store_e<E>(out, ((int64_t)b * T + t) * Cp + c, tile[lx][i]);
+    if (t < T && c < Cp) {
+      float v = tile[lx][i];
+      if (masked) v = t + 1 < len ? v * scale : 0.f;
+      store_e<E>(out, ((int64_t)b * T + t) * Cp + c, v);
+    }
   }
 }
 template <typename E>
@@ -711,10 +725,21 @@ extern "C" int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int3
   WAE_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && Cp >= C, "to_btc: bad arguments");
   dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
   if (dtype == WAE_BF16)
-    hipLaunchKernelGGL(to_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+    hipLaunchKernelGGL(to_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, nullptr, 1.f, 0);
   else
-    hipLaunchKernelGGL(to_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+    hipLaunchKernelGGL(to_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, nullptr, 1.f, 0);
   return wae_check_launch("to_btc");
+}
+extern "C" int wae_to_btc_masked(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
+                                 const int32_t* lengths, float scale, void* stream) {
+  WAE_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && Cp >= C, "to_btc_masked: bad arguments");
+  WAE_REQUIRE(dtype == WAE_F32 || dtype == WAE_BF16, "to_btc_masked: bad dtype");
+  dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
+  if (dtype == WAE_BF16)
+    hipLaunchKernelGGL(to_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, lengths, scale, 1);
+  else
+    hipLaunchKernelGGL(to_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, lengths, scale, 1);
+  return wae_check_launch("to_btc_masked");
 }
 extern "C" int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
                             void* stream) {

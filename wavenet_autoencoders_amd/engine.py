@@ -369,12 +369,16 @@ class WaeEngine:
                             test_inputs: Optional[torch.Tensor] = None, uniforms: Optional[torch.Tensor] = None,
                             init_idx: int = 127, c_is_upsampled: bool = False, want_logits: bool = False,
                             gvec: Optional[torch.Tensor] = None, u_mix: Optional[torch.Tensor] = None,
-                            u_log: Optional[torch.Tensor] = None, log_scale_min: float = -7.0, clamp_log_scale: bool = False):
+                            u_log: Optional[torch.Tensor] = None, log_scale_min: float = -7.0, clamp_log_scale: bool = False,
+                            n_forced: Optional[int] = None):
         """WaveNet.incremental_forward (wavenet.py:218-346) as one persistent launch.
 
         mode "logits": teacher-forced on test_inputs (B,T) class ids (softmax=False, quantize=False) -> logits (B,O,T);
         "argmax": greedy feedback; "sample": categorical draw from `uniforms` (B,T) in [0,1) (torch.rand if None).
-        Returns dict(idx (B,T) int32, logits (B,O,T) | None).
+        "probs" / "raw" (quantize=False, wavenet.py:335-338 skipped): the softmax probabilities / raw logits of a step are the
+        dense input of the next; they come back as `logits` (B,O,T).
+        n_forced: test_inputs covers only the first n_forced steps (default: its length), later steps run free in `mode`
+        (wavenet.py:300-305).  Returns dict(idx (B,T) int32, logits (B,O,T) | None).
         Scalar-input decoders: test_inputs (B,T) fp32 teacher-forces the inputs (mode "logits" -> the mixture parameters
         (B,3M,T) as `logits`); mode "sample" draws every step from the mixture of logistics on the uniforms u_mix (B,T,M),
         u_log (B,T) (torch.rand in (1e-5, 1-1e-5) if None) -> dict(x (B,T) fp32, logits | None)."""
@@ -383,8 +387,21 @@ class WaeEngine:
             self.pack_ar_weights()
         st = self.stream()
         B = c.shape[0] if c is not None else (test_inputs.shape[0] if test_inputs is not None else 1)
-        m = {"logits": 0, "argmax": 1, "sample": 2}[mode]
+        m = {"logits": 0, "argmax": 1, "sample": 2, "probs": 3, "raw": 4}[mode]
         dev = self.device
+        if test_inputs is not None:
+            nf = int(test_inputs.shape[1]) if n_forced is None else int(n_forced)
+            nf = max(0, min(nf, int(test_inputs.shape[1]), T))
+            if nf < T:                      # the kernels index inputs as (B, T)
+                pad = torch.zeros(test_inputs.shape[0], T, dtype=test_inputs.dtype, device=test_inputs.device)
+                pad[:, :nf] = test_inputs[:, :nf]
+                test_inputs = pad
+            if nf == 0:
+                test_inputs = None
+        else:
+            nf = 0
+        if m == 0 and nf < T:
+            raise ValueError("mode 'logits' is teacher-forced: test_inputs must cover all T steps (use 'raw' to feed logits back)")
         c_up = None
         if g.Ccp:
             c_up = torch.zeros(B, T, g.Ccp, dtype=self.tdtype, device=dev)
@@ -405,7 +422,8 @@ class WaeEngine:
                                   L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
         # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
         # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
-        coop = (B <= 8 and g.R <= 256 and g.S <= 256 and g.O <= 256 and not g.scalar_input and os.environ.get("WAE_AR_COOP", "1") != "0")
+        coop = (B <= 8 and g.R <= 256 and g.S <= 256 and g.O <= 256 and not g.scalar_input and m <= 2
+                and os.environ.get("WAE_AR_COOP", "1") != "0")
         C = max(1, min(int(os.environ.get("WAE_AR_COOP_C", "32")), 32, g.H, g.S)) if coop else 1
         ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
         if g.scalar_input:
@@ -421,13 +439,15 @@ class WaeEngine:
                 raise ValueError("mode 'logits' needs test_inputs")
             xs = torch.empty(B, T, dtype=torch.float32, device=dev) if um is not None else None
             params = torch.empty(B, g.O, T, dtype=torch.float32, device=dev) if (want_logits or m == 0) else None
+            if m >= 3:
+                raise ValueError("scalar-input decoders feed the drawn sample back: modes 'logits' and 'sample' only")
             d = L.ArDesc(self.dt, B, T, g.layers, g.R, g.Rp, g.G, g.Hp, g.S, g.O, max(g.Cc, 0), g.Ccp, g.k, m, 0, 1,
-                         math.sqrt(1.0 / g.layers))
+                         math.sqrt(1.0 / g.layers), nf)
             L.check(lib.wae_ar_generate_scalar(ctypes.byref(d), L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring),
                                                self.ar_ring_total, L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es,
                                                L.ptr(self.ar_b2), L.ptr(zb), L.ptr(self.first_tab), L.ptr(self.first_bias),
                                                L.ptr(self.ar_wh), L.ptr(self.ar_hb), L.ptr(c_up), self.dt,
-                                               L.ptr(tf) if m == 0 else None, L.ptr(um), L.ptr(ul), float(log_scale_min),
+                                               L.ptr(tf), L.ptr(um), L.ptr(ul), float(log_scale_min),
                                                int(bool(clamp_log_scale)), L.ptr(xs), L.ptr(params), st), "ar_generate_scalar")
             self._ar_keep = (c_up, zb, ring, tf, um, ul, gid32)
             return dict(x=xs, logits=params)
@@ -439,10 +459,10 @@ class WaeEngine:
             uniforms = torch.rand(B, T, device=dev)
         uni = uniforms.float().contiguous() if uniforms is not None else None
         out_idx = torch.empty(B, T, dtype=torch.int32, device=dev)
-        logits = torch.empty(B, g.O, T, dtype=torch.float32, device=dev) if (want_logits or m == 0) else None
+        logits = torch.empty(B, g.O, T, dtype=torch.float32, device=dev) if (want_logits or m == 0 or m >= 3) else None
         es = self.ar_w.element_size()
         d = L.ArDesc(self.dt, B, T, g.layers, g.R, g.Rp, g.G, g.Hp, g.S, g.O, max(g.Cc, 0), g.Ccp, g.k, m, int(init_idx), 0,
-                     math.sqrt(1.0 / g.layers))
+                     math.sqrt(1.0 / g.layers), nf)
         if coop:
             nv = lib.wae_ar_coop_msg_values(ctypes.byref(d), C)
             msg = torch.zeros(B * 2 * C * nv, dtype=torch.int64, device=dev)
@@ -488,19 +508,23 @@ class WaeEngine:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.opt_step = 0
 
-    def backward(self, x, gid, targets, lengths, gvec=None, loss_scale: float = 1.0, ext_dy=None):
+    def backward(self, x, gid, targets, lengths, gvec=None, loss_scale: float = 1.0, ext_dy=None, vq_scale: float = None,
+                 grad_sync=None):
         """Gradients of (masked CE or, with ext_dy (B,T,Op) = d loss / d logits, any output loss [+ vq_loss]) of the last
-        train-mode forward -> self.grads (flat arena)."""
+        train-mode forward -> self.grads (flat arena).  loss_scale multiplies the CE term, vq_scale (default: loss_scale) the
+        vq_loss term; grad_sync: see backward.decoder_backward."""
         from . import backward as BW
-        dc = BW.decoder_backward(self, x, targets, lengths, gid, gvec, ext_dy=ext_dy, loss_scale=loss_scale)
+        dc = BW.decoder_backward(self, x, targets, lengths, gid, gvec, ext_dy=ext_dy, loss_scale=loss_scale, grad_sync=grad_sync)
         if self.g.Ccp and self.g.upsample_scales:
-            BW.frontend_backward(self, dc, loss_scale)
+            BW.frontend_backward(self, dc, loss_scale if vq_scale is None else vq_scale)
         return BW.finish_grads(self)
 
     def dmol_loss_and_grad(self, y_hat: torch.Tensor, y: torch.Tensor, lengths, num_classes: int = 65536,
-                           log_scale_min: float = -7.0):
+                           log_scale_min: float = -7.0, scale: float = 1.0):
         """DiscretizedMixturelogisticLoss (vqwae_train.py:382-401 with the shift of :766): y_hat (B,3M,T) fp32, y (B,T) fp32
-        -> (masked mean loss, d loss / d y_hat as (B,T,Op) in the compute dtype for decoder_backward's ext_dy)."""
+        -> (masked mean loss, scale * d loss / d y_hat as (B,T,Op) in the compute dtype for decoder_backward's ext_dy).
+        Per-step loss and its gradient: wae_dmol_loss_fwd; masked mean: wae_masked_mean; mask, 1/count and the transposition
+        of the gradient: wae_to_btc_masked."""
         g, lib, st = self.g, self.lib, self.stream()
         B, _, T = y_hat.shape
         yf = y.contiguous().float()
@@ -508,22 +532,27 @@ class WaeEngine:
         dy = torch.empty_like(y_hat)
         L.check(lib.wae_dmol_loss_fwd(L.ptr(y_hat), L.ptr(yf), L.ptr(nll), L.ptr(dy), B, g.O // 3, T, int(num_classes),
                                       float(log_scale_min), 1, st), "dmol_loss")
-        tt = torch.arange(T, device=self.device)[None, :]
-        ln = (lengths.to(self.device) if lengths is not None else torch.full((B,), T, device=self.device)).clamp(max=T)
-        mask = (tt < (ln[:, None] - 1)).float()                      # t pairs with target t+1 < length
-        count = mask.sum().clamp(min=1.0)
-        loss = (nll * mask).sum() / count
+        if lengths is None:
+            count, ln = B * (T - 1), None
+        else:
+            count = int(torch.clamp(lengths.detach().to("cpu", torch.int64).clamp(max=T) - 1, min=0).sum())
+            ln = lengths.to(self.device, torch.int32).contiguous()
+        loss = torch.empty(2, dtype=torch.float32, device=self.device)
+        L.check(lib.wae_masked_mean(L.ptr(nll), L.ptr(ln), L.ptr(loss), B, T, st), "masked_mean")
         dyt = torch.zeros(B, T, g.Op, dtype=self.tdtype, device=self.device)
-        dy_scaled = (dy * (mask / count)[:, None, :]).contiguous()
-        L.check(lib.wae_to_btc(L.ptr(dy_scaled), L.ptr(dyt), B, g.O, T, g.Op, self.dt, st), "to_btc dy")
-        self._dmol_keep = (yf, nll, dy, dy_scaled)
-        return loss, dyt
+        L.check(lib.wae_to_btc_masked(L.ptr(dy), L.ptr(dyt), B, g.O, T, g.Op, self.dt, L.ptr(ln), float(scale) / max(count, 1), st),
+                "to_btc dy")
+        self._dmol_keep = (yf, nll, dy, ln)
+        return loss[0], dyt
 
     def train_step(self, x, c, gid, lengths=None, lr: float = 4e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                    weight_decay: float = 0.0, clip_thresh: float = 100.0, ema_decay: float = 0.9999, grad_hook=None,
-                   quantize_channels: int = 65536, log_scale_min: float = -7.0):
-        """One optimisation step: forward (teacher forced, targets = x shifted by one), backward, [grad_hook(grads) e.g.
-        the data-parallel all-reduce], clip_grad_norm_ + Adam + EMA.  Returns dict(loss, ce, vq_loss, perp, grad_norm).
+                   quantize_channels: int = 65536, log_scale_min: float = -7.0, grad_sync=None, ce_scale: float = 1.0):
+        """One optimisation step: forward (teacher forced, targets = x shifted by one), backward, [data parallel: grad_sync, a
+        distributed.GradSync -- its all-reduce starts inside backward and is awaited here; or grad_hook(grads)],
+        clip_grad_norm_ + Adam + EMA.  Returns dict(loss, ce, vq_loss, perp, grad_norm).
+        ce_scale: factor on the CE gradient (ragged data-parallel shards: n_local * world / n_global, so that the rank mean is
+        the gradient of the global masked mean of vqwae_train.py:374-379); vq_loss keeps weight 1 (rank mean, :759).
         Class-id input: masked cross-entropy; scalar input (hparams input_type "raw"): discretized mixture of logistics."""
         if not hasattr(self, "exp_avg"):
             self.init_optimizer()
@@ -533,9 +562,9 @@ class WaeEngine:
             out = fwd(x, c, gid, targets=None, lengths=None, want_logits=True, train=True)
             if not self.g.has_encoder:
                 self._fe = None
-            loss, dyt = self.dmol_loss_and_grad(out["logits"], x, lengths, quantize_channels, log_scale_min)
+            loss, dyt = self.dmol_loss_and_grad(out["logits"], x, lengths, quantize_channels, log_scale_min, scale=ce_scale)
             out["loss"] = loss
-            grads = self.backward(x, gid, None, lengths, ext_dy=dyt)
+            grads = self.backward(x, gid, None, lengths, ext_dy=dyt, vq_scale=1.0, grad_sync=grad_sync)
         elif self.g.has_encoder:
             out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True)
         else:
@@ -543,7 +572,9 @@ class WaeEngine:
                                        layer_events=getattr(self, "_layer_events", None))
             self._fe = None
         if not self.g.scalar_input:
-            grads = self.backward(x, gid, x, lengths)
+            grads = self.backward(x, gid, x, lengths, loss_scale=ce_scale, vq_scale=1.0, grad_sync=grad_sync)
+        if grad_sync is not None:
+            grad_sync.finish()
         if grad_hook is not None:
             grad_hook(grads)
         self.opt_step += 1

@@ -82,9 +82,21 @@ class VQVAE(ArenaModel):
             if initial_input is not None:
                 init = int(initial_input.reshape(initial_input.shape[0], -1)[0].argmax())
             gid = g.reshape(-1) if g is not None else None
-            out = eng.incremental_forward(quant, gid, int(T), mode="sample" if quantize else "argmax", init_idx=init)
-            idxs = out["idx"].long()
-            return torch.nn.functional.one_hot(idxs, self.out_channels).float().transpose(1, 2).contiguous()
+            if self.scalar_input:
+                M = self.out_channels // 3
+                dev = c.device
+                out = eng.incremental_forward(quant, gid, int(T), mode="sample", log_scale_min=log_scale_min,
+                                              u_mix=torch.rand(c.shape[0], int(T), M, device=dev) * (1 - 2e-5) + 1e-5,
+                                              u_log=torch.rand(c.shape[0], int(T), device=dev) * (1 - 2e-5) + 1e-5)
+                return out["x"].unsqueeze(1)
+            if quantize:
+                if not softmax:
+                    raise ValueError("quantize=True draws from the softmax probabilities: pass softmax=True")
+                out = eng.incremental_forward(quant, gid, int(T), mode="sample", init_idx=init)
+                idxs = out["idx"].long()
+                return torch.nn.functional.one_hot(idxs, self.out_channels).float().transpose(1, 2).contiguous()
+            # quantize=False: the probability / logit rows are the outputs and the fed-back inputs (wavenet.py:303-305,335-338)
+            return eng.incremental_forward(quant, gid, int(T), mode="probs" if softmax else "raw", init_idx=init)["logits"]
 
     def encode(self, x):
         """quantised latents of MFCC features (vqvae_model.py:80-84; inference_2019.py:243-262)."""

@@ -113,8 +113,8 @@ class WaveNet(ArenaModel):
 
     def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None, tqdm=lambda x: x,
                             softmax=True, quantize=True, log_scale_min=-50.0):
-        """wavenet.py:218-346 as one persistent kernel launch.  Supported: sampling (quantize=True) -> one-hot
-        (B, C, T); teacher forcing (test_inputs, quantize=False) -> logits / softmax (B, C, T)."""
+        """wavenet.py:218-346 as one persistent kernel launch: sampling (quantize=True) -> one-hot (B, C, T); quantize=False ->
+        the logits / softmax rows (B, C, T), fed back as the next step's input once test_inputs is used up."""
         if self.training:
             raise RuntimeError("incremental_forward only supports eval mode")          # conv.py:19-20
         eng = self.engine()
@@ -127,15 +127,14 @@ class WaveNet(ArenaModel):
                 tf = test_inputs
                 if tf.dim() == 3:
                     tf = tf.reshape(tf.shape[0], -1)                                     # (B,1,T) or (B,T,1) -> (B,T)
-                if tf.shape[1] < int(T or 0):
-                    raise NotImplementedError("partial teacher forcing followed by sampling is not implemented")
-                T = tf.shape[1]
+                T = max(int(T or 0), tf.shape[1])                                        # wavenet.py:259-262
             c_is_up = c is not None and (not self.geom.upsample_scales or c.shape[-1] == int(T))
             B = c.shape[0] if c is not None else (tf.shape[0] if tf is not None else 1)
             dev = next(self.parameters()).device
             M = self.out_channels // 3
             with torch.no_grad():
-                out = eng.incremental_forward(c, gid, int(T), mode="logits" if tf is not None else "sample", test_inputs=tf,
+                # every step draws from its mixture (wavenet.py:325-333); forced steps consume test_inputs instead of the draw
+                out = eng.incremental_forward(c, gid, int(T), mode="sample", test_inputs=tf,
                                               c_is_upsampled=c_is_up, gvec=gvec, log_scale_min=log_scale_min,
                                               u_mix=torch.rand(B, int(T), M, device=dev) * (1 - 2e-5) + 1e-5,
                                               u_log=torch.rand(B, int(T), device=dev) * (1 - 2e-5) + 1e-5)
@@ -143,7 +142,9 @@ class WaveNet(ArenaModel):
         tf = None
         if test_inputs is not None:
             tf = _ids_from_input(test_inputs, self.out_channels, False)
-            T = max(int(T or 0), tf.shape[1])
+            T = max(int(T or 0), tf.shape[1])                                            # wavenet.py:259-262
+        T = int(T)
+        nf = tf.shape[1] if tf is not None else 0
         init = 127                                                                      # wavenet.py:288
         if initial_input is not None:
             ii = initial_input
@@ -152,21 +153,21 @@ class WaveNet(ArenaModel):
             init = int(ii[0].argmax())
         gid = g.reshape(-1) if (g is not None and g.dtype in (torch.int32, torch.int64)) else None
         gvec = None if (g is None or gid is not None) else g.reshape(g.shape[0], -1).float().contiguous()
-        c_is_up = c is not None and (not self.geom.upsample_scales or c.shape[-1] == int(T))
+        c_is_up = c is not None and (not self.geom.upsample_scales or c.shape[-1] == T)
+        kw = dict(test_inputs=tf, n_forced=nf, init_idx=init, c_is_upsampled=c_is_up, gvec=gvec)
         with torch.no_grad():
             if quantize:
-                if tf is not None and tf.shape[1] < T:
-                    raise NotImplementedError("partial teacher forcing followed by sampling is not implemented")
-                out = eng.incremental_forward(c, gid, int(T), mode="sample" if tf is None else "logits", test_inputs=tf,
-                                              init_idx=init, c_is_upsampled=c_is_up, gvec=gvec)
-                idx = out["idx"].long()
-                return torch.nn.functional.one_hot(idx, self.out_channels).float().transpose(1, 2).contiguous()
-            if tf is None:
-                raise NotImplementedError("feeding soft probabilities back (quantize=False without test_inputs) is not implemented")
-            out = eng.incremental_forward(c, gid, int(T), mode="logits", test_inputs=tf, init_idx=init, c_is_upsampled=c_is_up,
-                                          gvec=gvec)
-            y = out["logits"]
-            return torch.softmax(y, dim=1) if softmax else y
+                if not softmax:
+                    # the reference hands raw logits to OneHotCategorical(probs=...), which rejects negative entries
+                    raise ValueError("quantize=True draws from the softmax probabilities: pass softmax=True")
+                # every step's output is a draw from its distribution (wavenet.py:335-338), forced or not
+                out = eng.incremental_forward(c, gid, T, mode="sample", **kw)
+                return torch.nn.functional.one_hot(out["idx"].long(), self.out_channels).float().transpose(1, 2).contiguous()
+            if nf >= T:                      # fully teacher-forced: logits (or probabilities) of every step
+                y = eng.incremental_forward(c, gid, T, mode="logits", **kw)["logits"]
+                return torch.softmax(y, dim=1) if softmax else y
+            # quantize=False, free-running: the probability (softmax=True) or logit vector itself is fed back (wavenet.py:303-305)
+            return eng.incremental_forward(c, gid, T, mode="probs" if softmax else "raw", **kw)["logits"]
 
     def clear_buffer(self):
         """The per-layer history lives inside one kernel launch; nothing persists between calls (wavenet.py:348-356)."""
