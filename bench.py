@@ -14,9 +14,11 @@ and the fused clip_grad_norm_ + Adam + EMA update.  Inputs are resident in HBM b
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, each rank trains on its own shard of the global
-batch (weak scaling: 8 clips per GPU), gradients all-reduced over RCCL, barrier + synchronize on both sides, MAX
-over ranks.
+batch (weak scaling: 8 clips per GPU), gradients all-reduced over RCCL (started inside backward, on a side stream),
+barrier + synchronize on both sides, MAX over ranks.  `python bench.py --gpus N` without a launcher starts the N ranks
+itself (torch.distributed.run as a child process, before this process has touched a GPU) and relays their line.
 """
+import subprocess
 import argparse
 import json
 import math
@@ -45,20 +47,27 @@ def synth_inputs(rank, device):
     return x.to(device), lat.to(device), g.to(device)
 
 
-def ar_leg(device, T_ar=4000):
+AR_CFG = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153,
+              upsample_scales=[4, 4, 8, 5], cin_pad=0)
+
+
+def ar_leg(device, T_ar=4000, cpu=True):
     """Second half of BASELINE.json's metric: autoregressive kHz of synthesis.py's incremental_forward on one GPU, one
     utterance (config C4: hps/vqwae.json decoder, 16 kHz; a 0.25 s prefix of the 10 s clip -- the per-sample cost is
-    constant), categorical sampling as in the reference (wavenet.py:300-338).  Untimed warm-up, then one timed run."""
+    constant), categorical sampling as in the reference (wavenet.py:300-338).  Untimed warm-up, then one timed run.
+    Roofline: AR is latency-bound; the bound quoted is streaming every effective weight once per sample
+    (5.9 M x e bytes at 8 TB/s).  cpu_baseline: the oracle's incremental loop on a 1600-sample prefix."""
     import torch
-    from oracle import wae_oracle as O          # closed-form weights only
+    from oracle import wae_oracle as O          # closed-form weights + the cpu_baseline leg only
     from wavenet_autoencoders_amd import Geometry
     from wavenet_autoencoders_amd.engine import WaeEngine
-    cfg = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153,
-               upsample_scales=[4, 4, 8, 5], cin_pad=0)
+    cfg = AR_CFG
     out = {}
+    sd = O.make_state_dict(dict(cfg), salt=7, with_encoder=False)
+    n_w = sum(v.numel() for k, v in sd.items() if k.endswith("weight_v") and ("conv_layers" in k or "last_conv" in k))
     for dt in ("fp32", "bf16"):
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dt, device=str(device))
-        eng.load_state_dict(O.make_state_dict(dict(cfg), salt=7, with_encoder=False))
+        eng.load_state_dict(sd)
         gen = torch.Generator(device="cpu").manual_seed(1234)
         lat = torch.randn(1, 64, T_ar // 640 + 1, generator=gen)[:, :, :max(T_ar // 640, 1)].to(device)
         Tg = lat.shape[-1] * 640
@@ -69,9 +78,37 @@ def ar_leg(device, T_ar=4000):
         eng.incremental_forward(lat, gid, Tg, mode="sample")
         torch.cuda.synchronize()
         out[dt] = Tg / (time.perf_counter() - t0) / 1e3
-    return {"metric": "autoregressive kHz (synthesis.py incremental_forward, 1 utterance, 1 GPU)", "value": max(out.values()),
-            "unit": "kHz", "fp32_khz": out["fp32"], "bf16_khz": out["bf16"], "samples": Tg,
-            "config": "C4: hps/vqwae.json decoder (20 layers, R=G=S=256), categorical sampling, one persistent launch"}
+    best = "bf16" if out["bf16"] >= out["fp32"] else "fp32"
+    us = 1e3 / out[best]
+    wbytes = n_w * (2 if best == "bf16" else 4)
+    bound_us = wbytes / (HBM_PEAK_GBS * 1e9) * 1e6
+    res = {"metric": "autoregressive kHz (synthesis.py incremental_forward, 1 utterance, 1 GPU)", "value": out[best],
+           "unit": "kHz", "fp32_khz": out["fp32"], "bf16_khz": out["bf16"], "samples": Tg, "us_per_sample": us,
+           "realtime_factor": out[best] / 16.0,
+           "roofline": {"bound": "latency (weight streaming as the stated floor)", "achieved": us, "peak": bound_us, "unit": "us/sample",
+                        "frac": bound_us / us, "weight_bytes_per_sample": wbytes,
+                        "note": "SURVEY 8(d): every effective weight once per sample (%d x %d B) / 8 TB/s; 20 strictly sequential "
+                                "layers + head per sample" % (n_w, 2 if best == "bf16" else 4)},
+           "config": "C4: hps/vqwae.json decoder (20 layers, R=G=S=256), categorical sampling, one persistent launch"}
+    if cpu:
+        nthreads = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(nthreads)
+        Tc = 1600
+        ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+        g = torch.Generator().manual_seed(1234)
+        latc = torch.randn(1, 64, 3, generator=g)
+        c_up = O.upsample_forward(sd, latc, cfg["upsample_scales"])[:, :, :Tc].contiguous()
+        u = torch.rand(1, Tc, generator=g)
+        with torch.no_grad():
+            O.incremental_forward(sd, ocfg, c_up[:, :, :32].contiguous(), torch.zeros(1, dtype=torch.long), 32, mode="sample", uniforms=u)
+            t0 = time.perf_counter()
+            O.incremental_forward(sd, ocfg, c_up, torch.zeros(1, dtype=torch.long), Tc, mode="sample", uniforms=u)
+            dtc = time.perf_counter() - t0
+        res["cpu_baseline"] = dict(value=Tc / dtc / 1e3, unit="kHz", cores=nthreads, kind="port",
+                                   sample=f"oracle/wae_oracle.py incremental_forward (O(1) ring lookup restatement of conv.py:17-62), "
+                                          f"{Tc}-sample prefix of the same decoder, torch CPU fp32, {nthreads} threads ({dtc:.1f} s, "
+                                          "after a 32-sample warm-up)")
+    return res
 
 
 def cpu_baseline_train(sd, nclips=8):
@@ -91,6 +128,10 @@ def cpu_baseline_train(sd, nclips=8):
     m = {k: torch.zeros_like(v) for k, v in sd.items()}
     v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
     sh = {k: v.clone() for k, v in sd.items()}
+    # warm-up on one clip (thread pool, oneDNN primitive caches), then ONE timed pass over the sample
+    O.masked_ce_loss(O.wavenet_forward(psd, ocfg, xin[:1], lat[:1], g[:1]), x[:1].unsqueeze(-1), torch.full((1,), T)).backward()
+    for p in psd.values():
+        p.grad = None
     t0 = time.perf_counter()
     y = O.wavenet_forward(psd, ocfg, xin, lat, g)
     loss = O.masked_ce_loss(y, x.unsqueeze(-1), torch.full((nclips,), T))
@@ -101,7 +142,7 @@ def cpu_baseline_train(sd, nclips=8):
     dt = time.perf_counter() - t0
     return dict(value=nclips * T / dt, unit="samples/s", cores=nthreads, kind="port",
                 sample=f"{nclips} of the {B_PER_GPU} clips x {T} samples, 1 train step (forward+CE+autograd backward+clip/Adam/EMA), "
-                       f"oracle/wae_oracle.py on torch CPU fp32, {nthreads} threads of {os.cpu_count()} cores ({dt:.1f} s)"), float(loss)
+                       f"oracle/wae_oracle.py on torch CPU fp32, {nthreads} threads of {os.cpu_count()} cores ({dt:.1f} s, after a one-clip warm-up)"), float(loss)
 
 
 def cpu_baseline(sd, nclips=8):
@@ -118,6 +159,7 @@ def cpu_baseline(sd, nclips=8):
     xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
     ocfg = dict(layers=C2["layers"], stacks=C2["stacks"], upsample_scales=C2["upsample_scales"], cin_pad=0)
     with torch.no_grad():
+        O.wavenet_forward(sd, ocfg, xin[:1], lat[:1], g[:1])       # warm-up (thread pool, oneDNN primitive caches)
         t0 = time.perf_counter()
         y = O.wavenet_forward(sd, ocfg, xin, lat, g)
         loss = O.masked_ce_loss(y, x.unsqueeze(-1), torch.full((nclips,), T))
@@ -125,6 +167,30 @@ def cpu_baseline(sd, nclips=8):
     return dict(value=nclips * T / dt, unit="samples/s", cores=nthreads, kind="port",
                 sample=f"{nclips} of the {B_PER_GPU} clips x {T} samples, 1 forward+CE pass, oracle/wae_oracle.py on "
                        f"torch CPU fp32, {nthreads} threads of {os.cpu_count()} cores ({dt:.1f} s)"), float(loss)
+
+
+def csrc_hash():
+    """sha256 over the kernel sources: profiles/*_pmc_traffic.json carries the hash of the build it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "wavenet_autoencoders_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "wae.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has not
+    initialised the GPU and never will), relay its output, exit with its code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -138,10 +204,15 @@ def main():
     ap.add_argument("--no-ar", action="store_true", help="skip the autoregressive leg (BASELINE config C4, rank 0 only)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -165,18 +236,13 @@ def main():
     xi = x.to(torch.int32)
 
     ev, ev_tn = [], []
-    hook = None
+    gsync = None
     if args.mode == "train":
         eng.init_optimizer()
         if dist is not None:
-            from wavenet_autoencoders_amd.distributed import GradBucketer, broadcast_params
+            from wavenet_autoencoders_amd.distributed import GradSync, broadcast_params
             broadcast_params(eng.params)
-            bucketer = {}
-
-            def hook(grads):   # noqa: E306
-                if "b" not in bucketer:
-                    bucketer["b"] = GradBucketer(grads)
-                bucketer["b"].finish()
+            gsync = GradSync(eng, timing=True)
 
     def step(record=False):
         if args.mode == "forward":
@@ -186,7 +252,7 @@ def main():
             return out["loss"]
         eng._layer_events = ev if record else None
         eng._tn_events = ev_tn if record else None
-        return eng.train_step(xi, lat, g, lengths=None, grad_hook=hook)["loss"]
+        return eng.train_step(xi, lat, g, lengths=None, grad_sync=gsync)["loss"]
 
     def sync():
         if dist is not None:
@@ -252,18 +318,28 @@ def main():
     fwd_bytes_per_sample = geom.layers * (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es + (C2["S"] + 0) * es + 4 + 1
     value = world * samples * args.steps / dt
 
-    # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (profiles/*pmc_traffic.json;
-    # bench.py cannot run the profiler on itself).  Only applied when the run matches the profiled configuration.
+    # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (bench.py cannot run the profiler
+    # on itself).  The file carries the hash of the kernel sources it was measured on: a different build reports null.
+    traffic_src = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)["kernels"]
-        if args.dtype == "bf16" and args.mode == "train":
-            for rf in [roof] + list(extra.values()):
-                for k, v in pmc.items():
-                    if rf["kernel"] in k:
-                        rf["traffic"] = v["hbm_bytes_per_launch"]
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        for fpath in reversed(cands):
+            with open(fpath) as fh:
+                doc = json.load(fh)
+            if doc.get("csrc_hash") == csrc_hash():
+                traffic_src = os.path.basename(fpath)
+                if args.dtype == "bf16" and args.mode == "train":
+                    for rf in [roof] + list(extra.values()):
+                        for k, v in doc["kernels"].items():
+                            if rf["kernel"] in k:
+                                rf["traffic"] = v["hbm_bytes_per_launch"]
+                                rf["traffic_source"] = traffic_src
+                break
     except (OSError, KeyError, ValueError):
         pass
+    if traffic_src is None:
+        roof["traffic_note"] = "no profiles/*_pmc_traffic.json matches this build's csrc hash %s: traffic not reported" % csrc_hash()
 
     if rank == 0:
         res = {
@@ -282,6 +358,12 @@ def main():
             "roofline_glu_fwd": fwd_roof,
         }
         res.update(extra)
+        if gsync is not None:
+            comm_ms, wait_ms = gsync.collect_timing()
+            res["allreduce"] = {"ms": comm_ms, "exposed_ms": wait_ms, "collectives_per_step": gsync.n_collectives / (args.steps + args.warmup),
+                                "bytes": int(eng.grads.numel()) * 4, "note": "RCCL all-reduce of the fp32 gradient arena, last timed step: "
+                                "ms = first launch to last collective done on the side stream (starts inside backward, after the "
+                                "layers' gradients); exposed_ms = how long the compute stream waited for it"}
         if args.mode == "train" and world == 1:
             # the same stack in inference (no z saved, no backward): the north star states its roofline target on this launch
             ev_f = []
@@ -309,7 +391,7 @@ def main():
                              "note": "inference launch (no z saved): SURVEY 8(d) forward bytes (2R+2S+Cc)*e x 64000 samples; HIP "
                                      "events around the 24-layer stack"}}
         if not args.no_ar and world == 1:
-            res["autoregressive"] = ar_leg(device)
+            res["autoregressive"] = ar_leg(device, cpu=not args.no_cpu)
         if not args.no_cpu and world == 1:
             cb, cpu_loss = cpu_baseline_train(sd) if args.mode == "train" else cpu_baseline(sd)
             res["cpu_baseline"] = cb

@@ -116,20 +116,30 @@ int wae_upsample_stage_fwd(const float* in, const float* w, void* out, int32_t B
  * eff[bias_off + l*layer_stride] and its conv1x1g weight (G,Cg) at eff[wg_off + l*layer_stride]. */
 int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride, const int32_t* gid,
                   int64_t emb_off, const float* gvec, float* zb, int32_t B, int32_t L, int32_t G, int32_t Hp,
-                  int32_t Cg, void* stream);
+                  int32_t Cg, int32_t n_speakers, int32_t* err, void* stream);
 
 /* backward of wae_gproj_fwd.  c1: the per-layer dW1 tiles of wae_gemm_tn_tiles (L x 2Hp x ld fp32) whose columns
  * ones_col + b hold sum_t dz[b,t,row] = d loss / d zb[b][l][row]; adds into d_eff: conv bias, conv1x1g weight and
  * (gid != NULL) the embedding rows. */
 int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride,
                   const int32_t* gid, int64_t emb_off, const float* gvec, const float* c1, int64_t c_layer_stride,
-                  int64_t ld, int32_t ones_col, int32_t B, int32_t L, int32_t G, int32_t Hp, int32_t Cg, void* stream);
+                  int64_t ld, int32_t ones_col, int32_t B, int32_t L, int32_t G, int32_t Hp, int32_t Cg,
+                  int32_t n_speakers, void* stream);
 
 /* ---- a5 first_conv on one-hot input = column gather + bias (wavenet.py:119-122,203) --------------------
  * idx (B*T) int32 class ids; table (O,Rp) fp32 = W^T ; x0 (B,T,Rp) dtype.  scalar mode: xs (B*T) fp32,
  * table (1,Rp). */
 int wae_first_conv_fwd(const int32_t* idx, const float* xs, const float* table, const float* bias, void* x0,
-                       int64_t BT, int32_t Rp, int32_t O, int32_t dtype, void* stream);
+                       int64_t BT, int32_t Rp, int32_t O, int32_t dtype, int32_t* err, void* stream);
+
+/* Ids that index tables (class ids -> first-conv table / targets, speaker ids -> embedding rows): the reference raises
+ * IndexError (nn.Embedding, wavenet.py:185-190; one-hot encoding, vqwae_train.py:511).  The kernels clamp an id outside its
+ * table -- no access leaves it -- and OR a WAE_ERR_* bit into the caller's sticky device word `err` (nullable); wae_check_ids
+ * does the same for any id array (e.g. the CE targets) against [lo, hi).  The host raises when it next reads the word. */
+#define WAE_ERR_CLASS_ID 1
+#define WAE_ERR_SPEAKER_ID 2
+#define WAE_ERR_TARGET_ID 4
+int wae_check_ids(const int32_t* ids, int64_t n, int32_t lo, int32_t hi, int32_t* err, int32_t code, void* stream);
 
 /* ---- a6 ResidualConv1dGLU._forward (modules.py:115-163) -------------------------------------------------
  * One fused layer: dilated causal conv + 1x1(c) + hoisted 1x1(g) + gate + 1x1 out + residual.  The skip 1x1

@@ -737,7 +737,47 @@ def gen_c5_probe():
          y_lse=torch.logsumexp(y, 1), y_sum=y.double().sum(), y_abs_sum=y.double().abs().sum())
 
 
+def gen_optim_state(cfg, salt):
+    """Section 8(f) rank 2: what a reference checkpoint's "optimizer" entry holds (vqwae_train.py:881) -- torch.optim.Adam's
+    state after one and after two steps of the reference model on one batch, flattened in named_parameters() order."""
+    sd = O.make_state_dict(cfg, salt)
+    c, x, xin, g, T = inputs_for(cfg, 2, 8, salt * 10)
+    model = build_ref_vqvae(cfg, {k: v.clone() for k, v in sd.items()}).train()
+    opt = torch.optim.Adam(model.parameters(), lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False)
+    names = [n for n, _ in model.named_parameters()]
+    lengths = torch.tensor([T, T])
+    y = x.unsqueeze(-1)
+    mask = O.sequence_mask(lengths, T).unsqueeze(-1)[:, 1:, :]
+    crit = torch.nn.CrossEntropyLoss(reduction="none")
+    out = {}
+
+    def flat(d):
+        return torch.cat([d[n].reshape(-1) for n in names])
+
+    for step in (1, 2):
+        opt.zero_grad()
+        y_hat, vq_loss, perp = model(xin, c, g, False)
+        loss = ((crit(y_hat[:, :, :-1].unsqueeze(-1), y[:, 1:, :]) * mask).sum()) / mask.sum() + vq_loss.mean()
+        loss.backward()
+        for p_ in model.parameters():
+            if p_.grad is None:
+                p_.grad = torch.zeros_like(p_)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 100.0)
+        opt.step()
+        st = opt.state_dict()
+        assert st["param_groups"][0]["params"] == list(range(len(names)))
+        out[f"params{step}"] = flat({n: p_.data for n, p_ in model.named_parameters()})
+        out[f"exp_avg{step}"] = flat({n: st["state"][i]["exp_avg"] for i, n in enumerate(names)})
+        out[f"exp_avg_sq{step}"] = flat({n: st["state"][i]["exp_avg_sq"] for i, n in enumerate(names)})
+        out[f"step{step}"] = np.array([float(st["state"][i]["step"]) for i in range(len(names))])
+        out[f"loss{step}"] = loss.detach()
+    group = {k: v for k, v in st["param_groups"][0].items() if k != "params"}
+    save(f"optim_{cfg['name']}", names=json.dumps(names), param_group=json.dumps(group), **out)
+
+
 def main():
+    if sys.argv[1:] == ["optim"]:
+        return gen_optim_state(CFG_A, 1)
     if sys.argv[1:] == ["c4"]:
         return gen_ar_c4()
     if sys.argv[1:] == ["train_vqwae"]:
@@ -758,6 +798,7 @@ def main():
         gen_ar(cfg, sd, model, ins, ocfg)
         if cfg is CFG_A:
             gen_train_step(cfg, sd, ins, ocfg)
+            gen_optim_state(cfg, salt)
     # scalar-input (DMoL) decoder
     sd, model, ins, ocfg = gen_model(CFG_S, 3)
     gen_ar_scalar(CFG_S, sd, model, ins, ocfg)

@@ -74,3 +74,79 @@ def test_shard_range_requires_divisible_batch():
     assert D.shard_range(64, 3, 8) == (24, 32)
     with pytest.raises(ValueError):
         D.shard_range(10, 0, 4)
+
+
+def _ddp_worker(rank, world, port, q):
+    """One data-parallel rank of a RAGGED global batch: local loss normalised by the local mask count (what the engine does),
+    CE gradient scaled by distributed.ragged_ce_scale, arena all-reduced through the bucketer with the layer-segment cuts."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from helpers import golden_model
+    from oracle import wae_oracle as O
+    from wavenet_autoencoders_amd import distributed as D
+    D.init_from_env("gloo")
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    T = ins["x"].shape[1]
+    # global batch of 4 clips = the two golden clips and their swapped copies; ragged lengths; rank r takes clips [2r, 2r+2)
+    xin = torch.cat([ins["xin"], ins["xin"].flip(0)]); x = torch.cat([ins["x"], ins["x"].flip(0)])
+    c = torch.cat([ins["c"], ins["c"].flip(0) * 0.5]); g = torch.cat([ins["g"], ins["g"].flip(0)])
+    lengths = torch.tensor([T, T - 300, T - 901, T - 77])
+    lo, hi = D.shard_range(4, rank, world)
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y, vq, perp, _ = O.vqvae_forward(psd, ocfg, xin[lo:hi], c[lo:hi], g[lo:hi])
+    ce_local = O.masked_ce_loss(y, x[lo:hi].unsqueeze(-1), lengths[lo:hi])           # normalised by the LOCAL mask sum
+    scale, N = D.ragged_ce_scale(lengths[lo:hi], T, hi - lo)
+    (ce_local * scale + vq).backward()
+    keys = sorted(psd)
+    flat = torch.cat([(psd[k].grad if psd[k].grad is not None else torch.zeros_like(psd[k])).reshape(-1) for k in keys])
+    n = flat.numel()
+    b = D.GradBucketer(flat, bucket_bytes=64 << 10, cuts=(n // 5, n // 2))
+    assert any(bb[0] == n // 5 for bb in b.bounds) and any(bb[1] == n // 2 for bb in b.bounds)
+    b.ready_range(n // 5, n // 2)                                                     # the slice backward finishes first
+    assert all(l == (n // 5 <= a and e <= n // 2) for l, (a, e) in zip(b.launched, b.bounds))
+    b.finish()
+    n_local = float(torch.clamp(lengths[lo:hi] - 1, min=0).sum())
+    gl = D.masked_loss_global(ce_local.detach() * n_local, torch.tensor(n_local))
+    q.put((rank, flat.numpy(), float(gl), float(N), float(vq)))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_ragged_step_equals_the_global_batch():
+    """vqwae_train.py:374-379,698-706,759: the reference gathers the replicas' logits and takes ONE masked mean over the global
+    batch, plus the mean of the replicas' vq_loss.  Two ranks with local normalisation + ragged_ce_scale + the averaged
+    all-reduce must produce exactly that loss and gradient."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import golden_model
+    from oracle import wae_oracle as O
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    T = ins["x"].shape[1]
+    xin = torch.cat([ins["xin"], ins["xin"].flip(0)]); x = torch.cat([ins["x"], ins["x"].flip(0)])
+    c = torch.cat([ins["c"], ins["c"].flip(0) * 0.5]); g = torch.cat([ins["g"], ins["g"].flip(0)])
+    lengths = torch.tensor([T, T - 300, T - 901, T - 77])
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ys, vqs = [], []
+    for r in range(world):                          # the replicas of data_parallel_workaround, then the gather
+        y, vq, perp, _ = O.vqvae_forward(psd, ocfg, xin[2 * r:2 * r + 2], c[2 * r:2 * r + 2], g[2 * r:2 * r + 2])
+        ys.append(y)
+        vqs.append(vq)
+    ce = O.masked_ce_loss(torch.cat(ys), x.unsqueeze(-1), lengths)
+    (ce + torch.stack(vqs).mean()).backward()
+    keys = sorted(psd)
+    want = torch.cat([(psd[k].grad if psd[k].grad is not None else torch.zeros_like(psd[k])).reshape(-1) for k in keys]).numpy()
+    import numpy as np
+    for rank, flat, gl, N, vq in res:
+        assert abs(gl - float(ce)) < 1e-5 * float(ce)
+        assert N == float(torch.clamp(lengths - 1, min=0).sum())
+        assert np.abs(flat - want).max() < 2e-5 * np.abs(want).max()
+    assert np.array_equal(res[0][1], res[1][1])     # both ranks hold the same reduced arena

@@ -90,3 +90,49 @@ def test_clip_adam_ema_matches_oracle(clip):
         assert rel_err(dsh.cpu(), sh["w"]) < 1e-6
         assert rel_err(dm.cpu(), m["w"]) < 1e-5
         assert rel_err(dv.cpu(), v["w"]) < 1e-5
+
+
+def test_resume_from_a_reference_optimizer_state():
+    """SURVEY 8f rank 2 (vqwae_train.py:878-892,959-976): a checkpoint written by the reference after its first step -- weights
+    + torch.optim.Adam.state_dict() -- is loaded, the engine takes the second step on the same batch and must land on the
+    reference's second-step weights and moments; its own optimizer dict then equals torch's."""
+    import json
+    from helpers import golden_model, load_npz
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import checkpoint as CK
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    z = load_npz("optim_A")
+    names = json.loads(str(z["names"]))
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype="fp32")
+    assert names == list(eng.lay.offsets)                           # optimizer index i = i-th arena tensor
+    shapes = [eng.lay.shapes[k] for k in names]
+    sizes = [int(np.prod(s)) for s in shapes]
+
+    def split(flat):
+        return [t.view(s) for t, s in zip(torch.from_numpy(flat).split(sizes), shapes)]
+
+    eng.load_state_dict(dict(zip(names, split(z["params1"]))))
+    group = dict(json.loads(str(z["param_group"])), params=list(range(len(names))))
+    ref_opt = {"state": {i: {"step": torch.tensor(float(z["step1"][i])), "exp_avg": m, "exp_avg_sq": v}
+                         for i, (m, v) in enumerate(zip(split(z["exp_avg1"]), split(z["exp_avg_sq1"])))},
+               "param_groups": [group]}
+    eng.init_optimizer()
+    got_group = CK.load_adam_state_dict(eng, ref_opt)
+    assert eng.opt_step == 1 and got_group["lr"] == 4e-4
+    T = ins["x"].shape[1]
+    res = eng.train_step(ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda(), lengths=None, lr=4e-4, clip_thresh=100.0)
+    torch.cuda.synchronize()
+    assert abs(float(res["loss"]) - float(z["loss2"])) < 1e-4 * abs(float(z["loss2"]))
+    mine = CK.adam_state_dict(eng, 4e-4)
+    assert float(mine["state"][0]["step"]) == 2.0
+    for i, (k, p2, m2, v2) in enumerate(zip(names, split(z["params2"]), split(z["exp_avg2"]), split(z["exp_avg_sq2"]))):
+        off, n = eng.lay.off(k), eng.lay.numel(k)
+        # second step: lr * m_hat / (sqrt(v_hat) + eps); gradients agree to ~1e-4 of their range, so do the moments
+        # (where a gradient cancels to ~0 -- some weight_g rows -- the step lr * m_hat / (sqrt(v_hat) + eps) inherits the
+        # moment's relative error, at most lr itself)
+        gm = float(m2.abs().max()) + 1e-12
+        tol = 4e-4 * torch.clamp(4 * (mine["state"][i]["exp_avg"] - m2).abs() / (m2.abs() + 1e-9), max=1.0) + 2e-6
+        assert bool(((eng.params[off:off + n].view(p2.shape).cpu() - p2).abs() <= tol).all()), k
+        assert float((mine["state"][i]["exp_avg"] - m2).abs().max()) < 1e-3 * gm + 1e-9, k
+        assert float((mine["state"][i]["exp_avg_sq"] - v2).abs().max()) < 2e-3 * float(v2.abs().max()) + 1e-14, k

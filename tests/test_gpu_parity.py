@@ -87,7 +87,7 @@ def test_single_glu_layer(name, d, dtype, tol):
     gvec = gv.view(B, -1).contiguous().cuda()
     L.check(eng.lib.wae_gproj_fwd(L.ptr(eng.eff), eng.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v"),
                                   eng.lay.off("wavenet.conv_layers.0.conv.bias"), eng.lay.layer_stride, None, 0,
-                                  L.ptr(gvec), L.ptr(zb), B, g.layers, g.G, g.Hp, g.Cg, st))
+                                  L.ptr(gvec), L.ptr(zb), B, g.layers, g.G, g.Hp, g.Cg, 0, None, st))
     xout = torch.zeros_like(xin)
     Ku = 2 * g.Hp + 64
     ubuf = torch.full((B, T, Ku), 7.0, dtype=eng.tdtype, device="cuda")

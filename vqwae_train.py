@@ -36,7 +36,8 @@ sys.path.insert(0, ROOT)
 
 from wavenet_autoencoders_amd import Geometry, lrschedule  # noqa: E402
 from wavenet_autoencoders_amd import distributed as D  # noqa: E402
-from wavenet_autoencoders_amd.data import CropBatcher, SyntheticBatcher, read_index  # noqa: E402
+from wavenet_autoencoders_amd.checkpoint import load_checkpoint, restore_parts, save_checkpoint  # noqa: E402
+from wavenet_autoencoders_amd.data import CropBatcher, Prefetcher, SyntheticBatcher, read_index  # noqa: E402
 from wavenet_autoencoders_amd.hparams import hparams  # noqa: E402
 
 
@@ -53,53 +54,26 @@ def build_geometry(hp) -> Geometry:
                     c_in=hp.dim_in, encoder_hid=hp.encoder_hid, K=256)
 
 
-def save_checkpoint(eng, step, epoch, checkpoint_dir, hp, rank):
-    """Reference layout (vqwae_train.py:878-910): {"state_dict","optimizer","global_step","global_epoch",
-    "global_test_step"} -> checkpoint_step{:09d}.pth + checkpoint_latest.pth, and an _ema twin with the shadow weights."""
-    if rank != 0:
-        return
-    os.makedirs(checkpoint_dir, exist_ok=True)
-    path = os.path.join(checkpoint_dir, "checkpoint_step{:09d}.pth".format(step))
-    sd = {k: v.cpu() for k, v in eng.state_dict().items()}
-    opt = None
-    if hp.save_optimizer_state and hasattr(eng, "exp_avg"):
-        opt = dict(exp_avg=eng.exp_avg.cpu(), exp_avg_sq=eng.exp_avg_sq.cpu(), step=eng.opt_step, layout="flat-arena")
-    torch.save({"state_dict": sd, "optimizer": opt, "global_step": step, "global_epoch": epoch, "global_test_step": 0}, path)
-    shutil.copyfile(path, os.path.join(checkpoint_dir, "checkpoint_latest.pth"))
-    if getattr(eng, "shadow", None) is not None:
-        ema_sd = {}
-        for k in eng.lay.offsets:
-            off, n = eng.lay.off(k), eng.lay.numel(k)
-            ema_sd[k] = eng.shadow[off:off + n].view(eng.lay.shapes[k]).cpu()
-        epath = os.path.join(checkpoint_dir, "checkpoint_step{:09d}_ema.pth".format(step))
-        torch.save({"state_dict": ema_sd, "optimizer": None, "global_step": step, "global_epoch": epoch, "global_test_step": 0}, epath)
-        shutil.copyfile(epath, os.path.join(checkpoint_dir, "checkpoint_latest_ema.pth"))
-    print("Saved checkpoint:", path)
-
-
-def load_checkpoint(path, eng, reset_optimizer):
-    """vqwae_train.py:959-976"""
-    ck = torch.load(path, map_location="cpu")
-    eng.load_state_dict(ck["state_dict"])
-    eng.init_optimizer()
-    opt = ck.get("optimizer")
-    if not reset_optimizer and isinstance(opt, dict) and opt.get("layout") == "flat-arena":
-        eng.exp_avg.copy_(opt["exp_avg"])
-        eng.exp_avg_sq.copy_(opt["exp_avg_sq"])
-        eng.opt_step = int(opt["step"])
-    return int(ck.get("global_step", 0)), int(ck.get("global_epoch", 0))
-
-
-def restore_parts(path, eng):
-    """load matching keys only (vqwae_train.py:980-999)"""
-    sd = torch.load(path, map_location="cpu")["state_dict"]
-    cur = eng.state_dict()
-    for k, v in sd.items():
-        if k in cur and tuple(cur[k].shape) == tuple(v.shape):
-            cur[k] = v
+def evaluate(eng, loader, device, hp):
+    """The dev phase of train_loop (vqwae_train.py:829-870 with train=False: model.eval(), forward and loss only, no update):
+    -> (loss, vq_loss, perplexity) averaged over the phase's batches as the reference's per-epoch log does."""
+    tot, n = torch.zeros(3, dtype=torch.float64), 0
+    for x, c, g, lengths in loader:
+        T = x.shape[1]
+        ln = None if bool((lengths == T).all()) else lengths
+        if eng.g.scalar_input:
+            out = eng.forward(x.to(device), c.to(device), g.to(device), want_logits=True, train=False)
+            ce, _ = eng.dmol_loss_and_grad(out["logits"], x.to(device), ln, hp.quantize_channels, hp.log_scale_min)
         else:
-            print("warn: skip", k)
-    eng.load_state_dict({k: v.cpu() for k, v in cur.items()})
+            out = eng.forward(x.to(device), c.to(device), g.to(device), targets=x.to(device), lengths=ln, want_logits=False, train=False)
+            ce = out["loss"]
+        tot += torch.stack([ce.float() + out["vq_loss"].float(), out["vq_loss"].float(), out["perp"].float()]).double().cpu()
+        n += 1
+    stats = (tot / max(n, 1)).float()
+    if device != "cpu":
+        stats = stats.to(device)
+    D.all_reduce_scalars(stats)
+    return [float(v) for v in stats.cpu()]
 
 
 def main(argv=None):
@@ -145,63 +119,90 @@ def main(argv=None):
     tmp = _Init()
     tmp._init_arena(geom, "")
     eng.load_state_dict({k: v.detach() for k, v in tmp.state_dict().items()})
-    step, epoch = 0, 0
+    step, epoch, test_step = 0, 0, 0
+    use_ema = bool(hp.exponential_moving_average)
     if args.restore_parts:
         restore_parts(args.restore_parts, eng)
     if args.checkpoint:
-        step, epoch = load_checkpoint(args.checkpoint, eng, args.reset_optimizer)
+        step, epoch, test_step = load_checkpoint(args.checkpoint, eng, args.reset_optimizer, ema=use_ema)
     D.broadcast_params(eng.params)
-    eng.init_optimizer(ema=bool(hp.exponential_moving_average)) if not hasattr(eng, "exp_avg") else None
+    if not hasattr(eng, "exp_avg"):
+        eng.init_optimizer(ema=use_ema)
+    elif use_ema:
+        eng.shadow.copy_(eng.params)                 # the shadow registers the (broadcast) weights it starts from (:822-826)
 
     if hp.batch_size % world != 0:
         raise ValueError("batch size % num gpu must be 0 (vqwae_train.py:754)")
     per_rank = hp.batch_size // world
     hop = hp.hop_size
+    dev_loader = None
     if args.synthetic or not args.dump_root:
         loader = SyntheticBatcher(per_rank, hop, hp.max_time_steps, hp.dim_in, hp.n_speakers, steps=args.max_steps or 20, rank=rank)
     else:
         feat = args.feat + (".norm.npy" if str(args.use_norm).lower() in ("true", "1") else ".npy")
-        items = read_index(args.dump_root, "train_no_dev", hp.max_time_steps // hop)
-        loader = CropBatcher(items, per_rank, hop, hp.max_time_steps, feat, hp.cin_pad, rank, world)
-    bucketer = {}
-
-    def grad_hook(grads):
-        if world > 1:
-            if "b" not in bucketer:
-                bucketer["b"] = D.GradBucketer(grads)
-            bucketer["b"].finish()
+        min_frames = (hp.max_time_steps // hop + 2 * hp.cin_pad) if hp.max_time_steps is not None else 0
+        items = read_index(args.dump_root, "train_no_dev", min_frames, hp.n_speakers)
+        loader = CropBatcher(items, hp.batch_size, hop, hp.max_time_steps, feat, hp.cin_pad, rank, world, train=True,
+                             n_classes=hp.quantize_channels)
+        if os.path.exists(os.path.join(args.dump_root, "dev", "train.txt")):
+            dev_items = read_index(args.dump_root, "dev", min_frames, hp.n_speakers)
+            if dev_items:
+                dev_loader = CropBatcher(dev_items, hp.batch_size, hop, hp.max_time_steps, feat, hp.cin_pad, rank, world,
+                                         train=False, n_classes=hp.quantize_channels)
+    sync = D.GradSync(eng) if world > 1 else None
 
     max_steps = args.max_steps or hp.max_train_steps
     sched = getattr(lrschedule, hp.lr_schedule) if hp.lr_schedule else None
-    t0 = time.time()
+    t0, step0 = time.time(), step
+    lr = hp.optimizer_params["lr"]
     try:
         while epoch < hp.nepochs and step < max_steps:
-            for x, c, g, lengths in loader:
+            run = torch.zeros(3, dtype=torch.float64, device=device)
+            nb = 0
+            for x, c, g, lengths in Prefetcher(loader, device):
                 lr = hp.optimizer_params["lr"]
                 if sched is not None:
                     lr = sched(lr, step, **hp.lr_schedule_kwargs)                     # vqwae_train.py:729-735
-                res = eng.train_step(x.to(device), c.to(device), g.to(device), lengths=None if bool((lengths == x.shape[1]).all())
-                                     else lengths, lr=lr, eps=hp.optimizer_params.get("eps", 1e-8),
+                T = x.shape[1]
+                ln = None if bool((lengths == T).all()) else lengths
+                # ragged shards: the CE is normalised by the mask sum of the GLOBAL batch (vqwae_train.py:374-379 after :705)
+                ce_scale, n_glob = D.ragged_ce_scale(ln, T, x.shape[0]) if world > 1 else (1.0, None)
+                res = eng.train_step(x, c, g, lengths=ln, lr=lr, eps=hp.optimizer_params.get("eps", 1e-8),
                                      weight_decay=hp.optimizer_params.get("weight_decay", 0.0), clip_thresh=hp.clip_thresh,
-                                     ema_decay=hp.ema_decay, grad_hook=grad_hook)
+                                     ema_decay=hp.ema_decay, grad_sync=sync, ce_scale=ce_scale,
+                                     quantize_channels=hp.quantize_channels, log_scale_min=hp.log_scale_min)
                 step += 1
+                ce = res["ce"].float() * ce_scale               # rank mean of this = the global masked mean
+                vq = res.get("vq_loss", torch.zeros((), device=device)).float()
+                run += torch.stack([ce + vq, vq, res.get("perp", torch.zeros((), device=device)).float()]).double()
+                nb += 1
                 if step % 10 == 0 or step == 1:
-                    stats = torch.stack([res["loss"].float(), res.get("vq_loss", res["loss"]).float(),
-                                         res.get("perp", res["loss"]).float()])
+                    stats = torch.stack([ce + vq, vq, res.get("perp", torch.zeros((), device=device)).float()])
                     D.all_reduce_scalars(stats)
                     if rank == 0:
-                        dt = (time.time() - t0) / step
+                        dt = (time.time() - t0) / max(step - step0, 1)
                         print(f"step {step} loss {float(stats[0]):.4f} vq {float(stats[1]):.4f} perp {float(stats[2]):.2f} "
-                              f"gnorm {float(res['grad_norm']):.3f} lr {lr:.2e} {hp.batch_size * x.shape[1] / dt / 1e6:.2f} Msamples/s")
+                              f"gnorm {float(res['grad_norm']):.3f} lr {lr:.2e} {hp.batch_size * T / dt / 1e6:.2f} Msamples/s")
                 if step % hp.checkpoint_interval == 0:
-                    save_checkpoint(eng, step, epoch, args.checkpoint_dir, hp, rank)
+                    save_checkpoint(eng, step, epoch, args.checkpoint_dir, hp, rank, test_step, lr)
                 if step >= max_steps:
+                    print("Training reached max train steps ({}). will exit".format(max_steps)) if rank == 0 else None
                     break
+            if nb:
+                avg = (run / nb).float()
+                D.all_reduce_scalars(avg)
+                if rank == 0:                                                         # vqwae_train.py:862-869
+                    print("Step {} [train_no_dev] Loss: {} vq: {} perp {}".format(step, float(avg[0]), float(avg[1]), float(avg[2])))
+            if dev_loader is not None and step < max_steps:
+                dl, dvq, dperp = evaluate(eng, Prefetcher(dev_loader, device), device, hp)
+                test_step += len(dev_loader)
+                if rank == 0:
+                    print("Step {} [dev] Loss: {} vq: {} perp {}".format(step, dl, dvq, dperp))
             epoch += 1
     except KeyboardInterrupt:
-        pass
+        print("Interrupted!")
     finally:
-        save_checkpoint(eng, step, epoch, args.checkpoint_dir, hp, rank)             # vqwae_train.py:1140-1145
+        save_checkpoint(eng, step, epoch, args.checkpoint_dir, hp, rank, test_step, lr)   # vqwae_train.py:1140-1145
     if rank == 0:
         print("Finished")
     return 0

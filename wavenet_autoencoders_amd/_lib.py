@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libwae_hip.so")
 
 WAE_F32, WAE_BF16 = 0, 1
 GLU_SAVE_Z, GLU_NO_OUT = 2, 4
+ERR_CLASS_ID, ERR_SPEAKER_ID, ERR_TARGET_ID = 1, 2, 4
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -67,15 +68,16 @@ SIGNATURES = {
     "wae_enc_conv_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp]),
     "wae_vq_nearest": (c_i32, [c_vp] * 6 + [c_i32] * 4 + [c_f32, c_vp]),
     "wae_upsample_stage_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
-    "wae_gproj_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
-    "wae_gproj_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64] + [c_i32] * 6 + [c_vp]),
+    "wae_gproj_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 6 + [c_vp, c_vp]),
+    "wae_gproj_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64] + [c_i32] * 7 + [c_vp]),
+    "wae_check_ids": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "wae_upsample_stage_bwd": (c_i32, [c_vp] * 5 + [c_i32] * 4 + [c_vp]),
     "wae_enc_conv_bwd": (c_i32, [c_vp] * 7 + [c_i32] * 9 + [c_vp]),
     "wae_vq_bwd": (c_i32, [c_vp] * 6 + [c_i32] * 3 + [c_f32, c_f32, c_vp]),
     "wae_vq_slice": (c_i32, [c_vp] * 6 + [c_i32] * 6 + [c_f32, c_i32, c_vp]),
     "wae_vq_ema_update": (c_i32, [c_vp] * 6 + [c_i32] * 6 + [c_f32, c_vp]),
     "wae_vq_slice_bwd": (c_i32, [c_vp] * 6 + [c_i32] * 5 + [c_f32, c_f32, c_vp]),
-    "wae_first_conv_fwd": (c_i32, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "wae_first_conv_fwd": (c_i32, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_glu_layer_fwd": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "wae_glu_packed_bytes": (c_i64, [ctypes.POINTER(GluDesc)]),
     "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 10),

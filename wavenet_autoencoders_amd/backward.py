@@ -457,7 +457,8 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     keep.append(gid32)
     L.check(lib.wae_gproj_bwd(L.ptr(eng.eff), L.ptr(eng.d_eff), wg_off, lay.off("wavenet.conv_layers.0.conv.bias"),
                               lay.layer_stride, L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec), L.ptr(c1),
-                              Z2 * sm["ld1"], sm["ld1"], g.k * g.Rp + g.Ccp, B, g.layers, g.G, g.Hp, max(g.Cg, 0), st),
+                              Z2 * sm["ld1"], sm["ld1"], g.k * g.Rp + g.Ccp, B, g.layers, g.G, g.Hp, max(g.Cg, 0),
+                              int(g.n_speakers or 0), st),
             "gproj_bwd")
     # ---- data parallel: the layers' + head's gradients are final -> weight-norm backward of that slice, then the all-reduce
     #      starts on its side stream while the launches below (and the front end's backward) still run ------------------------

@@ -511,16 +511,40 @@ extern "C" int wae_upsample_stage_fwd(const float* in, const float* w, void* out
 // ---------------------------------------------------------------------------------------------------
 // hoisted global conditioning (modules.py:148-152 re-convolves the same g at every t; exact hoist)
 // zb[b][l][row] , rows 0..Hp-1 = gate-a channels, Hp..2Hp-1 = gate-b channels (zero in the padding)
+// Ids index tables (the first-conv table, the speaker embedding): the reference raises IndexError from nn.Embedding / the
+// one-hot encoder for an id outside its table.  Here an id outside [0, n) is clamped -- no access ever leaves the table --
+// and reported through a sticky device word that the host turns into that IndexError at its next checkpoint.
+__device__ __forceinline__ int checked_id(int id, int n, int32_t* err, int code) {
+  if ((unsigned)id < (unsigned)n) return id;
+  if (err) atomicOr(err, code);
+  return id < 0 ? 0 : n - 1;
+}
+
+__global__ void __launch_bounds__(256) check_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int lo, int hi,
+                                                        int32_t* __restrict__ err, int code) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= ids[i] < lo || ids[i] >= hi;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(err, code);
+}
+extern "C" int wae_check_ids(const int32_t* ids, int64_t n, int32_t lo, int32_t hi, int32_t* err, int32_t code, void* stream) {
+  WAE_REQUIRE(ids && err && n > 0 && hi > lo, "check_ids: bad arguments");
+  const int grid = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(check_ids_kernel, dim3(grid), dim3(256), 0, as_stream(stream), ids, n, lo, hi, err, code);
+  return wae_check_launch("check_ids");
+}
+
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gproj_fwd_kernel(const float* __restrict__ eff, int64_t wg_off, int64_t bias_off,
                                                         int64_t layer_stride, const int32_t* __restrict__ gid,
                                                         int64_t emb_off, const float* __restrict__ gvec,
-                                                        float* __restrict__ zb, int L, int G, int Hp, int Cg) {
+                                                        float* __restrict__ zb, int L, int G, int Hp, int Cg, int n_speakers,
+                                                        int32_t* __restrict__ err) {
   const int l = blockIdx.x, b = blockIdx.y;
   const int H = G / 2;
   const float* wg = wg_off >= 0 ? eff + wg_off + (int64_t)l * layer_stride : nullptr;
   const float* bs = eff + bias_off + (int64_t)l * layer_stride;
-  const float* gv = gid ? eff + emb_off + (int64_t)gid[b] * Cg : (gvec ? gvec + (int64_t)b * Cg : nullptr);
+  const int sp = gid ? checked_id(gid[b], n_speakers, err, WAE_ERR_SPEAKER_ID) : 0;
+  const float* gv = gid ? eff + emb_off + (int64_t)sp * Cg : (gvec ? gvec + (int64_t)b * Cg : nullptr);
   float* o = zb + ((int64_t)b * L + l) * 2 * Hp;
   for (int r = threadIdx.x; r < 2 * Hp; r += 256) {
     const int half = r >= Hp, i = r - half * Hp;
@@ -537,10 +561,11 @@ __global__ void __launch_bounds__(256) gproj_fwd_kernel(const float* __restrict_
 
 extern "C" int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride, const int32_t* gid,
                              int64_t emb_off, const float* gvec, float* zb, int32_t B, int32_t L, int32_t G, int32_t Hp,
-                             int32_t Cg, void* stream) {
+                             int32_t Cg, int32_t n_speakers, int32_t* err, void* stream) {
   WAE_REQUIRE(eff && zb && B > 0 && L > 0 && G > 0 && G % 2 == 0 && Hp >= G / 2, "gproj: bad arguments");
+  WAE_REQUIRE(!gid || n_speakers > 0, "gproj: speaker ids need the size of the embedding table");
   hipLaunchKernelGGL(gproj_fwd_kernel, dim3(L, B), dim3(256), 0, as_stream(stream), eff, wg_off, bias_off, layer_stride,
-                     gid, emb_off, gvec, zb, L, G, Hp, Cg);
+                     gid, emb_off, gvec, zb, L, G, Hp, Cg, n_speakers, err);
   return wae_check_launch("gproj_fwd");
 }
 
@@ -550,7 +575,7 @@ __global__ void __launch_bounds__(256) gproj_bwd_kernel(const float* __restrict_
                                                         int64_t bias_off, int64_t layer_stride, const int32_t* __restrict__ gid,
                                                         int64_t emb_off, const float* __restrict__ gvec,
                                                         const float* __restrict__ c1, int64_t c_layer_stride, int64_t ld,
-                                                        int ones_col, int B, int G, int Hp, int Cg) {
+                                                        int ones_col, int B, int G, int Hp, int Cg, int n_speakers) {
   const int l = blockIdx.x;
   const int H = G / 2;
   const float* cl = c1 + (int64_t)l * c_layer_stride + ones_col;
@@ -570,7 +595,7 @@ __global__ void __launch_bounds__(256) gproj_bwd_kernel(const float* __restrict_
         for (int c = cs; c < Cg; c += 8) {
           float a = 0.f;
           for (int b = 0; b < B; ++b) {
-            const float e = gid ? eff[emb_off + (int64_t)gid[b] * Cg + c] : gvec[(int64_t)b * Cg + c];
+            const float e = gid ? eff[emb_off + (int64_t)checked_id(gid[b], n_speakers, nullptr, 0) * Cg + c] : gvec[(int64_t)b * Cg + c];
             a = fmaf(cl[(int64_t)r * ld + b], e, a);
           }
           dwg[c] += a;
@@ -589,16 +614,18 @@ __global__ void __launch_bounds__(256) gproj_bwd_kernel(const float* __restrict_
         if (i >= H) continue;
         a = fmaf(cl[(int64_t)r * ld + b], eff[wg_off + (int64_t)l * layer_stride + (int64_t)(half * H + i) * Cg + c], a);
       }
-      atomicAdd(d_eff + emb_off + (int64_t)gid[b] * Cg + c, a);
+      atomicAdd(d_eff + emb_off + (int64_t)checked_id(gid[b], n_speakers, nullptr, 0) * Cg + c, a);
     }
   }
 }
 extern "C" int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride,
                              const int32_t* gid, int64_t emb_off, const float* gvec, const float* c1, int64_t c_layer_stride,
-                             int64_t ld, int32_t ones_col, int32_t B, int32_t L, int32_t G, int32_t Hp, int32_t Cg, void* stream) {
+                             int64_t ld, int32_t ones_col, int32_t B, int32_t L, int32_t G, int32_t Hp, int32_t Cg,
+                             int32_t n_speakers, void* stream) {
   WAE_REQUIRE(eff && d_eff && c1 && B > 0 && L > 0 && G > 0 && G % 2 == 0, "gproj_bwd: bad arguments");
+  WAE_REQUIRE(!gid || n_speakers > 0, "gproj_bwd: speaker ids need the size of the embedding table");
   hipLaunchKernelGGL(gproj_bwd_kernel, dim3(L, (2 * Hp + 31) / 32), dim3(256), 0, as_stream(stream), eff, d_eff, (gid || gvec) ? wg_off : -1, bias_off,
-                     layer_stride, gid, emb_off, gvec, c1, c_layer_stride, ld, ones_col, B, G, Hp, Cg);
+                     layer_stride, gid, emb_off, gvec, c1, c_layer_stride, ld, ones_col, B, G, Hp, Cg, n_speakers);
   return wae_check_launch("gproj_bwd");
 }
 
@@ -634,7 +661,7 @@ extern "C" int wae_sum_rows(const float* src, int64_t off, int64_t stride, int32
 template <typename E>
 __global__ void __launch_bounds__(256) first_conv_kernel(const int32_t* __restrict__ idx, const float* __restrict__ xs,
                                                          const float* __restrict__ table, const float* __restrict__ bias,
-                                                         void* __restrict__ x0, int64_t BT, int Rp) {
+                                                         void* __restrict__ x0, int64_t BT, int Rp, int O, int32_t* __restrict__ err) {
   // thread = 8 consecutive residual channels of one sample (Rp is a multiple of 128): 16-byte table / bias loads, one
   // 16-byte bf16 store; a block covers 16 samples
   const int tpr = Rp >> 3;
@@ -645,7 +672,7 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const int32_t* __restri
     f32x4 v0, v1;
     const f32x4 b0 = *(const f32x4*)(bias + r), b1 = *(const f32x4*)(bias + r + 4);
     if (idx) {
-      const float* tr = table + (int64_t)idx[bt] * Rp + r;
+      const float* tr = table + (int64_t)checked_id(idx[bt], O, err, WAE_ERR_CLASS_ID) * Rp + r;
       v0 = *(const f32x4*)tr + b0;
       v1 = *(const f32x4*)(tr + 4) + b1;
     } else {
@@ -667,14 +694,14 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const int32_t* __restri
 }
 
 extern "C" int wae_first_conv_fwd(const int32_t* idx, const float* xs, const float* table, const float* bias, void* x0,
-                                  int64_t BT, int32_t Rp, int32_t O, int32_t dtype, void* stream) {
+                                  int64_t BT, int32_t Rp, int32_t O, int32_t dtype, int32_t* err, void* stream) {
   WAE_REQUIRE((idx || xs) && table && bias && x0 && BT > 0 && Rp > 0 && Rp % 8 == 0, "first_conv: bad arguments");
-  (void)O;
+  WAE_REQUIRE(!idx || O > 0, "first_conv: class ids need the number of classes");
   dim3 grid((unsigned)((BT + 15) / 16));
   if (dtype == WAE_BF16)
-    hipLaunchKernelGGL(first_conv_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp);
+    hipLaunchKernelGGL(first_conv_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp, O, err);
   else
-    hipLaunchKernelGGL(first_conv_kernel<float>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp);
+    hipLaunchKernelGGL(first_conv_kernel<float>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp, O, err);
   return wae_check_launch("first_conv_fwd");
 }
 

@@ -49,21 +49,32 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 class GradBucketer:
     """Bucketed, overlapped all-reduce (mean) of a flat fp32 gradient arena.
 
-    grads: 1-D tensor (the arena).  Buckets are contiguous slices of ~bucket_bytes, numbered from the FRONT of the
-    arena; backward fills the arena from the back, so `ready(lo)` launches every not-yet-launched bucket that lies
-    entirely at or above element offset `lo`.  `finish()` launches the rest, waits, and scales by 1/world."""
+    grads: 1-D tensor (the arena).  Buckets are contiguous slices of at most bucket_bytes; `cuts` (element offsets) are
+    forced bucket boundaries, so that a slice of the arena that becomes final early (the gated layers + head, ~95 % of
+    it: backward.layer_segment) is a whole number of buckets.  `ready_range(lo, hi)` launches every not-yet-launched
+    bucket inside [lo, hi) on the side stream -- adjacent ones as ONE collective: xGMI rings are per-link bound and reach
+    their bandwidth on large messages -- `ready(lo)` is ready_range(lo, end); `finish()` launches the rest, waits, and
+    scales by 1/world.  With timing=True the collectives are bracketed by events: `last_comm_ms` (first launch -> last
+    collective done, on the side stream) and `last_wait_ms` (how long the compute stream stood still in finish())."""
 
-    def __init__(self, grads: torch.Tensor, bucket_bytes: int = 8 << 20, group=None):
+    def __init__(self, grads: torch.Tensor, bucket_bytes: int = 16 << 20, group=None, cuts=(), timing: bool = False):
         assert grads.dim() == 1 and grads.dtype == torch.float32
         self.grads = grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = grads.numel()
         per = max(1, bucket_bytes // 4)
-        self.bounds: List[Tuple[int, int]] = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
+        edges = sorted({0, n, *[int(c) for c in cuts if 0 < int(c) < n]})
+        self.bounds: List[Tuple[int, int]] = []
+        for a, b in zip(edges[:-1], edges[1:]):
+            self.bounds += [(lo, min(b, lo + per)) for lo in range(a, b, per)]
         self.launched = [False] * len(self.bounds)
         self.handles = []
         self.comm_stream = torch.cuda.Stream(grads.device) if grads.is_cuda else None
+        self.timing = timing and grads.is_cuda
+        self._ev = []
+        self.last_comm_ms = self.last_wait_ms = 0.0
+        self.n_collectives = 0
 
     def _launch(self, i: int, j: Optional[int] = None):
         """all-reduce buckets i..j (contiguous) as ONE collective"""
@@ -74,43 +85,103 @@ class GradBucketer:
         if self.world == 1:
             return
         view = self.grads[lo:hi]
+        self.n_collectives += 1
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.grads.device))
             with torch.cuda.stream(self.comm_stream):
+                if self.timing and not self._ev:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(self.comm_stream)
+                    self._ev.append(e)
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def _launch_runs(self, idx):
+        """launch the not-yet-launched buckets among idx (ascending), every run of adjacent ones as one collective"""
+        run = []
+        for i in idx:
+            if self.launched[i]:
+                continue
+            if run and i != run[-1] + 1:
+                self._launch(run[0], run[-1])
+                run = []
+            run.append(i)
+        if run:
+            self._launch(run[0], run[-1])
+
+    def ready_range(self, lo: int, hi: int):
+        """Gradients at element offsets [lo, hi) are final."""
+        self._launch_runs([i for i, (a, b) in enumerate(self.bounds) if a >= lo and b <= hi])
+
     def ready(self, lo: int):
         """Gradients at element offsets >= lo are final."""
-        for i in range(len(self.bounds) - 1, -1, -1):
-            if self.bounds[i][0] < lo:
-                break
-            if not self.launched[i]:
-                self._launch(i)
+        self.ready_range(lo, self.grads.numel())
 
     def finish(self):
         # what backward did not hand over early goes out in as few collectives as possible: every run of adjacent buckets is
-        # one all-reduce (the whole arena when nothing was launched early -- a ring all-reduce over xGMI is per-link bound and
-        # reaches its bandwidth only on large messages; six 8-MiB calls pay six launch latencies for nothing)
-        i = len(self.bounds) - 1
-        while i >= 0:
-            if self.launched[i]:
-                i -= 1
-                continue
-            j = i
-            while i - 1 >= 0 and not self.launched[i - 1]:
-                i -= 1
-            self._launch(i, j)
-            i -= 1
+        # one all-reduce (the whole arena when nothing was launched early)
+        self._launch_runs(range(len(self.bounds)))
+        dev = self.grads.device
+        if self.timing and self.world > 1:
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record(torch.cuda.current_stream(dev))
         for h in self.handles:
             h.wait()
         if self.comm_stream is not None:
-            torch.cuda.current_stream(self.grads.device).wait_stream(self.comm_stream)
+            if self.timing and self._ev:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(self.comm_stream)
+                self._ev.append(e)
+            torch.cuda.current_stream(dev).wait_stream(self.comm_stream)
         if self.world > 1:
             self.grads.mul_(1.0 / self.world)
+            if self.timing:
+                w1.record(torch.cuda.current_stream(dev))
+                self._pending = (self._ev, (w0, w1))
+        self._ev = []
         self.handles = []
         self.launched = [False] * len(self.bounds)
+
+    def collect_timing(self):
+        """(comm_ms, wait_ms) of the last finished step; synchronises the events (call outside the timed region)."""
+        p = getattr(self, "_pending", None)
+        if p is None:
+            return 0.0, 0.0
+        ev, (w0, w1) = p
+        w1.synchronize()
+        self.last_comm_ms = ev[0].elapsed_time(ev[-1]) if len(ev) == 2 else 0.0
+        self.last_wait_ms = w0.elapsed_time(w1)
+        return self.last_comm_ms, self.last_wait_ms
+
+
+class GradSync(GradBucketer):
+    """The bucketer of a WaeEngine's gradient arena, cut at the boundaries of the slice that backward finishes first
+    (pass as train_step(grad_sync=...))."""
+
+    def __init__(self, eng, bucket_bytes: int = 16 << 20, group=None, timing: bool = False):
+        from . import backward as BW
+        BW._prepare_bwd(eng)
+        super().__init__(eng.grads, bucket_bytes, group, cuts=BW.layer_segment(eng), timing=timing)
+
+
+def ragged_ce_scale(lengths: Optional[torch.Tensor], T: int, batch: int, group=None) -> Tuple[float, float]:
+    """Data-parallel shards of a ragged global batch: the reference normalises the masked CE by the mask sum of the WHOLE
+    gathered batch (vqwae_train.py:374-379 after the gather of :705).  Rank r holds n_r = sum_b max(min(len_b, T) - 1, 0) of
+    the N = sum_r n_r loss positions; its engine normalises by n_r, so scaling its CE gradient by n_r * world / N makes the
+    rank MEAN of the gradients equal the gradient of the global masked mean.  -> (scale, N).  One 1-element all-reduce, and
+    only when lengths is given (equal-length crops -- every batch of the reference's own pipeline -- need none)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if lengths is None:
+        return 1.0, float(world * batch * (T - 1))
+    n_r = float(torch.clamp(lengths.detach().to("cpu", torch.int64).clamp(max=T) - 1, min=0).sum())
+    tot = torch.tensor([n_r], dtype=torch.float64)
+    if world > 1:
+        if dist.get_backend(group) == "nccl":
+            tot = tot.cuda()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    N = float(tot.item())
+    return (n_r * world / N if N > 0 else 1.0), N
 
 
 def all_reduce_scalars(values: torch.Tensor, group=None, average: bool = True) -> torch.Tensor:

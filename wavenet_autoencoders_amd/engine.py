@@ -75,6 +75,19 @@ class WaeEngine:
         self.b_head = torch.zeros(2 * g.Sp + g.Op, dtype=torch.float32, device=dev)   # [sum skip bias | b1 | b3]
         self._ws: Dict[tuple, dict] = {}
         self.weights_dirty = True
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)      # sticky WAE_ERR_* bits set by the kernels (include/wae.h)
+
+    def check_errors(self):
+        """Turn the kernels' sticky id-range flags into the IndexError the reference raises on the spot (nn.Embedding for a
+        speaker id >= n_speakers, the one-hot encoder / CrossEntropyLoss for a class id outside [0, out_channels)).  Reads one
+        device word (synchronises): the train script calls it where it already reads the logged scalars."""
+        bits = int(self.err.item())
+        if bits:
+            self.err.zero_()
+            what = [n for b, n in ((L.ERR_CLASS_ID, f"input class id outside [0, {self.g.O})"),
+                                   (L.ERR_SPEAKER_ID, f"speaker id outside [0, {self.g.n_speakers})"),
+                                   (L.ERR_TARGET_ID, f"target class id outside [0, {self.g.O})")) if bits & b]
+            raise IndexError("index out of range in self: " + "; ".join(what) + " (ids were clamped; results of that call are invalid)")
 
     # ------------------------------------------------------------------ parameters
     def stream(self):
@@ -260,16 +273,17 @@ class WaeEngine:
         L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
                                   self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
                                   L.ptr(gid) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
-                                  L.ptr(ws["zb"]), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
+                                  L.ptr(ws["zb"]), B, g.layers, g.G, g.Hp, max(g.Cg, 0), int(g.n_speakers or 0), L.ptr(self.err), st),
+                "gproj")
         # first conv
         if g.scalar_input:
             xs = x.contiguous().float()
             L.check(lib.wae_first_conv_fwd(None, L.ptr(xs), L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(ws["x"][0]),
-                                           B * T, g.Rp, 1, self.dt, st), "first_conv")
+                                           B * T, g.Rp, 1, self.dt, None, st), "first_conv")
         else:
             xi = x.to(torch.int32).contiguous()
             L.check(lib.wae_first_conv_fwd(L.ptr(xi), None, L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(ws["x"][0]),
-                                           B * T, g.Rp, g.O, self.dt, st), "first_conv")
+                                           B * T, g.Rp, g.O, self.dt, L.ptr(self.err), st), "first_conv")
         # gated residual stack
         es = self.w_glu.element_size()
         d = L.GluDesc(self.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, 1, 0)
@@ -295,6 +309,8 @@ class WaeEngine:
         hd = L.HeadDesc(self.dt, B, T, g.Ku, g.Sp, g.Op, g.O, math.sqrt(1.0 / g.layers))
         logits = torch.empty(B, g.O, T, dtype=torch.float32, device=self.device) if want_logits else None
         tg = targets.to(torch.int32).contiguous() if targets is not None else None
+        if tg is not None and tg.data_ptr() != (xi.data_ptr() if not g.scalar_input else 0):   # targets = inputs: already checked
+            L.check(lib.wae_check_ids(L.ptr(tg), B * T, 0, g.O, L.ptr(self.err), L.ERR_TARGET_ID, st), "check targets")
         if self.wide_head:
             self._head_fwd_wide(ws, B, T, logits, tg, train)
         else:
@@ -419,7 +435,8 @@ class WaeEngine:
         L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
                                   self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
                                   L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
-                                  L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), st), "gproj")
+                                  L.ptr(zb), B, g.layers, g.G, g.Hp, max(g.Cg, 0), int(g.n_speakers or 0), L.ptr(self.err), st),
+                "gproj")
         # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
         # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
         coop = (B <= 8 and g.R <= 256 and g.S <= 256 and g.O <= 256 and not g.scalar_input and m <= 2

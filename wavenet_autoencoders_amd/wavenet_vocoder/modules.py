@@ -57,7 +57,8 @@ class ResidualConv1dGLU(ArenaModel):
             gvec = g[:, :, 0].contiguous().float()
         wg_off = eng.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if gm.Cg > 0 else -1
         L.check(lib.wae_gproj_fwd(L.ptr(eng.eff), wg_off if gvec is not None else -1, eng.lay.off("wavenet.conv_layers.0.conv.bias"),
-                                  eng.lay.layer_stride, None, 0, L.ptr(gvec), L.ptr(ws["zb"]), B, 1, gm.G, gm.Hp, max(gm.Cg, 0), st),
+                                  eng.lay.layer_stride, None, 0, L.ptr(gvec), L.ptr(ws["zb"]), B, 1, gm.G, gm.Hp, max(gm.Cg, 0), 0, None,
+                                  st),
                 "gproj")
         ws["u"].zero_()
         d = L.GluDesc(eng.dt, B, T, gm.Rp, gm.Ccp, gm.Hp, gm.k, self.dilation, 0)
