@@ -118,7 +118,8 @@ def test_c4_sampled_rollout_and_partial_forcing_fp32(c4):
 
 def test_c4_bf16_follows_the_reference_sequence(c4):
     """bf16 storage cannot reproduce a 2560-step greedy path bit for bit; teacher-forced on the reference's path it must make
-    the reference's decision wherever the two best logits are 0.25 apart (5 % of the logit range is the stated bf16 bound)."""
+    the reference's decision wherever the two best logits are further apart than twice the stated bf16 bound (5 % of the
+    logit range on each)."""
     cfg, sd, z = c4
     eng = _engine(cfg, sd, "bf16")
     T = z["x"].shape[1]
@@ -127,8 +128,9 @@ def test_c4_bf16_follows_the_reference_sequence(c4):
     tf = eng.incremental_forward(lat, g, T, mode="logits", test_inputs=seq)
     torch.cuda.synchronize()
     am = tf["logits"].cpu()[0].argmax(0).numpy()
-    clear = z["greedy_margin"][0] > 0.25
-    assert clear.sum() > 50 and (am == z["greedy"][0])[clear].all()
+    bound = 5e-2 * float(np.abs(z["tf_probe"]).max())              # the stated bf16 tolerance on one logit
+    clear = z["greedy_margin"][0] > 2 * bound
+    assert clear.sum() > 300 and (am == z["greedy"][0])[clear].all()
 
 
 # --------------------------------------------------------------------------------------------------------------- C1 / C3
