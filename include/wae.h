@@ -10,8 +10,10 @@
  *   - nothing here allocates, frees, synchronises or owns memory; kernels are enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream)
  *   - returns WAE_OK (0) or a negative error code; wae_last_error() gives a thread-local message
- *   - dtype: WAE_F32 (fp32 storage, exact-fp32 MFMA 32x32x2) or WAE_BF16 (bf16 storage, MFMA 32x32x16,
- *     fp32 accumulate).  Skip accumulators, biases, losses and the encoder/VQ are always fp32.
+ *   - dtype: WAE_F32 (fp32 storage, exact-fp32 MFMA 32x32x2), WAE_BF16 (bf16 storage, MFMA 32x32x16, fp32 accumulate) or
+ *     WAE_F16 (fp16 storage, MFMA 32x32x16 f16, fp32 accumulate; same packing as bf16; backward on loss-scaled gradients:
+ *     the caller folds the scale into inv_count / ext_dy and 1/scale into the alpha of the weight-gradient tables).
+ *     Skip accumulators, biases, losses and the encoder/VQ are always fp32.
  *   - activation layout inside the decoder stack is time-major rows, channels innermost:
  *     x[b][t][Cp] with Cp = channels padded to a multiple of 128 (64 for c; pad channels are zero).  The
  *     reference's (B,C,T) tensors enter/leave through wae_to_btc / wae_from_btc, the first-conv gather
@@ -35,10 +37,13 @@ extern "C" {
 
 #define WAE_F32 0
 #define WAE_BF16 1
+#define WAE_F16 2   /* fp16 storage, MFMA 32x32x16 f16, fp32 accumulate (BASELINE config C5); same packing as WAE_BF16 */
 
 /* flags of wae_glu_desc.flags */
 #define WAE_GLU_SAVE_Z 2    /* also store the pre-activation z (B,T,2Hp) for backward */
 #define WAE_GLU_NO_OUT 4    /* do not compute/store x' (last layer: the reference's x' is dead, wavenet.py:205-207) */
+#define WAE_GLU_WAVES4 8    /* bf16: 128-step tiles, 4 waves, two workgroups per CU instead of one 256-step / 8-wave workgroup
+                               (same results bit for bit; an A/B switch per launch, not process state) */
 
 const char* wae_version(void);
 const char* wae_last_error(void);
@@ -291,6 +296,8 @@ typedef struct wae_tm_desc {
                     fetch the same rows into the same L2 (w_packed follows the same order) */
 } wae_tm_desc;
 #define WAE_TM_INTERLEAVE 1
+#define WAE_TM_ONE_WG 2   /* bf16 gate-backward / residual / ReLU-backward launches: one 4-wave workgroup per CU with the 8 KiB
+                             staging tiles instead of two per CU (same results; an A/B switch per launch) */
 int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
                 const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,
                 int64_t out_stride, const void* aux, int64_t aux_stride, void* stream);
@@ -379,8 +386,9 @@ typedef struct wae_ts_job {
 typedef struct wae_ts_seg {
   int32_t job, slab_begin, slab_end;
 } wae_ts_seg;
-int wae_gemm_tn_stream(const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
-                       int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, void* stream);
+int wae_gemm_tn_stream(int32_t dtype /* WAE_BF16 or WAE_F16 */, const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev,
+                       const int32_t* team_seg_dev, int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T,
+                       void* stream);
 
 /* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
  * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).
@@ -402,6 +410,10 @@ int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int32_t T, int3
 int wae_to_btc_masked(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
                       const int32_t* lengths, float scale, void* stream);
 int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, void* stream);
+/* wae_from_btc with every element multiplied by `scale` (fp16 runs: undoes the loss scale where the conditioning gradient
+ * leaves the 16-bit stack for the fp32 front end) */
+int wae_from_btc_scaled(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, float scale,
+                        void* stream);
 
 #ifdef __cplusplus
 }

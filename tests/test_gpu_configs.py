@@ -186,10 +186,11 @@ def test_vqwae_full_geometry_train_step_fp32():
         if e64 > 5e-4 * gmax + 2e-8 or e32 > 1e-3 * gmax + 2e-8 or abs(sq - z["grad64_sq"][i]) > 2e-3 * z["grad64_sq"][i] + 1e-12:
             bad[k] = (e64, e32, gmax, sq, float(z["grad64_sq"][i]))
         # the first Adam step moves every weight by lr * g / (|g| + eps): where |g| is not far above eps = 1e-8 (weight_g
-        # rows whose gradient cancels to ~0) the step inherits the gradient's relative error, at most lr itself
+        # rows whose gradient cancels to ~0) the step inherits the gradient's relative error -- at most 2 lr, when the sign of a
+        # ~1e-9 gradient differs
         pk, sk = params[o:o + n], shadow[o:o + n]
         gr = torch.from_numpy(z["grad_probe"][sl])
-        tol = 4e-4 * torch.clamp(4 * (gk[idx] - gr).abs() / (gr.abs() + 1e-8), max=1.0) + 2e-6
+        tol = 8e-4 * torch.clamp(4 * (gk[idx] - gr).abs() / (gr.abs() + 1e-8), max=1.0) + 2e-6
         assert bool(((pk[idx] - torch.from_numpy(z["new_probe"][sl])).abs() <= tol).all()), k
         assert bool(((sk[idx] - torch.from_numpy(z["ema_probe"][sl])).abs() <= 1e-4 * tol + 1e-6).all()), k
     assert not bad, bad

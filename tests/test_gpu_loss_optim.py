@@ -130,9 +130,9 @@ def test_resume_from_a_reference_optimizer_state():
         off, n = eng.lay.off(k), eng.lay.numel(k)
         # second step: lr * m_hat / (sqrt(v_hat) + eps); gradients agree to ~1e-4 of their range, so do the moments
         # (where a gradient cancels to ~0 -- some weight_g rows -- the step lr * m_hat / (sqrt(v_hat) + eps) inherits the
-        # moment's relative error, at most lr itself)
+        # moment's relative error, at most 2 lr)
         gm = float(m2.abs().max()) + 1e-12
-        tol = 4e-4 * torch.clamp(4 * (mine["state"][i]["exp_avg"] - m2).abs() / (m2.abs() + 1e-9), max=1.0) + 2e-6
+        tol = 8e-4 * torch.clamp(4 * (mine["state"][i]["exp_avg"] - m2).abs() / (m2.abs() + 1e-9), max=1.0) + 2e-6
         assert bool(((eng.params[off:off + n].view(p2.shape).cpu() - p2).abs() <= tol).all()), k
         assert float((mine["state"][i]["exp_avg"] - m2).abs().max()) < 1e-3 * gm + 1e-9, k
         assert float((mine["state"][i]["exp_avg_sq"] - v2).abs().max()) < 2e-3 * float(v2.abs().max()) + 1e-14, k

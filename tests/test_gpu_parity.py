@@ -229,6 +229,7 @@ def test_glu_workgroup_shapes_agree(dtype):
     """the fused layer kernel's two workgroup shapes (8 waves x 256 steps, the default; 4 waves x 128 steps) contract in the same
     order: identical logits on a model with ragged T"""
     from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import _lib as L
     from wavenet_autoencoders_amd.engine import WaeEngine
     cfg, sd, ins, z, ocfg = golden_model("B")
     c_up = torch.from_numpy(z["c_up"])
@@ -236,14 +237,11 @@ def test_glu_workgroup_shapes_agree(dtype):
     outs = []
     for nw in (8, 4):
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
-        eng.lib.wae_debug_set_glu_waves(nw)
-        try:
-            eng.load_state_dict(sd)
-            out = eng.decoder_forward(ins["x"][:, :T].cuda(), c_up[:, :, :T].cuda(), ins["g"].cuda(), c_is_upsampled=True)
-            torch.cuda.synchronize()
-            outs.append(out["logits"].cpu())
-        finally:
-            eng.lib.wae_debug_set_glu_waves(8)
+        eng.glu_flags = L.GLU_WAVES4 if nw == 4 else 0              # wae_glu_desc.flags of every layer launch
+        eng.load_state_dict(sd)
+        out = eng.decoder_forward(ins["x"][:, :T].cuda(), c_up[:, :, :T].cuda(), ins["g"].cuda(), c_is_upsampled=True)
+        torch.cuda.synchronize()
+        outs.append(out["logits"].cpu())
     assert torch.equal(outs[0], outs[1])
 
 

@@ -28,8 +28,8 @@ xo = torch.empty_like(x)
 ubuf = torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype)
 zb = torch.zeros(B, 2 * g.Hp, device="cuda")
 st = eng.stream()
-eng.lib.wae_debug_set_glu_waves.argtypes = [ctypes.c_int]
-eng.lib.wae_debug_set_glu_waves(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+pass  # shape: eng.glu_flags (wae_glu_desc.flags)
+eng.glu_flags = 8 if (int(sys.argv[2]) if len(sys.argv) > 2 else 4) == 4 else 0
 variants = {"full": 0, "no_dma": 0x100, "no_bload": 0x200, "no_epi": 0x400, "no_gate": 0x800,
             "no_dma_bload": 0x300, "coalesced_b": 0x1000, "coalesced_b_no_dma": 0x1100, "mfma_only": 0xF00}
 

@@ -28,9 +28,9 @@ ubuf = torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype)
 zsave = torch.zeros(B, T, 2 * g.Hp, device="cuda").to(eng.tdtype)
 zb = torch.zeros(B, 2 * g.Hp, device="cuda")
 st = eng.stream()
-eng.lib.wae_debug_set_glu_waves.argtypes = [ctypes.c_int]
+pass  # shape: eng.glu_flags (wae_glu_desc.flags)
 eng.lib.wae_debug_set_glu_slots.argtypes = [ctypes.c_int]
-eng.lib.wae_debug_set_glu_waves(nw)
+eng.glu_flags = 8 if nw == 4 else 0
 eng.lib.wae_debug_set_glu_slots(slots)
 for i in range(n):
     desc = L.GluDesc(eng.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, 4, 2 if save_z else 0)

@@ -9,8 +9,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwae_hip.so")
 
-WAE_F32, WAE_BF16 = 0, 1
-GLU_SAVE_Z, GLU_NO_OUT = 2, 4
+WAE_F32, WAE_BF16, WAE_F16 = 0, 1, 2
+GLU_SAVE_Z, GLU_NO_OUT, GLU_WAVES4 = 2, 4, 8
+TM_INTERLEAVE, TM_ONE_WG = 1, 2
 ERR_CLASS_ID, ERR_SPEAKER_ID, ERR_TARGET_ID = 1, 2, 4
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -88,7 +89,7 @@ SIGNATURES = {
     "wae_gemm_tn_tiles": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "wae_glu_bwd_fused_supported": (c_i32, [c_i32, c_i32]),
     "wae_glu_bwd_fused": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "wae_gemm_tn_stream": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "wae_gemm_tn_stream": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "wae_sum_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_dmol_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
     "wae_to_btc_masked": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp, c_f32, c_vp]),
     "wae_from_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
+    "wae_from_btc_scaled": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_f32, c_vp]),
 }
 
 _lib = None

@@ -31,8 +31,10 @@ def _prepare_bwd(eng):
         return
     g, dev, lay = eng.g, eng.device, eng.lay
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    if os.environ.get("WAE_TM_OCC"):     # A/B switch: bit 1 gate-backward, bit 2 residual launches with two workgroups per CU
-        eng.lib.wae_debug_set_tm_occ(int(os.environ["WAE_TM_OCC"]))
+    # A/B switch: WAE_TM_OCC bit 1 (2) gate-backward, bit 2 (4) residual launches with two workgroups per CU (default: both)
+    occ = int(os.environ.get("WAE_TM_OCC", "6"))
+    eng.tm_flags_u = 0 if occ & 2 else L.TM_ONE_WG
+    eng.tm_flags_x = 0 if occ & 4 else L.TM_ONE_WG
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
     # Fusing K_X(l) with K_U(l-1) (csrc/glu_bwd.hip) measured SLOWER than the two launches at C2 (118 us vs 60 + 50 us:
@@ -214,7 +216,7 @@ class StreamTable:
 
     def launch(self):
         eng = self.eng
-        L.check(eng.lib.wae_gemm_tn_stream(L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
+        L.check(eng.lib.wae_gemm_tn_stream(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
                                            self.team_size, self.nwg, self.B, self.T, eng.stream()), "gemm_tn_stream")
 
 
@@ -222,7 +224,7 @@ def use_stream_tn(eng):
     """bf16 runs take every layer's weight gradients in one wae_gemm_tn_stream launch after the backward sweep (needs the
     residual-stream gradient of every layer kept); fp32 (the parity mode) keeps one wae_gemm_tn_tiles launch per layer."""
     import os
-    return eng.dt == L.WAE_BF16 and os.environ.get("WAE_TN_STREAM", "1") != "0"
+    return eng.dt in (L.WAE_BF16, L.WAE_F16) and os.environ.get("WAE_TN_STREAM", "1") != "0"
 
 
 def bwd_workspace(eng, B, T):
@@ -253,6 +255,7 @@ def _build_tile_tables(eng, ws, fw, B, T):
     Z2 = 2 * g.Hp
     dzs = g.layers * Z2
     c1, co = eng.cview["c1"], eng.cview["co"]
+    ia = 1.0 / eng.grad_scale       # fp16: the 16-bit gradients are loss-scaled, the fp32 weight gradients are not
     ws["tt_layer"] = []
     ws["stream"] = None
     if use_stream_tn(eng):
@@ -265,12 +268,12 @@ def _build_tile_tables(eng, ws, fw, B, T):
             xl = fw["x"][l]
             for tap in range(g.k):
                 last = tap == g.k - 1 and not g.Ccp
-                stt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), 1.0, dz_ptr, dzs, xl.data_ptr(), g.Rp,
+                stt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, dz_ptr, dzs, xl.data_ptr(), g.Rp,
                         c1l + tap * g.Rp * 4, sm["ld1"])
             if g.Ccp:
-                stt.add(Z2, g.Ccp, 0, g.Ccp, 1.0, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
+                stt.add(Z2, g.Ccp, 0, g.Ccp, ia, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
             has_out = l < g.layers - 1
-            stt.add(g.Rp, g.Hp, 0, g.Hp, 1.0, ws["gx"][l + 1].data_ptr() if has_out else 0, g.Rp,
+            stt.add(g.Rp, g.Hp, 0, g.Hp, ia, ws["gx"][l + 1].data_ptr() if has_out else 0, g.Rp,
                     fw["u"].data_ptr() + l * g.Hp * es, g.Ku, co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
         ws["stream"] = stt.finalize()
     for l in range(g.layers if ws["stream"] is None else 0):
@@ -281,27 +284,27 @@ def _build_tile_tables(eng, ws, fw, B, T):
         xl = fw["x"][l]
         for tap in range(g.k):
             last = tap == g.k - 1 and not g.Ccp
-            tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), 1.0, dz_ptr, dzs, xl.data_ptr(), g.Rp,
+            tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, dz_ptr, dzs, xl.data_ptr(), g.Rp,
                    c1l + tap * g.Rp * 4, sm["ld1"])
         if g.Ccp:
-            tt.add(Z2, g.Ccp, 0, g.Ccp, 1.0, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
+            tt.add(Z2, g.Ccp, 0, g.Ccp, ia, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
         if l < g.layers - 1:
             g_next = ws["gx"][(l + 1) % len(ws["gx"])]
-            tt.add(g.Rp, g.Hp, 0, g.Hp, 1.0, g_next.data_ptr(), g.Rp, fw["u"].data_ptr() + l * g.Hp * es, g.Ku,
+            tt.add(g.Rp, g.Hp, 0, g.Hp, ia, g_next.data_ptr(), g.Rp, fw["u"].data_ptr() + l * g.Hp * es, g.Ku,
                    co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
         ws["tt_layer"].append(tt.finalize(B))
     tt = TileTable(eng)
     c3, c1h, cs, ctab = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"], eng.cview["ctab"]
-    tt.add(g.Op, g.Sp, 0, g.Sp, 1.0, ws["dy"].data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
-    tt.add(g.Sp, g.Sp, 0, g.Sp, 1.0, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
-    tt.add(g.Sp, g.Ku, 0, g.Ku, 1.0, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
+    tt.add(g.Op, g.Sp, 0, g.Sp, ia, ws["dy"].data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
+    tt.add(g.Sp, g.Sp, 0, g.Sp, ia, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
+    tt.add(g.Sp, g.Ku, 0, g.Ku, ia, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
     ws["tt_head"] = tt.finalize(B)
     tt = TileTable(eng)
     g0 = ws["gx"][0]                                    # dxhat_0 lands in gx[0 % 2]
     if g.scalar_input:     # rows 0 / 1 of the tile = d weight / d bias:  sum_t [x[t] | 1] (x) dx0[t]
-        tt.add(64, g.Rp, 0, -1, 1.0 / RS, ws["xs1"].data_ptr(), 64, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp)
+        tt.add(64, g.Rp, 0, -1, ia / RS, ws["xs1"].data_ptr(), 64, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp)
     else:
-        tt.add(g.O, g.Rp, 0, -1, 1.0 / RS, 0, 0, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp, onehot_ptr=ws["ids"].data_ptr())
+        tt.add(g.O, g.Rp, 0, -1, ia / RS, 0, 0, g0.data_ptr(), g.Rp, ctab.data_ptr(), g.Rp, onehot_ptr=ws["ids"].data_ptr())
     ws["tt_first"] = tt.finalize(B)
 
 
@@ -347,7 +350,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         count = B * (T - 1)
     else:
         count = int(torch.clamp(lengths.detach().to("cpu", torch.int64).clamp(max=T) - 1, min=0).sum())
-    inv_count = loss_scale / max(count, 1)
+    inv_count = loss_scale * eng.grad_scale / max(count, 1)
     xi = x_ids.to(torch.int32).contiguous() if not g.scalar_input else None
     tg = targets.to(torch.int32).contiguous() if targets is not None else None
     ln = lengths.to(torch.int32).to(eng.device).contiguous() if lengths is not None else None
@@ -383,17 +386,18 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     c1, co = eng.cview["c1"], eng.cview["co"]
     g_next = ws["gzero"]                      # dxhat_{L} = 0: the last layer's x' is dead (wavenet.py:205-207)
     ngx = len(ws["gx"])
-    ck = 64 if eng.dt == L.WAE_BF16 else 32
+    ck = 64 if eng.dt in (L.WAE_BF16, L.WAE_F16) else 32
     us_off = (g.Rp // ck) * g.NP * 4 * 1024   # bytes: the W_skip chunks follow the W_out chunks in the mode-2 stream
 
     def k_u(l, gn):                            # du -> dz of layer l
         _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
-            eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2)
+            eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2,
+            flags=eng.tm_flags_u)
 
     def k_x(l, gn, gc):                        # dx-hat of layer l
         srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
         _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp,
-            flags=P.TM_INTERLEAVE)
+            flags=P.TM_INTERLEAVE | eng.tm_flags_x)
 
     def tn_layer(l):                           # per-layer weight gradients (fp32 path; bf16 takes them all at the end)
         if ws["stream"] is not None:
@@ -532,7 +536,7 @@ def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0, stop_at_qu
     B, T = dc.shape[0], dc.shape[1]
     dev = eng.device
     d = torch.empty(B, g.Cc, T, dtype=torch.float32, device=dev)
-    L.check(lib.wae_from_btc(L.ptr(dc), L.ptr(d), B, g.Cc, T, g.Ccp, eng.dt, st), "from_btc")
+    L.check(lib.wae_from_btc_scaled(L.ptr(dc), L.ptr(d), B, g.Cc, T, g.Ccp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc")
     acts = eng._up_acts                      # [conv_in input, stage-0 input, stage-1 input, ...]
     keep = [d]
     for i in range(len(g.upsample_scales) - 1, -1, -1):

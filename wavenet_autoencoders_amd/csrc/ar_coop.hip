@@ -71,6 +71,13 @@ __device__ __forceinline__ void arc_load_w<__bf16>(const char* p, float (&w)[8])
   }
 }
 
+template <>
+__device__ __forceinline__ void arc_load_w<f16>(const char* p, float (&w)[8]) {
+  const f16x8 v = *(const f16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = (float)v[i];
+}
+
 // rows [r0, r0+nr) of a blocked matrix ([k/EPL][rows_pad][EPL]) times v (LDS): thread -> (row i = tid % nr, slice tid / nr);
 // partial sums to psum[slice * nr + i]
 template <typename E>
@@ -105,6 +112,13 @@ __device__ __forceinline__ void arc_unpack<__bf16>(const f32x4& raw, float (&w)[
     w[2 * i] = __uint_as_float(r[i] << 16);
     w[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
   }
+}
+
+template <>
+__device__ __forceinline__ void arc_unpack<f16>(const f32x4& raw, float (&w)[8]) {
+  const f16x8 v = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = (float)v[i];
 }
 
 // sum_{kb = kb0, kb0 + kstep, .. < nkb} W[kb][row] . v[kb]: U packets are requested before the first is used (a loop that
@@ -357,7 +371,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
     if (tid < p.R) xbuf[tid] = p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
     for (int cc = tid; cc < p.Cc; cc += ARC_THREADS) {
       const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
-      vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : ((const float*)p.c_up)[ci];
+      vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : (p.c_dtype == WAE_F16 ? (float)((const f16*)p.c_up)[ci] : ((const float*)p.c_up)[ci]);
     }
     float skip_part = 0.f;   // this member's contribution to skip row tid, summed over the layers (the skip path is linear)
     arc_barrier();
@@ -643,7 +657,7 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
                                     uint64_t* msg, float* acc, int32_t* error, void* stream) {
   WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias &&
                   out_idx && msg && acc && error, "ar_generate_coop: null pointer argument");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate_coop: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "ar_generate_coop: bad dtype");
   WAE_REQUIRE(d->B > 0 && d->B <= 8, "ar_generate_coop: 1..8 utterances per launch (one XCD each); use wae_ar_generate for more");
   WAE_REQUIRE(C >= 1 && C <= 32, "ar_generate_coop: 1..32 cooperating workgroups per utterance");
   WAE_REQUIRE(d->T > 0 && d->L > 0 && d->R > 0 && d->R <= ARC_THREADS && d->G > 0 && d->G % 2 == 0 && d->S > 0 &&
@@ -668,7 +682,7 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
   a.n_forced = inputs ? (d->n_forced > 0 && d->n_forced < d->T ? d->n_forced : d->T) : 0;
   a.out_logits = out_logits; a.msg = (unsigned long long*)msg; a.NV = hc > sc ? hc : sc; a.acc = acc; a.error = error;
-  const int epl = d->dtype == WAE_BF16 ? 8 : 4;
+  const int epl = wae_is16(d->dtype) ? 8 : 4;
   auto ru = [](int x, int mm) { return (x + mm - 1) / mm * mm; };
   const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
                                               2 * ru(d->S, epl) + ru(d->O, 4) + ARC_THREADS + ru(hc > sc ? hc : sc, 4) + 8);
@@ -677,6 +691,9 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   if (d->dtype == WAE_BF16) {
     (void)hipFuncSetAttribute((const void*)ar_coop_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ar_coop_kernel<__bf16>, dim3(8 * C), dim3(ARC_THREADS), lds, st, a);
+  } else if (d->dtype == WAE_F16) {
+    (void)hipFuncSetAttribute((const void*)ar_coop_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_coop_kernel<f16>, dim3(8 * C), dim3(ARC_THREADS), lds, st, a);
   } else {
     (void)hipFuncSetAttribute((const void*)ar_coop_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ar_coop_kernel<float>, dim3(8 * C), dim3(ARC_THREADS), lds, st, a);

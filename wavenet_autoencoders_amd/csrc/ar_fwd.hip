@@ -122,6 +122,13 @@ __device__ __forceinline__ void layout_rows(int rows, int& rows_pad, int& RW, in
   if (NS < 1) NS = 1;
 }
 
+template <>
+__device__ __forceinline__ void load_w<f16>(const char* p, float (&w)[8]) {
+  const f16x8 v = *(const f16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = (float)v[i];
+}
+
 template <typename E>
 __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(AR_THREADS) ar_kernel(ArArgs p) {
     }
     for (int cc = AR_THREADS - 1 - tid; cc < p.Cc; cc += AR_THREADS) {   // local conditioning of this step -> tail of the operand vector
       const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
-      vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : ((const float*)p.c_up)[ci];
+      vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : (p.c_dtype == WAE_F16 ? (float)((const f16*)p.c_up)[ci] : ((const float*)p.c_up)[ci]);
     }
     for (int i = tid; i < p.S; i += AR_THREADS) skipb[i] = 0.f;
     __syncthreads();
@@ -323,7 +330,7 @@ static int ar_launch(const wae_ar_desc* d, const int32_t* dilations, const int64
   a.n_forced = (inputs || inputs_f) ? (d->n_forced > 0 && d->n_forced < d->T ? d->n_forced : d->T) : 0; a.uniforms = uniforms; a.out_idx = out_idx;
   a.out_logits = out_logits; a.scalar = d->scalar_input ? 1 : 0; a.inputs_f = inputs_f; a.u_mix = u_mix; a.u_log = u_log;
   a.out_f = out_f; a.log_scale_min = log_scale_min; a.clamp_log_scale = clamp_log_scale;
-  const int epl = d->dtype == WAE_BF16 ? 8 : 4;
+  const int epl = wae_is16(d->dtype) ? 8 : 4;
   const int H = d->G / 2;
   auto ru = [](int x, int m) { return (x + m - 1) / m * m; };
   int psz = AR_THREADS;
@@ -335,6 +342,9 @@ static int ar_launch(const wae_ar_desc* d, const int32_t* dilations, const int64
   if (d->dtype == WAE_BF16) {
     (void)hipFuncSetAttribute((const void*)ar_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ar_kernel<__bf16>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
+  } else if (d->dtype == WAE_F16) {
+    (void)hipFuncSetAttribute((const void*)ar_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ar_kernel<f16>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
   } else {
     (void)hipFuncSetAttribute((const void*)ar_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ar_kernel<float>, dim3(d->B), dim3(AR_THREADS), lds, st, a);
@@ -350,7 +360,7 @@ extern "C" int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, c
                                void* stream) {
   WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias &&
                   out_idx, "ar_generate: null pointer argument");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "ar_generate: bad dtype");
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0 && d->O > 0,
               "ar_generate: bad sizes");
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate: Cc > 0 but c_up is null");
@@ -375,7 +385,7 @@ extern "C" int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilat
                                       int32_t clamp_log_scale, float* out_samples, float* out_params, void* stream) {
   WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias,
               "ar_generate_scalar: null pointer argument");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "ar_generate_scalar: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "ar_generate_scalar: bad dtype");
   WAE_REQUIRE(d->scalar_input && d->O > 0 && d->O % 3 == 0, "ar_generate_scalar: needs a scalar-input decoder with 3M output channels");
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->L > 0 && d->R > 0 && d->G > 0 && d->G % 2 == 0 && d->S > 0, "ar_generate_scalar: bad sizes");
   WAE_REQUIRE(d->Cc <= 0 || c_up, "ar_generate_scalar: Cc > 0 but c_up is null");

@@ -58,6 +58,7 @@ struct TmArgs {
   float alpha;
   int B, T, mode;
   int interleave;  // chunk q -> source q % nsrc, column block q / nsrc (all sources equally wide)
+  int flags;       // wae_tm_desc.flags
   TmCe ce;
 };
 
@@ -391,23 +392,16 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
   }
 }
 
-static int g_tm_occ = 2 | 4;   // bit 1: gate-backward launches, bit 2: residual launches run two workgroups per CU
-extern "C" void wae_debug_set_tm_occ(int occ) { g_tm_occ = occ; }
+// gate-backward / residual / ReLU-backward launches run two workgroups per CU unless the caller sets WAE_TM_ONE_WG in
+// wae_tm_desc.flags (A/B measurements; the one-workgroup shape is also what fp32 and odd tile counts use)
 
 template <typename E, int NT, int MODE, int OCC>
 static int launch_tm_occ(const TmArgs& a, int nslices, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
   constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD) && NT % 2 == 0 && sizeof(E) == 2;
   const size_t lds = PAIRED ? 2 * CHB : 2 * CHB + 4 * STG_BYTES;
-  static size_t attr_done = 0;
-  if (attr_done < lds) {
-    if (hipFuncSetAttribute((const void*)gemm_tm_kernel<E, NT, MODE, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
-      wae_set_error("gemm_tm: cannot raise dynamic LDS to %zu", lds);
-      return WAE_EHIP;
-    }
-    attr_done = lds;
-  }
+  static WaeLdsCache lds_cache;
+  if (int rc = wae_ensure_lds((const void*)gemm_tm_kernel<E, NT, MODE, OCC>, lds_cache, lds, "gemm_tm"); rc != WAE_OK) return rc;
   const int tiles = (a.T + 127) / 128;
   hipLaunchKernelGGL((gemm_tm_kernel<E, NT, MODE, OCC>), dim3(a.B * tiles, nslices), dim3(256), lds, st, a);
   return wae_check_launch("gemm_tm");
@@ -415,7 +409,7 @@ static int launch_tm_occ(const TmArgs& a, int nslices, hipStream_t st) {
 template <typename E, int NT, int MODE>
 static int launch_tm(const TmArgs& a, int nslices, hipStream_t st) {
   if constexpr (sizeof(E) == 2 && NT % 2 == 0 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD)) {
-    if (g_tm_occ & (MODE == TM_GATE_BWD ? 2 : 4)) return launch_tm_occ<E, NT, MODE, 2>(a, nslices, st);
+    if (!(a.flags & WAE_TM_ONE_WG)) return launch_tm_occ<E, NT, MODE, 2>(a, nslices, st);
   }
   return launch_tm_occ<E, NT, MODE, 1>(a, nslices, st);
 }
@@ -478,14 +472,14 @@ static int tm_run(const wae_tm_desc* d, const void* const* src, const int64_t* s
                   const int32_t* src_shift, const void* w_packed, void* out, int64_t out_stride, const void* aux,
                   int64_t aux_stride, const wae_tm_ce* ce, void* stream) {
   WAE_REQUIRE(d && src && src_stride && src_cols && src_shift && w_packed, "gemm_tm: null pointer argument");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "gemm_tm: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "gemm_tm: bad dtype");
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->M > 0 && d->M % 32 == 0, "gemm_tm: bad sizes");
   WAE_REQUIRE(d->nsrc >= 1 && d->nsrc <= TM_MAX_SRC, "gemm_tm: 1..%d sources", TM_MAX_SRC);
   WAE_REQUIRE(d->mode >= 0 && d->mode <= TM_CE_BWD, "gemm_tm: bad mode");
   WAE_REQUIRE(d->mode == TM_PLAIN || aux, "gemm_tm: this mode needs aux");
   WAE_REQUIRE(d->mode == TM_CE || out, "gemm_tm: null output");
   WAE_REQUIRE((d->mode != TM_CE && d->mode != TM_CE_BWD) || ce, "gemm_tm: modes 5/6 go through wae_gemm_tm_ce");
-  const int ck = d->dtype == WAE_BF16 ? 64 : 32;
+  const int ck = wae_is16(d->dtype) ? 64 : 32;
   TmArgs a;
   for (int s = 0; s < TM_MAX_SRC; ++s) {
     const bool on = s < d->nsrc;
@@ -498,6 +492,7 @@ static int tm_run(const wae_tm_desc* d, const void* const* src, const int64_t* s
   a.nsrc = d->nsrc; a.w = (const char*)w_packed; a.out = (char*)out; a.out_stride = out_stride; a.aux = (const char*)aux;
   a.aux_stride = aux_stride; a.alpha = d->alpha; a.B = d->B; a.T = d->T; a.mode = d->mode;
   a.interleave = (d->flags & WAE_TM_INTERLEAVE) ? 1 : 0;
+  a.flags = d->flags;
   if (a.interleave)
     for (int s = 1; s < d->nsrc; ++s) WAE_REQUIRE(src_cols[s] == src_cols[0], "gemm_tm: interleaved sources must be equally wide");
   a.ce = TmCe{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
@@ -510,6 +505,7 @@ static int tm_run(const wae_tm_desc* d, const void* const* src, const int64_t* s
   hipStream_t st = as_stream(stream);
   const int nt = d->M / 32;
   if (d->dtype == WAE_BF16) return dispatch_mode<__bf16>(d->mode, nt, a, st);
+  if (d->dtype == WAE_F16) return dispatch_mode<f16>(d->mode, nt, a, st);
   return dispatch_mode<float>(d->mode, nt, a, st);
 }
 

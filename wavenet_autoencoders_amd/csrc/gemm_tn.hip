@@ -35,8 +35,12 @@ struct TnArgs {
   int tchunk;  // time steps per workgroup
   int dbg;     // timing-only ablation bits (tools/ablate_tn.py): 1 no global loads, 2 no LDS reads/MFMA, 4 no atomics
 };
+#ifdef WAE_DEBUG_KNOBS   // tools/ablate_tn.py only (make EXTRA=-DWAE_DEBUG_KNOBS)
 static int g_tn_dbg = 0;
 extern "C" void wae_debug_set_tn(int bits) { g_tn_dbg = bits; }
+#else
+static constexpr int g_tn_dbg = 0;
+#endif
 
 #define TN_KT 32      // time rows per LDS slab
 #define TN_PITCH_BF16 320   // bytes per slab row (128 bf16 + pad): conflict-free transposed reads
@@ -46,8 +50,9 @@ extern "C" void wae_debug_set_tn(int bits) { g_tn_dbg = bits; }
 // bf16: 8 consecutive k (time rows k0 + 8h + 0..7) of column cbase + (lane & 31): two ds_read_b64_tr_b16 each; all eight
 // reads are issued back to back and retired by ONE wait that carries every destination (cdna_hip_programming.md 5.7 ii).
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-__device__ __forceinline__ void tn_load_frags(const char* sp, const char* sq, int k0, int wm, int wn, int lane, bf16x8 (&a)[2],
-                                              bf16x8 (&b)[2]) {
+template <typename V8>   // bf16x8 or f16x8: the transposed read moves 16-bit elements whatever their format
+__device__ __forceinline__ void tn_load_frags16(const char* sp, const char* sq, int k0, int wm, int wn, int lane, V8 (&a)[2],
+                                                V8 (&b)[2]) {
   const int grp = (lane >> 4) & 1, h = lane >> 5, q = (lane & 15) >> 2, pp = lane & 3;
   const unsigned rowoff = (k0 + 8 * h + q) * TN_PITCH_BF16 + (16 * grp + 4 * pp) * 2;
   const unsigned ap = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)sp + rowoff + wm * 2;
@@ -68,9 +73,17 @@ __device__ __forceinline__ void tn_load_frags(const char* sp, const char* sq, in
   for (int i = 0; i < 2; ++i) {
     u32x4 va = {r[2 * i].x, r[2 * i].y, r[2 * i + 1].x, r[2 * i + 1].y};
     u32x4 vb = {r[4 + 2 * i].x, r[4 + 2 * i].y, r[4 + 2 * i + 1].x, r[4 + 2 * i + 1].y};
-    a[i] = __builtin_bit_cast(bf16x8, va);
-    b[i] = __builtin_bit_cast(bf16x8, vb);
+    a[i] = __builtin_bit_cast(V8, va);
+    b[i] = __builtin_bit_cast(V8, vb);
   }
+}
+__device__ __forceinline__ void tn_load_frags(const char* sp, const char* sq, int k0, int wm, int wn, int lane, bf16x8 (&a)[2],
+                                              bf16x8 (&b)[2]) {
+  tn_load_frags16(sp, sq, k0, wm, wn, lane, a, b);
+}
+__device__ __forceinline__ void tn_load_frags(const char* sp, const char* sq, int k0, int wm, int wn, int lane, f16x8 (&a)[2],
+                                              f16x8 (&b)[2]) {
+  tn_load_frags16(sp, sq, k0, wm, wn, lane, a, b);
 }
 // fp32: fragment = 4 k-pairs; element j pairs time rows (k0 + 2j + h) -> one ds_read_b32 each (compiler scheduled)
 __device__ __forceinline__ f32x4 tn_frag_f32(const char* slab, int k0, int cbase, int lane) {
@@ -151,8 +164,8 @@ __global__ void __launch_bounds__(256, sizeof(E) == 2 ? 2 : 1) gemm_tn_kernel(Tn
           const int id = tl.onehot[(int64_t)b * p.T + t] - tl.m0;
           if (id >= colp && id < colp + EP) {
             if constexpr (ES == 2) {
-              bf16x8 oh = {};
-              oh[id - colp] = (__bf16)1.0f;
+              typename ET<E>::frag oh = {};
+              oh[id - colp] = (E)1.0f;
               xp[i] = __builtin_bit_cast(f32x4, oh);
             } else {
               float* o4 = (float*)&xp[i];
@@ -166,8 +179,8 @@ __global__ void __launch_bounds__(256, sizeof(E) == 2 ? 2 : 1) gemm_tn_kernel(Tn
         if (colq < tl.n_valid && tq >= 0 && tq < p.T) xq[i] = *(const f32x4*)(tl.Q + (((int64_t)b * p.T + tq) * tl.q_stride + colq) * ES);
         if (tl.ones_col >= colq && tl.ones_col < colq + EP) {   // virtual all-ones column
           if constexpr (ES == 2) {
-            bf16x8 v = __builtin_bit_cast(bf16x8, xq[i]);
-            v[tl.ones_col - colq] = (__bf16)1.0f;
+            typename ET<E>::frag v = __builtin_bit_cast(typename ET<E>::frag, xq[i]);
+            v[tl.ones_col - colq] = (E)1.0f;
             xq[i] = __builtin_bit_cast(f32x4, v);
           } else {
             float* v = (float*)&xq[i];
@@ -236,7 +249,7 @@ __global__ void __launch_bounds__(256, sizeof(E) == 2 ? 2 : 1) gemm_tn_kernel(Tn
 extern "C" int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, int32_t ntiles, int32_t B, int32_t T,
                                  int32_t splits, void* stream) {
   WAE_REQUIRE(tiles_dev && ntiles > 0 && B > 0 && T > 0 && splits >= 1, "gemm_tn_tiles: bad arguments");
-  WAE_REQUIRE(dtype == WAE_F32 || dtype == WAE_BF16, "gemm_tn_tiles: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(dtype), "gemm_tn_tiles: bad dtype");
   static_assert(sizeof(wae_tn_tile) == sizeof(TnTile), "wae_tn_tile and TnTile must have the same layout");
   TnArgs a;
   a.tiles = (const TnTile*)tiles_dev;
@@ -245,12 +258,14 @@ extern "C" int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, in
   tchunk = (tchunk + TN_KT - 1) / TN_KT * TN_KT;
   a.tchunk = tchunk;
   const int nsp = (T + tchunk - 1) / tchunk;
-  const int pitch = dtype == WAE_BF16 ? TN_PITCH_BF16 : TN_PITCH_F32;
+  const int pitch = wae_is16(dtype) ? TN_PITCH_BF16 : TN_PITCH_F32;
   const size_t lds = (size_t)4 * TN_KT * pitch;
   hipStream_t st = as_stream(stream);
   dim3 grid(ntiles, B * nsp);
   if (dtype == WAE_BF16) {
     hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, dim3(256), lds, st, a);
+  } else if (dtype == WAE_F16) {
+    hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, dim3(256), lds, st, a);
   } else {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), lds, st, a);

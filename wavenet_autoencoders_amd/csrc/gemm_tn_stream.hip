@@ -66,6 +66,7 @@ __device__ __forceinline__ void ts_wait_vmcnt(int w) {
 #undef TS_VMC
 }
 
+template <typename E>   // __bf16 or f16: 16-bit operands (the DMA and the transposed LDS reads move bits), fp32 result
 __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
       for (int i = threadIdx.x; i < TS_NS * TS_KT * p.B; i += TS_NW * 64) {
         const int bb = i % p.B, rr = i / p.B;
         const int slot = rr / TS_KT, r = rr - slot * TS_KT;
-        *(__bf16*)(smem + slot * TS_SLOT + TS_SP + r * TS_QP + (jb.ones_col + bb) * 2) = (__bf16)0.0f;
+        *(E*)(smem + slot * TS_SLOT + TS_SP + r * TS_QP + (jb.ones_col + bb) * 2) = (E)0.0f;
       }
     }
 
@@ -240,9 +241,9 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
       if (jb.ones_col >= 0 && cc.b != cur_b) {   // clip change (workgroup-uniform): move the ones to the new clip's column
         if (threadIdx.x < TS_NS * TS_KT) {
           const int slot2 = threadIdx.x / TS_KT, r = threadIdx.x - slot2 * TS_KT;
-          __bf16* qrow = (__bf16*)(smem + slot2 * TS_SLOT + TS_SP + r * TS_QP) + jb.ones_col;
-          if (cur_b >= 0) qrow[cur_b] = (__bf16)0.0f;
-          qrow[cc.b] = (__bf16)1.0f;
+          E* qrow = (E*)(smem + slot2 * TS_SLOT + TS_SP + r * TS_QP) + jb.ones_col;
+          if (cur_b >= 0) qrow[cur_b] = (E)0.0f;
+          qrow[cc.b] = (E)1.0f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
         // (24 VGPRs this 168-register kernel does not have).  v[144:151] = A fragments of M-tiles 0,1;
         // v[152:167] = B fragments of N-tiles 0..3.  Tiles beyond the job's valid region are computed too (their
         // results are never written out).
-#define TS_KSTEP(KO)                                                                                                       \
+#define TS_KSTEP(KO, MF)                                                                                                     \
         asm volatile(                                                                                                      \
             "ds_read_b64_tr_b16 v[144:145], %8 offset:%10\n\t"                                                             \
             "ds_read_b64_tr_b16 v[146:147], %8 offset:%11\n\t"                                                             \
@@ -270,18 +271,18 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
             "ds_read_b64_tr_b16 v[164:165], %9 offset:%20\n\t"                                                             \
             "ds_read_b64_tr_b16 v[166:167], %9 offset:%21\n\t"                                                             \
             "s_waitcnt lgkmcnt(8)\n\t"                                                                                     \
-            "v_mfma_f32_32x32x16_bf16 %0, v[144:147], v[152:155], %0\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %0, v[144:147], v[152:155], %0\n\t"                                                  \
             "s_waitcnt lgkmcnt(6)\n\t"                                                                                     \
-            "v_mfma_f32_32x32x16_bf16 %1, v[144:147], v[156:159], %1\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %1, v[144:147], v[156:159], %1\n\t"                                                  \
             "s_waitcnt lgkmcnt(4)\n\t"                                                                                     \
-            "v_mfma_f32_32x32x16_bf16 %4, v[148:151], v[152:155], %4\n\t"                                                  \
-            "v_mfma_f32_32x32x16_bf16 %5, v[148:151], v[156:159], %5\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %4, v[148:151], v[152:155], %4\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %5, v[148:151], v[156:159], %5\n\t"                                                  \
             "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
-            "v_mfma_f32_32x32x16_bf16 %2, v[144:147], v[160:163], %2\n\t"                                                  \
-            "v_mfma_f32_32x32x16_bf16 %6, v[148:151], v[160:163], %6\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %2, v[144:147], v[160:163], %2\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %6, v[148:151], v[160:163], %6\n\t"                                                  \
             "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-            "v_mfma_f32_32x32x16_bf16 %3, v[144:147], v[164:167], %3\n\t"                                                  \
-            "v_mfma_f32_32x32x16_bf16 %7, v[148:151], v[164:167], %7\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %3, v[144:147], v[164:167], %3\n\t"                                                  \
+            "v_mfma_f32_32x32x16_" MF " %7, v[148:151], v[164:167], %7\n\t"                                                  \
             : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),        \
               "+v"(acc[1][2]), "+v"(acc[1][3])                                                                             \
             : "v"(ap), "v"(bp), "n"((KO) * TS_PP), "n"((KO) * TS_PP + 4 * TS_PP), "n"((KO) * TS_PP + 64),                   \
@@ -290,8 +291,13 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
               "n"((KO) * TS_QP + 192), "n"((KO) * TS_QP + 4 * TS_QP + 192)                                                  \
             : "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", \
               "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167")
-        TS_KSTEP(0);
-        TS_KSTEP(16);
+        if constexpr (sizeof(E) == 2 && ET<E>::DT == WAE_F16) {
+          TS_KSTEP(0, "f16");
+          TS_KSTEP(16, "f16");
+        } else {
+          TS_KSTEP(0, "bf16");
+          TS_KSTEP(16, "bf16");
+        }
 #undef TS_KSTEP
       }
       slot_c = slot_c + 1 == TS_NS ? 0 : slot_c + 1;
@@ -324,8 +330,9 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
   }
 }
 
-extern "C" int wae_gemm_tn_stream(const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
+extern "C" int wae_gemm_tn_stream(int32_t dtype, const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
                                   int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, void* stream) {
+  WAE_REQUIRE(dtype == WAE_BF16 || dtype == WAE_F16, "gemm_tn_stream: 16-bit operands only (fp32 runs take wae_gemm_tn_tiles)");
   WAE_REQUIRE(jobs_dev && segs_dev && team_seg_dev && nteams > 0 && team_size > 0 && nwg >= nteams * team_size && B > 0 && T > 0,
               "gemm_tn_stream: bad arguments");
   WAE_REQUIRE(B <= 64, "gemm_tn_stream: at most 64 clips per launch (one all-ones column per clip)");
@@ -339,14 +346,14 @@ extern "C" int wae_gemm_tn_stream(const wae_ts_job* jobs_dev, const wae_ts_seg* 
   a.nteams = nteams; a.team_size = team_size;
   a.B = B; a.T = T; a.spc = (T + TS_KT - 1) / TS_KT;
   const size_t lds = (size_t)TS_NS * TS_SLOT;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)gemm_tn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      wae_set_error("gemm_tn_stream: cannot raise dynamic LDS to %zu", lds);
-      return WAE_EHIP;
-    }
-    attr_done = true;
+  if (dtype == WAE_F16) {
+    static WaeLdsCache lds_cache;
+    if (int rc = wae_ensure_lds((const void*)gemm_tn_stream_kernel<f16>, lds_cache, lds, "gemm_tn_stream"); rc != WAE_OK) return rc;
+    hipLaunchKernelGGL(gemm_tn_stream_kernel<f16>, dim3(nwg), dim3(TS_NW * 64), lds, as_stream(stream), a);
+  } else {
+    static WaeLdsCache lds_cache;
+    if (int rc = wae_ensure_lds((const void*)gemm_tn_stream_kernel<__bf16>, lds_cache, lds, "gemm_tn_stream"); rc != WAE_OK) return rc;
+    hipLaunchKernelGGL(gemm_tn_stream_kernel<__bf16>, dim3(nwg), dim3(TS_NW * 64), lds, as_stream(stream), a);
   }
-  hipLaunchKernelGGL(gemm_tn_stream_kernel, dim3(nwg), dim3(TS_NW * 64), lds, as_stream(stream), a);
   return wae_check_launch("gemm_tn_stream");
 }

@@ -197,15 +197,8 @@ template <typename E, int NTX, int NTU>
 static int launch_gb(const GbArgs& a, hipStream_t st) {
   constexpr int CHX = NTX * 4 * 1024;
   const size_t lds = 2 * CHX + 4 * STG_BYTES;
-  static size_t attr_done = 0;
-  if (attr_done < lds) {
-    if (hipFuncSetAttribute((const void*)glu_bwd_fused_kernel<E, NTX, NTU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
-      wae_set_error("glu_bwd_fused: cannot raise dynamic LDS to %zu", lds);
-      return WAE_EHIP;
-    }
-    attr_done = lds;
-  }
+  static WaeLdsCache lds_cache;
+  if (int rc = wae_ensure_lds((const void*)glu_bwd_fused_kernel<E, NTX, NTU>, lds_cache, lds, "glu_bwd_fused"); rc != WAE_OK) return rc;
   const int tiles = (a.T + 127) / 128;
   hipLaunchKernelGGL((glu_bwd_fused_kernel<E, NTX, NTU>), dim3(a.B * tiles), dim3(256), lds, st, a);
   return wae_check_launch("glu_bwd_fused");
@@ -233,8 +226,8 @@ extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int6
                                  const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
                                  const void* w_us, void* stream) {
   WAE_REQUIRE(d && dz && g_next && g_out && dskip && z_prev && dz_prev && w_x && w_uo && w_us, "glu_bwd_fused: null pointer argument");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "glu_bwd_fused: bad dtype");
-  const int ck = d->dtype == WAE_BF16 ? 64 : 32;
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "glu_bwd_fused: bad dtype");
+  const int ck = wae_is16(d->dtype) ? 64 : 32;
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->Rp % 128 == 0 && d->Hp % 32 == 0 && d->Sp % ck == 0 && d->Sp > 0 && d->ktaps >= 1 &&
                   d->dilation >= 1 && (2 * d->Hp) % ck == 0,
               "glu_bwd_fused: bad sizes");
@@ -245,5 +238,6 @@ extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int6
   a.ktaps = d->ktaps; a.dilation = d->dilation;
   hipStream_t st = as_stream(stream);
   if (d->dtype == WAE_BF16) return dispatch_gb<__bf16>(d->Rp / 32, d->Hp / 32, a, st);
+  if (d->dtype == WAE_F16) return dispatch_gb<f16>(d->Rp / 32, d->Hp / 32, a, st);
   return dispatch_gb<float>(d->Rp / 32, d->Hp / 32, a, st);
 }

@@ -55,8 +55,17 @@ struct GluArgs {
   unsigned long long* stamps;  // diagnostic only (wae_debug_set_stamps): 16 x u64 per workgroup, else null
 };
 
+// Diagnostics (tools/stamps_glu.py, tools/time_glu.py) exist only in a `make EXTRA=-DWAE_DEBUG_KNOBS` build: the product
+// library has no process-global switches (include/wae.h: every entry is re-entrant; shapes are chosen by descriptor flags).
+#ifdef WAE_DEBUG_KNOBS
 static unsigned long long* g_stamps = nullptr;
 extern "C" void wae_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = dev_buf; }
+static int g_glu_slots = 0;  // 0 = as many ring slots as fit (<= 4)
+extern "C" void wae_debug_set_glu_slots(int n) { g_glu_slots = n; }
+#else
+static constexpr unsigned long long* g_stamps = nullptr;
+static constexpr int g_glu_slots = 0;
+#endif
 #ifdef WAE_GLU_STAMPS
 #define STAMP(i)                                                              \
   do {                                                                        \
@@ -448,11 +457,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
 // waves per workgroup: 8 (one 256-step workgroup per CU) or 4 (two workgroups per CU).  With the XCD-contiguous tile order and
 // the tap-interleaved chunk stream the 8-wave shape measures 2-5 % faster at C2 (59.8 vs 61.2 us inference, 67.4 vs 71.1 us
 // with z saved; A/B on one box, WAE_GLU_WAVES=4|8); before those two changes the 4-wave shape was the faster one.
-static int g_glu_nw = 8;
-extern "C" void wae_debug_set_glu_waves(int nw) { g_glu_nw = nw == 8 ? 8 : 4; }
-
-static int g_glu_slots = 0;  // 0 = as many ring slots as fit (<= 6)
-extern "C" void wae_debug_set_glu_slots(int n) { g_glu_slots = n; }
+// The caller picks the shape per launch with WAE_GLU_WAVES4 in wae_glu_desc.flags (default: 8 waves).
 
 template <typename E, int NP, int NPH, bool EXACT, int NW>
 static int launch_glu_nw(GluArgs a, hipStream_t st) {
@@ -470,15 +475,8 @@ static int launch_glu_nw(GluArgs a, hipStream_t st) {
   }
   a.nslot = nslot;
   const size_t lds = fixed + (size_t)nslot * CHB;
-  static size_t attr_done = 0;
-  if (attr_done < lds) {
-    if (hipFuncSetAttribute((const void*)glu_fwd_kernel<E, NP, NPH, EXACT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      wae_set_error("glu_fwd: cannot raise dynamic LDS to %zu", lds);
-      return WAE_EHIP;
-    }
-    attr_done = lds;
-  }
+  static WaeLdsCache lds_cache;
+  if (int rc = wae_ensure_lds((const void*)glu_fwd_kernel<E, NP, NPH, EXACT, NW>, lds_cache, lds, "glu_fwd"); rc != WAE_OK) return rc;
   const int tiles = (a.T + NW * 32 - 1) / (NW * 32);
   hipLaunchKernelGGL((glu_fwd_kernel<E, NP, NPH, EXACT, NW>), dim3(a.B * tiles), dim3(NW * 64), lds, st, a);
   return wae_check_launch("glu_fwd");
@@ -490,7 +488,7 @@ static int launch_glu(const GluArgs& a, hipStream_t st) {
   if constexpr (sizeof(E) == 2) {
     // two 4-wave workgroups per CU need a two-slot ring in 80 KiB each; wider layers take the whole CU with 8 waves
     const bool fits4 = 4 * 4096 + (size_t)(a.Rp + 2 * a.Hp) * 4 + 2 * (2 * NPH * 4096) <= 80 * 1024;
-    if (g_glu_nw == 8 || !fits4) return launch_glu_nw<E, NP, NPH, EXACT, 8>(a, st);
+    if (!(a.flags & WAE_GLU_WAVES4) || !fits4) return launch_glu_nw<E, NP, NPH, EXACT, 8>(a, st);
   }
   return launch_glu_nw<E, NP, NPH, EXACT, 4>(a, st);
 }
@@ -513,7 +511,7 @@ static int dispatch_np(int np, const GluArgs& a, hipStream_t st) {
 
 static int glu_validate(const wae_glu_desc* d) {
   WAE_REQUIRE(d != nullptr, "glu: null desc");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "glu: bad dtype %d", d->dtype);
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "glu: bad dtype %d", d->dtype);
   WAE_REQUIRE(d->B > 0 && d->T > 0, "glu: B,T must be positive");
   WAE_REQUIRE(d->Rp > 0 && d->Rp % 128 == 0 && d->Ccp >= 0 && d->Ccp % 64 == 0,
               "glu: Rp must be a multiple of 128 and Ccp of 64 (got %d,%d)", d->Rp, d->Ccp);
@@ -524,9 +522,9 @@ static int glu_validate(const wae_glu_desc* d) {
 
 extern "C" int64_t wae_glu_packed_bytes(const wae_glu_desc* d) {
   if (glu_validate(d) != WAE_OK) return WAE_EINVAL;
-  const int ck = d->dtype == WAE_BF16 ? 64 : 32;
+  const int ck = wae_is16(d->dtype) ? 64 : 32;
   const int np = d->Hp / 32, nph = np == 3 ? 3 : (np % 2 == 0 ? np / 2 : np);
-  const int mt2 = (d->dtype == WAE_BF16 ? 4 : 2) * nph / np;
+  const int mt2 = (wae_is16(d->dtype) ? 4 : 2) * nph / np;
   const int64_t chb = (int64_t)2 * nph * 4 * 1024;
   const int64_t nq1 = (int64_t)d->ktaps * (d->Rp / ck) + d->Ccp / ck;
   const int64_t nq2 = (d->Rp / 32) / mt2;
@@ -550,5 +548,6 @@ extern "C" int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* 
   a.dilation = d->dilation; a.flags = d->flags; a.stamps = g_stamps;
   hipStream_t st = as_stream(stream);
   if (d->dtype == WAE_BF16) return dispatch_np<__bf16, false>(d->Hp / 32, a, st);
+  if (d->dtype == WAE_F16) return dispatch_np<f16, false>(d->Hp / 32, a, st);
   return dispatch_np<float, true>(d->Hp / 32, a, st);
 }

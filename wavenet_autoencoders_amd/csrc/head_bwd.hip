@@ -190,15 +190,8 @@ template <typename E, int NTO, int NTS>
 static int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
   constexpr int CHMAX = (NTO > NTS ? NTO : NTS) * 4 * 1024;
   const size_t lds = 2 * CHMAX + 4 * STG_BYTES + (size_t)a.Op * 4;
-  static size_t attr_done = 0;
-  if (attr_done < lds) {
-    if (hipFuncSetAttribute((const void*)head_bwd_kernel<E, NTO, NTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
-      wae_set_error("head_bwd: cannot raise dynamic LDS to %zu", lds);
-      return WAE_EHIP;
-    }
-    attr_done = lds;
-  }
+  static WaeLdsCache lds_cache;
+  if (int rc = wae_ensure_lds((const void*)head_bwd_kernel<E, NTO, NTS>, lds_cache, lds, "head_bwd"); rc != WAE_OK) return rc;
   const int tiles = (a.T + 127) / 128;
   hipLaunchKernelGGL((head_bwd_kernel<E, NTO, NTS>), dim3(a.B * tiles), dim3(256), lds, st, a);
   return wae_check_launch("head_bwd");
@@ -217,8 +210,8 @@ static int dispatch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
 
 extern "C" int64_t wae_head_bwd_packed_bytes(const wae_head_desc* d) {
   if (!d) return WAE_EINVAL;
-  const int ck = d->dtype == WAE_BF16 ? 64 : 32;
-  const int mt2 = d->dtype == WAE_BF16 ? 2 : 1;
+  const int ck = wae_is16(d->dtype) ? 64 : 32;
+  const int mt2 = wae_is16(d->dtype) ? 2 : 1;
   const int64_t cha = (int64_t)(d->Op / 32) * 4 * 1024, chc = (int64_t)(d->Sp / 32) * 4 * 1024;
   return (int64_t)(d->Sp / ck) * cha + (int64_t)((d->Sp / 32) / mt2) * (cha + chc);
 }
@@ -228,12 +221,13 @@ extern "C" int wae_head_bwd(const wae_head_desc* d, const void* h0, const void* 
                             void* dy_out, void* dh1_out, void* dskip_out, void* stream) {
   WAE_REQUIRE(d && h0 && h1 && w_packed && dh1_out && dskip_out, "head_bwd: null pointer argument");
   WAE_REQUIRE(ext_dy || (b3 && lse && target && dy_out), "head_bwd: CE mode needs b3, lse, target, dy_out");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "head_bwd: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "head_bwd: bad dtype");
   HeadBwdArgs a;
   a.h0 = (const char*)h0; a.h1 = (const char*)h1; a.w = (const char*)w_packed; a.b3 = b3; a.lse = lse; a.target = target;
   a.lengths = lengths; a.ext_dy = (const char*)ext_dy; a.dy_out = (char*)dy_out; a.dh1_out = (char*)dh1_out;
   a.dskip_out = (char*)dskip_out; a.B = d->B; a.T = d->T; a.Sp = d->Sp; a.Op = d->Op; a.O = d->O; a.scale = d->scale;
   a.inv_count = inv_count;
   hipStream_t st = as_stream(stream);
+  if (d->dtype == WAE_F16) return dispatch_head_bwd<f16>(a, st);
   return d->dtype == WAE_BF16 ? dispatch_head_bwd<__bf16>(a, st) : dispatch_head_bwd<float>(a, st);
 }

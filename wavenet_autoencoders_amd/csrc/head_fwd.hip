@@ -222,15 +222,8 @@ template <typename E, int NT>
 static int launch_head(const HeadArgs& a, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
   const size_t lds = 3 * CHB + 4 * STG_BYTES + (size_t)(2 * a.Sp + a.Op) * 4;
-  static size_t attr_done = 0;
-  if (attr_done < lds) {
-    if (hipFuncSetAttribute((const void*)head_fwd_kernel<E, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
-      wae_set_error("head_fwd: cannot raise dynamic LDS to %zu", lds);
-      return WAE_EHIP;
-    }
-    attr_done = lds;
-  }
+  static WaeLdsCache lds_cache;
+  if (int rc = wae_ensure_lds((const void*)head_fwd_kernel<E, NT>, lds_cache, lds, "head_fwd"); rc != WAE_OK) return rc;
   const int tiles = (a.T + 127) / 128;
   hipLaunchKernelGGL((head_fwd_kernel<E, NT>), dim3(a.B * tiles), dim3(256), lds, st, a);
   return wae_check_launch("head_fwd");
@@ -238,7 +231,7 @@ static int launch_head(const HeadArgs& a, hipStream_t st) {
 
 static int head_validate(const wae_head_desc* d) {
   WAE_REQUIRE(d != nullptr, "head: null desc");
-  WAE_REQUIRE(d->dtype == WAE_F32 || d->dtype == WAE_BF16, "head: bad dtype %d", d->dtype);
+  WAE_REQUIRE(wae_dtype_ok(d->dtype), "head: bad dtype %d", d->dtype);
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->O > 0, "head: B,T,O must be positive");
   WAE_REQUIRE(d->Ku > 0 && d->Ku % 64 == 0, "head: Ku must be a positive multiple of 64 (got %d)", d->Ku);
   WAE_REQUIRE(d->Sp == 128 || d->Sp == 256, "head: Sp must be 128 or 256 (got %d)", d->Sp);
@@ -248,8 +241,8 @@ static int head_validate(const wae_head_desc* d) {
 
 extern "C" int64_t wae_head_packed_bytes(const wae_head_desc* d) {
   if (head_validate(d) != WAE_OK) return WAE_EINVAL;
-  const int ck = d->dtype == WAE_BF16 ? 64 : 32;
-  const int mt2 = d->dtype == WAE_BF16 ? 2 : 1;
+  const int ck = wae_is16(d->dtype) ? 64 : 32;
+  const int mt2 = wae_is16(d->dtype) ? 2 : 1;
   const int64_t chb = (int64_t)(d->Sp / 32) * 4 * 1024;
   return (int64_t)(d->Ku / ck + (d->Sp / 32) / mt2 + (d->Op / 32) / mt2) * chb;
 }
@@ -267,5 +260,6 @@ extern "C" int wae_head_fwd(const wae_head_desc* d, const void* u, const void* w
   hipStream_t st = as_stream(stream);
   const int nt = d->Sp / 32;
   if (d->dtype == WAE_BF16) return nt == 4 ? launch_head<__bf16, 4>(a, st) : launch_head<__bf16, 8>(a, st);
+  if (d->dtype == WAE_F16) return nt == 4 ? launch_head<f16, 4>(a, st) : launch_head<f16, 8>(a, st);
   return nt == 4 ? launch_head<float, 4>(a, st) : launch_head<float, 8>(a, st);
 }

@@ -34,12 +34,16 @@ template <>
 __device__ __forceinline__ void store_e<float>(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
 template <>
 __device__ __forceinline__ void store_e<__bf16>(void* p, int64_t i, float v) { ((__bf16*)p)[i] = (__bf16)v; }
+template <>
+__device__ __forceinline__ void store_e<f16>(void* p, int64_t i, float v) { ((f16*)p)[i] = (f16)v; }
 template <typename E>
 __device__ __forceinline__ float load_e(const void* p, int64_t i);
 template <>
 __device__ __forceinline__ float load_e<float>(const void* p, int64_t i) { return ((const float*)p)[i]; }
 template <>
 __device__ __forceinline__ float load_e<__bf16>(const void* p, int64_t i) { return (float)((const __bf16*)p)[i]; }
+template <>
+__device__ __forceinline__ float load_e<f16>(const void* p, int64_t i) { return (float)((const f16*)p)[i]; }
 
 // ---------------------------------------------------------------------------------------------------
 // weight norm: one wave per weight row (modules.py:18: w = g * v / ||v||, norm over all dims but 0)
@@ -142,10 +146,13 @@ __global__ void __launch_bounds__(256) pack_gather_kernel(const float* __restric
 extern "C" int wae_pack_gather(const float* src, const int32_t* map, void* dst, int64_t n, int32_t nbatch,
                                int64_t src_stride, int64_t dst_stride, int32_t dtype, void* stream) {
   WAE_REQUIRE(src && map && dst && n > 0 && nbatch > 0, "pack_gather: bad arguments");
-  WAE_REQUIRE(dtype == WAE_F32 || dtype == WAE_BF16, "pack_gather: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(dtype), "pack_gather: bad dtype");
   const int gx = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   if (dtype == WAE_BF16)
     hipLaunchKernelGGL(pack_gather_kernel<__bf16>, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
+                       src_stride, dst_stride);
+  else if (dtype == WAE_F16)
+    hipLaunchKernelGGL(pack_gather_kernel<f16>, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
                        src_stride, dst_stride);
   else
     hipLaunchKernelGGL(pack_gather_kernel<float>, dim3(gx, nbatch), dim3(256), 0, as_stream(stream), src, map, dst, n,
@@ -494,6 +501,8 @@ extern "C" int wae_upsample_stage_fwd(const float* in, const float* w, void* out
       dim3 g2((Tout + UPT - 1) / UPT, B);
       if (dtype == WAE_BF16)
         hipLaunchKernelGGL(upsample_last_kernel<__bf16>, g2, dim3(256), lds, st, in, w, out, C, Tin, s, Cp, nfp | 1);
+      else if (dtype == WAE_F16)
+        hipLaunchKernelGGL(upsample_last_kernel<f16>, g2, dim3(256), lds, st, in, w, out, C, Tin, s, Cp, nfp | 1);
       else
         hipLaunchKernelGGL(upsample_last_kernel<float>, g2, dim3(256), lds, st, in, w, out, C, Tin, s, Cp, nfp | 1);
       return wae_check_launch("upsample_stage_fwd");
@@ -502,6 +511,8 @@ extern "C" int wae_upsample_stage_fwd(const float* in, const float* w, void* out
     dim3 grid((unsigned)((n + 255) / 256), 1, B);
     if (dtype == WAE_BF16)
       hipLaunchKernelGGL(upsample_stage_kernel<__bf16>, grid, dim3(256), 0, st, in, w, out, C, Tin, s, 1, Cp);
+    else if (dtype == WAE_F16)
+      hipLaunchKernelGGL(upsample_stage_kernel<f16>, grid, dim3(256), 0, st, in, w, out, C, Tin, s, 1, Cp);
     else
       hipLaunchKernelGGL(upsample_stage_kernel<float>, grid, dim3(256), 0, st, in, w, out, C, Tin, s, 1, Cp);
   }
@@ -682,10 +693,10 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const int32_t* __restri
       for (int k = 0; k < 4; ++k) { v0[k] = fmaf(t0[k], x, b0[k]); v1[k] = fmaf(t1[k], x, b1[k]); }
     }
     if constexpr (sizeof(E) == 2) {
-      bf16x8 o;
+      typename ET<E>::frag o;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { o[k] = (__bf16)v0[k]; o[4 + k] = (__bf16)v1[k]; }
-      *(bf16x8*)((__bf16*)x0 + bt * Rp + r) = o;
+      for (int k = 0; k < 4; ++k) { o[k] = (E)v0[k]; o[4 + k] = (E)v1[k]; }
+      *(typename ET<E>::frag*)((E*)x0 + bt * Rp + r) = o;
     } else {
       *(f32x4*)((float*)x0 + bt * Rp + r) = v0;
       *(f32x4*)((float*)x0 + bt * Rp + r + 4) = v1;
@@ -700,6 +711,8 @@ extern "C" int wae_first_conv_fwd(const int32_t* idx, const float* xs, const flo
   dim3 grid((unsigned)((BT + 15) / 16));
   if (dtype == WAE_BF16)
     hipLaunchKernelGGL(first_conv_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp, O, err);
+  else if (dtype == WAE_F16)
+    hipLaunchKernelGGL(first_conv_kernel<f16>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp, O, err);
   else
     hipLaunchKernelGGL(first_conv_kernel<float>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp, O, err);
   return wae_check_launch("first_conv_fwd");
@@ -732,7 +745,7 @@ __global__ void __launch_bounds__(256) to_btc_kernel(const float* __restrict__ i
 }
 template <typename E>
 __global__ void __launch_bounds__(256) from_btc_kernel(const void* __restrict__ in, float* __restrict__ out, int C, int T,
-                                                       int Cp) {
+                                                       int Cp, float scale) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
@@ -743,7 +756,7 @@ __global__ void __launch_bounds__(256) from_btc_kernel(const void* __restrict__ 
   __syncthreads();
   for (int i = ly; i < 64; i += 4) {
     const int c = c0 + i, t = t0 + lx;
-    if (c < C && t < T) out[((int64_t)b * C + c) * T + t] = tile[lx][i];
+    if (c < C && t < T) out[((int64_t)b * C + c) * T + t] = tile[lx][i] * scale;
   }
 }
 
@@ -753,6 +766,8 @@ extern "C" int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int3
   dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
   if (dtype == WAE_BF16)
     hipLaunchKernelGGL(to_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, nullptr, 1.f, 0);
+  else if (dtype == WAE_F16)
+    hipLaunchKernelGGL(to_btc_kernel<f16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, nullptr, 1.f, 0);
   else
     hipLaunchKernelGGL(to_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, nullptr, 1.f, 0);
   return wae_check_launch("to_btc");
@@ -760,23 +775,31 @@ extern "C" int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int3
 extern "C" int wae_to_btc_masked(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
                                  const int32_t* lengths, float scale, void* stream) {
   WAE_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && Cp >= C, "to_btc_masked: bad arguments");
-  WAE_REQUIRE(dtype == WAE_F32 || dtype == WAE_BF16, "to_btc_masked: bad dtype");
+  WAE_REQUIRE(wae_dtype_ok(dtype), "to_btc_masked: bad dtype");
   dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
   if (dtype == WAE_BF16)
     hipLaunchKernelGGL(to_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, lengths, scale, 1);
+  else if (dtype == WAE_F16)
+    hipLaunchKernelGGL(to_btc_kernel<f16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, lengths, scale, 1);
   else
     hipLaunchKernelGGL(to_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, lengths, scale, 1);
   return wae_check_launch("to_btc_masked");
 }
-extern "C" int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
-                            void* stream) {
+extern "C" int wae_from_btc_scaled(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
+                                   float scale, void* stream) {
   WAE_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && Cp >= C, "from_btc: bad arguments");
   dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
   if (dtype == WAE_BF16)
-    hipLaunchKernelGGL(from_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+    hipLaunchKernelGGL(from_btc_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, scale);
+  else if (dtype == WAE_F16)
+    hipLaunchKernelGGL(from_btc_kernel<f16>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, scale);
   else
-    hipLaunchKernelGGL(from_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp);
+    hipLaunchKernelGGL(from_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, scale);
   return wae_check_launch("from_btc");
+}
+extern "C" int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
+                            void* stream) {
+  return wae_from_btc_scaled(in, out, B, C, T, Cp, dtype, 1.0f, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -7,12 +7,39 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 void wae_set_error(const char* fmt, ...);
 int wae_check_launch(const char* what);
+
+// Dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: the largest size
+// already granted is remembered per device (one cache object per kernel instantiation), so a process that drives several
+// GPUs -- or threads that launch concurrently -- never skips the call on a device that has not seen it.  Setting the
+// attribute twice is harmless; the cache only saves the driver call.
+#include <atomic>
+#define WAE_MAX_DEVICES 64
+struct WaeLdsCache {
+  std::atomic<size_t> granted[WAE_MAX_DEVICES];
+};
+static inline int wae_ensure_lds(const void* kernel, WaeLdsCache& c, size_t lds, const char* what) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WAE_MAX_DEVICES) dev = -1;
+  if (dev >= 0 && c.granted[dev].load(std::memory_order_relaxed) >= lds) return WAE_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    wae_set_error("%s: cannot raise dynamic LDS to %zu bytes", what, lds);
+    return WAE_EHIP;
+  }
+  if (dev >= 0) {
+    size_t cur = c.granted[dev].load(std::memory_order_relaxed);
+    while (cur < lds && !c.granted[dev].compare_exchange_weak(cur, lds, std::memory_order_relaxed)) {}
+  }
+  return WAE_OK;
+}
 
 #define WAE_REQUIRE(cond, ...)      \
   do {                              \
@@ -50,6 +77,22 @@ struct ET<__bf16> {
   static constexpr int DT = WAE_BF16;
 };
 
+// fp16 storage (WAE_F16, BASELINE config C5 "fp16 + MFMA"): same fragment geometry and MFMA rate as bf16
+// (v_mfma_f32_32x32x16_f16), fp32 accumulate; 10 mantissa bits instead of 7, 5 exponent bits instead of 8 -- the backward
+// pass therefore runs on loss-scaled gradients (engine.py: grad_scale).
+template <>
+struct ET<f16> {
+  using frag = f16x8;
+  using vec4 = f16x4;
+  static constexpr int EPL = 8;
+  static constexpr int CK = 64;
+  static constexpr int KBU = 2;
+  static constexpr int MT2 = 4;
+  static constexpr int DT = WAE_F16;
+};
+static inline bool wae_dtype_ok(int dt) { return dt == WAE_F32 || dt == WAE_BF16 || dt == WAE_F16; }
+static inline bool wae_is16(int dt) { return dt == WAE_BF16 || dt == WAE_F16; }
+
 __device__ __forceinline__ void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
@@ -60,7 +103,16 @@ __device__ __forceinline__ void mma32(f32x16& acc, const bf16x8& a, const bf16x8
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 
+__device__ __forceinline__ void mma32(f32x16& acc, const f16x8& a, const f16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 to_f32x4(const f32x4& v) { return v; }
+__device__ __forceinline__ f32x4 to_f32x4(const f16x4& v) {
+  f32x4 r;
+  r.x = (float)v.x; r.y = (float)v.y; r.z = (float)v.z; r.w = (float)v.w;
+  return r;
+}
 __device__ __forceinline__ f32x4 to_f32x4(const bf16x4& v) {
   f32x4 r;
   r.x = (float)v.x; r.y = (float)v.y; r.z = (float)v.z; r.w = (float)v.w;
@@ -77,6 +129,13 @@ __device__ __forceinline__ bf16x4 from_f32x4<__bf16>(const f32x4& v) {
   return r;
 }
 
+template <>
+__device__ __forceinline__ f16x4 from_f32x4<f16>(const f32x4& v) {
+  f16x4 r;
+  r.x = (f16)v.x; r.y = (f16)v.y; r.z = (f16)v.z; r.w = (f16)v.w;
+  return r;
+}
+
 // 16 accumulator registers of a 32x32 tile -> the KBU operand fragments of the NEXT MFMA that sums over
 // the tile's row index.  bf16: k-step s takes registers 8s..8s+7 (row 16s+8(j>>2)+4h+(j&3)); f32: k-block
 // g takes registers 4g..4g+3 (row 8g+4h+j).  The host packs the A operand in the matching k order.
@@ -85,6 +144,12 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& u, bf16x8 (&f)[2]) {
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[s][j] = (__bf16)u[8 * s + j];
+}
+__device__ __forceinline__ void acc_to_frags(const f32x16& u, f16x8 (&f)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[s][j] = (f16)u[8 * s + j];
 }
 __device__ __forceinline__ void acc_to_frags(const f32x16& u, f32x4 (&f)[4]) {
 #pragma unroll
@@ -126,6 +191,8 @@ template <int CNT>
 __device__ __forceinline__ void lds_wait(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
 template <int CNT>
 __device__ __forceinline__ void lds_wait(bf16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
 
 template <int OFF, typename frag>
 __device__ __forceinline__ void lds_read_async(frag& dst, unsigned addr) {
@@ -384,8 +451,8 @@ __device__ __forceinline__ void stage_unpack_tiles(char* stg, f32x16* y, const f
 // group 2(f%2)+1 of tile f/2 for this lane's half.
 template <int N>
 __device__ __forceinline__ void residual_to_acc_layout(f32x4 (&)[N]) {}
-template <int N>
-__device__ __forceinline__ void residual_to_acc_layout(bf16x8 (&res)[N]) {
+template <typename V8, int N>
+__device__ __forceinline__ void residual_swap16(V8 (&res)[N]) {
 #pragma unroll
   for (int f = 0; f < N; ++f) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -393,14 +460,25 @@ __device__ __forceinline__ void residual_to_acc_layout(bf16x8 (&res)[N]) {
     auto s0 = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
     auto s1 = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
     r.x = s0[0]; r.z = s0[1]; r.y = s1[0]; r.w = s1[1];
-    res[f] = __builtin_bit_cast(bf16x8, r);
+    res[f] = __builtin_bit_cast(V8, r);
   }
 }
+template <int N>
+__device__ __forceinline__ void residual_to_acc_layout(bf16x8 (&res)[N]) { residual_swap16(res); }
+template <int N>
+__device__ __forceinline__ void residual_to_acc_layout(f16x8 (&res)[N]) { residual_swap16(res); }
 template <typename E, int N>
 __device__ __forceinline__ f32x4 residual_piece(const f32x4 (&res)[N], int mt, int g) { return res[4 * mt + g]; }
 template <typename E, int N>
 __device__ __forceinline__ f32x4 residual_piece(const bf16x8 (&res)[N], int mt, int g) {
   const bf16x8 v = res[2 * mt + (g >> 1)];
+  const int o = 4 * (g & 1);
+  f32x4 r = {(float)v[o], (float)v[o + 1], (float)v[o + 2], (float)v[o + 3]};
+  return r;
+}
+template <typename E, int N>
+__device__ __forceinline__ f32x4 residual_piece(const f16x8 (&res)[N], int mt, int g) {
+  const f16x8 v = res[2 * mt + (g >> 1)];
   const int o = 4 * (g & 1);
   f32x4 r = {(float)v[o], (float)v[o + 1], (float)v[o + 2], (float)v[o + 3]};
   return r;

@@ -25,19 +25,27 @@ def _dt(dtype) -> int:
         return L.WAE_BF16
     if dtype in ("fp32", "f32", torch.float32, L.WAE_F32):
         return L.WAE_F32
-    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32' or 'bf16')")
+    if dtype in ("fp16", "f16", "half", torch.float16, L.WAE_F16) and not isinstance(dtype, bool):
+        return L.WAE_F16
+    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32', 'bf16' or 'fp16')")
 
 
 class WaeEngine:
     def __init__(self, geom: P.Geometry, dtype="bf16", device="cuda:0"):
+        """dtype: 'fp32' (exact, the parity mode), 'bf16' (default throughput mode) or 'fp16' (BASELINE config C5) storage of
+        activations and packed weights; accumulation, biases, losses, gradients of parameters and the optimizer are fp32."""
         if not torch.cuda.is_available():
             raise L.WaeError("WaeEngine needs a ROCm GPU: the hot path has no CPU implementation")
         self.lib = L.lib()
-        if os.environ.get("WAE_GLU_WAVES"):      # A/B switch of the fused layer kernel's workgroup shape (4 or 8 waves)
-            self.lib.wae_debug_set_glu_waves(int(os.environ["WAE_GLU_WAVES"]))
+        # A/B switch of the fused layer kernel's workgroup shape (4 or 8 waves): a descriptor flag of every launch
+        self.glu_flags = L.GLU_WAVES4 if os.environ.get("WAE_GLU_WAVES") == "4" else 0
         self.g = geom
         self.dt = _dt(dtype)
-        self.tdtype = torch.bfloat16 if self.dt == L.WAE_BF16 else torch.float32
+        self.tdtype = {L.WAE_BF16: torch.bfloat16, L.WAE_F16: torch.float16, L.WAE_F32: torch.float32}[self.dt]
+        # fp16 has 5 exponent bits: the backward pass runs on gradients multiplied by grad_scale (a power of two: exact), the
+        # weight-gradient contractions carry 1/grad_scale in their alpha, so everything fp32 sees is unscaled.  Bounds: the
+        # largest 16-bit gradient is |dy| <= grad_scale / count <= 4096 << 65504; at C5 (count 8e4) dy ~ 2e-4 stays normal.
+        self.grad_scale = 4096.0 if self.dt == L.WAE_F16 else 1.0
         self.device = torch.device(device)
         self.lay = P.ParamLayout(geom)
         dev = self.device
@@ -293,7 +301,7 @@ class WaeEngine:
         for i, dil in enumerate(g.dilations):
             d.dilation = dil
             last = i == g.layers - 1
-            d.flags = (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0)
+            d.flags = (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0) | self.glu_flags
             xin = ws["x"][i if train else i % 2]
             xout = ws["x"][(i + 1) if train else (i + 1) % 2]
             L.check(lib.wae_glu_layer_fwd(ctypes.byref(d), L.ptr(xin), None if last else L.ptr(xout), L.ptr(ws["c_up"]),
@@ -557,7 +565,8 @@ class WaeEngine:
         loss = torch.empty(2, dtype=torch.float32, device=self.device)
         L.check(lib.wae_masked_mean(L.ptr(nll), L.ptr(ln), L.ptr(loss), B, T, st), "masked_mean")
         dyt = torch.zeros(B, T, g.Op, dtype=self.tdtype, device=self.device)
-        L.check(lib.wae_to_btc_masked(L.ptr(dy), L.ptr(dyt), B, g.O, T, g.Op, self.dt, L.ptr(ln), float(scale) / max(count, 1), st),
+        L.check(lib.wae_to_btc_masked(L.ptr(dy), L.ptr(dyt), B, g.O, T, g.Op, self.dt, L.ptr(ln),
+                                      float(scale) * self.grad_scale / max(count, 1), st),
                 "to_btc dy")
         self._dmol_keep = (yf, nll, dy, ln)
         return loss[0], dyt

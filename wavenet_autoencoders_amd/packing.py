@@ -29,7 +29,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2    # include/wae.h WAE_F32 / WAE_BF16 / WAE_F16 (fp16 packs exactly like bf16)
 
 
 def _ru(x: int, m: int) -> int:
@@ -172,7 +172,7 @@ class ParamLayout:
 
 
 def _traits(dtype: int):
-    if dtype == BF16:
+    if dtype in (BF16, F16):
         return dict(EPL=8, CK=64, KBU=2, MT2=4, ES=2)
     return dict(EPL=4, CK=32, KBU=4, MT2=2, ES=4)
 
@@ -181,7 +181,7 @@ def u_row_index(dtype: int, kb: np.ndarray, h: np.ndarray, j: np.ndarray) -> np.
     """k index (row of the previous accumulator tile stack) held by element j of lane-half h in k-block kb."""
     t = _traits(dtype)
     ut, s = kb // t["KBU"], kb % t["KBU"]
-    if dtype == BF16:
+    if dtype in (BF16, F16):
         return 32 * ut + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
     return 32 * ut + 8 * s + 4 * h + j
 

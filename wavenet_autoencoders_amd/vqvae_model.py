@@ -27,6 +27,8 @@ class _VQVAEFn(torch.autograd.Function):
         B, O, T = dy.shape
         ext = torch.zeros(B, T, g.Op, dtype=eng.tdtype, device=dy.device)
         dyc = dy.contiguous().float()
+        if eng.grad_scale != 1.0:               # fp16 stack: its backward runs on loss-scaled gradients (engine.py: grad_scale)
+            dyc = dyc * eng.grad_scale
         L.check(eng.lib.wae_to_btc(L.ptr(dyc), L.ptr(ext), B, O, T, g.Op, eng.dt, eng.stream()), "to_btc")
         dc = BW.decoder_backward(eng, ctx.ids, None, None, ctx.gid, None, ext_dy=ext)
         BW.frontend_backward(eng, dc, float(dvq) if dvq is not None else 0.0)

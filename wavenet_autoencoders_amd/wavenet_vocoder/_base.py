@@ -77,7 +77,7 @@ class ArenaModel(nn.Module):
         self._pnames = register_params(self, geom, strip)
 
     def set_compute_dtype(self, dtype: str):
-        """'fp32' (exact, default) or 'bf16' (bf16 storage, fp32 accumulate)."""
+        """'fp32' (exact, default), 'bf16' or 'fp16' (16-bit storage of activations and packed weights, fp32 accumulate)."""
         if dtype != self._compute_dtype:
             if self._engine is not None:
                 sd = {k: v.detach().clone() for k, v in self.state_dict().items()}

@@ -53,13 +53,16 @@ class _DecoderFn(torch.autograd.Function):
         B, O, T = dy.shape
         ext = torch.zeros(B, T, g.Op, dtype=eng.tdtype, device=dy.device)
         dyc = dy.contiguous().float()
+        if eng.grad_scale != 1.0:               # fp16 stack: its backward runs on loss-scaled gradients (engine.py: grad_scale)
+            dyc = dyc * eng.grad_scale
         L.check(eng.lib.wae_to_btc(L.ptr(dyc), L.ptr(ext), B, O, T, g.Op, eng.dt, eng.stream()), "to_btc")
         dc = BW.decoder_backward(eng, ctx.ids, None, None, ctx.gid, ctx.gvec, ext_dy=ext)
         dc_in = None
         if ctx.c_shape is not None:
             if ctx.c_is_up or not g.upsample_scales:
                 dc_in = torch.empty(B, g.Cc, T, dtype=torch.float32, device=dy.device)
-                L.check(eng.lib.wae_from_btc(L.ptr(dc), L.ptr(dc_in), B, g.Cc, T, g.Ccp, eng.dt, eng.stream()), "from_btc")
+                L.check(eng.lib.wae_from_btc_scaled(L.ptr(dc), L.ptr(dc_in), B, g.Cc, T, g.Ccp, eng.dt, 1.0 / eng.grad_scale,
+                                                    eng.stream()), "from_btc")
             else:
                 dc_in = BW.frontend_backward(eng, dc, 1.0, stop_at_quant=True)
         grads = BW.finish_grads(eng)
