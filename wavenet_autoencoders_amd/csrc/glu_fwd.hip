@@ -96,9 +96,12 @@ __device__ __forceinline__ float vmax_nocanon(float a, float b) {
   return r;
 }
 
-// NPH = gate-channel tiles per pass (per half); NW = waves per workgroup
-template <typename E, int NP, int NPH, bool EXACT, int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) glu_fwd_kernel(GluArgs p) {
+// NPH = gate-channel tiles per pass (per half); NW = waves per workgroup; CG = 32-column groups per wave.
+// CG = 2 (bf16 / fp16, 4 waves, one per SIMD, up to 512 registers each): a wave owns 64 time columns, every A fragment it
+// reads from LDS feeds two MFMAs.  With CG = 1 the kernel is co-limited by the LDS port and the matrix pipe (DESIGN 3.1:
+// eight waves x 24 fragments per chunk step = 1536 cycles of the port's 128 B/clk, exactly the MFMAs' 1536 cycles).
+template <typename E, int NP, int NPH, bool EXACT, int NW, int CG>
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1) ? 2 : 1) glu_fwd_kernel(GluArgs p) {
   using T_ = ET<E>;
   using frag = typename T_::frag;
   static_assert(NP % NPH == 0, "passes must tile the gate channels");
@@ -122,14 +125,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 31, h = lane >> 5;
-  constexpr int TW = NW * 32;
+  constexpr int TW = NW * 32 * CG;
   const int tiles_per_b = (p.T + TW - 1) / TW;
   const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int b = tile_id / tiles_per_b;
-  const int t0w = (tile_id % tiles_per_b) * TW + wave * 32;
-  const int t = t0w + n;
-  const bool tvalid = t < p.T;
-  const int rows_valid = min(max(p.T - t0w, 0), 32);
+  const int t0w = (tile_id % tiles_per_b) * TW + wave * 32 * CG;   // first column of this wave; group c starts at t0w + 32 c
+  const int t = t0w + n;                                            // this lane's column in group 0 (group c: t + 32 c)
 
   const int cpr = p.Rp / T_::CK;  // chunks per tap
   const int nq_conv = p.ktaps * cpr;
@@ -146,17 +147,17 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
   // The activation operand is requested TWO chunks ahead into a rotating set of three fragment groups (an L2/HBM
   // round trip under load is longer than one chunk of MFMAs).  Loads are always issued (rows clamped into the clip)
   // so that the number of outstanding VMEM ops is known; columns outside [0, T) are zeroed at use (causal pad).
-  frag S0[4], S1[4], S2[4];
-  // per-lane address of this lane's first fragment of activation chunk q (its row clamped into the clip)
-  auto b_src = [&](int q) -> const char* {
+  frag S0[CG][4] = {}, S1[CG][4] = {}, S2[CG][4] = {};   // defined: the asm loads tie their destination to its previous register
+  // per-lane address of this lane's first fragment of activation chunk q, column group c (its row clamped into the clip)
+  auto b_src = [&](int q, int c) -> const char* {
     const char* base;
     int64_t rp;
-    int ts = t;
+    int ts = t + 32 * c;
     if (q < nq_conv) {
       // column block by column block, the taps of one block back to back: a tile reads x[t - d] right after x[t] while the
       // tile d rows earlier reads the same rows as its last tap -- they meet in L2 (packing.py: glu_w1_map, same order)
       const int cblk = q / p.ktaps, tap = q - cblk * p.ktaps;
-      ts = t - (p.ktaps - 1 - tap) * p.dilation;
+      ts -= (p.ktaps - 1 - tap) * p.dilation;
       base = xb + cblk * 128 + h * 16;
       rp = row_x;
     } else {
@@ -165,8 +166,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
     }
     return base + (int64_t)min(max(ts, 0), p.T - 1) * rp;
   };
-  // bf16 only: the fp32 (parity) instantiations spill a few registers, and a fragment group spilled between its request and
-  // the counted wait would be saved before it has landed -- they keep plain loads and the compiler's own waits.
+  // bf16 / fp16 only: the fp32 (parity) instantiations spill a few registers, and a fragment group spilled between its request
+  // and the counted wait would be saved before it has landed -- they keep plain loads and the compiler's own waits.
 #ifdef WAE_GLU_PLAIN_LOADS   // tools/check_asm_loads.py: the same kernel with compiler-managed loads, for a bitwise comparison
   constexpr bool ASM_B = false;
 #else
@@ -176,32 +177,40 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
   // loads they made hipcc put s_waitcnt vmcnt(0) in front of the first use of every loop-carried fragment group (the zero
   // fill in fix_B, right after the barrier of each chunk) -- which drained the DMA pieces and operand requests of the NEXT
   // chunks: the ring and the two-chunks-ahead requests bought nothing, every variant of this kernel measured 60 +- 2 us.
-  auto load_B = [&](int q, frag (&Bf)[4]) {
+  auto load_B = [&](int q, frag (&Bf)[CG][4]) {
     if (ABL(p.flags, DBG_NO_BLOAD)) return;
-    const char* src = b_src(q);
-    if constexpr (ASM_B) {
-      gload_async<0>(Bf[0], src); gload_async<32>(Bf[1], src); gload_async<64>(Bf[2], src); gload_async<96>(Bf[3], src);
-    } else {
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) Bf[blk] = *(const frag*)(src + blk * 32);
+    for (int c = 0; c < CG; ++c) {
+      const char* src = b_src(q, c);
+      if constexpr (ASM_B) {
+        gload_async<0>(Bf[c][0], src); gload_async<32>(Bf[c][1], src); gload_async<64>(Bf[c][2], src); gload_async<96>(Bf[c][3], src);
+      } else {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) Bf[c][blk] = *(const frag*)(src + blk * 32);
+      }
     }
   };
-  auto fix_B = [&](int q, frag (&Bf)[4]) {
+  auto fix_B = [&](int q, frag (&Bf)[CG][4]) {
     const int shift = q < nq_conv ? (p.ktaps - 1 - q % p.ktaps) * p.dilation : 0;
-    const bool ok = tvalid && t - shift >= 0 && !ABL(p.flags, DBG_NO_BLOAD);
-    if (__any(!ok)) {
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-        if (!ok) {
-          frag zf = {};
-          Bf[blk] = zf;
-        }
+    for (int c = 0; c < CG; ++c) {
+      const int tc = t + 32 * c;
+      const bool ok = tc < p.T && tc - shift >= 0 && !ABL(p.flags, DBG_NO_BLOAD);
+      if (__any(!ok)) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+          if (!ok) {
+            frag zf = {};
+            Bf[c][blk] = zf;
+          }
+      }
     }
   };
 
   // out bias and this clip's zb -> LDS once (read back with ds_read: keeps accumulator inits off vmcnt, where they
   // would drain the LDS-DMA queue)
   constexpr int PPW = CHB / NW / 1024;  // LDS-DMA instructions per wave and chunk
+  constexpr int NBL = 4 * CG;           // operand loads per wave and chunk
   const int D = p.nslot - 1;            // weight prefetch distance in chunks
   char* ring_end = smem + p.nslot * CHB;
   char* stg = ring_end + wave * STG;
@@ -220,25 +229,27 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
   STAMP(1);
 
   const bool no_epi = ABL(p.flags, DBG_NO_EPI);
-  frag uf[NKB];
+  frag uf[CG][NKB];
   // ring bookkeeping: slot_c = slot of the current chunk, slot_n = slot the next DMA goes to (chunk qi + D)
   int slot_c = 0, slot_n = 1 % p.nslot;
   // Top of chunk qi: retire B(qi) and DMA(qi), meet the other waves.  The requests for later chunks -- the weights
-  // D chunks ahead (PPW LDS-DMA pieces per wave) and the activations two chunks ahead (4 loads) -- are then issued
-  // BETWEEN the MFMAs of chunk qi (every SP-th step), pieces first: a burst of 10 VMEM instructions per wave at the
+  // D chunks ahead (PPW LDS-DMA pieces per wave) and the activations two chunks ahead (NBL loads) -- are then issued
+  // BETWEEN the MFMAs of chunk qi (every SP-th step), pieces first: a burst of VMEM instructions per wave at the
   // chunk top queued at the CU's texture-address unit for ~1000 cycles per chunk with the matrix pipe idle.
   // Loads retire in order, so B(qi) -- the last thing issued in chunk qi-2 -- and everything older (DMA(qi) included,
   // D >= 2) have landed once at most w_next = (ops issued during chunk qi-1) VMEM ops are outstanding.  Stores issued
   // in between only make the wait stricter.  D == 1: DMA(qi) is itself part of chunk qi-1, only that chunk's B loads
   // may stay in flight.
-  constexpr int NSTEP = 4 * NM, NOPS = PPW + 4, SP = NSTEP / NOPS >= 1 ? NSTEP / NOPS : 1;
+  constexpr int NSTEP = 4 * NM * CG, NOPS = PPW + NBL, SP = NSTEP / NOPS >= 1 ? NSTEP / NOPS : 1;
   static_assert(NOPS * SP <= NSTEP + SP - 1 && NOPS <= NSTEP, "not enough MFMA steps to carry the chunk's VMEM issue");
   const int per_wave = CHB / NW;
   const char* w_lane = p.w + wave * per_wave + lane * 16;
-  int w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : 4;  // the prologue's B(1)
+  int w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : NBL;  // the prologue's B(1)
   const char* dsrc = nullptr;  // this chunk's DMA request (wave-uniform validity), per-lane source
   char* ddst = nullptr;
-  const char* bsrc = nullptr;  // this chunk's activation request
+  const char* bsrc[CG];        // this chunk's activation requests (null: none)
+#pragma unroll
+  for (int c = 0; c < CG; ++c) bsrc[c] = nullptr;
 #ifdef WAE_GLU_STAMPS
   unsigned long long acc_wait = 0, acc_bar = 0, acc_issue = 0, acc_gemm = 0;
 #define TICK() (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime())
@@ -276,8 +287,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
       issued += PPW;
     }
     const bool lb = q_load >= 0 && !ABL(p.flags, DBG_NO_BLOAD);
-    bsrc = lb ? b_src(q_load) : nullptr;
-    const int nb = lb ? 4 : 0;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) bsrc[c] = lb ? b_src(q_load, c) : nullptr;   // CG == 2: always a chunk of this pass
+    const int nb = lb ? NBL : 0;
     // at chunk 1 DMA(1) -- the oldest chunk of chunk 0's burst -- must have landed as well
     w_next = D == 1 ? nb : (qi == 0 && issued > 0 ? issued - PPW + nb : issued + nb);
 #ifdef WAE_GLU_STAMPS
@@ -288,21 +300,30 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     // ---- accumulators start from zb = conv bias + hoisted global conditioning ---------------------------
-    f32x16 acc[NM];
+    f32x16 acc[CG][NM];
     if (ps == 0) __syncthreads();  // zb/bias tables visible
 #pragma unroll
-    for (int m = 0; m < NM; ++m)
-      init_rows(acc[m], zb_lds + (m < NPH ? 32 * (ps * NPH + m) : p.Hp + 32 * (ps * NPH + m - NPH)), h);
+    for (int m = 0; m < NM; ++m) {
+      init_rows(acc[0][m], zb_lds + (m < NPH ? 32 * (ps * NPH + m) : p.Hp + 32 * (ps * NPH + m - NPH)), h);
+      if constexpr (CG == 2) acc[1][m] = acc[0][m];
+    }
 
     // ---- GEMM 1, pass ps -----------------------------------------------------------------------------------
     // Chunks run in statically unrolled triples so that the three fragment groups rotate without register moves
     // (a move of a group whose load is still in flight would stall on it): chunk q computes from group q % 3 while
     // chunk q + 2 is requested into group (q + 2) % 3.  Every pass restarts the rotation at group 0.
     {
-      auto step = [&](int q, frag (&Bcur)[4], frag (&Bload)[4]) {
-        chunk_top(ps * nq1 + q, q + 2 < nq1 ? q + 2 : -1);
+      auto step = [&](int q, frag (&Bcur)[CG][4], frag (&Bload)[CG][4]) {
+        // CG == 2 requests UNCONDITIONALLY (the last two chunks of a pass re-request their own rows, L2 hits, into the group
+        // that is idle anyway): a request under its own branch gave its destination two reaching definitions, and with the
+        // register pressure of 64 columns per wave hipcc then loads into a scratch register and copies it home after the join
+        // -- before the data has landed (tools/check_asm_regs.py).  The pass end drains them (below).
+        chunk_top(ps * nq1 + q, q + 2 < nq1 ? q + 2 : (CG == 2 ? q : -1));
         // the fragments of this chunk have landed (counted wait in chunk_top): every use comes after this point
-        if constexpr (ASM_B) asm volatile("" : "+v"(Bcur[0]), "+v"(Bcur[1]), "+v"(Bcur[2]), "+v"(Bcur[3]));
+        if constexpr (ASM_B) {
+#pragma unroll
+          for (int c = 0; c < CG; ++c) asm volatile("" : "+v"(Bcur[c][0]), "+v"(Bcur[c][1]), "+v"(Bcur[c][2]), "+v"(Bcur[c][3]));
+        }
         fix_B(q, Bcur);
         const char* buf = smem + slot_c * CHB + lane * 16;
         auto filler = [&](auto ic) {
@@ -312,9 +333,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
             if constexpr (k < PPW) {
               if (dsrc) dma_piece(dsrc + k * 1024, ddst + k * 1024);
             } else {
-              if (bsrc) {
-                if constexpr (ASM_B) gload_async<(k - PPW) * 32>(Bload[k - PPW], bsrc);
-                else Bload[k - PPW] = *(const frag*)(bsrc + (k - PPW) * 32);
+              constexpr int c = (k - PPW) / 4, blk = (k - PPW) % 4;
+              if (CG == 2 || bsrc[c]) {
+                if constexpr (ASM_B) gload_async<blk * 32>(Bload[c][blk], bsrc[c]);
+                else Bload[c][blk] = *(const frag*)(bsrc[c] + blk * 32);
               }
             }
           }
@@ -322,7 +344,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
 #ifdef WAE_GLU_STAMPS
         const unsigned long long g0 = TICK();
 #endif
-        gemm_chunk_fill<NSTEP, NM, 4, false, 4>(buf, Bcur, acc, filler);
+        gemm_chunk_fill_cg<4 * NM, NM, 4, CG, false, 4>(buf, Bcur, acc, filler);
 #ifdef WAE_GLU_STAMPS
         acc_gemm += TICK() - g0;
 #endif
@@ -336,57 +358,72 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
       }
       if (q < nq1) step(q, S0, S2);
       if (q + 1 < nq1) step(q + 1, S1, S0);
+      if constexpr (CG == 2 && ASM_B) {
+        // retire the re-requests of the pass's last two chunks before their registers can be given to anything else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+          asm volatile("" : "+v"(S0[c][0]), "+v"(S0[c][1]), "+v"(S0[c][2]), "+v"(S0[c][3]));
+          asm volatile("" : "+v"(S1[c][0]), "+v"(S1[c][1]), "+v"(S1[c][2]), "+v"(S1[c][3]));
+          asm volatile("" : "+v"(S2[c][0]), "+v"(S2[c][1]), "+v"(S2[c][2]), "+v"(S2[c][3]));
+        }
+      }
       if (ps + 1 < NPASS) {  // the next pass's first two chunks travel under the gate
         load_B(0, S0);
         load_B(1, S1);
-        w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : 4;
+        w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : NBL;
       }
     }
     if (ps == 0) STAMP(2);
 
-    // ---- optional z save (training): rows of 2Hp elements, a-half then b-half --------------------------
-    if ((p.flags & WAE_GLU_SAVE_Z) && rows_valid > 0) {
-      char* zr = p.z_save + (((int64_t)b * p.T + t0w) * (2 * p.Hp) + ps * NPH * 32) * ES;
-      stage_store_tiles<E, NPH, PITCH>(stg, &acc[0], zr, (int64_t)2 * p.Hp * ES, rows_valid, lane);
-      stage_store_tiles<E, NPH, PITCH>(stg, &acc[NPH], zr + (int64_t)p.Hp * ES, (int64_t)2 * p.Hp * ES, rows_valid, lane);
-    }
-
-    // ---- gate: u = tanh(a) * sigmoid(b); stored once for the head's skip GEMM, and converted in place to the
-    //      operand fragments of GEMM 2 -------------------------------------------------------------------
 #pragma unroll
-    for (int pr = 0; pr < NPH; ++pr) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float a = acc[pr][r], g = acc[NPH + pr][r];
-        float u;
-        if (ABL(p.flags, DBG_NO_GATE)) {
-          u = a * g;
-        } else if constexpr (EXACT) {
-          u = tanhf(a) * (1.0f / (1.0f + expf(-g)));
-        } else {
-          // tanh(a)*sigmoid(g) = (1-ea) / ((1+ea)(1+eg)), ea = e^-2a, eg = e^-g.  a is clamped from below so that
-          // ea stays finite (tanh(-15) == -1 in fp32); eg = inf gives rcp(inf) = 0, the correct limit.
-          const f32x2 sc = {-2.885390081777927f, -1.4426950408889634f};
-          f32x2 ag = {vmax_nocanon(a, -15.0f), g};
-          ag = ag * sc;
-          const float ea = __builtin_amdgcn_exp2f(ag.x);
-          const float eg = __builtin_amdgcn_exp2f(ag.y);
-          const f32x2 one = {1.0f, 1.0f};
-          const f32x2 e2 = {ea, eg};
-          const f32x2 d = e2 + one;
-          u = (1.0f - ea) * fast_rcp(d.x * d.y);
-        }
-        acc[pr][r] = u;
+    for (int c = 0; c < CG; ++c) {
+      const int rows_valid = min(max(p.T - (t0w + 32 * c), 0), 32);
+      const int64_t row0 = (int64_t)b * p.T + t0w + 32 * c;
+      // ---- optional z save (training): rows of 2Hp elements, a-half then b-half --------------------------
+      if ((p.flags & WAE_GLU_SAVE_Z) && rows_valid > 0) {
+        char* zr = p.z_save + (row0 * (2 * p.Hp) + ps * NPH * 32) * ES;
+        stage_store_tiles<E, NPH, PITCH>(stg, &acc[c][0], zr, (int64_t)2 * p.Hp * ES, rows_valid, lane);
+        stage_store_tiles<E, NPH, PITCH>(stg, &acc[c][NPH], zr + (int64_t)p.Hp * ES, (int64_t)2 * p.Hp * ES, rows_valid, lane);
       }
-      frag tmp[KBU];
-      acc_to_frags(acc[pr], tmp);
+
+      // ---- gate: u = tanh(a) * sigmoid(b); stored once for the head's skip GEMM, and converted in place to the
+      //      operand fragments of GEMM 2 -------------------------------------------------------------------
 #pragma unroll
-      for (int s = 0; s < KBU; ++s) uf[(ps * NPH + pr) * KBU + s] = tmp[s];
-      __builtin_amdgcn_sched_barrier(0);  // one tile at a time: keeps the gate's temporaries from piling up
-    }
-    if (!no_epi && rows_valid > 0) {
-      char* ur = p.u_out + (((int64_t)b * p.T + t0w) * p.u_stride + ps * NPH * 32) * ES;
-      stage_store_tiles<E, NPH, PITCH>(stg, &acc[0], ur, p.u_stride * ES, rows_valid, lane);
+      for (int pr = 0; pr < NPH; ++pr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = acc[c][pr][r], g = acc[c][NPH + pr][r];
+          float u;
+          if (ABL(p.flags, DBG_NO_GATE)) {
+            u = a * g;
+          } else if constexpr (EXACT) {
+            u = tanhf(a) * (1.0f / (1.0f + expf(-g)));
+          } else {
+            // tanh(a)*sigmoid(g) = (1-ea) / ((1+ea)(1+eg)), ea = e^-2a, eg = e^-g.  a is clamped from below so that
+            // ea stays finite (tanh(-15) == -1 in fp32); eg = inf gives rcp(inf) = 0, the correct limit.
+            const f32x2 sc = {-2.885390081777927f, -1.4426950408889634f};
+            f32x2 ag = {vmax_nocanon(a, -15.0f), g};
+            ag = ag * sc;
+            const float ea = __builtin_amdgcn_exp2f(ag.x);
+            const float eg = __builtin_amdgcn_exp2f(ag.y);
+            const f32x2 one = {1.0f, 1.0f};
+            const f32x2 e2 = {ea, eg};
+            const f32x2 d = e2 + one;
+            u = (1.0f - ea) * fast_rcp(d.x * d.y);
+          }
+          acc[c][pr][r] = u;
+        }
+        frag tmp[KBU];
+        acc_to_frags(acc[c][pr], tmp);
+#pragma unroll
+        for (int s = 0; s < KBU; ++s) uf[c][(ps * NPH + pr) * KBU + s] = tmp[s];
+        __builtin_amdgcn_sched_barrier(0);  // one tile at a time: keeps the gate's temporaries from piling up
+      }
+      if (!no_epi && rows_valid > 0) {
+        char* ur = p.u_out + (row0 * p.u_stride + ps * NPH * 32) * ES;
+        stage_store_tiles<E, NPH, PITCH>(stg, &acc[c][0], ur, p.u_stride * ES, rows_valid, lane);
+      }
     }
   }
   STAMP(3);
@@ -409,38 +446,48 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
     // residual x[t] for this chunk's channels, as operand-shaped 16-byte fragments (L2 hits: tap k-1 of GEMM 1
     // read the same bytes); issued now, consumed after the MFMAs
     constexpr int NRES = ES == 2 ? 2 * MT2 : 4 * MT2;  // 16-byte fragments per lane (32 bytes of the row per pair)
-    frag res[NRES];
-    {
-      const char* rsrc = xb + (int64_t)(tvalid ? t : 0) * row_x + (int64_t)gm0 * 32 * ES + h * 16;
+    frag res[CG][NRES];
 #pragma unroll
-      for (int f = 0; f < NRES; ++f) res[f] = *(const frag*)(rsrc + f * 32);
+    for (int c = 0; c < CG; ++c) {
+      const int tc = t + 32 * c;
+      const char* rsrc = xb + (int64_t)(tc < p.T ? tc : 0) * row_x + (int64_t)gm0 * 32 * ES + h * 16;
+#pragma unroll
+      for (int f = 0; f < NRES; ++f) res[c][f] = *(const frag*)(rsrc + f * 32);
     }
-    f32x16 y[MT2];
+    f32x16 y[CG][MT2];
 #pragma unroll
-    for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], bias_lds + 32 * (gm0 + mt), h);
-    gemm_chunk<MT2 * NKB, MT2, NKB, true>(buf, uf, y);
+    for (int mt = 0; mt < MT2; ++mt) {
+      init_rows(y[0][mt], bias_lds + 32 * (gm0 + mt), h);
+      if constexpr (CG == 2) y[1][mt] = y[0][mt];
+    }
+    NoFiller nf;
+    gemm_chunk_fill_cg<MT2 * NKB, MT2, NKB, CG, true, 8>(buf, uf, y, nf);
     if (no_epi) {
-      if (y[0][0] == 12345.678f && tvalid) p.x_out[t] = (char)y[MT2 - 1][3];  // keep the MFMAs alive
+      if (y[0][0][0] == 12345.678f && t < p.T) p.x_out[t] = (char)y[CG - 1][MT2 - 1][3];  // keep the MFMAs alive
       continue;
     }
     // x' = (y + x) * sqrt(.5) in the accumulator layout
     const f32x2 rs = {0.70710678118654752440f, 0.70710678118654752440f};
-    residual_to_acc_layout(res);
 #pragma unroll
-    for (int mt = 0; mt < MT2; ++mt) {
+    for (int c = 0; c < CG; ++c) {
+      residual_to_acc_layout(res[c]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 r4 = residual_piece<E>(res, mt, g);
-        f32x2 lo = {y[mt][4 * g + 0], y[mt][4 * g + 1]}, hi = {y[mt][4 * g + 2], y[mt][4 * g + 3]};
-        const f32x2 rlo = {r4.x, r4.y}, rhi = {r4.z, r4.w};
-        lo = (lo + rlo) * rs;
-        hi = (hi + rhi) * rs;
-        y[mt][4 * g + 0] = lo.x; y[mt][4 * g + 1] = lo.y; y[mt][4 * g + 2] = hi.x; y[mt][4 * g + 3] = hi.y;
+      for (int mt = 0; mt < MT2; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 r4 = residual_piece<E>(res[c], mt, g);
+          f32x2 lo = {y[c][mt][4 * g + 0], y[c][mt][4 * g + 1]}, hi = {y[c][mt][4 * g + 2], y[c][mt][4 * g + 3]};
+          const f32x2 rlo = {r4.x, r4.y}, rhi = {r4.z, r4.w};
+          lo = (lo + rlo) * rs;
+          hi = (hi + rhi) * rs;
+          y[c][mt][4 * g + 0] = lo.x; y[c][mt][4 * g + 1] = lo.y; y[c][mt][4 * g + 2] = hi.x; y[c][mt][4 * g + 3] = hi.y;
+        }
       }
-    }
-    if (rows_valid > 0) {
-      char* orow = p.x_out + ((int64_t)b * p.T + t0w) * row_x + (int64_t)gm0 * 32 * ES;
-      stage_store_tiles<E, MT2, PITCH>(stg, y, orow, row_x, rows_valid, lane);
+      const int rows_valid = min(max(p.T - (t0w + 32 * c), 0), 32);
+      if (rows_valid > 0) {
+        char* orow = p.x_out + ((int64_t)b * p.T + t0w + 32 * c) * row_x + (int64_t)gm0 * 32 * ES;
+        stage_store_tiles<E, MT2, PITCH>(stg, y[c], orow, row_x, rows_valid, lane);
+      }
     }
   }
   STAMP(4);
@@ -459,11 +506,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2) ? 2 : 1) 
 // with z saved; A/B on one box, WAE_GLU_WAVES=4|8); before those two changes the 4-wave shape was the faster one.
 // The caller picks the shape per launch with WAE_GLU_WAVES4 in wae_glu_desc.flags (default: 8 waves).
 
-template <typename E, int NP, int NPH, bool EXACT, int NW>
+template <typename E, int NP, int NPH, bool EXACT, int NW, int CG>
 static int launch_glu_nw(GluArgs a, hipStream_t st) {
   constexpr int CHB = 2 * NPH * 4 * 1024;
   const size_t fixed = NW * 4096 + (size_t)(a.Rp + 2 * a.Hp) * 4;
-  const size_t budget = ((NW == 4 && sizeof(E) == 2) ? 80 : 160) * 1024;   // bf16, NW == 4: two workgroups share a CU
+  const size_t budget = ((NW == 4 && sizeof(E) == 2 && CG == 1) ? 80 : 160) * 1024;   // 16-bit, NW == 4, CG == 1: two workgroups share a CU
   int nslot = fixed + 2 * CHB <= budget ? (int)((budget - fixed) / CHB) : 0;
   // four slots (weights three chunks ahead) measure best once the requests really stay in flight: 57.2 us against 58.1 (3
   // slots) and 59.1 (5) at C2 inference, tools/time_glu.py
@@ -476,9 +523,9 @@ static int launch_glu_nw(GluArgs a, hipStream_t st) {
   a.nslot = nslot;
   const size_t lds = fixed + (size_t)nslot * CHB;
   static WaeLdsCache lds_cache;
-  if (int rc = wae_ensure_lds((const void*)glu_fwd_kernel<E, NP, NPH, EXACT, NW>, lds_cache, lds, "glu_fwd"); rc != WAE_OK) return rc;
-  const int tiles = (a.T + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL((glu_fwd_kernel<E, NP, NPH, EXACT, NW>), dim3(a.B * tiles), dim3(NW * 64), lds, st, a);
+  if (int rc = wae_ensure_lds((const void*)glu_fwd_kernel<E, NP, NPH, EXACT, NW, CG>, lds_cache, lds, "glu_fwd"); rc != WAE_OK) return rc;
+  const int tiles = (a.T + NW * 32 * CG - 1) / (NW * 32 * CG);
+  hipLaunchKernelGGL((glu_fwd_kernel<E, NP, NPH, EXACT, NW, CG>), dim3(a.B * tiles), dim3(NW * 64), lds, st, a);
   return wae_check_launch("glu_fwd");
 }
 
@@ -486,11 +533,13 @@ template <typename E, int NP, int NPH, bool EXACT>
 static int launch_glu(const GluArgs& a, hipStream_t st) {
   // fp32 (the parity mode) keeps 4 waves with 512 registers each: its operand fragments are twice as many
   if constexpr (sizeof(E) == 2) {
+    // WAE_GLU_CG2: 4 waves x 64 columns, one wave per SIMD, every A fragment feeds two MFMAs
+    if (a.flags & WAE_GLU_CG2) return launch_glu_nw<E, NP, NPH, EXACT, 4, 2>(a, st);
     // two 4-wave workgroups per CU need a two-slot ring in 80 KiB each; wider layers take the whole CU with 8 waves
     const bool fits4 = 4 * 4096 + (size_t)(a.Rp + 2 * a.Hp) * 4 + 2 * (2 * NPH * 4096) <= 80 * 1024;
-    if (!(a.flags & WAE_GLU_WAVES4) || !fits4) return launch_glu_nw<E, NP, NPH, EXACT, 8>(a, st);
+    if (!(a.flags & WAE_GLU_WAVES4) || !fits4) return launch_glu_nw<E, NP, NPH, EXACT, 8, 1>(a, st);
   }
-  return launch_glu_nw<E, NP, NPH, EXACT, 4>(a, st);
+  return launch_glu_nw<E, NP, NPH, EXACT, 4, 1>(a, st);
 }
 
 template <typename E, bool EXACT>

@@ -252,13 +252,58 @@ __device__ __forceinline__ void gemm_chunk(const char* buf, const frag (&B)[NB],
   gemm_chunk_fill<N, NM, NB, KMAJOR, PDMAX>(buf, B, acc, nf);
 }
 
+// The same chunk against CG column groups per wave (CG = 2: 64 time columns): every A fragment read from LDS feeds CG MFMAs,
+// so the LDS read traffic per MFMA is 1/CG KiB.  With CG = 1 the matrix pipe and the LDS port are exactly co-limited (one
+// 1-KiB fragment per 32-cycle MFMA per SIMD = 128 B/clk); CG = 2 leaves the port half idle for the DMA writes and the
+// staging tiles.  The filler runs after every MFMA (index I * CG + c).
+template <int I, int N, int NM, int PD, int NB, int CG, bool KMAJOR, typename frag, typename F>
+struct GemmChunkStepCG {
+  static __device__ __forceinline__ void run(unsigned addr, frag (&a)[PD], const frag (&B)[CG][NB], f32x16 (&acc)[CG][NM], F& filler) {
+    constexpr int remaining = N - 1 - I;
+    constexpr int cnt = remaining < PD - 1 ? remaining : PD - 1;
+    lds_wait<cnt>(a[I % PD]);
+    if constexpr (KMAJOR)
+      mma32(acc[0][I / NB], a[I % PD], B[0][I % NB]);
+    else
+      mma32(acc[0][I % NM], a[I % PD], B[0][I / NM]);
+    filler(IntC<I * CG>{});
+    if constexpr (CG == 2) {
+      if constexpr (KMAJOR)
+        mma32(acc[1][I / NB], a[I % PD], B[1][I % NB]);
+      else
+        mma32(acc[1][I % NM], a[I % PD], B[1][I / NM]);
+      filler(IntC<I * CG + 1>{});
+    }
+    if constexpr (I + PD < N) lds_read_async<(I + PD) * 1024>(a[I % PD], addr);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 1 < N) GemmChunkStepCG<I + 1, N, NM, PD, NB, CG, KMAJOR, frag, F>::run(addr, a, B, acc, filler);
+  }
+};
+template <int N, int NM, int NB, int CG, bool KMAJOR = false, int PDMAX = 8, typename frag, typename F>
+__device__ __forceinline__ void gemm_chunk_fill_cg(const char* buf, const frag (&B)[CG][NB], f32x16 (&acc)[CG][NM], F& filler) {
+  constexpr int PD = N < PDMAX ? N : PDMAX;
+  static_assert((N - 1) * 1024 < 65536, "ds_read offset field is 16 bits");
+  static_assert(CG == 1 || CG == 2, "one or two column groups per wave");
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)buf;
+  frag a[PD];
+  __builtin_amdgcn_sched_barrier(0);
+  GemmChunkPrologue<0, PD, frag>::run(addr, a);
+  GemmChunkStepCG<0, N, NM, PD, NB, CG, KMAJOR, frag, F>::run(addr, a, B, acc, filler);
+}
+
 // Operand fragments requested by inline asm and retired by a counted wait that carries the destinations ("+v": every use
 // comes after it).  hipcc's own bookkeeping puts s_waitcnt vmcnt(0) in front of the first use of a loop-carried plain load,
 // which drains the LDS-DMA requests of the NEXT chunks that were issued after it (vmcnt retires in order).
+// The destination is a READ-WRITE operand ("+v"): the load lands in the register that held the fragment's previous value.
+// With a write-only output hipcc may (a) give a conditionally executed request a scratch destination and copy it to the
+// fragment's home register right after the join -- reading it before it has landed, after which the landing load overwrites
+// whatever the scratch register holds by then (a wild pointer, in the first 64-column build of glu_fwd) -- or (b) treat a
+// request whose result is overwritten before use as a dead definition and point it at registers that are in use.
+// tools/check_asm_regs.py scans the built ISA for any instruction that touches a requested register before its counted wait.
 template <int OFF, typename F>
 __device__ __forceinline__ void gload_async(F& dst, const char* ptr) {
   static_assert(sizeof(F) == 16, "one 16-byte fragment");
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF));
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(ptr), "n"(OFF));
 }
 template <int CNT, typename F>
 __device__ __forceinline__ void wait_vmcnt_frags(F (&a)[4]) {

@@ -39,6 +39,8 @@ class WaeEngine:
         self.lib = L.lib()
         # A/B switch of the fused layer kernel's workgroup shape (4 or 8 waves): a descriptor flag of every launch
         self.glu_flags = L.GLU_WAVES4 if os.environ.get("WAE_GLU_WAVES") == "4" else 0
+        if os.environ.get("WAE_GLU_CG", "1") == "2":
+            self.glu_flags |= L.GLU_CG2
         self.g = geom
         self.dt = _dt(dtype)
         self.tdtype = {L.WAE_BF16: torch.bfloat16, L.WAE_F16: torch.float16, L.WAE_F32: torch.float32}[self.dt]

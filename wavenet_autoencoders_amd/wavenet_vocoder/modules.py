@@ -14,15 +14,14 @@ class ResidualConv1dGLU(ArenaModel):
     """x' , s = layer(x, c, g):  z = conv_dilated(x) + conv1x1c(c) + conv1x1g(g); u = tanh(z_a) * sigmoid(z_b);
     s = conv1x1_skip(u); x' = (conv1x1_out(u) + x) * sqrt(.5)   (modules.py:115-163).
 
-    Same constructor as the reference (modules.py:71-75).  Supported: causal=True, bias=True, dropout 0 (what the
-    reference's WaveNet builds, wavenet.py:127-134), global features constant over time (the reference expands one
+    Same constructor as the reference (modules.py:71-75).  Supported: causal=True, bias=True (what the reference's WaveNet builds,
+    wavenet.py:127-134), any dropout in eval mode and dropout 0 in train mode, global features constant over time (the reference expands one
     speaker vector, wavenet.py:185-194)."""
 
     def __init__(self, residual_channels, gate_channels, kernel_size, skip_out_channels=None, cin_channels=-1, gin_channels=-1,
                  dropout=1 - 0.95, padding=None, dilation=1, causal=True, bias=True, *args, **kwargs):
         super().__init__()
-        if dropout not in (0, 0.0):
-            raise NotImplementedError("dropout > 0 is not supported by the fused layer kernel (all presets use 0.0)")
+        self.dropout = float(dropout)          # identity in eval mode (modules.py:127-128); a train-mode call with p > 0 raises
         if not causal or not bias:
             raise NotImplementedError("only the causal, biased layer the reference's WaveNet builds is implemented")
         if padding is not None and padding != (kernel_size - 1) * dilation:
@@ -39,6 +38,9 @@ class ResidualConv1dGLU(ArenaModel):
 
     # ------------------------------------------------------------------ kernels
     def _run(self, x, c, g):
+        if self.training and self.dropout > 0:
+            raise NotImplementedError(f"training-mode forward with dropout={self.dropout} is not implemented (every preset uses 0.0; "
+                                      "eval mode is exact for any value): pass dropout=0.0 or call .eval()")
         eng = self.engine()
         gm, lib, st = eng.g, eng.lib, eng.stream()
         B, R, T = x.shape

@@ -77,9 +77,11 @@ class WaveNet(ArenaModel):
                  upsample_params={"upsample_scales": [4, 4, 4, 4]}, scalar_input=False, use_speaker_embedding=False,
                  output_distribution="Logistic", cin_pad=0, _prefix=""):
         super().__init__()
-        if dropout not in (0, 0.0):
-            # every shipped preset has dropout 0.0 (hps/*.json); the fused layer kernel has no dropout stage
-            raise NotImplementedError("dropout > 0 is not supported by the fused layer kernel (all presets use 0.0)")
+        # modules.py:127-128 applies F.dropout(x, p, training=self.training) in front of every dilated convolution: identity in
+        # eval mode (synthesis, feature export, the dev phase) for any p.  The reference's constructor default is 0.05
+        # (wavenet.py:98-111) while every shipped preset trains with 0.0 (hps/*.json): the model is built for any p, and a
+        # TRAIN-mode forward with p > 0 raises (the fused layer kernel has no mask stage) instead of silently training without.
+        self.dropout = float(dropout)
         if upsample_conditional_features and upsample_net != "ConvInUpsampleNetwork":
             raise NotImplementedError("only ConvInUpsampleNetwork (the reference default) is implemented")
         self.scalar_input = scalar_input
@@ -111,6 +113,9 @@ class WaveNet(ArenaModel):
         c_is_up = not bool(self.geom.upsample_scales)
         params = [p for _, p in sorted(((n, p) for n, p in self.named_parameters()), key=lambda kv: self._pnames.index(kv[0]))]
         train = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or (c is not None and c.requires_grad))
+        if self.training and self.dropout > 0:
+            raise NotImplementedError(f"training-mode forward with dropout={self.dropout} is not implemented (every preset uses 0.0; "
+                                      "eval mode is exact for any value): pass dropout=0.0 or call .eval()")
         y = _DecoderFn.apply(self, ids, c, g, c_is_up, train, *params)
         return torch.softmax(y, dim=1) if softmax else y
 
