@@ -237,3 +237,38 @@ def test_c2_full_size_backward_properties(monkeypatch):
     g_alone, _ = grads_of("fp32", "0", x[:1], lat[:1], g[:1], torch.tensor([T]))
     rel = float((g_masked - g_alone).double().norm() / g_alone.double().norm())
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_grad_sync_path_equals_plain_backward(dtype):
+    """Data-parallel step order: with a GradSync the layers' + head's slice of the arena goes through the sliced
+    weight-norm backward and is handed over inside decoder_backward, the rest in finish_grads.  Single process (no collective
+    runs): the gradients and the updated weights must equal those of the plain order."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.distributed import GradSync
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    lengths = torch.tensor([x.shape[1], x.shape[1] - 333])
+    got = {}
+    for tag in ("plain", "sync"):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        eng.init_optimizer()
+        seen = {}
+        sync = GradSync(eng) if tag == "sync" else None
+        if sync is not None:
+            lo, hi = BW.layer_segment(eng)
+            assert 0 < lo < hi < eng.lay.total and (hi - lo) > 0.5 * eng.lay.total
+            assert any(b[0] == lo for b in sync.bounds) and any(b[1] == hi for b in sync.bounds)
+        r = eng.train_step(x, c, g, lengths=lengths, grad_sync=sync, grad_hook=lambda gr: seen.setdefault("g", gr.clone()))
+        torch.cuda.synchronize()
+        if sync is not None:
+            assert sync.launched == [False] * len(sync.bounds)          # finish() re-armed the buckets
+        got[tag] = (seen["g"].cpu(), eng.params.cpu().clone(), float(r["loss"]), float(r["grad_norm"]))
+    ga, gb = got["plain"][0], got["sync"][0]
+    tol = 1e-6 if dtype == "fp32" else 1e-5            # fp32 atomics arrive in another order
+    assert float((ga - gb).abs().max()) <= tol * float(ga.abs().max())
+    assert float((got["plain"][1] - got["sync"][1]).abs().max()) < 1e-6
+    assert abs(got["plain"][2] - got["sync"][2]) < 1e-6 and abs(got["plain"][3] - got["sync"][3]) < 1e-4 * got["plain"][3]

@@ -212,12 +212,20 @@ class StreamTable:
         self.jobs_dev = torch.frombuffer(bytearray(bytes((L.TsJob * len(jobs))(*jobs))), dtype=torch.uint8).to(dev)
         self.segs_dev = torch.frombuffer(bytearray(bytes((L.TsSeg * len(segs))(*segs))), dtype=torch.uint8).to(dev)
         self.team_seg_dev = torch.tensor(team_seg, dtype=torch.int32, device=dev)
+        # team pacing (csrc/gemm_tn_stream.hip): one row of consumed-slab positions per team, zeroed before every launch
+        self.pace = torch.zeros(self.nteams * 8, dtype=torch.int32, device=dev)
+        # A/B only: measured SLOWER at C2 (unpaced 1.46-1.70 ms; window 2 / 4 / 8 / 16 / 32 slabs: 1.96 / 1.87 / 1.83 / 1.81 /
+        # 1.82 ms, tools/ab_tn_pace.py) -- the launch is bound by the per-slab issue / barrier pipeline, not by HBM bytes
+        self.window = int(os.environ.get("WAE_TN_PACE", "0"))      # slabs; 0 = no pacing (default)
         return self
 
     def launch(self):
         eng = self.eng
+        if self.window > 0:
+            self.pace.zero_()
         L.check(eng.lib.wae_gemm_tn_stream(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
-                                           self.team_size, self.nwg, self.B, self.T, eng.stream()), "gemm_tn_stream")
+                                           self.team_size, self.nwg, self.B, self.T, L.ptr(self.pace), self.window, eng.stream()),
+                "gemm_tn_stream")
 
 
 def use_stream_tn(eng):

@@ -38,6 +38,8 @@ struct TsArgs {
   const int* team_seg;   // [nteams + 1] prefix offsets into segs
   int nteams, team_size;
   int B, T, spc;
+  int* pace;     // [nteams][8] slab positions consumed by each member (zeroed by the caller before the launch), or null
+  int window;    // a member requests at most `window` slabs beyond the slowest member of its team
 };
 
 #define TS_KT 32
@@ -66,7 +68,29 @@ __device__ __forceinline__ void ts_wait_vmcnt(int w) {
 #undef TS_VMC
 }
 
-template <typename E>   // __bf16 or f16: 16-bit operands (the DMA and the transposed LDS reads move bits), fp32 result
+// Team pacing.  The members of a team (the jobs of one layer: three taps, the conditioning 1x1, conv1x1_out) stream the same
+// time slabs, and four of them read the same dz slab as their P operand -- but the XCD's 4 MiB L2 is shared by ~6 teams, a team's
+// share holds about five slabs of everything it streams, and unpaced members drift apart by more than that (the light jobs run
+// ahead): round 1 measured an L2 hit rate of 28 % and 6.07 GB fetched for 3.47 GB of unique operands -- no sharing at all.
+// Each member publishes the position it has consumed ((segment << 20) | slab in segment); wave 0 keeps a copy of the team's row,
+// refreshed by a scalar load (SMEM: counted by lgkmcnt, so the vmcnt bookkeeping of the LDS-DMA ring is untouched) that was
+// issued one slab earlier, and holds the whole workgroup in front of its barrier while its next REQUEST would run more than
+// `window` slabs ahead of the slowest member.  Purely a timing device: a wait that does not end within ~0.3 ms switches pacing
+// off for the rest of the launch (no member can hang the device), results never depend on it.
+typedef __attribute__((ext_vector_type(8))) int ts_i32x8;
+__device__ __forceinline__ void ts_row_request(ts_i32x8& row, const int* p) {
+  asm volatile("s_load_dwordx8 %0, %1, 0x0 glc" : "=s"(row) : "s"(p));
+}
+__device__ __forceinline__ void ts_row_wait(ts_i32x8& row) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(row)); }
+__device__ __forceinline__ int ts_row_min_others(const ts_i32x8& row, int me, int n) {
+  int m = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < n && i != me) m = min(m, row[i]);
+  return m;
+}
+
+template <typename E, bool PACED>   // E: __bf16 or f16 (the DMA and the transposed LDS reads move bits), fp32 result
 __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -83,10 +107,24 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
   const int team = logical / p.team_size, member = logical - team * p.team_size;
   if (team >= p.nteams) return;
   const int seg_b = p.team_seg[team], seg_e = p.team_seg[team + 1];
+  int* pace_row = PACED ? p.pace + team * 8 : nullptr;
+  bool pacing = PACED;
+  ts_i32x8 row = {};
+  // a member publishes the position of its next REQUEST: requests are what fetch from HBM / L2, and the member with the
+  // smallest request position never waits (no cycle of waits can form, whatever slabs the members skip)
+  auto publish = [&](int pos) {   // one lane, fire and forget (an agent-scope store: visible to the other CUs' scalar loads)
+    if constexpr (PACED) {
+      if (threadIdx.x == 0) __hip_atomic_store(pace_row + member, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   for (int si = seg_b; si < seg_e; ++si) {
     const TsSeg sg = p.segs[si];
     const TsJob jb = p.jobs[sg.job + member];
-    if (jb.m_valid <= 0) continue;   // null job (e.g. the last layer has no conv1x1_out gradient)
+    const int seg_pos = (si - seg_b) << 20;
+    if (jb.m_valid <= 0) {   // null job (e.g. the last layer has no conv1x1_out gradient): done with this segment at once
+      publish(seg_pos + (1 << 20));
+      continue;
+    }
     const int up_valid = (jb.m_valid + 7) >> 3, uq_valid = (jb.n_valid + 7) >> 3;
     // This wave's DMA pieces: piece pc = wave + 12 j of the slot image [P slab | Q slab]; lane -> one 16-byte unit.
     // Per lane and piece: validity bit and byte offset from the slab's first row (kept in 5 registers across the MFMA
@@ -225,8 +263,27 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
       slot_i = slot_i + 1 == TS_NS ? 0 : slot_i + 1;
       cur_adv(ci);
     }
+    if constexpr (PACED) {
+      publish(seg_pos + min(ci.s, sg.slab_end) - sg.slab_begin);
+      if (pacing && wave == 0) ts_row_request(row, pace_row);
+    }
     while (cc.s < sg.slab_end) {
       ts_wait_vmcnt(np_issued * (ahead - 1));   // the oldest requested slab has landed; younger requests stay in flight
+      if constexpr (PACED) {
+        if (pacing && wave == 0 && ci.s < sg.slab_end) {
+          // the slab about to be requested against the slowest other member's request position (one slab old, refreshed below)
+          ts_row_wait(row);
+          const int mine = seg_pos + (ci.s - sg.slab_begin);
+          int spins = 0;
+          while (mine - ts_row_min_others(row, member, p.team_size) > p.window) {
+            __builtin_amdgcn_s_sleep(4);
+            ts_row_request(row, pace_row);
+            ts_row_wait(row);
+            if (++spins > 512) { pacing = false; break; }   // ~0.5 ms: give up pacing, never hang
+          }
+          if (pacing) ts_row_request(row, pace_row);
+        }
+      }
       zero_invalid_rows(cc, slot_c);
       // bare barrier (not __syncthreads(): its fence is lowered to s_waitcnt vmcnt(0) and would drain the prefetch);
       // the zero-fill stores, if any, are retired first
@@ -237,6 +294,7 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
         slot_i = slot_i + 1 == TS_NS ? 0 : slot_i + 1;
         cur_adv(ci);
         ++ahead;
+        publish(seg_pos + min(ci.s, sg.slab_end) - sg.slab_begin);
       }
       if (jb.ones_col >= 0 && cc.b != cur_b) {   // clip change (workgroup-uniform): move the ones to the new clip's column
         if (threadIdx.x < TS_NS * TS_KT) {
@@ -304,6 +362,10 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
       --ahead;
       cur_adv(cc);
     }
+    if constexpr (PACED) {
+      if (wave == 0) ts_row_wait(row);           // no scalar load left in flight across the epilogue
+      publish(seg_pos + (1 << 20));              // this member is done with the segment
+    }
 
     // the MFMAs above are opaque to the compiler's hazard recogniser: cover the MFMA-result -> VALU-read wait states here
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -331,7 +393,8 @@ __global__ void __launch_bounds__(TS_NW * 64, 1) gemm_tn_stream_kernel(TsArgs p)
 }
 
 extern "C" int wae_gemm_tn_stream(int32_t dtype, const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
-                                  int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, void* stream) {
+                                  int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, int32_t* pace,
+                                  int32_t window, void* stream) {
   WAE_REQUIRE(dtype == WAE_BF16 || dtype == WAE_F16, "gemm_tn_stream: 16-bit operands only (fp32 runs take wae_gemm_tn_tiles)");
   WAE_REQUIRE(jobs_dev && segs_dev && team_seg_dev && nteams > 0 && team_size > 0 && nwg >= nteams * team_size && B > 0 && T > 0,
               "gemm_tn_stream: bad arguments");
@@ -345,15 +408,19 @@ extern "C" int wae_gemm_tn_stream(int32_t dtype, const wae_ts_job* jobs_dev, con
   a.team_seg = team_seg_dev;
   a.nteams = nteams; a.team_size = team_size;
   a.B = B; a.T = T; a.spc = (T + TS_KT - 1) / TS_KT;
+  a.pace = window > 0 ? pace : nullptr;
+  a.window = window;
   const size_t lds = (size_t)TS_NS * TS_SLOT;
-  if (dtype == WAE_F16) {
-    static WaeLdsCache lds_cache;
-    if (int rc = wae_ensure_lds((const void*)gemm_tn_stream_kernel<f16>, lds_cache, lds, "gemm_tn_stream"); rc != WAE_OK) return rc;
-    hipLaunchKernelGGL(gemm_tn_stream_kernel<f16>, dim3(nwg), dim3(TS_NW * 64), lds, as_stream(stream), a);
-  } else {
-    static WaeLdsCache lds_cache;
-    if (int rc = wae_ensure_lds((const void*)gemm_tn_stream_kernel<__bf16>, lds_cache, lds, "gemm_tn_stream"); rc != WAE_OK) return rc;
-    hipLaunchKernelGGL(gemm_tn_stream_kernel<__bf16>, dim3(nwg), dim3(TS_NW * 64), lds, as_stream(stream), a);
-  }
+  const bool paced = a.pace != nullptr && team_size > 1 && team_size <= 8;
+  auto go = [&](auto kernel) -> int {
+    static WaeLdsCache lds_cache;   // one per instantiation of this lambda's call operator, i.e. per kernel
+    if (int rc = wae_ensure_lds((const void*)kernel, lds_cache, lds, "gemm_tn_stream"); rc != WAE_OK) return rc;
+    hipLaunchKernelGGL(kernel, dim3(nwg), dim3(TS_NW * 64), lds, as_stream(stream), a);
+    return WAE_OK;
+  };
+  int rc;
+  if (dtype == WAE_F16) rc = paced ? go(gemm_tn_stream_kernel<f16, true>) : go(gemm_tn_stream_kernel<f16, false>);
+  else rc = paced ? go(gemm_tn_stream_kernel<__bf16, true>) : go(gemm_tn_stream_kernel<__bf16, false>);
+  if (rc != WAE_OK) return rc;
   return wae_check_launch("gemm_tn_stream");
 }
