@@ -167,6 +167,19 @@ typedef struct wae_glu_desc {
 int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* x_out, const void* c_up, void* u_out,
                       int64_t u_stride, const float* zb, int64_t zb_stride, void* z_save, const void* w_packed,
                       const float* bias_out, void* stream);
+/* The same layer in TRAINING with dropout > 0 (modules.py:127-128: F.dropout in front of the dilated convolution only; the
+ * residual path keeps the layer's input): x_conv = wae_dropout_fwd(x_in) is the operand of the convolution taps, x_in that
+ * of the residual add.  wae_glu_layer_fwd is this entry with x_conv = x_in. */
+int wae_glu_layer_fwd_drop(const wae_glu_desc* d, const void* x_in, const void* x_conv, void* x_out, const void* c_up, void* u_out,
+                           int64_t u_stride, const float* zb, int64_t zb_stride, void* z_save, const void* w_packed,
+                           const float* bias_out, void* stream);
+/* xd[i] = keep(seed, i) ? x[i] / (1 - p) : 0 over n elements of `dtype`; keep = a counter-based hash of (seed, i) whose top 24
+ * bits are >= p * 2^24 (restated by the oracle).  Backward of the convolution input through the same mask, fused with the
+ * residual add of modules.py:161: out[i] = alpha * (g_next[i] + (keep ? acc[i] / (1 - p) : 0)), acc = the tap contraction
+ * W1^T dz (wae_gemm_tm mode 0); the weight gradient dW1 contracts dz against xd. */
+int wae_dropout_fwd(const void* x, void* xd, int64_t n, uint64_t seed, float p, int32_t dtype, void* stream);
+int wae_dropout_bwd(const void* acc, const void* g_next, void* out, int64_t n, uint64_t seed, float p, float alpha, int32_t dtype,
+                    void* stream);
 int64_t wae_glu_packed_bytes(const wae_glu_desc* d);
 
 /* ---- a7+a8+a9 skip sum + head (wavenet.py:204-214) + MaskedCrossEntropyLoss (vqwae_train.py:363-379,:764) ---

@@ -205,18 +205,36 @@ def upsample_forward(sd: SD, c: torch.Tensor, scales: Sequence[int], prefix: str
 # --------------------------------------------------------------------------
 # a6: one gated residual layer (modules.py:115-163)
 # --------------------------------------------------------------------------
+def dropout_keep(seed: int, B: int, R: int, T: int, p: float) -> torch.Tensor:
+    """The keep mask (B, R, T) of the engine's dropout (csrc/misc.hip: dropout_keep): a counter-based hash of (seed, element
+    index in the engine's (B, T, Rp) layout, Rp = R rounded up to 128); keep iff the top 24 bits of the mix >= p * 2^24.
+    The reference draws its mask from torch's RNG (modules.py:127-128: F.dropout); the engine cannot reproduce that stream, so
+    parity is checked mask-for-mask: the oracle applies THIS mask where the reference applies torch's."""
+    Rp = (R + 127) // 128 * 128
+    e = (np.arange(B * T, dtype=np.uint64)[:, None] * np.uint64(Rp) + np.arange(R, dtype=np.uint64)[None, :])
+    with np.errstate(over="ignore"):
+        h = (e + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)) * np.uint64(0x9E3779B97F4A7C15)
+        h ^= h >> np.uint64(32)
+        h *= np.uint64(0xD6E8FEB86659FD93)
+        h ^= h >> np.uint64(32)
+    keep = (h >> np.uint64(40)).astype(np.int64) >= int(p * 16777216.0 + 0.5)
+    return torch.from_numpy(keep.reshape(B, T, R)).permute(0, 2, 1).contiguous()
+
+
 def glu_layer_forward(sd: SD, prefix: str, x: torch.Tensor, c: Optional[torch.Tensor],
-                      g: Optional[torch.Tensor], dilation: int):
+                      g: Optional[torch.Tensor], dilation: int, keep: Optional[torch.Tensor] = None, p: float = 0.0):
     """x (B,R,T), c (B,Cc,T) | None, g (B,Cg,T) or (B,Cg,1) | None -> (x' (B,R,T), s (B,S,T)).
 
+    residual = x; x = F.dropout(x, p, training) (:126-128: `keep` (B,R,T) bool is the mask in training, None = eval);
     causal dilated conv with pad (k-1)*d, tail trimmed (:134-136); split a|b (:138); add 1x1(c),
     1x1(g) halves (:141-152); tanh(a)*sigmoid(b) (:154); skip and out 1x1 (:157-160);
-    (out + residual) * sqrt(0.5) (:162).  dropout is p=0 in every preset and omitted.
+    (out + residual) * sqrt(0.5) (:162).
     """
     T = x.shape[-1]
     w = eff_weight(sd, prefix + "conv")
     k = w.shape[-1]
-    z = F.conv1d(x, w, sd.get(prefix + "conv.bias"), padding=(k - 1) * dilation, dilation=dilation)[:, :, :T]
+    xc = x if keep is None else x * keep.to(x.dtype) / (1.0 - p)
+    z = F.conv1d(xc, w, sd.get(prefix + "conv.bias"), padding=(k - 1) * dilation, dilation=dilation)[:, :, :T]
     if c is not None:
         z = z + F.conv1d(c, eff_weight(sd, prefix + "conv1x1c"))
     if g is not None:
@@ -260,7 +278,7 @@ def receptive_field_size(total_layers: int, num_cycles: int, kernel_size: int) -
 # --------------------------------------------------------------------------
 def wavenet_forward(sd: SD, cfg: dict, x: torch.Tensor, c: Optional[torch.Tensor] = None,
                     g: Optional[torch.Tensor] = None, softmax: bool = False, prefix: str = "wavenet.",
-                    return_intermediates: bool = False):
+                    return_intermediates: bool = False, dropout: Optional[Tuple[float, Sequence[int]]] = None):
     """x (B,C,T) one-hot or scalar (C=1); c (B,Cc,Tc); g (B,) int64 speaker ids or (B,Cg,1) floats.
 
     cfg keys: layers, stacks, upsample_scales (or None), cin_pad.
@@ -281,7 +299,8 @@ def wavenet_forward(sd: SD, cfg: dict, x: torch.Tensor, c: Optional[torch.Tensor
     skips = 0
     inter = []
     for i, d in enumerate(layer_dilations(cfg["layers"], cfg["stacks"])):
-        h, s = glu_layer_forward(sd, f"{prefix}conv_layers.{i}.", h, c, gb, d)
+        keep = dropout_keep(dropout[1][i], B, h.shape[1], T, dropout[0]) if dropout is not None else None   # training mode
+        h, s = glu_layer_forward(sd, f"{prefix}conv_layers.{i}.", h, c, gb, d, keep, dropout[0] if dropout is not None else 0.0)
         skips = skips + s
         if return_intermediates:
             inter.append((h, s))

@@ -272,3 +272,68 @@ def test_grad_sync_path_equals_plain_backward(dtype):
     assert float((ga - gb).abs().max()) <= tol * float(ga.abs().max())
     assert float((got["plain"][1] - got["sync"][1]).abs().max()) < 1e-6
     assert abs(got["plain"][2] - got["sync"][2]) < 1e-6 and abs(got["plain"][3] - got["sync"][3]) < 1e-4 * got["plain"][3]
+
+
+@pytest.mark.parametrize("p_drop", [0.05, 0.3])
+def test_dropout_forward_and_backward_against_oracle(p_drop):
+    """modules.py:127-128: F.dropout on the input of every dilated convolution in training mode (the residual path keeps the
+    undropped input).  The engine's mask is a counter-based hash; the oracle applies the SAME mask (oracle.dropout_keep restates
+    the hash) where the reference draws from torch's RNG: loss and every decoder parameter gradient against autograd, fp32."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype="fp32", dropout=p_drop, drop_seed=77)
+    eng.load_state_dict(sd)
+    x, g = ins["x"], ins["g"]
+    B, T = x.shape
+    c_up = torch.from_numpy(z["c_up"])
+    lengths = torch.tensor([T, T - 137])
+    out = eng.decoder_forward(x.cuda(), c_up.cuda(), g.cuda(), targets=x.cuda(), lengths=lengths.cuda(), train=True,
+                              c_is_upsampled=True, want_logits=True)
+    seeds = list(eng._drop_seeds)
+    assert seeds == [eng.layer_drop_seed(1, l) for l in range(cfg["layers"])]
+    keep0 = O.dropout_keep(seeds[0], B, cfg["R"], T, p_drop)
+    assert abs(float(keep0.float().mean()) - (1 - p_drop)) < 0.01                      # Bernoulli(1 - p)
+    assert not torch.equal(keep0, O.dropout_keep(seeds[1], B, cfg["R"], T, p_drop))    # a fresh mask per layer
+    BW.decoder_backward(eng, x.cuda(), x.cuda(), lengths, g.cuda())
+    grads = BW.finish_grads(eng)
+    torch.cuda.synchronize()
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("wavenet.") and "upsample_net" not in k}
+    y = O.wavenet_forward(psd, dict(ocfg, upsample_scales=None), ins["xin"], c_up, g, dropout=(p_drop, seeds))
+    loss = O.masked_ce_loss(y, x.unsqueeze(-1), lengths)
+    loss.backward()
+    assert rel_err(out["logits"].cpu(), y.detach()) < 1e-4
+    assert abs(float(out["loss"]) - float(loss.detach())) < 1e-5 * float(loss.detach())
+    bad = {}
+    for k, v in psd.items():
+        gref = v.grad if v.grad is not None else torch.zeros_like(v)
+        got = grads[eng.lay.off(k):eng.lay.off(k) + eng.lay.numel(k)].view(eng.lay.shapes[k]).cpu()
+        err, ref = float((got - gref).abs().max()), float(gref.abs().max())
+        if err > 1e-3 * max(ref, 1e-6) + 1e-7:
+            bad[k] = (err, ref)
+    assert not bad, bad
+    # eval-mode forward of the same engine: no mask
+    ev = eng.decoder_forward(x.cuda(), c_up.cuda(), g.cuda(), c_is_upsampled=True)["logits"].cpu()
+    y0 = O.wavenet_forward(sd, dict(ocfg, upsample_scales=None), ins["xin"], c_up, g)
+    assert rel_err(ev, y0) < 1e-4
+
+
+def test_dropout_train_step_bf16_learns():
+    """full VQVAE train steps with dropout 0.05 (the reference's constructor default) in bf16: finite, the loss of a repeated
+    batch goes down, a second engine with the same seed reproduces the first step exactly (the mask is a pure function of seed,
+    call number and layer)."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    runs = []
+    for _ in range(2):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16", dropout=0.05, drop_seed=5)
+        eng.load_state_dict(sd)
+        eng.init_optimizer()
+        runs.append([float(eng.train_step(x, c, g, lr=2e-3)["ce"]) for _ in range(6)])
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(eng.params).all())
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][-1] < runs[0][0]

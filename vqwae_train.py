@@ -15,7 +15,7 @@ options:
     --use-norm=<bool>            Use normalised features [default: true].
     --feat=<name>                Feature file stem [default: mfcc].
     --speaker-id=<N>             Ignored, as in the reference (vqwae_train.py:1072-1073).
-    --dtype=<fp32|bf16>          Compute precision of the decoder stack [default: bf16].
+    --dtype=<fp32|bf16|fp16>     Storage precision of the decoder stack [default: bf16].
     --synthetic                  Train on synthetic batches (no dataset needed).
     --max-steps=<N>              Stop after N steps (overrides max_train_steps).
 
@@ -89,7 +89,7 @@ def main(argv=None):
     ap.add_argument("--use-norm", default="true")
     ap.add_argument("--feat", default="mfcc")
     ap.add_argument("--speaker-id")
-    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--max-steps", type=int)
     args = ap.parse_args(argv)
@@ -109,7 +109,7 @@ def main(argv=None):
 
     from wavenet_autoencoders_amd.engine import WaeEngine
     geom = build_geometry(hp)
-    eng = WaeEngine(geom, dtype=args.dtype, device=device)
+    eng = WaeEngine(geom, dtype=args.dtype, device=device, dropout=float(hp.dropout))            # vqwae_train.py:933
     # reference initialisation, identical on every rank
     torch.manual_seed(1234)
     from wavenet_autoencoders_amd.wavenet_vocoder._base import ArenaModel, register_params

@@ -243,6 +243,7 @@ def bwd_workspace(eng, B, T):
         ws = dict(dz=torch.zeros(B, T, g.layers * 2 * g.Hp, dtype=td, device=dev),
                   gx=[torch.zeros(B, T, g.Rp, dtype=td, device=dev) for _ in range(g.layers if use_stream_tn(eng) else 2)],
                   gzero=torch.zeros(B, T, g.Rp, dtype=td, device=dev),
+                  gtmp=torch.zeros(B, T, g.Rp, dtype=td, device=dev) if eng.dropout > 0 else None,
                   dy=torch.zeros(B, T, g.Op, dtype=td, device=dev),
                   dh1=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
                   dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
@@ -273,7 +274,7 @@ def _build_tile_tables(eng, ws, fw, B, T):
             stt.begin_group()
             dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
             c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
-            xl = fw["x"][l]
+            xl = fw["xd"][l] if "xd" in fw else fw["x"][l]      # dW1 contracts dz against the convolution's operand
             for tap in range(g.k):
                 last = tap == g.k - 1 and not g.Ccp
                 stt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, dz_ptr, dzs, xl.data_ptr(), g.Rp,
@@ -289,7 +290,7 @@ def _build_tile_tables(eng, ws, fw, B, T):
         tt = TileTable(eng)
         dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
         c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
-        xl = fw["x"][l]
+        xl = fw["xd"][l] if "xd" in fw else fw["x"][l]
         for tap in range(g.k):
             last = tap == g.k - 1 and not g.Ccp
             tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, dz_ptr, dzs, xl.data_ptr(), g.Rp,
@@ -402,10 +403,20 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2,
             flags=eng.tm_flags_u)
 
+    seeds = getattr(eng, "_drop_seeds", None)   # set by the train-mode forward when dropout is active
+
     def k_x(l, gn, gc):                        # dx-hat of layer l
         srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
-        _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp,
-            flags=P.TM_INTERLEAVE | eng.tm_flags_x)
+        if seeds is None:
+            _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp,
+                flags=P.TM_INTERLEAVE | eng.tm_flags_x)
+        else:
+            # dropout: the tap contraction alone (mode 0), then out = sqrt(.5) * (g_next + keep * acc / (1 - p)) with the mask
+            # the forward applied to this layer's convolution operand
+            _tm(eng, B, T, g.Rp, 0, 1.0, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, ws["gtmp"].data_ptr(), g.Rp,
+                flags=P.TM_INTERLEAVE)
+            L.check(lib.wae_dropout_bwd(L.ptr(ws["gtmp"]), L.ptr(gn), L.ptr(gc), B * T * g.Rp, seeds[l], eng.dropout, RS, eng.dt, st),
+                    "dropout_bwd")
 
     def tn_layer(l):                           # per-layer weight gradients (fp32 path; bf16 takes them all at the end)
         if ws["stream"] is not None:
@@ -424,7 +435,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % ngx].data_ptr()
         tn_layer(l)                            # needs dz_l and dx_{l+1}-hat
         g_cur = ws["gx"][l % ngx]
-        if l > 0 and eng.fused_bwd:
+        if l > 0 and eng.fused_bwd and seeds is None:
             # K_X of layer l and K_U of layer l-1 in one launch (csrc/glu_bwd.hip)
             d = L.GluBwdDesc(eng.dt, B, T, g.Rp, g.Hp, g.Sp, g.k, g.dilations[l], RS)
             L.check(lib.wae_glu_bwd_fused(ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),

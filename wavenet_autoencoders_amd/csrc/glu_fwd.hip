@@ -41,6 +41,7 @@
 
 struct GluArgs {
   const char* x_in;
+  const char* x_conv;  // operand of the dilated convolution: x_in, or dropout(x_in) in training with p > 0 (modules.py:127-128)
   char* x_out;
   const char* c_up;
   char* u_out;
@@ -140,7 +141,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
 
   const int64_t row_x = (int64_t)p.Rp * ES;
   const int64_t row_c = (int64_t)p.Ccp * ES;
-  const char* xb = p.x_in + (int64_t)b * p.T * row_x;
+  const char* xb = p.x_in + (int64_t)b * p.T * row_x;      // residual path: the layer's input itself (modules.py:126,161)
+  const char* xcb = p.x_conv + (int64_t)b * p.T * row_x;   // convolution operand
   const char* cb = p.c_up ? p.c_up + (int64_t)b * p.T * row_c : nullptr;
 
   const bool dbg_dma = !ABL(p.flags, DBG_NO_DMA);
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
       // tile d rows earlier reads the same rows as its last tap -- they meet in L2 (packing.py: glu_w1_map, same order)
       const int cblk = q / p.ktaps, tap = q - cblk * p.ktaps;
       ts -= (p.ktaps - 1 - tap) * p.dilation;
-      base = xb + cblk * 128 + h * 16;
+      base = xcb + cblk * 128 + h * 16;
       rp = row_x;
     } else {
       base = cb + (q - nq_conv) * 128 + h * 16;
@@ -580,18 +582,27 @@ extern "C" int64_t wae_glu_packed_bytes(const wae_glu_desc* d) {
   return ((np / nph) * nq1 + nq2) * chb;
 }
 
+extern "C" int wae_glu_layer_fwd_drop(const wae_glu_desc* d, const void* x_in, const void* x_conv, void* x_out, const void* c_up,
+                                      void* u_out, int64_t u_stride, const float* zb, int64_t zb_stride, void* z_save,
+                                      const void* w_packed, const float* bias_out, void* stream);
 extern "C" int wae_glu_layer_fwd(const wae_glu_desc* d, const void* x_in, void* x_out, const void* c_up, void* u_out,
                                  int64_t u_stride, const float* zb, int64_t zb_stride, void* z_save, const void* w_packed,
                                  const float* bias_out, void* stream) {
+  return wae_glu_layer_fwd_drop(d, x_in, x_in, x_out, c_up, u_out, u_stride, zb, zb_stride, z_save, w_packed, bias_out, stream);
+}
+
+extern "C" int wae_glu_layer_fwd_drop(const wae_glu_desc* d, const void* x_in, const void* x_conv, void* x_out, const void* c_up,
+                                      void* u_out, int64_t u_stride, const float* zb, int64_t zb_stride, void* z_save,
+                                      const void* w_packed, const float* bias_out, void* stream) {
   int rc = glu_validate(d);
   if (rc != WAE_OK) return rc;
-  WAE_REQUIRE(x_in && u_out && zb && w_packed, "glu: null pointer argument");
+  WAE_REQUIRE(x_in && x_conv && u_out && zb && w_packed, "glu: null pointer argument");
   WAE_REQUIRE(u_stride >= d->Hp, "glu: u_stride (%lld) < Hp", (long long)u_stride);
   WAE_REQUIRE((d->flags & WAE_GLU_NO_OUT) || (x_out && bias_out), "glu: x_out/bias_out null but WAE_GLU_NO_OUT is not set");
   WAE_REQUIRE(d->Ccp == 0 || c_up, "glu: Ccp > 0 but c_up is null");
   WAE_REQUIRE(!(d->flags & WAE_GLU_SAVE_Z) || z_save, "glu: WAE_GLU_SAVE_Z without z_save");
   GluArgs a;
-  a.x_in = (const char*)x_in; a.x_out = (char*)x_out; a.c_up = (const char*)c_up; a.u_out = (char*)u_out; a.zb = zb;
+  a.x_in = (const char*)x_in; a.x_conv = (const char*)x_conv; a.x_out = (char*)x_out; a.c_up = (const char*)c_up; a.u_out = (char*)u_out; a.zb = zb;
   a.z_save = (char*)z_save; a.w = (const char*)w_packed; a.bias_out = bias_out; a.zb_stride = zb_stride;
   a.u_stride = u_stride; a.B = d->B; a.T = d->T; a.Rp = d->Rp; a.Ccp = d->Ccp; a.Hp = d->Hp; a.ktaps = d->ktaps;
   a.dilation = d->dilation; a.flags = d->flags; a.stamps = g_stamps;

@@ -842,3 +842,60 @@ extern "C" int wae_masked_mean(const float* nll, const int32_t* lengths, float* 
   hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, as_stream(stream), nll, lengths, out, B, T);
   return wae_check_launch("masked_mean");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// dropout in front of the dilated convolution (modules.py:127-128: x = F.dropout(x, p, training)), training with p > 0 only.
+// The mask is a counter-based hash of (seed, element index) -- keep iff the top 24 bits of the mix are >= p * 2^24 -- so the
+// forward kernel and the backward kernel regenerate the same mask and the CPU oracle can restate it (oracle: dropout_keep).
+// forward:  xd = x * keep / (1 - p)          (xd is the conv operand of wae_glu_layer_fwd_drop and the Q operand of dW1)
+// backward: out = alpha * (g_next + acc * keep / (1 - p))    (acc = sum_taps W1_tap^T dz, wae_gemm_tm mode 0)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t e, uint32_t thr) {
+  uint64_t h = (e + seed) * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ull;
+  h ^= h >> 32;
+  return (uint32_t)(h >> 40) >= thr;
+}
+template <typename E>
+__global__ void __launch_bounds__(256) dropout_fwd_kernel(const void* __restrict__ x, void* __restrict__ xd, int64_t n, uint64_t seed,
+                                                          uint32_t thr, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    store_e<E>(xd, i, dropout_keep(seed, (uint64_t)i, thr) ? load_e<E>(x, i) * scale : 0.f);
+}
+template <typename E>
+__global__ void __launch_bounds__(256) dropout_bwd_kernel(const void* __restrict__ acc, const void* __restrict__ g_next,
+                                                          void* __restrict__ out, int64_t n, uint64_t seed, uint32_t thr, float scale,
+                                                          float alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = dropout_keep(seed, (uint64_t)i, thr) ? load_e<E>(acc, i) * scale : 0.f;
+    store_e<E>(out, i, alpha * (load_e<E>(g_next, i) + a));
+  }
+}
+static int dropout_args(float p, uint32_t* thr, float* scale) {
+  WAE_REQUIRE(p >= 0.f && p < 1.f, "dropout: p must be in [0, 1)");
+  *thr = (uint32_t)((double)p * 16777216.0 + 0.5);
+  *scale = 1.0f / (1.0f - p);
+  return WAE_OK;
+}
+extern "C" int wae_dropout_fwd(const void* x, void* xd, int64_t n, uint64_t seed, float p, int32_t dtype, void* stream) {
+  WAE_REQUIRE(x && xd && n > 0 && wae_dtype_ok(dtype), "dropout_fwd: bad arguments");
+  uint32_t thr; float scale;
+  if (int rc = dropout_args(p, &thr, &scale); rc != WAE_OK) return rc;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  if (dtype == WAE_BF16) hipLaunchKernelGGL(dropout_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, seed, thr, scale);
+  else if (dtype == WAE_F16) hipLaunchKernelGGL(dropout_fwd_kernel<f16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, seed, thr, scale);
+  else hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, seed, thr, scale);
+  return wae_check_launch("dropout_fwd");
+}
+extern "C" int wae_dropout_bwd(const void* acc, const void* g_next, void* out, int64_t n, uint64_t seed, float p, float alpha,
+                               int32_t dtype, void* stream) {
+  WAE_REQUIRE(acc && g_next && out && n > 0 && wae_dtype_ok(dtype), "dropout_bwd: bad arguments");
+  uint32_t thr; float scale;
+  if (int rc = dropout_args(p, &thr, &scale); rc != WAE_OK) return rc;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  if (dtype == WAE_BF16) hipLaunchKernelGGL(dropout_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, seed, thr, scale, alpha);
+  else if (dtype == WAE_F16) hipLaunchKernelGGL(dropout_bwd_kernel<f16>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, seed, thr, scale, alpha);
+  else hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, seed, thr, scale, alpha);
+  return wae_check_launch("dropout_bwd");
+}

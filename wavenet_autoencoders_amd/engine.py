@@ -31,9 +31,14 @@ def _dt(dtype) -> int:
 
 
 class WaeEngine:
-    def __init__(self, geom: P.Geometry, dtype="bf16", device="cuda:0"):
+    def __init__(self, geom: P.Geometry, dtype="bf16", device="cuda:0", dropout: float = 0.0, drop_seed: int = 0x5EED):
         """dtype: 'fp32' (exact, the parity mode), 'bf16' (default throughput mode) or 'fp16' (BASELINE config C5) storage of
-        activations and packed weights; accumulation, biases, losses, gradients of parameters and the optimizer are fp32."""
+        activations and packed weights; accumulation, biases, losses, gradients of parameters and the optimizer are fp32.
+        dropout: probability of the F.dropout in front of every dilated convolution (modules.py:127-128); applied in
+        train-mode forwards only, with a counter-based mask (seed, call number, layer) that backward regenerates."""
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout}")     # F.dropout's own check
+        self.dropout, self.drop_seed, self.drop_calls = float(dropout), int(drop_seed), 0
         if not torch.cuda.is_available():
             raise L.WaeError("WaeEngine needs a ROCm GPU: the hot path has no CPU implementation")
         self.lib = L.lib()
@@ -171,6 +176,8 @@ class WaeEngine:
             )
             if train:
                 ws["z"] = [torch.empty(B, T, 2 * g.Hp, dtype=td, device=dev) for _ in range(g.layers)]
+                if self.dropout > 0:       # dropout(x_l): operand of layer l's convolution and of its weight gradient
+                    ws["xd"] = [torch.empty(B, T, g.Rp, dtype=td, device=dev) for _ in range(g.layers)]
                 ws["lse"] = torch.zeros(B, T, dtype=torch.float32, device=dev)
             if train or self.wide_head:       # the wide head passes h0 / h1 through HBM in inference too
                 ws["h0"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
@@ -244,11 +251,15 @@ class WaeEngine:
                 self._up_acts.append(x)
         return out
 
+    def layer_drop_seed(self, call: int, layer: int) -> int:
+        """64-bit seed of layer `layer`'s dropout mask in the call-th train-mode forward (csrc/misc.hip: dropout_keep)"""
+        return ((self.drop_seed * 0x100000001B3 + call) * 1024 + layer) & 0xFFFFFFFFFFFFFFFF
+
     # ------------------------------------------------------------------ decoder
     def decoder_forward(self, x: torch.Tensor, c: Optional[torch.Tensor], gid: Optional[torch.Tensor],
                         targets: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
                         want_logits: bool = True, train: bool = False, c_is_upsampled: bool = False,
-                        gvec: Optional[torch.Tensor] = None, layer_events: Optional[list] = None):
+                        gvec: Optional[torch.Tensor] = None, layer_events: Optional[list] = None, dropout_on: bool = True):
         """WaveNet.forward (wavenet.py:164-216) on class ids.
 
         x: (B,T) int32 class ids (mulaw-quantize) or (B,T) fp32 scalars (scalar_input).
@@ -297,6 +308,12 @@ class WaeEngine:
         # gated residual stack
         es = self.w_glu.element_size()
         d = L.GluDesc(self.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, 1, 0)
+        # dropout (modules.py:127-128) only in a train-mode forward of a model in training mode; eval is the identity
+        drop = self.dropout if (train and dropout_on) else 0.0
+        self._drop_seeds = None
+        if drop > 0:
+            self.drop_calls += 1
+            self._drop_seeds = [self.layer_drop_seed(self.drop_calls, i) for i in range(g.layers)]
         if layer_events is not None:   # HIP events on the launch stream around the whole gated stack (bench.py)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
@@ -306,7 +323,15 @@ class WaeEngine:
             d.flags = (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0) | self.glu_flags
             xin = ws["x"][i if train else i % 2]
             xout = ws["x"][(i + 1) if train else (i + 1) % 2]
-            L.check(lib.wae_glu_layer_fwd(ctypes.byref(d), L.ptr(xin), None if last else L.ptr(xout), L.ptr(ws["c_up"]),
+            xconv = xin
+            if drop > 0:
+                xconv = ws["xd"][i]
+                L.check(lib.wae_dropout_fwd(L.ptr(xin), L.ptr(xconv), B * T * g.Rp, self._drop_seeds[i], drop, self.dt, st), "dropout")
+            elif train and "xd" in ws:
+                # an engine built with dropout > 0 running a train-mode forward of a model in eval mode: the weight-gradient
+                # tables of this (B, T) point at xd, so it must hold the (undropped) operand
+                L.check(lib.wae_dropout_fwd(L.ptr(xin), L.ptr(ws["xd"][i]), B * T * g.Rp, 0, 0.0, self.dt, st), "dropout (identity)")
+            L.check(lib.wae_glu_layer_fwd_drop(ctypes.byref(d), L.ptr(xin), L.ptr(xconv), None if last else L.ptr(xout), L.ptr(ws["c_up"]),
                                           ctypes.c_void_p(ws["u"].data_ptr() + i * g.Hp * es), g.Ku,
                                           ctypes.c_void_p(ws["zb"].data_ptr() + i * 2 * g.Hp * 4),
                                           g.layers * 2 * g.Hp, L.ptr(ws["z"][i]) if train else None,
@@ -515,13 +540,13 @@ class WaeEngine:
 
     # ------------------------------------------------------------------ full autoencoder
     def forward(self, x: torch.Tensor, c: torch.Tensor, gid: Optional[torch.Tensor], targets=None, lengths=None,
-                want_logits=True, train=False, beta: float = 0.25):
+                want_logits=True, train=False, beta: float = 0.25, dropout_on: bool = True):
         """VQVAE.forward (vqvae_model.py:66-72) -> dict(logits, vq_loss, perp, latents, idx, quant, loss)."""
         if self.weights_dirty:
             self.prepare_weights()
         lat = self.encoder_forward(c)
         quant, idx, stats = self.vq_forward(lat, beta)
-        out = self.decoder_forward(x, quant, gid, targets, lengths, want_logits, train)
+        out = self.decoder_forward(x, quant, gid, targets, lengths, want_logits, train, dropout_on=dropout_on)
         out.update(latents=lat, quant=quant, idx=idx, vq_loss=stats[0], perp=stats[1])
         self._fe = dict(lat=lat, quant=quant, idx=idx, beta=beta)
         return out

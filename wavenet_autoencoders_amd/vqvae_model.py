@@ -13,7 +13,7 @@ class _VQVAEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, ids, c, gid, train, *params):
         eng = model.engine()
-        out = eng.forward(ids, c, gid, want_logits=True, train=train)
+        out = eng.forward(ids, c, gid, want_logits=True, train=train, dropout_on=model.training)
         ctx.model, ctx.ids, ctx.gid = model, ids, gid
         return out["logits"], out["vq_loss"].reshape(()), out["perp"].reshape(())
 
@@ -52,6 +52,7 @@ class VQVAE(ArenaModel):
                           scalar_input=wg.scalar_input, use_speaker_embedding=wg.use_speaker_embedding, c_in=c_in,
                           encoder_hid=encoder_hid, K=K)
         self.out_channels, self.scalar_input = wavenet.out_channels, wavenet.scalar_input
+        self.dropout = float(getattr(wavenet, "dropout", 0.0))          # the decoder layers' dropout (modules.py:127-128)
         self._init_arena(geom, "")
         # keep the decoder's initial values (the reference builds the WaveNet first: vqwae_train.py:926-946)
         own = dict(self.named_parameters())
@@ -67,6 +68,7 @@ class VQVAE(ArenaModel):
         gid = g.reshape(-1) if g is not None else None
         params = self._params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (inside Function.forward grad mode is off)
+        train = train or (self.training and self.dropout > 0)                       # F.dropout follows module.training
         y, vq_loss, perp = _VQVAEFn.apply(self, ids, c.float(), gid, train, *params)
         if softmax:
             y = torch.softmax(y, dim=1)

@@ -94,7 +94,7 @@ class ArenaModel(nn.Module):
             raise WaeError("this model has no CPU implementation: move it to a ROCm GPU first (model.cuda())")
         if self._engine is None or self._engine.device != p0.device:
             from ..engine import WaeEngine
-            eng = WaeEngine(self.geom, dtype=self._compute_dtype, device=str(p0.device))
+            eng = WaeEngine(self.geom, dtype=self._compute_dtype, device=str(p0.device), dropout=float(getattr(self, "dropout", 0.0)))
             params = dict(self.named_parameters())
             for rel in self._pnames:
                 full = self._strip + rel

@@ -40,7 +40,8 @@ class _DecoderFn(torch.autograd.Function):
         gid = g if (g is not None and g.dtype in (torch.int32, torch.int64)) else None
         gvec = None if (g is None or gid is not None) else g.reshape(g.shape[0], -1).float().contiguous()
         ctx.gid, ctx.gvec = gid, gvec
-        out = eng.decoder_forward(ids, c, gid, want_logits=True, train=train, c_is_upsampled=c_is_up, gvec=gvec)
+        out = eng.decoder_forward(ids, c, gid, want_logits=True, train=train, c_is_upsampled=c_is_up, gvec=gvec,
+                                  dropout_on=model.training)
         return out["logits"]
 
     @staticmethod
@@ -78,9 +79,9 @@ class WaveNet(ArenaModel):
                  output_distribution="Logistic", cin_pad=0, _prefix=""):
         super().__init__()
         # modules.py:127-128 applies F.dropout(x, p, training=self.training) in front of every dilated convolution: identity in
-        # eval mode (synthesis, feature export, the dev phase) for any p.  The reference's constructor default is 0.05
-        # (wavenet.py:98-111) while every shipped preset trains with 0.0 (hps/*.json): the model is built for any p, and a
-        # TRAIN-mode forward with p > 0 raises (the fused layer kernel has no mask stage) instead of silently training without.
+        # eval mode for any p.  The reference's constructor default is 0.05 (wavenet.py:98-111); every shipped preset trains with
+        # 0.0 (hps/*.json).  In training mode the engine applies a counter-based mask (wae_dropout_fwd / wae_dropout_bwd): same
+        # distribution as torch's, not the same random stream.
         self.dropout = float(dropout)
         if upsample_conditional_features and upsample_net != "ConvInUpsampleNetwork":
             raise NotImplementedError("only ConvInUpsampleNetwork (the reference default) is implemented")
@@ -113,9 +114,10 @@ class WaveNet(ArenaModel):
         c_is_up = not bool(self.geom.upsample_scales)
         params = [p for _, p in sorted(((n, p) for n, p in self.named_parameters()), key=lambda kv: self._pnames.index(kv[0]))]
         train = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or (c is not None and c.requires_grad))
-        if self.training and self.dropout > 0:
-            raise NotImplementedError(f"training-mode forward with dropout={self.dropout} is not implemented (every preset uses 0.0; "
-                                      "eval mode is exact for any value): pass dropout=0.0 or call .eval()")
+        if self.training and self.dropout > 0 and not train:
+            # F.dropout is active whenever module.training is set, gradients or not: run the train-mode path (it is the one that
+            # applies the mask) even when nothing requires a gradient
+            train = True
         y = _DecoderFn.apply(self, ids, c, g, c_is_up, train, *params)
         return torch.softmax(y, dim=1) if softmax else y
 
