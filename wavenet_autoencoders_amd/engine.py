@@ -309,6 +309,8 @@ class WaeEngine:
         es = self.w_glu.element_size()
         d = L.GluDesc(self.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, 1, 0)
         # dropout (modules.py:127-128) only in a train-mode forward of a model in training mode; eval is the identity
+        if train:
+            self.fwd_gen = getattr(self, "fwd_gen", 0) + 1       # the saved activations now belong to THIS forward
         drop = self.dropout if (train and dropout_on) else 0.0
         self._drop_seeds = None
         if drop > 0:

@@ -15,6 +15,7 @@ class _VQVAEFn(torch.autograd.Function):
         eng = model.engine()
         out = eng.forward(ids, c, gid, want_logits=True, train=train, dropout_on=model.training)
         ctx.model, ctx.ids, ctx.gid = model, ids, gid
+        ctx.gen, ctx.train = getattr(eng, "fwd_gen", 0), train
         return out["logits"], out["vq_loss"].reshape(()), out["perp"].reshape(())
 
     @staticmethod
@@ -23,6 +24,9 @@ class _VQVAEFn(torch.autograd.Function):
         from . import backward as BW
         model = ctx.model
         eng = model._engine
+        if ctx.train and getattr(eng, "fwd_gen", 0) != ctx.gen:
+            raise RuntimeError("backward through a forward whose saved activations were overwritten by a later training-mode forward "
+                               "of the same model: call backward before the next forward")
         g = eng.g
         B, O, T = dy.shape
         ext = torch.zeros(B, T, g.Op, dtype=eng.tdtype, device=dy.device)

@@ -42,6 +42,7 @@ class _DecoderFn(torch.autograd.Function):
         ctx.gid, ctx.gvec = gid, gvec
         out = eng.decoder_forward(ids, c, gid, want_logits=True, train=train, c_is_upsampled=c_is_up, gvec=gvec,
                                   dropout_on=model.training)
+        ctx.gen = getattr(eng, "fwd_gen", 0)
         return out["logits"]
 
     @staticmethod
@@ -50,6 +51,10 @@ class _DecoderFn(torch.autograd.Function):
         from .. import backward as BW
         model = ctx.model
         eng = model._engine
+        if ctx.train and getattr(eng, "fwd_gen", 0) != ctx.gen:
+            # the activations live in the engine's per-(B, T) workspace, not in this autograd node
+            raise RuntimeError("backward through a forward whose saved activations were overwritten by a later training-mode forward "
+                               "of the same model: call backward before the next forward")
         g = eng.g
         B, O, T = dy.shape
         ext = torch.zeros(B, T, g.Op, dtype=eng.tdtype, device=dy.device)
