@@ -10,7 +10,7 @@ dx}, conditioning/upsample gradients, weight-norm backward), [N > 1: bucketed RC
 and the fused clip_grad_norm_ + Adam + EMA update.  Inputs are resident in HBM before the timed region.
 `--mode forward` times the teacher-forced forward pass alone.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--mode train|forward] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--mode train|forward] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, each rank trains on its own shard of the global
@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ar", action="store_true", help="skip the autoregressive leg (BASELINE config C4, rank 0 only)")
@@ -277,14 +277,14 @@ def main():
     # every timed step; average per launch (includes the inter-kernel gaps, so it is conservative)
     stack_ms = [a.elapsed_time(b) for a, b in ev]
     glu_ms = sum(stack_ms) / len(stack_ms) / geom.layers
-    es = 2 if args.dtype == "bf16" else 4
+    es = 4 if args.dtype == "fp32" else 2
     samples = B_PER_GPU * T
     bytes_per_launch = (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es * samples        # SURVEY 8(d) per layer
     H = C2["G"] // 2
     flops_per_launch = 2 * (C2["G"] * C2["R"] * C2["k"] + C2["G"] * C2["Cc"] + H * C2["R"] + H * C2["S"]) * samples
     achieved_gbs = bytes_per_launch / (glu_ms * 1e-3) / 1e9
     achieved_tf = flops_per_launch / (glu_ms * 1e-3) / 1e12
-    peak_tf = MFMA_PEAK_TF if args.dtype == "bf16" else FP32_MFMA_PEAK_TF
+    peak_tf = FP32_MFMA_PEAK_TF if args.dtype == "fp32" else MFMA_PEAK_TF      # fp16 and bf16 MFMA run at the same dense rate
     fwd_roof = {"bound": "hbm", "kernel": "glu_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": glu_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "mfma_achieved_tflops": achieved_tf,
@@ -329,7 +329,7 @@ def main():
                 doc = json.load(fh)
             if doc.get("csrc_hash") == csrc_hash():
                 traffic_src = os.path.basename(fpath)
-                if args.dtype == "bf16" and args.mode == "train":
+                if args.dtype in ("bf16", "fp16") and args.mode == "train":
                     for rf in [roof] + list(extra.values()):
                         for k, v in doc["kernels"].items():
                             if rf["kernel"] in k:
