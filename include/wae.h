@@ -215,6 +215,15 @@ int wae_sum_rows(const float* src, int64_t off, int64_t stride, int32_t L, int32
 
 /* masked mean of per-sample losses: out[0] = sum_{b,t<len[b]-1} nll / sum mask  (vqwae_train.py:379) */
 int wae_masked_mean(const float* nll, const int32_t* lengths, float* out, int32_t B, int32_t T, void* stream);
+/* The criterion object of vqwae_train.py:363-379 on EXPLICIT logits (the drop-in MaskedCrossEntropyLoss; training proper uses
+ * the CE fused into wae_head_fwd): logits (B,C,T) fp32, target (B,T) int64 -> nll (B,T), lse (B,T); backward
+ * dlogits = (softmax - onehot) * w[b,t].  A target outside [0, C) is clamped and flagged in err (WAE_ERR_TARGET_ID).
+ * wae_weighted_mean: out[0] = sum(v*m) / sum(m), out[1] = sum(m) for any mask m (:374-379). */
+int wae_ce_logits_fwd(const float* logits, const int64_t* target, float* nll, float* lse, int32_t B, int32_t C, int32_t T,
+                      int32_t* err, void* stream);
+int wae_ce_logits_bwd(const float* logits, const int64_t* target, const float* lse, const float* w, float* dlogits, int32_t B,
+                      int32_t C, int32_t T, void* stream);
+int wae_weighted_mean(const float* v, const float* m, int64_t n, float* out, void* stream);
 
 /* ---- a10 discretized mixture of logistics (mixture.py:26-106; wrapper vqwae_train.py:382-401, shift :766) --
  * y_hat (B,3M,T) fp32 = [logit pi | mu | log s]; y (B,T) fp32 in [-1,1].  nll[b,t] = -log p(y[b,t+shift] | y_hat[b,:,t])

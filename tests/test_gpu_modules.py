@@ -267,3 +267,27 @@ def test_backward_after_a_second_forward_raises():
     with pytest.raises(RuntimeError, match="overwritten"):
         y1.sum().backward()
     y2.sum().backward()                                   # the latest forward is fine
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_masked_cross_entropy_module_on_explicit_logits(name):
+    """losses.MaskedCrossEntropyLoss (vqwae_train.py:363-379) called the reference's way -- criterion(y_hat[:, :, :-1, :],
+    y[:, 1:, :], mask=mask) -- runs wae_ce_logits_fwd / _bwd + wae_weighted_mean: value and d loss / d logits against the
+    vectors the reference produced (ce_<name>.npz), and IndexError for a target outside the classes."""
+    from wavenet_autoencoders_amd.losses import MaskedCrossEntropyLoss, sequence_mask
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    z = load_npz("ce_" + name)
+    y_hat = torch.from_numpy(zm["y_hat"]).cuda().requires_grad_(True)
+    y = ins["x"].unsqueeze(-1).cuda()
+    lengths = torch.from_numpy(z["lengths"]).cuda()
+    T = y.shape[1]
+    mask = sequence_mask(lengths, T).unsqueeze(-1)[:, 1:, :]
+    loss = MaskedCrossEntropyLoss()(y_hat.unsqueeze(-1)[:, :, :-1, :], y[:, 1:, :], mask=mask)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(z["loss"])) < 1e-5 * float(z["loss"])
+    assert rel_err(y_hat.grad.cpu()[:, :, ::29], z["dlogits_probe"]) < 1e-4
+    bad = y[:, 1:, :].clone()
+    bad[0, 3, 0] = cfg["O"]
+    with pytest.raises(IndexError):
+        MaskedCrossEntropyLoss()(y_hat.detach().unsqueeze(-1)[:, :, :-1, :], bad, mask=mask)

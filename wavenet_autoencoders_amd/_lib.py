@@ -106,6 +106,9 @@ SIGNATURES = {
     "wae_ar_coop_acc_floats": (c_i64, [ctypes.POINTER(ArDesc)]),
     "wae_ar_generate_coop": (c_i32, [ctypes.POINTER(ArDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7
                              + [c_i32] + [c_vp] * 8),
+    "wae_ce_logits_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "wae_ce_logits_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "wae_weighted_mean": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "wae_masked_mean": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_to_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
     "wae_to_btc_masked": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp, c_f32, c_vp]),

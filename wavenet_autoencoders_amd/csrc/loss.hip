@@ -199,3 +199,81 @@ extern "C" int wae_clip_adam_ema(float* params, const float* grads, float* exp_a
                      (float)eps, (float)weight_decay, (float)sqrt(bc2), (float)clip_thresh, (float)(1.0 - ema_decay));
   return wae_check_launch("clip_adam_ema");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Cross-entropy on explicit logits (the criterion object of vqwae_train.py:363-379 called on (B, C, T, 1) logits -- the
+// drop-in MaskedCrossEntropyLoss; the training path proper uses the CE fused into the head kernel) and the masked mean with an
+// arbitrary (B, T) weight mask.  logits (B, C, T) fp32: thread = one (b, t), classes strided by T (coalesced along t).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ce_logits_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                            float* __restrict__ nll, float* __restrict__ lse, int C, int T,
+                                                            int32_t* __restrict__ err) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float* l = logits + (int64_t)b * C * T + t;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, l[(int64_t)c * T]);
+  float den = 0.f;
+  for (int c = 0; c < C; ++c) den += expf(l[(int64_t)c * T] - mx);
+  const float ls = mx + logf(den);
+  int64_t y = target[(int64_t)b * T + t];
+  if (y < 0 || y >= C) {   // nn.CrossEntropyLoss raises: clamp and flag (WAE_ERR_TARGET_ID)
+    if (err) atomicOr(err, 4);
+    y = y < 0 ? 0 : C - 1;
+  }
+  nll[(int64_t)b * T + t] = ls - l[y * T];
+  lse[(int64_t)b * T + t] = ls;
+}
+// dlogits[b,c,t] = (softmax - onehot(target)) * w[b,t]
+__global__ void __launch_bounds__(256) ce_logits_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                            const float* __restrict__ lse, const float* __restrict__ w,
+                                                            float* __restrict__ dlogits, int C, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int64_t o = (int64_t)b * C * T + t;
+  const float ls = lse[(int64_t)b * T + t], wt = w[(int64_t)b * T + t];
+  int64_t y = target[(int64_t)b * T + t];
+  y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+  for (int c = 0; c < C; ++c) dlogits[o + (int64_t)c * T] = (expf(logits[o + (int64_t)c * T] - ls) - (c == y ? 1.f : 0.f)) * wt;
+}
+extern "C" int wae_ce_logits_fwd(const float* logits, const int64_t* target, float* nll, float* lse, int32_t B, int32_t C, int32_t T,
+                                 int32_t* err, void* stream) {
+  WAE_REQUIRE(logits && target && nll && lse && B > 0 && C > 0 && T > 0, "ce_logits_fwd: bad arguments");
+  hipLaunchKernelGGL(ce_logits_fwd_kernel, dim3((T + 255) / 256, B), dim3(256), 0, as_stream(stream), logits, target, nll, lse, C, T, err);
+  return wae_check_launch("ce_logits_fwd");
+}
+extern "C" int wae_ce_logits_bwd(const float* logits, const int64_t* target, const float* lse, const float* w, float* dlogits,
+                                 int32_t B, int32_t C, int32_t T, void* stream) {
+  WAE_REQUIRE(logits && target && lse && w && dlogits && B > 0 && C > 0 && T > 0, "ce_logits_bwd: bad arguments");
+  hipLaunchKernelGGL(ce_logits_bwd_kernel, dim3((T + 255) / 256, B), dim3(256), 0, as_stream(stream), logits, target, lse, w, dlogits, C, T);
+  return wae_check_launch("ce_logits_bwd");
+}
+
+// out[0] = sum(v * m) / sum(m), out[1] = sum(m) over n elements (vqwae_train.py:379 with any mask); double accumulation
+__global__ void __launch_bounds__(1024) weighted_mean_kernel(const float* __restrict__ v, const float* __restrict__ m, int64_t n,
+                                                             float* __restrict__ out) {
+  __shared__ double ps[16], pm[16];
+  double s = 0.0, c = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float mi = m[i];
+    s += (double)v[i] * (double)mi;
+    c += (double)mi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); c += __shfl_xor(c, o); }
+  if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = s; pm[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int i = 0; i < 16; ++i) { ts += ps[i]; tc += pm[i]; }
+    out[0] = (float)(ts / tc);
+    out[1] = (float)tc;
+  }
+}
+extern "C" int wae_weighted_mean(const float* v, const float* m, int64_t n, float* out, void* stream) {
+  WAE_REQUIRE(v && m && out && n > 0, "weighted_mean: bad arguments");
+  hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(1024), 0, as_stream(stream), v, m, n, out);
+  return wae_check_launch("weighted_mean");
+}

@@ -16,19 +16,71 @@ def sequence_mask(sequence_length, max_len=None):
     return (r < sequence_length.unsqueeze(1)).float()
 
 
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _MaskedMeanFn(torch.autograd.Function):
+    """sum(losses * mask) / sum(mask) (vqwae_train.py:379) by wae_weighted_mean; d/dlosses = mask / sum(mask)."""
+
+    @staticmethod
+    def forward(ctx, losses, mask):
+        lf, mf = losses.contiguous().float(), mask.contiguous().float()
+        out = torch.empty(2, dtype=torch.float32, device=lf.device)
+        L.check(L.lib().wae_weighted_mean(L.ptr(lf), L.ptr(mf), lf.numel(), L.ptr(out), _stream(lf)), "weighted_mean")
+        ctx.save_for_backward(mf, out)
+        ctx.shape = losses.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        mf, out = ctx.saved_tensors
+        return (mf * (g / out[1])).view(ctx.shape), None
+
+
+class _CELogitsFn(torch.autograd.Function):
+    """per-position cross-entropy of (B, C, T) logits by wae_ce_logits_fwd / _bwd"""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        lg = logits.contiguous().float()
+        tg = target.contiguous().to(torch.int64)
+        B, C, T = lg.shape
+        nll = torch.empty(B, T, dtype=torch.float32, device=lg.device)
+        lse = torch.empty(B, T, dtype=torch.float32, device=lg.device)
+        err = torch.zeros(1, dtype=torch.int32, device=lg.device)
+        L.check(L.lib().wae_ce_logits_fwd(L.ptr(lg), L.ptr(tg), L.ptr(nll), L.ptr(lse), B, C, T, L.ptr(err), _stream(lg)), "ce_logits")
+        if int(err.item()):
+            raise IndexError("Target out of bounds")              # what nn.CrossEntropyLoss raises
+        ctx.save_for_backward(lg, tg, lse)
+        return nll
+
+    @staticmethod
+    def backward(ctx, dnll):
+        lg, tg, lse = ctx.saved_tensors
+        B, C, T = lg.shape
+        w = dnll.contiguous().float()
+        dl = torch.empty_like(lg)
+        L.check(L.lib().wae_ce_logits_bwd(L.ptr(lg), L.ptr(tg), L.ptr(lse), L.ptr(w), L.ptr(dl), B, C, T, _stream(lg)), "ce_logits_bwd")
+        return dl, None
+
+
 class MaskedCrossEntropyLoss(nn.Module):
     """forward(input (B, C, T, 1), target (B, T, 1), lengths=None, mask=None, max_len=None) -> sum(CE*mask)/sum(mask)
-    (vqwae_train.py:363-379).  The CE itself is torch's device op on the logits the engine produced; the fused
-    head+CE kernel (WaeEngine.train_step) is the fast path that never materialises the logits."""
+    (vqwae_train.py:363-379) on explicit logits: wae_ce_logits_fwd / _bwd and wae_weighted_mean.  (WaeEngine.train_step uses the
+    CE fused into the head kernel instead, which never materialises the logits.)"""
 
     def forward(self, input, target, lengths=None, mask=None, max_len=None):
         if lengths is None and mask is None:
             raise RuntimeError("Should provide either lengths or mask")
+        if not input.is_cuda:
+            raise L.WaeError("MaskedCrossEntropyLoss has no CPU implementation here: pass ROCm tensors")
         if mask is None:
             mask = sequence_mask(lengths, max_len).unsqueeze(-1)
         mask_ = mask.expand_as(target)
-        losses = torch.nn.functional.cross_entropy(input, target, reduction="none")
-        return (losses * mask_).sum() / mask_.sum()
+        B, C = input.shape[0], input.shape[1]
+        losses = _CELogitsFn.apply(input.reshape(B, C, -1), target.reshape(B, -1))
+        return _MaskedMeanFn.apply(losses.view(target.shape), mask_)
 
 
 class DiscretizedMixturelogisticLoss(nn.Module):
@@ -47,7 +99,7 @@ class DiscretizedMixturelogisticLoss(nn.Module):
         losses = discretized_mix_logistic_loss(input, target, num_classes=self.num_classes, log_scale_min=self.log_scale_min,
                                                reduce=False)
         assert losses.size() == target.size()
-        return (losses * mask_).sum() / mask_.sum()
+        return _MaskedMeanFn.apply(losses, mask_)
 
 
 class ExponentialMovingAverage(object):
