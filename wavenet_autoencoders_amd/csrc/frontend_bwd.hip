@@ -180,6 +180,224 @@ __global__ void __launch_bounds__(64) conv_bwd_w_kernel(const float* __restrict_
     if (dbias && ci == 0 && j == 0) atomicAdd(dbias + co, accb);
   }
 }
+// Tiled forms (round 2; see csrc/misc.hip: enc_conv_fwd_tiled_kernel).  The one-thread-per-output kernels above took 170 us
+// (input gradient) and 43 us (weight gradient) per encoder block at hps/vqwae.json's training shapes.
+#define ECB_T 32
+#define ECB_NS 8
+#define ECB_CH 256
+#define ECB_WB 8
+#define ECB_RT 8    // (clip, step tile) pairs staged per round of the weight-gradient kernel
+// dx[b][ci][ti] = sum_{co, j} w[co][ci][j] * dpre[b][co][(ti + PAD - j) / S]: block = 32 input channels x 32 input steps of one
+// clip, thread = (channel, slice of the co reduction); dpre windows of 256 output channels are staged in LDS.  ti0 is a multiple
+// of 32, so which (ti, j) pairs hit a whole output step, and where it sits in the staged window, is known at compile time.
+template <int K, int S, int PAD>
+__global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ y, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int Cin, int Tin, int Cout, int Tout, int relu,
+                                                               int residual) {
+  extern __shared__ float sm[];
+  constexpr int R0 = (((PAD - K + 1) % S) + S) % S;        // (ti0 + PAD - K + 1) mod S for ti0 = 0 mod S
+  constexpr int BASE = K - 1 + R0;                         // ti_l - j + BASE = S * (to - tb) when that is a whole step
+  constexpr int TWIN = (ECB_T - 1 + BASE) / S + 1;
+  constexpr int TP = (TWIN + 3) & ~3;
+  const int b = blockIdx.z, ci0 = blockIdx.y * ECB_T, ti0 = blockIdx.x * ECB_T;
+  const int tb = (ti0 + PAD - (K - 1) - R0) / S;           // exact: the numerator is a multiple of S (may be negative)
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int ci = ci0 + col;
+  float acc[ECB_T];
+#pragma unroll
+  for (int i = 0; i < ECB_T; ++i) acc[i] = 0.f;
+  const float* xb = x + (int64_t)b * Cin * Tin;
+  const float* yb = y ? y + (int64_t)b * Cout * Tout : nullptr;
+  const float* dyb = dy + (int64_t)b * Cout * Tout;
+  for (int c0 = 0; c0 < Cout; c0 += ECB_CH) {
+    const int nc = min(ECB_CH, Cout - c0);
+    __syncthreads();
+    for (int i0 = threadIdx.x; i0 < nc * TP; i0 += 256 * 8) {   // batches of 8 independent loads per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int co = i / TP, tl = i - co * TP, to = tb + tl;
+        v[u] = (i < nc * TP && tl < TWIN && to >= 0 && to < Tout)
+                   ? conv_dpre(dyb, yb, xb, (int64_t)(c0 + co) * Tout + to, (int64_t)(c0 + co) * Tin + to, relu, residual)
+                   : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 256 < nc * TP) sm[i0 + u * 256] = v[u];
+    }
+    __syncthreads();
+    const int per = (nc + ECB_NS - 1) / ECB_NS;
+    const int ca = sl * per, cb = min(nc, ca + per);
+    if (ci < Cin)
+      for (int cc = ca; cc < cb; cc += ECB_WB) {   // weights of ECB_WB output channels requested together (one round trip)
+        float wv[ECB_WB][K];
+#pragma unroll
+        for (int u = 0; u < ECB_WB; ++u)
+#pragma unroll
+          for (int j = 0; j < K; ++j) wv[u][j] = cc + u < cb ? w[((int64_t)(c0 + cc + u) * Cin + ci) * K + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < ECB_WB; ++u) {
+          const f32x4* gr4 = (const f32x4*)(sm + min(cc + u, cb - 1) * TP);
+          float gw[TP];
+#pragma unroll
+          for (int q = 0; q < TP / 4; ++q) {
+            const f32x4 v = gr4[q];
+            gw[4 * q] = v.x; gw[4 * q + 1] = v.y; gw[4 * q + 2] = v.z; gw[4 * q + 3] = v.w;
+          }
+#pragma unroll
+          for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int t = 0; t < ECB_T; ++t)   // (t, j, BASE, S are compile-time after unrolling: the test folds away)
+              if ((t - j + BASE) >= 0 && (t - j + BASE) % S == 0) acc[t] = fmaf(wv[u][j], gw[(t - j + BASE) / S], acc[t]);
+        }
+      }
+  }
+  __syncthreads();
+  float* red = sm;
+#pragma unroll
+  for (int t = 0; t < ECB_T; ++t) red[(sl * ECB_T + t) * 33 + col] = acc[t];
+  __syncthreads();
+  for (int o = threadIdx.x; o < ECB_T * ECB_T; o += 256) {
+    const int tl = o & 31, cl = o >> 5;
+    const int oc = ci0 + cl, ot = ti0 + tl;
+    if (oc >= Cin || ot >= Tin) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < ECB_NS; ++q) v += red[(q * ECB_T + tl) * 33 + cl];
+    if (residual) v += dyb[(int64_t)oc * Tout + ot];
+    dx[((int64_t)b * Cin + oc) * Tin + ot] = v;
+  }
+}
+// dw[co][ci][j] += sum_{b, to} dpre[b][co][to] * x[b][ci][to*S + j - pad] (+ dbias[co] += sum dpre): block = 32 output x 32 input
+// channels over every clip and step (the unique owner of its outputs: plain read-modify-write), thread = (co, 4 input channels).
+template <int K, int S>
+__global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ dy, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int B, int Cin, int Tin, int Cout, int Tout,
+                                                               int pad, int relu, int residual) {
+  constexpr int WIN = (ECB_T - 1) * S + K;
+  constexpr int WP = (WIN + 3) & ~3, GP = 36;      // row pitches: whole 16-byte reads
+  constexpr int GSZ = ECB_T * GP, XSZ = ECB_T * WP;
+  extern __shared__ float sm[];     // ECB_RT x (dpre tile [32 co][GP] + x window [32 ci][WP]): one round of (clip, step tile) pairs
+  const int co0 = blockIdx.x * ECB_T, ci0 = blockIdx.y * ECB_T;
+  const int col = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  float acc[4][K];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[c][j] = 0.f;
+  float accb = 0.f;
+  const int tpc = (Tout + ECB_T - 1) / ECB_T;      // step tiles per clip
+  const int ntile = B * tpc;
+  for (int r0 = 0; r0 < ntile; r0 += ECB_RT) {
+    const int nr = min(ECB_RT, ntile - r0);
+    __syncthreads();
+    // every global load of the round is issued before the first LDS store of the round is needed: one round trip per round
+    for (int i0 = threadIdx.x; i0 < nr * ECB_T * ECB_T; i0 += 256 * 8) {   // batches of 8 independent loads per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int r = i / (ECB_T * ECB_T), e = i - r * (ECB_T * ECB_T);
+        const int tl = e & 31, cl = e >> 5;
+        const int b = min((r0 + r) / tpc, B - 1), to = ((r0 + r) % tpc) * ECB_T + tl, co = co0 + cl;
+        const float* xb = x + (int64_t)b * Cin * Tin;
+        v[u] = (i < nr * ECB_T * ECB_T && co < Cout && to < Tout)
+                   ? conv_dpre(dy + (int64_t)b * Cout * Tout, y ? y + (int64_t)b * Cout * Tout : nullptr, xb, (int64_t)co * Tout + to,
+                               (int64_t)co * Tin + to, relu, residual)
+                   : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int r = i / (ECB_T * ECB_T), e = i - r * (ECB_T * ECB_T);
+        if (i < nr * ECB_T * ECB_T) sm[r * (GSZ + XSZ) + (e >> 5) * GP + (e & 31)] = v[u];
+      }
+    }
+    for (int i0 = threadIdx.x; i0 < nr * XSZ; i0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int r = i / XSZ, e = i - r * XSZ;
+        const int cl = e / WP, wv = e - cl * WP;
+        const int b = min((r0 + r) / tpc, B - 1), to0 = ((r0 + r) % tpc) * ECB_T;
+        const int ci = ci0 + cl, ti = to0 * S - pad + wv;
+        v[u] = (i < nr * XSZ && wv < WIN && ci < Cin && ti >= 0 && ti < Tin) ? x[((int64_t)b * Cin + ci) * Tin + ti] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int r = i / XSZ, e = i - r * XSZ;
+        if (i < nr * XSZ) sm[r * (GSZ + XSZ) + GSZ + e] = v[u];
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < nr; ++r) {
+      const float* gs = sm + r * (GSZ + XSZ);
+      const float* xs = gs + GSZ;
+      float g[ECB_T];   // this thread's output channel, the tile's 32 steps
+#pragma unroll
+      for (int q = 0; q < ECB_T / 4; ++q) {
+        const f32x4 v = *(const f32x4*)(gs + col * GP + 4 * q);
+        g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        accb += (v.x + v.y) + (v.z + v.w);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4* xr4 = (const f32x4*)(xs + (cg * 4 + c) * WP);
+        float xw[WP];
+#pragma unroll
+        for (int q = 0; q < WP / 4; ++q) {
+          const f32x4 v = xr4[q];
+          xw[4 * q] = v.x; xw[4 * q + 1] = v.y; xw[4 * q + 2] = v.z; xw[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+          for (int t = 0; t < ECB_T; ++t) acc[c][j] = fmaf(g[t], xw[t * S + j], acc[c][j]);
+      }
+    }
+  }
+  const int co = co0 + col;
+  if (co < Cout) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ci = ci0 + cg * 4 + c;
+      if (ci < Cin)
+#pragma unroll
+        for (int j = 0; j < K; ++j) dw[((int64_t)co * Cin + ci) * K + j] += acc[c][j];
+    }
+    if (dbias && cg == 0 && blockIdx.y == 0) dbias[co] += accb;
+  }
+}
+template <int K, int S, int PAD>
+static void launch_conv_bwd_tiled(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* dbias,
+                                  int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual, hipStream_t st) {
+  if (dx) {
+    constexpr int R0 = (((PAD - K + 1) % S) + S) % S;
+    constexpr int TWIN = (ECB_T - 1 + K - 1 + R0) / S + 1;
+    constexpr int TP = (TWIN + 3) & ~3;
+    const size_t a = (size_t)(Cout < ECB_CH ? Cout : ECB_CH) * TP, r = (size_t)ECB_NS * ECB_T * 33;
+    const size_t lds = (a > r ? a : r) * sizeof(float);
+    static WaeLdsCache cache;
+    if (wae_ensure_lds((const void*)conv_bwd_x_tiled_kernel<K, S, PAD>, cache, lds, "enc_conv_bwd") != WAE_OK) return;
+    hipLaunchKernelGGL((conv_bwd_x_tiled_kernel<K, S, PAD>), dim3((Tin + ECB_T - 1) / ECB_T, (Cin + ECB_T - 1) / ECB_T, B), dim3(256), lds,
+                       st, x, w, y, dy, dx, Cin, Tin, Cout, Tout, relu, residual);
+  }
+  {
+    constexpr int WIN = (ECB_T - 1) * S + K;
+    constexpr int WP = (WIN + 3) & ~3;
+    const size_t lds = (size_t)ECB_RT * (ECB_T * 36 + ECB_T * WP) * sizeof(float);
+    static WaeLdsCache cache;
+    if (wae_ensure_lds((const void*)conv_bwd_w_tiled_kernel<K, S>, cache, lds, "enc_conv_bwd") != WAE_OK) return;
+    hipLaunchKernelGGL((conv_bwd_w_tiled_kernel<K, S>), dim3((Cout + ECB_T - 1) / ECB_T, (Cin + ECB_T - 1) / ECB_T), dim3(256), lds, st, x,
+                       y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, PAD, relu, residual);
+  }
+}
+
 extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
                                 float* dbias, int32_t B, int32_t Cin, int32_t Tin, int32_t Cout, int32_t k, int32_t stride,
                                 int32_t pad, int32_t relu, int32_t residual, void* stream) {
@@ -188,11 +406,21 @@ extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, 
   WAE_REQUIRE(!relu || y, "enc_conv_bwd: relu needs the forward output y");
   const int Tout = (Tin + 2 * pad - k) / stride + 1;
   hipStream_t st = as_stream(stream);
-  if (dx)
-    hipLaunchKernelGGL(conv_bwd_x_kernel, dim3((Tin + 63) / 64, (Cin + 3) / 4, B), dim3(256), 0, st, x, w, y, dy, dx, Cin, Tin,
-                       Cout, Tout, k, stride, pad, relu, residual);
-  hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(Cout * Cin * k), dim3(64), 0, st, x, y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, k,
-                     stride, pad, relu, residual);
+#define WAE_ECB(K_, S_, P_) launch_conv_bwd_tiled<K_, S_, P_>(x, w, y, dy, dx, dw, dbias, B, Cin, Tin, Cout, Tout, relu, residual, st)
+  if (k == 1 && stride == 1 && pad == 0) WAE_ECB(1, 1, 0);
+  else if (k == 3 && stride == 1 && pad == 1) WAE_ECB(3, 1, 1);
+  else if (k == 3 && stride == 1 && pad == 0) WAE_ECB(3, 1, 0);
+  else if (k == 5 && stride == 2 && pad == 2) WAE_ECB(5, 2, 2);
+  else if (k == 5 && stride == 1 && pad == 2) WAE_ECB(5, 1, 2);
+  else if (k == 5 && stride == 1 && pad == 0) WAE_ECB(5, 1, 0);
+  else {   // any other shape: the plain one-thread-per-output kernels
+    if (dx)
+      hipLaunchKernelGGL(conv_bwd_x_kernel, dim3((Tin + 63) / 64, (Cin + 3) / 4, B), dim3(256), 0, st, x, w, y, dy, dx, Cin, Tin,
+                         Cout, Tout, k, stride, pad, relu, residual);
+    hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(Cout * Cin * k), dim3(64), 0, st, x, y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, k,
+                       stride, pad, relu, residual);
+  }
+#undef WAE_ECB
   return wae_check_launch("enc_conv_bwd");
 }
 

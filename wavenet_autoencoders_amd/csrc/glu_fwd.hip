@@ -551,7 +551,7 @@ static int dispatch_np(int np, const GluArgs& a, hipStream_t st) {
     case 1: return launch_glu<E, 1, 1, EXACT>(a, st);
     case 2: return launch_glu<E, 2, 1, EXACT>(a, st);
     case 3: return launch_glu<E, 3, 3, EXACT>(a, st);
-    case 4: return launch_glu<E, 4, 2, EXACT>(a, st);
+    case 4: return launch_glu<E, 4, 4, EXACT>(a, st);   // Hp = 128 (hps/vqwae.json): all 8 gate tiles in ONE pass
     case 6: return launch_glu<E, 6, 3, EXACT>(a, st);
     case 8: return launch_glu<E, 8, 4, EXACT>(a, st);
     default:
@@ -574,7 +574,7 @@ static int glu_validate(const wae_glu_desc* d) {
 extern "C" int64_t wae_glu_packed_bytes(const wae_glu_desc* d) {
   if (glu_validate(d) != WAE_OK) return WAE_EINVAL;
   const int ck = wae_is16(d->dtype) ? 64 : 32;
-  const int np = d->Hp / 32, nph = np == 3 ? 3 : (np % 2 == 0 ? np / 2 : np);
+  const int np = d->Hp / 32, nph = (np == 3 || np == 4) ? np : (np % 2 == 0 ? np / 2 : np);
   const int mt2 = (wae_is16(d->dtype) ? 4 : 2) * nph / np;
   const int64_t chb = (int64_t)2 * nph * 4 * 1024;
   const int64_t nq1 = (int64_t)d->ktaps * (d->Rp / ck) + d->Ccp / ck;

@@ -238,6 +238,108 @@ __global__ void __launch_bounds__(256) enc_conv_fwd_kernel(const float* __restri
   y[((int64_t)b * Cout + co) * Tout + to] = acc;
 }
 
+// Tiled form (round 2).  At the training shapes of hps/vqwae.json -- 8 clips x 32 frames, 256 channels -- the kernel above runs
+// one thread per output with a serial 768-term reduction, half of its lanes idle (Tout = 32 of 64) and ~90 us per layer: twelve
+// of them plus their backward were 3.5 ms of a 7.5 ms train step.  Here a block owns 32 output channels x 32 output steps of
+// one clip: the input window of every input channel is staged in LDS (chunks of 256 channels), thread = (channel, one of 8
+// slices of the reduction), 32 accumulators per thread, the window reads are broadcasts; the slices meet in LDS.
+#define EC_T 32     // outputs per block along time and along channels
+#define EC_NS 8     // reduction slices
+#define EC_CH 256   // input channels staged per chunk
+#define EC_WB 8     // channels whose weights a thread requests together
+template <int K, int S>
+__global__ void __launch_bounds__(256) enc_conv_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int Cin,
+                                                                 int Tin, int Cout, int Tout, int pad, int relu, int residual) {
+  extern __shared__ float sm[];
+  constexpr int WIN = (EC_T - 1) * S + K;
+  constexpr int WP = (WIN + 3) & ~3;   // LDS row pitch: whole 16-byte reads
+  const int b = blockIdx.z, co0 = blockIdx.y * EC_T, to0 = blockIdx.x * EC_T;
+  const int ti0 = to0 * S - pad;
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int co = co0 + col;
+  float acc[EC_T];
+#pragma unroll
+  for (int i = 0; i < EC_T; ++i) acc[i] = 0.f;
+  const float* xb = x + (int64_t)b * Cin * Tin;
+  for (int c0 = 0; c0 < Cin; c0 += EC_CH) {
+    const int nc = min(EC_CH, Cin - c0);
+    __syncthreads();
+    // staged in batches of 8 independent loads per thread (a load -> LDS-store loop with a run-time trip count was one L2 /
+    // HBM round trip per element: 32 dependent round trips, most of the launch)
+    for (int i0 = threadIdx.x; i0 < nc * WP; i0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int ci = i / WP, wv = i - ci * WP, ti = ti0 + wv;
+        v[u] = (i < nc * WP && wv < WIN && ti >= 0 && ti < Tin) ? xb[(int64_t)(c0 + ci) * Tin + ti] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 256 < nc * WP) sm[i0 + u * 256] = v[u];
+    }
+    __syncthreads();
+    const int per = (nc + EC_NS - 1) / EC_NS;
+    const int ca = sl * per, cb = min(nc, ca + per);
+    if (co < Cout) {
+      // the weights of a thread (row co, channels [ca, cb): one contiguous run) come in batches of EC_WB channels requested
+      // together: one L2 round trip per batch instead of one per channel (32 dependent round trips were most of the launch)
+      const float* wrow = w + ((int64_t)co * Cin + c0) * K;
+      for (int cc = ca; cc < cb; cc += EC_WB) {
+        float wv[EC_WB][K];
+#pragma unroll
+        for (int u = 0; u < EC_WB; ++u)
+#pragma unroll
+          for (int j = 0; j < K; ++j) wv[u][j] = cc + u < cb ? wrow[(cc + u) * K + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < EC_WB; ++u) {
+          // the channel's input window moves LDS -> registers once (16-byte broadcast reads) and serves every tap
+          const f32x4* xr4 = (const f32x4*)(sm + min(cc + u, cb - 1) * WP);
+          float xw[WP];
+#pragma unroll
+          for (int q = 0; q < WP / 4; ++q) {
+            const f32x4 v = xr4[q];
+            xw[4 * q] = v.x; xw[4 * q + 1] = v.y; xw[4 * q + 2] = v.z; xw[4 * q + 3] = v.w;
+          }
+#pragma unroll
+          for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int t = 0; t < EC_T; ++t) acc[t] = fmaf(wv[u][j], xw[t * S + j], acc[t]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* red = sm;   // [slice][t][33]
+#pragma unroll
+  for (int t = 0; t < EC_T; ++t) red[(sl * EC_T + t) * 33 + col] = acc[t];
+  __syncthreads();
+  for (int o = threadIdx.x; o < EC_T * EC_T; o += 256) {
+    const int tl = o & 31, cl = o >> 5;
+    const int oc = co0 + cl, ot = to0 + tl;
+    if (oc >= Cout || ot >= Tout) continue;
+    float v = bias ? bias[oc] : 0.f;
+#pragma unroll
+    for (int q = 0; q < EC_NS; ++q) v += red[(q * EC_T + tl) * 33 + cl];
+    if (relu) v = fmaxf(v, 0.f);
+    if (residual) v += xb[(int64_t)oc * Tin + ot];
+    y[((int64_t)b * Cout + oc) * Tout + ot] = v;
+  }
+}
+template <int K, int S>
+static void launch_enc_fwd_tiled(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Tin, int Cout,
+                                 int Tout, int pad, int relu, int residual, hipStream_t st) {
+  constexpr int WIN = (EC_T - 1) * S + K;
+  constexpr int WP = (WIN + 3) & ~3;
+  const size_t a = (size_t)(Cin < EC_CH ? Cin : EC_CH) * WP, r = (size_t)EC_NS * EC_T * 33;
+  const size_t lds = (a > r ? a : r) * sizeof(float);
+  static WaeLdsCache cache;
+  if (wae_ensure_lds((const void*)enc_conv_fwd_tiled_kernel<K, S>, cache, lds, "enc_conv_fwd") != WAE_OK) return;
+  hipLaunchKernelGGL((enc_conv_fwd_tiled_kernel<K, S>), dim3((Tout + EC_T - 1) / EC_T, (Cout + EC_T - 1) / EC_T, B), dim3(256), lds, st,
+                     x, w, bias, y, Cin, Tin, Cout, Tout, pad, relu, residual);
+}
+
 extern "C" int wae_enc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
                                 int32_t Tin, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t relu,
                                 int32_t residual, void* stream) {
@@ -246,8 +348,14 @@ extern "C" int wae_enc_conv_fwd(const float* x, const float* w, const float* bia
   WAE_REQUIRE(!residual || (stride == 1 && Cin == Cout && 2 * pad == k - 1), "enc_conv: residual needs a same-shape conv");
   const int Tout = (Tin + 2 * pad - k) / stride + 1;
   WAE_REQUIRE(Tout > 0, "enc_conv: empty output");
-  hipLaunchKernelGGL(enc_conv_fwd_kernel, dim3((Tout + 63) / 64, (Cout + 3) / 4, B), dim3(256), 0, as_stream(stream), x,
-                     w, bias, y, B, Cin, Tin, Cout, Tout, k, stride, pad, relu, residual);
+  hipStream_t st = as_stream(stream);
+  if (k == 1 && stride == 1) launch_enc_fwd_tiled<1, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  else if (k == 3 && stride == 1) launch_enc_fwd_tiled<3, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  else if (k == 5 && stride == 2) launch_enc_fwd_tiled<5, 2>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  else if (k == 5 && stride == 1) launch_enc_fwd_tiled<5, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  else   // any other shape (e.g. a wider conv_in, cin_pad > 2): the plain one-thread-per-output kernel
+    hipLaunchKernelGGL(enc_conv_fwd_kernel, dim3((Tout + 63) / 64, (Cout + 3) / 4, B), dim3(256), 0, st, x, w, bias, y, B, Cin, Tin,
+                       Cout, Tout, k, stride, pad, relu, residual);
   return wae_check_launch("enc_conv_fwd");
 }
 

@@ -190,7 +190,7 @@ def glu_pass_tiles(NP: int) -> int:
     """Gate-channel tiles per GEMM-1 pass (csrc/glu_fwd.hip dispatch_np must agree)."""
     if NP not in (1, 2, 3, 4, 6, 8):
         raise ValueError(f"gate_channels/2 padded to {32 * NP} is not supported by the fused layer kernel (Hp/32 must be 1,2,3,4,6,8)")
-    return {1: 1, 2: 1, 3: 3, 4: 2, 6: 3, 8: 4}[NP]
+    return {1: 1, 2: 1, 3: 3, 4: 4, 6: 3, 8: 4}[NP]
 
 
 def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
