@@ -410,13 +410,14 @@ typedef struct wae_ts_job {
 typedef struct wae_ts_seg {
   int32_t job, slab_begin, slab_end;
 } wae_ts_seg;
-/* pace: nteams x 8 int32, ZEROED by the caller before every launch (or NULL / window <= 0: no pacing): the members of a team
- * publish the slab position they have consumed and no member requests more than `window` slabs beyond the slowest, so that the
- * operand slabs the jobs of a layer share are fetched from HBM once and found in the XCD's L2 by the others.  Timing only:
- * results do not depend on it, and a wait that does not end switches it off (the launch can never hang). */
+/* pace: nteams x 8 int32, ZEROED by the caller before every launch (or NULL / window <= 0: no pacing): members [0, pace_from) of
+ * a team (the full-size jobs: the taps) publish the slab position of their next request, and members [pace_from, team_size) (the
+ * narrow jobs, which would run ahead) request no more than `window` slabs beyond the slowest of them, so that the operand slabs
+ * the jobs of a layer share are fetched from HBM once and found in the XCD's L2 by the others.  Timing only: results do not
+ * depend on it, and a wait that does not end switches it off (the launch can never hang). */
 int wae_gemm_tn_stream(int32_t dtype /* WAE_BF16 or WAE_F16 */, const wae_ts_job* jobs_dev, const wae_ts_seg* segs_dev,
                        const int32_t* team_seg_dev, int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T,
-                       int32_t* pace, int32_t window, void* stream);
+                       int32_t* pace, int32_t window, int32_t pace_from, void* stream);
 
 /* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
  * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).

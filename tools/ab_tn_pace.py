@@ -25,21 +25,40 @@ eng.train_step(xi, lat, g, lengths=None)
 torch.cuda.synchronize()
 st = eng._ws[("bwd",) + tuple(xi.shape)]["stream"]
 ref = None
-for w in [int(v) for v in (sys.argv[1:] or ["0", "2", "4", "8", "16", "0"])]:
+windows = [int(v) for v in (sys.argv[1:] or ["0", "2", "4", "8", "16"])]
+res = {w: [] for w in windows}
+for rnd in range(4):                      # interleaved rounds: the launch time drifts by 10 % over a process's life
+    for w in windows:
+        st.window = w
+        if rnd == 0:
+            eng.cbuf.zero_()
+            st.launch()
+            torch.cuda.synchronize()
+            c = eng.cbuf.clone()
+            if ref is None:
+                ref = c
+            print(f"window {w:3d}: max |dW - dW(unpaced)| / max|dW| = {float((c - ref).abs().max() / ref.abs().max()):.2e}", flush=True)
+        for i in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st.launch()
+            e1.record()
+            torch.cuda.synchronize()
+            if i:
+                res[w].append(e0.elapsed_time(e1))
+for w in windows:
+    v = sorted(res[w])
+    print(f"window {w:3d}: launch ms min {v[0]:.3f} median {v[len(v) // 2]:.3f} max {v[-1]:.3f}", flush=True)
+# inside a train step (the launch follows the backward sweep: other cache contents, other clocks)
+for w in windows:
     st.window = w
-    eng.cbuf.zero_()
-    st.launch()
+    for _ in range(3):
+        eng.train_step(xi, lat, g, lengths=None)
     torch.cuda.synchronize()
-    c = eng.cbuf.clone()
-    if ref is None:
-        ref = c
-    ts = []
-    for i in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        st.launch()
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    print(f"window {w:3d}: launch ms {min(ts):.3f} (median {sorted(ts)[2]:.3f});  max |dW - dW(unpaced)| / max|dW| = "
-          f"{float((c - ref).abs().max() / ref.abs().max()):.2e}", flush=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        eng.train_step(xi, lat, g, lengths=None)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"window {w:3d}: train step {e0.elapsed_time(e1) / 20:.3f} ms", flush=True)

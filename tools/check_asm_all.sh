@@ -15,6 +15,21 @@ for f in glu_fwd head_fwd gemm_tm; do
   done
 done
 } > $OUT
+# second check: accidental drains of an asynchronous pipeline (scratch reloads / compiler-generated vmcnt(0) inside the innermost
+# loops that keep LDS-DMA pieces or inline-asm requests in flight) -- tools/check_asm_drains.py
+DR=${OUT%_load_check.txt}_drain_check.txt
+[ "$DR" = "$OUT" ] && DR=${OUT%.txt}_drains.txt
+{
+echo "# tools/check_asm_drains.py over every 16-bit kernel with asynchronous requests: scratch reloads and compiler-generated"
+echo "# s_waitcnt vmcnt(0) inside the innermost loops that issue LDS-DMA pieces / inline-asm loads (fp32 instantiations use plain"
+echo "# loads and are expected to wait; they are not listed)"
+for f in gemm_tn_stream glu_fwd head_fwd gemm_tm head_bwd gemm_tn glu_bwd; do
+  [ -f $TMP/$f.s ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only $ROOT/wavenet_autoencoders_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
+  python3 $ROOT/tools/check_asm_drains.py $TMP/$f.s IDF16 | grep -v "^_Z.*: 0 loop"
+done
+} > $DR
 rm -rf $TMP
 grep -c " 0 violation" $OUT | sed 's/$/ kernels clean/'
+grep -c ", 0 scratch" $DR | sed 's/$/ kernels without drains in their asynchronous loops/'
+grep "^_Z" $DR | grep -v ", 0 scratch" | sed 's/: .*loop(s) with asynchronous requests,/:/' | head -20
 grep -v " 0 violation" $OUT | grep -v "^#" | head

@@ -153,6 +153,32 @@ class TileTable:
         L.check(eng.lib.wae_gemm_tn_tiles(eng.dt, L.ptr(self.dev), self.n, B, T, self.splits, eng.stream()), "gemm_tn_tiles")
 
 
+def weighted_shares(items, nsl, nshares):
+    """Cuts the work list [(job, weight per slab)] x nsl slabs, in order, into nshares contiguous shares of (nearly) equal total
+    weight; a share is a list of (job, slab_begin, slab_end).  Every (job, slab) lands in exactly one share."""
+    total = sum(w for _, w in items) * nsl
+    shares, it, pos, cum = [], 0, 0, 0.0
+    for k in range(nshares):
+        target = total * (k + 1) / nshares
+        cur = []
+        while it < len(items):
+            job, w = items[it]
+            if k + 1 == nshares:
+                take = nsl - pos
+            else:
+                if target - cum < 0.5 * w:
+                    break
+                take = min(nsl - pos, max(1, int((target - cum) / w + 0.5)))
+            cur.append((job, pos, pos + take))
+            pos += take
+            cum += take * w
+            if pos == nsl:
+                it, pos = it + 1, 0
+        shares.append(cur)
+    assert it == len(items) and pos == 0
+    return shares
+
+
 class StreamTable:
     """Host builder for wae_gemm_tn_stream (csrc/gemm_tn_stream.hip): the weight-gradient contractions of every layer as
     ONE launch.  A *group* is the list of jobs of one layer (every dilated-conv tap, the conditioning 1x1 with the per-clip
@@ -163,6 +189,7 @@ class StreamTable:
     def __init__(self, eng, B, T):
         self.eng, self.B, self.T = eng, B, T
         self.groups = []          # list of lists of L.TsJob
+        self.lead_jobs = 0        # the first lead_jobs jobs of every group are full-size (the taps): the pacing reference
         self.shifts = []          # most negative shift per group (slabs that pair only with rows before the clip are skipped)
 
     def begin_group(self):
@@ -191,22 +218,45 @@ class StreamTable:
         gs = len(self.groups[0])
         assert all(len(g) == gs for g in self.groups), "every layer must contribute the same list of jobs"
         ncu = torch.cuda.get_device_properties(eng.device).multi_processor_count
-        self.team_size = gs
-        self.nteams = max(1, ncu // gs)
-        self.nwg = ncu if ncu % 8 == 0 and ncu >= self.nteams * gs else self.nteams * gs
         spc = (T + self.KT - 1) // self.KT
-        # Every member of a team sweeps the same slab range; a slab is skipped by a member when all of its rows pair with
-        # rows before the clip (kernel: useful()).  Shares are cut on the raw slab count: the skipped slabs differ by tap.
-        total = len(self.groups) * B * spc
         segs, team_seg = [], [0]
-        for t in range(self.nteams):
-            lo, hi = total * t // self.nteams, total * (t + 1) // self.nteams
-            while lo < hi:
-                grp = lo // (B * spc)
-                end = min(hi, (grp + 1) * B * spc)
-                segs.append(L.TsSeg(grp * gs, lo - grp * B * spc, end - grp * B * spc))
-                lo = end
-            team_seg.append(len(segs))
+        mode = os.environ.get("WAE_TN_SHARES", "teams")
+        if mode == "weighted":
+            # One workgroup per share of the (layer, job, slab) list, shares of equal estimated TIME: a slab of a narrow job (the
+            # conditioning 1x1: 36 of 96 tiles; conv1x1_out: 56) costs less than a slab of a full 384 x 256 tap job, and a team
+            # that gives every job of a layer its own workgroup over the same slab range leaves the narrow jobs' CUs idle for
+            # the difference (tools/ab_tn_shares.py).  Cost per slab = a fixed part (DMA wait, barrier, issue: the same for
+            # every job) + the share of active 64 x 128 wave blocks.
+            fixed = float(os.environ.get("WAE_TN_SHARE_FIXED", "0.45"))
+            self.team_size = 1
+            self.nteams = self.nwg = ncu
+            items = []                   # (job index, weight per slab)
+            for gi, grp in enumerate(self.groups):
+                for ji, jb in enumerate(grp):
+                    if jb.m_valid <= 0:
+                        continue
+                    n_end = jb.ones_col + B if jb.ones_col >= 0 else jb.n_valid
+                    blocks = ((jb.m_valid + 63) // 64) * ((n_end + 127) // 128)            # of 6 x 2 wave blocks
+                    useful = max(0.02, 1.0 - abs(jb.shift) / T)      # slabs that pair only with rows outside the clip are skipped
+                    items.append((gi * gs + ji, (fixed + (1.0 - fixed) * blocks / 12.0) * useful))
+            for share in weighted_shares(items, B * spc, self.nwg):
+                segs += [L.TsSeg(job, lo, hi) for job, lo, hi in share]
+                team_seg.append(len(segs))
+        else:
+            self.team_size = gs
+            self.nteams = max(1, ncu // gs)
+            self.nwg = ncu if ncu % 8 == 0 and ncu >= self.nteams * gs else self.nteams * gs
+            # Every member of a team sweeps the same slab range; a slab is skipped by a member when all of its rows pair with
+            # rows before the clip (kernel: useful()).  Shares are cut on the raw slab count: the skipped slabs differ by tap.
+            total = len(self.groups) * B * spc
+            for t in range(self.nteams):
+                lo, hi = total * t // self.nteams, total * (t + 1) // self.nteams
+                while lo < hi:
+                    grp = lo // (B * spc)
+                    end = min(hi, (grp + 1) * B * spc)
+                    segs.append(L.TsSeg(grp * gs, lo - grp * B * spc, end - grp * B * spc))
+                    lo = end
+                team_seg.append(len(segs))
         jobs = [j for g in self.groups for j in g]
         dev = eng.device
         self.jobs_dev = torch.frombuffer(bytearray(bytes((L.TsJob * len(jobs))(*jobs))), dtype=torch.uint8).to(dev)
@@ -217,6 +267,7 @@ class StreamTable:
         # A/B only: measured SLOWER at C2 (unpaced 1.46-1.70 ms; window 2 / 4 / 8 / 16 / 32 slabs: 1.96 / 1.87 / 1.83 / 1.81 /
         # 1.82 ms, tools/ab_tn_pace.py) -- the launch is bound by the per-slab issue / barrier pipeline, not by HBM bytes
         self.window = int(os.environ.get("WAE_TN_PACE", "0"))      # slabs; 0 = no pacing (default)
+        self.pace_from = int(os.environ.get("WAE_TN_PACE_FROM", str(self.lead_jobs)))
         return self
 
     def launch(self):
@@ -224,7 +275,7 @@ class StreamTable:
         if self.window > 0:
             self.pace.zero_()
         L.check(eng.lib.wae_gemm_tn_stream(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
-                                           self.team_size, self.nwg, self.B, self.T, L.ptr(self.pace), self.window, eng.stream()),
+                                           self.team_size, self.nwg, self.B, self.T, L.ptr(self.pace), self.window, self.pace_from, eng.stream()),
                 "gemm_tn_stream")
 
 
@@ -284,6 +335,7 @@ def _build_tile_tables(eng, ws, fw, B, T):
             has_out = l < g.layers - 1
             stt.add(g.Rp, g.Hp, 0, g.Hp, ia, ws["gx"][l + 1].data_ptr() if has_out else 0, g.Rp,
                     fw["u"].data_ptr() + l * g.Hp * es, g.Ku, co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
+        stt.lead_jobs = g.k
         ws["stream"] = stt.finalize()
     for l in range(g.layers if ws["stream"] is None else 0):
         d = g.dilations[l]

@@ -434,27 +434,45 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
   // Each chunk = MT2 M-tiles (MT2*32 output channels = one staging pass per time row) against all of u.
   for (int q2 = 0; q2 < nq2; ++q2) {
     const int qi = NPASS * nq1 + q2;
+    constexpr int NRES = ES == 2 ? 2 * MT2 : 4 * MT2;  // 16-byte fragments per lane (32 bytes of the row per pair)
+    const bool dma_now = qi + D < nq_total && dbg_dma;
     // DMA(qi) was requested D chunks ago.  If that was before this phase's first drain (q2 == 0) nothing is pending
-    // for it any more; otherwise drain (the previous epilogue's stores and residual loads are younger than it).
-    if (q2 == 0 || q2 - D >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (qi + D < nq_total && dbg_dma) {
-      dma_chunk<NW>(p.w + (int64_t)(qi + D) * CHB, smem + slot_n * CHB, CHB, wave, lane);
-      slot_n = slot_n + 1 == p.nslot ? 0 : slot_n + 1;
+    // for it any more.  Otherwise (16-bit): every later chunk has issued its CG * NRES residual requests and its PPW pieces
+    // (stores -- none for an all-padding tile -- only make the wait stricter), so DMA(qi) has landed once at most that many
+    // operations are outstanding and the younger chunks' pieces stay in flight.  fp32: plain loads, drain.
+    if (q2 == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (q2 - D >= 0) {
+      if constexpr (ASM_B) {
+        int younger = 0;
+        for (int j = q2 - D + 1; j < q2; ++j) younger += CG * NRES + (j < nq2 - D && dbg_dma ? PPW : 0);
+        wait_vmcnt_upto(younger);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
+    __builtin_amdgcn_s_barrier();
     const char* buf = smem + slot_c * CHB + lane * 16;
     slot_c = slot_c + 1 == p.nslot ? 0 : slot_c + 1;
     const int gm0 = q2 * MT2;
     // residual x[t] for this chunk's channels, as operand-shaped 16-byte fragments (L2 hits: tap k-1 of GEMM 1
-    // read the same bytes); issued now, consumed after the MFMAs
-    constexpr int NRES = ES == 2 ? 2 * MT2 : 4 * MT2;  // 16-byte fragments per lane (32 bytes of the row per pair)
+    // read the same bytes); requested FIRST (loads retire in order: the wait for them below then leaves this chunk's
+    // DMA pieces in flight), consumed after the MFMAs
     frag res[CG][NRES];
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
       const int tc = t + 32 * c;
       const char* rsrc = xb + (int64_t)(tc < p.T ? tc : 0) * row_x + (int64_t)gm0 * 32 * ES + h * 16;
+      if constexpr (ASM_B) {
+        gload_async_n<0, NRES>(res[c], rsrc);
+      } else {
 #pragma unroll
-      for (int f = 0; f < NRES; ++f) res[c][f] = *(const frag*)(rsrc + f * 32);
+        for (int f = 0; f < NRES; ++f) res[c][f] = *(const frag*)(rsrc + f * 32);
+      }
+    }
+    if (dma_now) {
+      dma_chunk<NW>(p.w + (int64_t)(qi + D) * CHB, smem + slot_n * CHB, CHB, wave, lane);
+      slot_n = slot_n + 1 == p.nslot ? 0 : slot_n + 1;
     }
     f32x16 y[CG][MT2];
 #pragma unroll
@@ -470,6 +488,14 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
     }
     // x' = (y + x) * sqrt(.5) in the accumulator layout
     const f32x2 rs = {0.70710678118654752440f, 0.70710678118654752440f};
+    if constexpr (ASM_B) {   // the residual fragments have landed once only this chunk's pieces (issued after them) are outstanding
+      if (dma_now) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int f = 0; f < NRES; ++f) asm volatile("" : "+v"(res[c][f]));
+    }
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
       residual_to_acc_layout(res[c]);

@@ -305,6 +305,12 @@ __device__ __forceinline__ void gload_async(F& dst, const char* ptr) {
   static_assert(sizeof(F) == 16, "one 16-byte fragment");
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(ptr), "n"(OFF));
 }
+// N consecutive requests: fragment f of dst from ptr + 32 f
+template <int I, int N, typename F>
+__device__ __forceinline__ void gload_async_n(F (&dst)[N], const char* ptr) {
+  gload_async<I * 32>(dst[I], ptr);
+  if constexpr (I + 1 < N) gload_async_n<I + 1, N>(dst, ptr);
+}
 template <int CNT, typename F>
 __device__ __forceinline__ void wait_vmcnt_frags(F (&a)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(CNT));
