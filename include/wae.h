@@ -78,6 +78,27 @@ int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int
                            int64_t src_stride, int64_t dst_stride, int32_t src_cols, int64_t src_ld, int32_t unique,
                            void* stream);
 
+/* Several of either in ONE launch (a train step packs / scatters eleven families; the reference holds weights in one layout and
+ * needs neither).  jobs_host: HOST array of at most WAE_MULTI_MAX jobs, copied into the kernel arguments; the fields mean what
+ * the arguments of the single-job entries mean.  The scatter jobs of one call must write disjoint slots when unique != 0. */
+#define WAE_MULTI_MAX 16
+typedef struct wae_gather_job {
+  const float* src;
+  const int32_t* map;
+  void* dst;
+  int64_t n, src_stride, dst_stride;
+  int32_t nbatch, dtype;
+} wae_gather_job;
+typedef struct wae_scatter_job {
+  const float* src;
+  const int32_t* map;
+  float* dst;
+  int64_t n, src_stride, dst_stride, src_ld;
+  int32_t nbatch, src_cols, unique, pad_;
+} wae_scatter_job;
+int wae_pack_gather_multi(const wae_gather_job* jobs_host, int32_t njobs, void* stream);
+int wae_unpack_scatter_add_multi(const wae_scatter_job* jobs_host, int32_t njobs, void* stream);
+
 /* ---- a1 encoder block (vqvae_model.py:17-23): y = relu(conv1d(x,w,b,stride,pad=k/2)) (+x) ; fp32 (B,C,T)
  * relu/residual/pad selectable so the same entry serves Encoder.lin (vqvae_model.py:50, k=1) and the
  * upsample net's conv_in (upsample.py:77-78: k = 2*cin_pad+1, pad 0, no bias).  Tout = (Tin+2*pad-k)/stride+1 */

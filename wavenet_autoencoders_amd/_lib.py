@@ -53,6 +53,19 @@ class TsSeg(ctypes.Structure):           # include/wae.h: wae_ts_seg
     _fields_ = [("job", c_i32), ("slab_begin", c_i32), ("slab_end", c_i32)]
 
 
+class GatherJob(ctypes.Structure):       # include/wae.h: wae_gather_job (host array element)
+    _fields_ = [("src", c_vp), ("map", c_vp), ("dst", c_vp), ("n", c_i64), ("src_stride", c_i64), ("dst_stride", c_i64),
+                ("nbatch", c_i32), ("dtype", c_i32)]
+
+
+class ScatterJob(ctypes.Structure):      # include/wae.h: wae_scatter_job (host array element)
+    _fields_ = [("src", c_vp), ("map", c_vp), ("dst", c_vp), ("n", c_i64), ("src_stride", c_i64), ("dst_stride", c_i64),
+                ("src_ld", c_i64), ("nbatch", c_i32), ("src_cols", c_i32), ("unique", c_i32), ("pad_", c_i32)]
+
+
+MULTI_MAX = 16
+
+
 class HeadDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "Ku", "Sp", "Op", "O")] + [("scale", c_f32)]
 
@@ -66,6 +79,8 @@ SIGNATURES = {
     "wae_weight_norm_bwd_range": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wae_pack_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "wae_unpack_scatter_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i64, c_i32, c_vp]),
+    "wae_pack_gather_multi": (c_i32, [ctypes.POINTER(GatherJob), c_i32, c_vp]),
+    "wae_unpack_scatter_add_multi": (c_i32, [ctypes.POINTER(ScatterJob), c_i32, c_vp]),
     "wae_enc_conv_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp]),
     "wae_vq_nearest": (c_i32, [c_vp] * 6 + [c_i32] * 4 + [c_f32, c_vp]),
     "wae_upsample_stage_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),

@@ -72,25 +72,23 @@ def _prepare_bwd(eng):
 def pack_bwd_weights(eng):
     _prepare_bwd(eng)
     lib, st, g, lay = eng.lib, eng.stream(), eng.g, eng.lay
-    L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bu), L.ptr(eng.w_bu), eng.n_bu, g.layers, lay.layer_stride, eng.n_bu,
-                                eng.dt, st), "pack bwd U")
-    L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bx), L.ptr(eng.w_bx), eng.n_bx, g.layers, lay.layer_stride, eng.n_bx,
-                                eng.dt, st), "pack bwd X")
-    if eng.fused_bwd:
-        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_buo), L.ptr(eng.w_buo), eng.n_buo, g.layers, lay.layer_stride,
-                                    eng.n_buo, eng.dt, st), "pack bwd UO")
-        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bxf), L.ptr(eng.w_bxf), eng.n_bx, g.layers, lay.layer_stride,
-                                    eng.n_bx, eng.dt, st), "pack bwd X (tap by tap)")
-    if g.Ccp:
-        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_bc), L.ptr(eng.w_bc), eng.m_bc.numel(), 1, 0, 0, eng.dt, st),
-                "pack bwd C")
-    if eng.wide_head:
-        for k in ("w3t", "w1t"):
-            L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_hwide[k]), L.ptr(eng.w_hwide[k]), eng.m_hwide[k].numel(), 1, 0, 0,
-                                        eng.dt, st), "pack wide head " + k)
-    else:
-        L.check(lib.wae_pack_gather(L.ptr(eng.eff), L.ptr(eng.m_hb_w), L.ptr(eng.w_hb), eng.m_hb_w.numel(), 1, 0, 0, eng.dt, st),
-                "pack head bwd")
+    jobs = getattr(eng, "_pack_bwd_jobs", None)
+    if jobs is None:
+        eff = eng.eff.data_ptr()
+        J = lambda mp, dst, n, nb, ss, ds: L.GatherJob(eff, mp.data_ptr(), dst.data_ptr(), n, ss, ds, nb, eng.dt)
+        lst = [J(eng.m_bu, eng.w_bu, eng.n_bu, g.layers, lay.layer_stride, eng.n_bu),
+               J(eng.m_bx, eng.w_bx, eng.n_bx, g.layers, lay.layer_stride, eng.n_bx)]
+        if eng.fused_bwd:
+            lst += [J(eng.m_buo, eng.w_buo, eng.n_buo, g.layers, lay.layer_stride, eng.n_buo),
+                    J(eng.m_bxf, eng.w_bxf, eng.n_bx, g.layers, lay.layer_stride, eng.n_bx)]       # tap by tap
+        if g.Ccp:
+            lst.append(J(eng.m_bc, eng.w_bc, eng.m_bc.numel(), 1, 0, 0))
+        if eng.wide_head:
+            lst += [J(eng.m_hwide[k], eng.w_hwide[k], eng.m_hwide[k].numel(), 1, 0, 0) for k in ("w3t", "w1t")]
+        else:
+            lst.append(J(eng.m_hb_w, eng.w_hb, eng.m_hb_w.numel(), 1, 0, 0))
+        jobs = eng._pack_bwd_jobs = (L.GatherJob * len(lst))(*lst)
+    L.check(lib.wae_pack_gather_multi(jobs, len(jobs), st), "pack backward weights")
 
 
 def _arr(ctype, vals):
@@ -511,19 +509,22 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             e1.record(torch.cuda.current_stream(eng.device))
             ev.append((e0, e1))
     # ---- scatter the dense tiles of the layers and the head into the effective-weight gradient arena -----------------------
-    def scat(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1):
-        L.check(lib.wae_unpack_scatter_add(ctypes.c_void_p(src.data_ptr() + off * 4), L.ptr(mp), L.ptr(eng.d_eff), rows * cols, nb,
-                                           ss, ds, cols, ld, unique, st), "scatter")
+    def sjob(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1):
+        return L.ScatterJob(src.data_ptr() + off * 4, mp.data_ptr(), eng.d_eff.data_ptr(), rows * cols, ss, ds, ld, nb, cols, unique, 0)
     OP = P.ONES_PAD
-    scat(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], nb=g.layers, ss=Z2 * sm["ld1"], ds=lay.layer_stride)
-    scat(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride)
-    scat(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=2)
-    scat(cs, sm["ws"], g.Sp, g.Ku, sm["lds"])
-    scat(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=2)
-    scat(c3, sm["w3"], g.Op, g.Sp, sm["ldh"])
-    scat(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2)
-    scat(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"])
-    scat(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)
+    jobs = ws.get("scatter_jobs")
+    if jobs is None:           # disjoint slots: one launch (the tables and the arena never move)
+        lst = [sjob(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], nb=g.layers, ss=Z2 * sm["ld1"], ds=lay.layer_stride),
+               sjob(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride),
+               sjob(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=2),
+               sjob(cs, sm["ws"], g.Sp, g.Ku, sm["lds"]),
+               sjob(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=2),
+               sjob(c3, sm["w3"], g.Op, g.Sp, sm["ldh"]),
+               sjob(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2),
+               sjob(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"]),
+               sjob(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)]
+        jobs = ws["scatter_jobs"] = (L.ScatterJob * len(lst))(*lst)
+    L.check(lib.wae_unpack_scatter_add_multi(jobs, len(jobs), st), "scatter layer and head gradients")
     # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
     wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
     emb_off = lay.offsets.get("wavenet.embed_speakers.weight", 0)
@@ -558,8 +559,11 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         ws["ids"].copy_(xi)
         ws["tt_first"].launch(B, T)
         L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
-    scat(ctab, sm["tab"], 1 if g.scalar_input else g.O, g.Rp, g.Rp)
-    scat(fb, sm["fb"], 1, g.Rp, g.Rp)
+    jobs = ws.get("scatter_jobs_first")
+    if jobs is None:
+        lst = [sjob(ctab, sm["tab"], 1 if g.scalar_input else g.O, g.Rp, g.Rp), sjob(fb, sm["fb"], 1, g.Rp, g.Rp)]
+        jobs = ws["scatter_jobs_first"] = (L.ScatterJob * len(lst))(*lst)
+    L.check(lib.wae_unpack_scatter_add_multi(jobs, len(jobs), st), "scatter first-conv gradients")
     eng._bwd_keep = keep
     return ws["dc"]
 

@@ -135,27 +135,24 @@ class WaeEngine:
         lib, st, g, lay = self.lib, self.stream(), self.g, self.lay
         L.check(lib.wae_weight_norm_fwd(L.ptr(self.params), L.ptr(self.eff), lay.total, L.ptr(self.wn_v), L.ptr(self.wn_g),
                                         L.ptr(self.wn_c), len(lay.wn_cols), st), "weight_norm_fwd")
-        es = self.w_glu.element_size()
-        w2 = ctypes.c_void_p(self.w_glu.data_ptr() + self.n_w1 * es)
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_w1), L.ptr(self.w_glu), self.n_w1, g.layers,
-                                    lay.layer_stride, self.glu_elems, self.dt, st), "pack W1")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_w2), w2, self.n_w2, g.layers, lay.layer_stride,
-                                    self.glu_elems, self.dt, st), "pack W2")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_b2), L.ptr(self.b_glu), g.Rp, g.layers,
-                                    lay.layer_stride, g.Rp, L.WAE_F32, st), "pack out bias")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_tab), L.ptr(self.first_tab), self.m_tab.numel(), 1, 0, 0,
-                                    L.WAE_F32, st), "pack first table")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_fb), L.ptr(self.first_bias), g.Rp, 1, 0, 0, L.WAE_F32, st),
-                "pack first bias")
-        if self.wide_head:
-            for k in ("skip", "w1", "w3"):
-                L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hwide[k]), L.ptr(self.w_hwide[k]), self.m_hwide[k].numel(),
-                                            1, 0, 0, self.dt, st), "pack wide head " + k)
-        else:
-            L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hw), L.ptr(self.w_head), self.m_hw.numel(), 1, 0, 0,
-                                        self.dt, st), "pack head W")
-        L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_hb), ctypes.c_void_p(self.b_head.data_ptr() + g.Sp * 4),
-                                    g.Sp + g.Op, 1, 0, 0, L.WAE_F32, st), "pack head bias")
+        jobs = getattr(self, "_pack_jobs", None)
+        if jobs is None:       # the pointers never change: one host array, one launch for every family
+            es = self.w_glu.element_size()
+            eff = self.eff.data_ptr()
+            J = lambda mp, dst, n, nb, ss, ds, dt: L.GatherJob(eff, mp.data_ptr(), dst, n, ss, ds, nb, dt)
+            lst = [J(self.m_w1, self.w_glu.data_ptr(), self.n_w1, g.layers, lay.layer_stride, self.glu_elems, self.dt),
+                   J(self.m_w2, self.w_glu.data_ptr() + self.n_w1 * es, self.n_w2, g.layers, lay.layer_stride, self.glu_elems, self.dt),
+                   J(self.m_b2, self.b_glu.data_ptr(), g.Rp, g.layers, lay.layer_stride, g.Rp, L.WAE_F32),
+                   J(self.m_tab, self.first_tab.data_ptr(), self.m_tab.numel(), 1, 0, 0, L.WAE_F32),
+                   J(self.m_fb, self.first_bias.data_ptr(), g.Rp, 1, 0, 0, L.WAE_F32)]
+            if self.wide_head:
+                lst += [J(self.m_hwide[k], self.w_hwide[k].data_ptr(), self.m_hwide[k].numel(), 1, 0, 0, self.dt)
+                        for k in ("skip", "w1", "w3")]
+            else:
+                lst.append(J(self.m_hw, self.w_head.data_ptr(), self.m_hw.numel(), 1, 0, 0, self.dt))
+            lst.append(J(self.m_hb, self.b_head.data_ptr() + g.Sp * 4, g.Sp + g.Op, 1, 0, 0, L.WAE_F32))
+            jobs = self._pack_jobs = (L.GatherJob * len(lst))(*lst)
+        L.check(lib.wae_pack_gather_multi(jobs, len(jobs), st), "pack weights")
         L.check(lib.wae_sum_rows(L.ptr(self.eff), lay.off("wavenet.conv_layers.0.conv1x1_skip.bias"), lay.layer_stride,
                                  g.layers, g.S, g.Sp, L.ptr(self.b_head), st), "sum skip bias")
         self.weights_dirty = False
