@@ -218,8 +218,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("WAE_BENCH_SHARED_GPU", "0") != "0":
+            # plumbing check of the N > 1 path on a box with ONE GPU: every rank on cuda:0, collectives over gloo.  The line it
+            # prints is labelled as such and is not a measurement of anything.
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -358,6 +364,8 @@ def main():
             "roofline_glu_fwd": fwd_roof,
         }
         res.update(extra)
+        if world > 1 and os.environ.get("WAE_BENCH_SHARED_GPU", "0") != "0":
+            res["data"] = "synthetic; PLUMBING CHECK: %d ranks share ONE GPU over gloo -- not a measurement" % world
         if gsync is not None:
             comm_ms, wait_ms = gsync.collect_timing()
             res["allreduce"] = {"ms": comm_ms, "exposed_ms": wait_ms, "collectives_per_step": gsync.n_collectives / (args.steps + args.warmup),
