@@ -153,6 +153,35 @@ def test_stream_weight_gradients_match_per_layer_tiles(name, lengths, monkeypatc
     assert not bad, bad
 
 
+@pytest.mark.parametrize("env", [{"WAE_TN_PACE": "2"}, {"WAE_TN_PACE": "8", "WAE_TN_PACE_FROM": "1"}, {"WAE_TN_SHARES": "weighted"}])
+def test_stream_schedules_do_not_change_the_gradients(env, monkeypatch):
+    """The opt-in schedules of the one weight-gradient launch (narrow jobs paced against the taps; equal-time shares instead of
+    teams) are timing devices: same operands, same fp32 sums, only the arrival order of the atomics differs (1e-6 of the range)."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    x, g = ins["x"].cuda(), ins["g"].cuda()
+    c_up = torch.from_numpy(z["c_up"]).cuda()
+    ln = torch.tensor([1280, 1280 - 137])
+    got = []
+    for e in ({}, env):
+        for k in ("WAE_TN_PACE", "WAE_TN_PACE_FROM", "WAE_TN_SHARES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+        eng.load_state_dict(sd)
+        eng.decoder_forward(x, c_up, g, targets=x, lengths=ln.cuda(), train=True, c_is_upsampled=True, want_logits=False)
+        BW.decoder_backward(eng, x, x, ln, g)
+        st = BW.bwd_workspace(eng, *x.shape)["stream"]
+        assert st is not None and (st.window > 0) == ("WAE_TN_PACE" in e) and (st.team_size == 1) == ("WAE_TN_SHARES" in e)
+        got.append(BW.finish_grads(eng).clone())
+        torch.cuda.synchronize()
+    err, ref = float((got[0] - got[1]).abs().max()), float(got[0].abs().max())
+    assert err < 1e-6 * ref + 1e-9, (err, ref)
+
+
 def test_full_train_step_against_golden():
     """(7) of SURVEY 8c: parameter gradients of one step, post-Adam weights and EMA shadow of the reference."""
     from helpers import load_npz
