@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
   constexpr bool BIASED = MODE == TM_BIAS_RELU || MODE == TM_CE || MODE == TM_CE_BWD;
   // PAIRED: two workgroups per CU; the gate-backward epilogue then walks the tiles two at a time (fetch of the next
   // pair under the math of this one) so that it fits 256 registers, and stages through 4 KiB per wave
-  constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD) && NT % 2 == 0 && sizeof(E) == 2;
+  constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD || MODE == TM_BIAS_RELU) && NT % 2 == 0 && sizeof(E) == 2;
   constexpr int STGB = PAIRED ? 4096 : STG_BYTES;
   // PAIRED stages through the (then idle) weight ring after the chunk loop: 2 x (2 CHB) <= 128 KiB of LDS per CU
   char* stg = PAIRED ? smem + wave * STGB : smem + 2 * CHB + wave * STGB;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = fmaxf(acc[m][r] * p.alpha, 0.f);
     char* orow = p.out + (((int64_t)b * p.T + t0w) * p.out_stride + col0) * ES;
-    stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
+    stage_store_tiles<E, NT, PAIRED ? 128 : 256>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
   } else if constexpr (MODE == TM_CE) {
     // logits (B,O,T) and / or the shifted cross-entropy: same arithmetic as csrc/head_fwd.hip, all O tiles at once
     const TmCe& c = p.ce;
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_tm_kernel(TmArgs p) {
 template <typename E, int NT, int MODE, int OCC>
 static int launch_tm_occ(const TmArgs& a, int nslices, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
-  constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD) && NT % 2 == 0 && sizeof(E) == 2;
+  constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD || MODE == TM_BIAS_RELU) && NT % 2 == 0 && sizeof(E) == 2;
   const size_t lds = PAIRED ? 2 * CHB : 2 * CHB + 4 * STG_BYTES;
   static WaeLdsCache lds_cache;
   if (int rc = wae_ensure_lds((const void*)gemm_tm_kernel<E, NT, MODE, OCC>, lds_cache, lds, "gemm_tm"); rc != WAE_OK) return rc;
@@ -408,7 +408,7 @@ static int launch_tm_occ(const TmArgs& a, int nslices, hipStream_t st) {
 }
 template <typename E, int NT, int MODE>
 static int launch_tm(const TmArgs& a, int nslices, hipStream_t st) {
-  if constexpr (sizeof(E) == 2 && NT % 2 == 0 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD)) {
+  if constexpr (sizeof(E) == 2 && NT % 2 == 0 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD || MODE == TM_BIAS_RELU)) {
     if (!(a.flags & WAE_TM_ONE_WG)) return launch_tm_occ<E, NT, MODE, 2>(a, nslices, st);
   }
   return launch_tm_occ<E, NT, MODE, 1>(a, nslices, st);
