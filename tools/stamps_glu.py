@@ -9,6 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wavenet_autoencoders_amd import Geometry, _lib as L  # noqa: E402
+if os.path.exists(os.path.join(os.path.dirname(L.LIB_PATH), "libwae_stamps.so")):
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libwae_stamps.so")   # built with -DWAE_DEBUG_KNOBS -DWAE_GLU_STAMPS
 from wavenet_autoencoders_amd.engine import WaeEngine  # noqa: E402
 
 C2 = dict(layers=2, stacks=1, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=4, upsample_scales=None)
@@ -26,13 +28,13 @@ xo = torch.empty_like(x)
 ubuf = torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype)
 zb = torch.zeros(B, 2 * g.Hp, device="cuda")
 st = eng.stream()
-NW = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+NW = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+if NW == 4:
+    flags |= L.GLU_WAVES4
 nwg = B * ((T + 32 * NW - 1) // (32 * NW))
-stamps = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
 lib = eng.lib
 lib.wae_debug_set_stamps.argtypes = [ctypes.c_void_p]
-lib.wae_debug_set_glu_waves.argtypes = [ctypes.c_int]
-lib.wae_debug_set_glu_waves(NW)
 
 
 def run(fl, d=4):
@@ -48,7 +50,8 @@ for _ in range(3):
     run(flags)
 torch.cuda.synchronize()
 lib.wae_debug_set_stamps(None)
-s = stamps.cpu().numpy().reshape(nwg, 16)
+full = stamps.cpu().numpy().reshape(nwg, 64)
+s = full[:, :16]
 names = ["init(zb, first dma/B issue)", "GEMM1 pass 0", "z-save+gate+u-store (+ later passes)", "GEMM2+epilogue"]
 d = np.diff(s[:, :5].astype(np.int64), axis=1)
 print(f"flags={flags:#x} workgroups={nwg}; s_memtime ticks per phase (median / p10 / p90) over workgroups:")
@@ -65,3 +68,8 @@ end = s[:, 5].astype(np.int64)
 start = s[:, 14].astype(np.int64)
 print(f"  launch span {(end.max() - start.min()) / 100.0:.2f} us; starts (us after first): median "
       f"{(np.median(start) - start.min()) / 100.0:.2f}, max {(start.max() - start.min()) / 100.0:.2f}")
+
+pw = full[:, 16:16 + 4 * NW].reshape(nwg, NW, 4).astype(np.int64)
+print("  per wave (median over workgroups): vmcnt wait / barrier / issue / ds_read+MFMA")
+for w in range(NW):
+    print(f"    wave {w}: " + "  ".join(f"{int(np.median(pw[:, w, i])):7d}" for i in range(4)))

@@ -26,6 +26,9 @@
 // rows, channels innermost), zero-filled before t=0 (causal pad).  Outputs leave through a wave-private swizzled
 // LDS tile so that every global store is a full-row 16-B access.
 #include "wae_common.hpp"
+#ifndef WAE_GLU_PD
+#define WAE_GLU_PD 4      // A-fragment reads in flight per wave in GEMM 1 (8 measured the same: round 2)
+#endif
 
 // timing-only ablation bits (tools/ablate_glu.py): compiled in only with -DWAE_GLU_ABLATE (a run-time test of these
 // bits inside the gate loop cost 2x on that phase); outputs are wrong when any is set
@@ -99,8 +102,8 @@ __device__ __forceinline__ float vmax_nocanon(float a, float b) {
 
 // NPH = gate-channel tiles per pass (per half); NW = waves per workgroup; CG = 32-column groups per wave.
 // CG = 2 (bf16 / fp16, 4 waves, one per SIMD, up to 512 registers each): a wave owns 64 time columns, every A fragment it
-// reads from LDS feeds two MFMAs.  With CG = 1 the kernel is co-limited by the LDS port and the matrix pipe (DESIGN 3.1:
-// eight waves x 24 fragments per chunk step = 1536 cycles of the port's 128 B/clk, exactly the MFMAs' 1536 cycles).
+// reads from LDS feeds two MFMAs.  Opt-in and slower than CG = 1 (the LDS port, measured at 256 B/clk, was never
+// the limit; one wave per SIMD exposes every wait of that wave).
 template <typename E, int NP, int NPH, bool EXACT, int NW, int CG>
 __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1) ? 2 : 1) glu_fwd_kernel(GluArgs p) {
   using T_ = ET<E>;
@@ -146,6 +149,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
   const char* cb = p.c_up ? p.c_up + (int64_t)b * p.T * row_c : nullptr;
 
   const bool dbg_dma = !ABL(p.flags, DBG_NO_DMA);
+  // chunk -> (column block, tap) once per chunk in b_src / fix_B: q / ktaps as a multiply (exact for q < 65536 / ktaps)
+  const unsigned kinv = (65536u + (unsigned)p.ktaps - 1u) / (unsigned)p.ktaps;
   // The activation operand is requested TWO chunks ahead into a rotating set of three fragment groups (an L2/HBM
   // round trip under load is longer than one chunk of MFMAs).  Loads are always issued (rows clamped into the clip)
   // so that the number of outstanding VMEM ops is known; columns outside [0, T) are zeroed at use (causal pad).
@@ -158,7 +163,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
     if (q < nq_conv) {
       // column block by column block, the taps of one block back to back: a tile reads x[t - d] right after x[t] while the
       // tile d rows earlier reads the same rows as its last tap -- they meet in L2 (packing.py: glu_w1_map, same order)
-      const int cblk = q / p.ktaps, tap = q - cblk * p.ktaps;
+      const int cblk = (int)(((unsigned)q * kinv) >> 16), tap = q - cblk * p.ktaps;   // q / ktaps without the division sequence
       ts -= (p.ktaps - 1 - tap) * p.dilation;
       base = xcb + cblk * 128 + h * 16;
       rp = row_x;
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
     }
   };
   auto fix_B = [&](int q, frag (&Bf)[CG][4]) {
-    const int shift = q < nq_conv ? (p.ktaps - 1 - q % p.ktaps) * p.dilation : 0;
+    const int shift = q < nq_conv ? (p.ktaps - 1 - (q - (int)(((unsigned)q * kinv) >> 16) * p.ktaps)) * p.dilation : 0;
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
       const int tc = t + 32 * c;
@@ -258,21 +263,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
 #endif
   auto chunk_top = [&](int qi, int q_load) {
 #ifdef WAE_GLU_STAMPS
-    const unsigned long long c0 = TICK();
+    const unsigned long long c00 = TICK();
 #endif
-    wait_vmcnt_upto(w_next);
-#ifdef WAE_GLU_STAMPS
-    const unsigned long long c1 = TICK();
-#endif
-    // a bare s_barrier: __syncthreads() is fence + barrier, and hipcc lowers the fence to s_waitcnt vmcnt(0), which
-    // would drain the very prefetch queue the counted wait above leaves in flight.  Every wave has retired its LDS
-    // reads of the previous chunk (gemm_chunk exits with lgkmcnt(0)), and its own DMA pieces by the counted wait.
-    __builtin_amdgcn_s_barrier();
-#ifdef WAE_GLU_STAMPS
-    const unsigned long long c2 = TICK();
-    acc_wait += c1 - c0;
-    acc_bar += c2 - c1;
-#endif
+    // Bookkeeping of this chunk's requests first, the wait and the barrier after it (nothing here touches LDS or memory but the
+    // chunk-0 burst, which goes to ring slots nobody has read yet).  Per-wave stamps (tools/stamps_glu.py, C2, eight waves): the
+    // older wave of a SIMD gets the matrix pipe first, finishes its 24 MFMAs after ~1390 clocks and waits ~870 at the barrier;
+    // the younger one needs ~2030, then ~300 for this bookkeeping and ~200 for the wait: 2630 clocks per chunk of 1536 MFMA
+    // clocks.  Forming the NEXT chunk's requests inside the MFMA stream instead (built and measured, round 2) moved those 300
+    // clocks into the stream one for one: the waves' instruction streams, not the matrix pipe, set the pace of a chunk.
+    const int w_cur = w_next;
     int issued = 0;
     dsrc = nullptr;
     if (qi == 0) {
@@ -295,7 +294,21 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
     // at chunk 1 DMA(1) -- the oldest chunk of chunk 0's burst -- must have landed as well
     w_next = D == 1 ? nb : (qi == 0 && issued > 0 ? issued - PPW + nb : issued + nb);
 #ifdef WAE_GLU_STAMPS
-    acc_issue += TICK() - c2;
+    const unsigned long long c0 = TICK();
+    acc_issue += c0 - c00;
+#endif
+    wait_vmcnt_upto(qi == 0 ? w_cur + issued : w_cur);
+#ifdef WAE_GLU_STAMPS
+    const unsigned long long c1 = TICK();
+#endif
+    // a bare s_barrier: __syncthreads() is fence + barrier, and hipcc lowers the fence to s_waitcnt vmcnt(0), which
+    // would drain the very prefetch queue the counted wait above leaves in flight.  Every wave has retired its LDS
+    // reads of the previous chunk (gemm_chunk exits with lgkmcnt(0)), and its own DMA pieces by the counted wait.
+    __builtin_amdgcn_s_barrier();
+#ifdef WAE_GLU_STAMPS
+    const unsigned long long c2 = TICK();
+    acc_wait += c1 - c0;
+    acc_bar += c2 - c1;
 #endif
   };
 
@@ -346,7 +359,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
 #ifdef WAE_GLU_STAMPS
         const unsigned long long g0 = TICK();
 #endif
-        gemm_chunk_fill_cg<4 * NM, NM, 4, CG, false, 4>(buf, Bcur, acc, filler);
+        gemm_chunk_fill_cg<4 * NM, NM, 4, CG, false, WAE_GLU_PD>(buf, Bcur, acc, filler);
 #ifdef WAE_GLU_STAMPS
         acc_gemm += TICK() - g0;
 #endif
@@ -520,11 +533,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
   }
   STAMP(4);
 #ifdef WAE_GLU_STAMPS
+  if (p.stamps && lane == 0) {   // every wave: its own sums of the GEMM-1 chunk loop
+    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 64 + 16 + wave * 4;
+    o[0] = acc_wait; o[1] = acc_bar; o[2] = acc_issue; o[3] = acc_gemm;
+  }
   if (p.stamps && threadIdx.x == 0) {
     st_[5] = __builtin_amdgcn_s_memrealtime();
     st_[6] = acc_wait; st_[7] = acc_bar; st_[8] = acc_issue; st_[9] = acc_gemm;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 16 + i] = st_[i];
+    for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 64 + i] = st_[i];
   }
 #endif
 }

@@ -253,9 +253,9 @@ __device__ __forceinline__ void gemm_chunk(const char* buf, const frag (&B)[NB],
 }
 
 // The same chunk against CG column groups per wave (CG = 2: 64 time columns): every A fragment read from LDS feeds CG MFMAs,
-// so the LDS read traffic per MFMA is 1/CG KiB.  With CG = 1 the matrix pipe and the LDS port are exactly co-limited (one
-// 1-KiB fragment per 32-cycle MFMA per SIMD = 128 B/clk); CG = 2 leaves the port half idle for the DMA writes and the
-// staging tiles.  The filler runs after every MFMA (index I * CG + c).
+// so the LDS read traffic per MFMA is 1/CG KiB.  (Round 1 priced the LDS port at 128 B/clk and expected CG = 2 to relieve it;
+// tools/micro/lds_read.hip measures 256 B/clk, and one fragment per MFMA keeps the matrix pipe 98 % busy: CG = 2 buys nothing.)
+// The filler runs after every MFMA (index I * CG + c).
 template <int I, int N, int NM, int PD, int NB, int CG, bool KMAJOR, typename frag, typename F>
 struct GemmChunkStepCG {
   static __device__ __forceinline__ void run(unsigned addr, frag (&a)[PD], const frag (&B)[CG][NB], f32x16 (&acc)[CG][NM], F& filler) {
