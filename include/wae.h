@@ -44,6 +44,9 @@ extern "C" {
 #define WAE_GLU_NO_OUT 4    /* do not compute/store x' (last layer: the reference's x' is dead, wavenet.py:205-207) */
 #define WAE_GLU_CG2 16      /* 16-bit dtypes: 4 waves x 64 time columns (one wave per SIMD), every weight fragment read from LDS feeds
                                two MFMAs -- half the LDS read traffic of the default shape; same results bit for bit */
+#define WAE_GLU_PAIR 32     /* GEMM 1 meets at a workgroup barrier on every SECOND weight chunk (four ring slots, weights two chunks ahead): the
+                               waves of a SIMD drift by up to one chunk, so one wave's chunk bookkeeping runs under the other's MFMAs;
+                               same results bit for bit */
 #define WAE_GLU_WAVES4 8    /* bf16: 128-step tiles, 4 waves, two workgroups per CU instead of one 256-step / 8-wave workgroup
                                (same results bit for bit; an A/B switch per launch, not process state) */
 

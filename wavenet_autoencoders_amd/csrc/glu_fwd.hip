@@ -27,7 +27,7 @@
 // LDS tile so that every global store is a full-row 16-B access.
 #include "wae_common.hpp"
 #ifndef WAE_GLU_PD
-#define WAE_GLU_PD 4      // A-fragment reads in flight per wave in GEMM 1 (8 measured the same: round 2)
+#define WAE_GLU_PD 4      // A-fragment reads in flight per wave in GEMM 1 (5, 6, 8: the C2 instantiation is at 256 registers and spills)
 #endif
 
 // timing-only ablation bits (tools/ablate_glu.py): compiled in only with -DWAE_GLU_ABLATE (a run-time test of these
@@ -218,7 +218,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
   // would drain the LDS-DMA queue)
   constexpr int PPW = CHB / NW / 1024;  // LDS-DMA instructions per wave and chunk
   constexpr int NBL = 4 * CG;           // operand loads per wave and chunk
-  const int D = p.nslot - 1;            // weight prefetch distance in chunks
+  // WAE_GLU_PAIR: the workgroup barrier of GEMM 1 on even chunks only.  Safe with four ring slots and the weights TWO chunks ahead:
+  //  * slot reuse: DMA(c + 2), issued during chunk c, overwrites the slot of chunk c - 2, which every wave left before the last
+  //    barrier (top of c for even c, top of c - 1 for odd c); a wave that runs one chunk ahead reads slot c % 4 and writes
+  //    slot (c + 2) % 4 while the others read slot (c - 1) % 4;
+  //  * visibility: at an even top every wave waits until only its operand requests of the previous chunk are outstanding, i.e.
+  //    its pieces of DMA(c) AND of DMA(c + 1) (issued ahead of those requests in the previous chunk's stream) have landed
+  //    before anybody passes the barrier -- nobody meets again before reading chunk c + 1.
+  const bool pair = CG == 1 && (p.flags & WAE_GLU_PAIR) && p.nslot == 4;
+  const int D = pair ? 2 : p.nslot - 1;   // weight prefetch distance in chunks
   char* ring_end = smem + p.nslot * CHB;
   char* stg = ring_end + wave * STG;
   float* bias_lds = (float*)(ring_end + NW * STG);
@@ -252,6 +260,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
   const int per_wave = CHB / NW;
   const char* w_lane = p.w + wave * per_wave + lane * 16;
   int w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : NBL;  // the prologue's B(1)
+  int nb_last = w_next;   // operand requests issued by the previous chunk's stream (they follow its DMA pieces)
   const char* dsrc = nullptr;  // this chunk's DMA request (wave-uniform validity), per-lane source
   char* ddst = nullptr;
   const char* bsrc[CG];        // this chunk's activation requests (null: none)
@@ -297,14 +306,18 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
     const unsigned long long c0 = TICK();
     acc_issue += c0 - c00;
 #endif
-    wait_vmcnt_upto(qi == 0 ? w_cur + issued : w_cur);
+    const bool meet = !pair || (qi & 1) == 0;
+    int allow = qi == 0 ? w_cur + issued : w_cur;
+    if (pair && meet && qi > 0) allow = min(allow, nb_last);   // DMA(qi + 1) too (see `pair` above)
+    nb_last = nb;
+    wait_vmcnt_upto(allow);
 #ifdef WAE_GLU_STAMPS
     const unsigned long long c1 = TICK();
 #endif
     // a bare s_barrier: __syncthreads() is fence + barrier, and hipcc lowers the fence to s_waitcnt vmcnt(0), which
     // would drain the very prefetch queue the counted wait above leaves in flight.  Every wave has retired its LDS
     // reads of the previous chunk (gemm_chunk exits with lgkmcnt(0)), and its own DMA pieces by the counted wait.
-    __builtin_amdgcn_s_barrier();
+    if (meet) __builtin_amdgcn_s_barrier();
 #ifdef WAE_GLU_STAMPS
     const unsigned long long c2 = TICK();
     acc_wait += c1 - c0;
@@ -387,6 +400,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && sizeof(E) == 2 && CG == 1
         load_B(0, S0);
         load_B(1, S1);
         w_next = ABL(p.flags, DBG_NO_BLOAD) ? 0 : NBL;
+        nb_last = w_next;
       }
     }
     if (ps == 0) STAMP(2);
