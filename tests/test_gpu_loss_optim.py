@@ -136,3 +136,57 @@ def test_resume_from_a_reference_optimizer_state():
         assert bool(((eng.params[off:off + n].view(p2.shape).cpu() - p2).abs() <= tol).all()), k
         assert float((mine["state"][i]["exp_avg"] - m2).abs().max()) < 1e-3 * gm + 1e-9, k
         assert float((mine["state"][i]["exp_avg_sq"] - v2).abs().max()) < 2e-3 * float(v2.abs().max()) + 1e-14, k
+
+
+def test_multi_job_gather_and_scatter_equal_the_single_job_entries():
+    """wae_pack_gather_multi / wae_unpack_scatter_add_multi (one launch for the weight families / gradient blocks of a step)
+    against the single-job entries: same destinations bit for bit (plain, row-sum and atomic modes; fp32, bf16, fp16)."""
+    import ctypes
+    from wavenet_autoencoders_amd import _lib as L
+    lib = L.lib()
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(3)
+    src = torch.randn(50000, generator=gen).to(dev)
+    jobs, single = [], []
+    keep = []
+    for n, nb, ss, ds, dt in ((4097, 3, 9000, 5000, L.WAE_BF16), (300, 1, 0, 0, L.WAE_F32), (70001 // 7, 2, 12000, 10001, L.WAE_F16),
+                              (1, 1, 0, 0, L.WAE_F32)):
+        mp = torch.randint(-1, 20000, (n,), generator=gen, dtype=torch.int32).to(dev)
+        tdt = {L.WAE_BF16: torch.bfloat16, L.WAE_F16: torch.float16, L.WAE_F32: torch.float32}[dt]
+        d1 = torch.zeros(nb * max(ds, n), dtype=tdt, device=dev)
+        d2 = torch.zeros_like(d1)
+        keep += [mp, d1, d2]
+        L.check(lib.wae_pack_gather(L.ptr(src), L.ptr(mp), L.ptr(d1), n, nb, ss, ds, dt, None), "single")
+        jobs.append(L.GatherJob(src.data_ptr(), mp.data_ptr(), d2.data_ptr(), n, ss, ds, nb, dt))
+        single.append((d1, d2))
+    arr = (L.GatherJob * len(jobs))(*jobs)
+    L.check(lib.wae_pack_gather_multi(arr, len(jobs), None), "multi")
+    torch.cuda.synchronize()
+    for d1, d2 in single:
+        assert torch.equal(d1, d2)
+    # scatter: unique plain adds, row sums (unique == 2) and atomics (unique == 0; integer-valued data: order-independent sums)
+    sj, pairs = [], []
+    for rows, cols, ld, nb, unique in ((37, 24, 32, 2, 1), (19, 128, 160, 3, 2), (64, 16, 16, 1, 0)):
+        n = rows * cols
+        srcm = torch.randint(-8, 9, (nb * rows * ld + 7,), generator=gen).float().to(dev)
+        if unique == 1:
+            mp = torch.randperm(6000, generator=gen)[:n].to(torch.int32)
+            mp[::5] = -1
+        elif unique == 2:
+            mp = torch.randperm(6000, generator=gen)[:rows].to(torch.int32).repeat_interleave(cols)
+        else:
+            mp = torch.randint(0, 50, (n,), generator=gen, dtype=torch.int32)
+        mp = mp.to(dev)
+        d1 = torch.zeros(nb * 7000, device=dev)
+        d2 = torch.zeros_like(d1)
+        keep += [srcm, mp, d1, d2]
+        L.check(lib.wae_unpack_scatter_add(L.ptr(srcm), L.ptr(mp), L.ptr(d1), n, nb, rows * ld, 7000, cols, ld, unique, None), "single")
+        sj.append(L.ScatterJob(srcm.data_ptr(), mp.data_ptr(), d2.data_ptr(), n, rows * ld, 7000, ld, nb, cols, unique, 0))
+        pairs.append((d1, d2))
+    arr2 = (L.ScatterJob * len(sj))(*sj)
+    L.check(lib.wae_unpack_scatter_add_multi(arr2, len(sj), None), "multi scatter")
+    torch.cuda.synchronize()
+    for d1, d2 in pairs:
+        assert torch.equal(d1, d2) and float(d1.abs().sum()) > 0
+    with pytest.raises(L.WaeError):
+        L.check(lib.wae_pack_gather_multi(arr, 0, None), "no jobs")
