@@ -300,3 +300,31 @@ def test_glu_64_column_shape_is_bitwise_identical(dtype):
         outs.append((out["logits"].cpu(), float(out["loss"]), [zz.clone() for zz in eng._ws[(2, T, True)]["z"]]))
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
     assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
+
+
+@pytest.mark.parametrize("R,G", [(256, 368), (256, 256), (512, 512)])
+def test_glu_barrier_on_every_second_chunk_is_bitwise_identical(R, G, monkeypatch):
+    """WAE_GLU_PAIR (the default of inference launches): GEMM 1 meets at a workgroup barrier on even weight chunks only.  A timing
+    device -- the logits of a few layers at C2 / hps/vqwae.json / C5 widths must not differ by a bit from the per-chunk barriers,
+    on ragged shapes and on repeats (a race would show as run-to-run differences)."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=6, stacks=2, R=R, G=G, S=R, O=256, Cc=64, Cg=32, k=3, n_speakers=10, upsample_scales=[4, 4, 4, 5], cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+    ref = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WAE_GLU_PAIR", mode)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+        eng.load_state_dict(sd)
+        for B, F in ((1, 3), (3, 13), (8, 9)):
+            T = F * 320
+            x = torch.randint(0, 256, (B, T), generator=torch.Generator().manual_seed(B * 100 + F)).to(torch.int32).cuda()
+            lat = torch.randn(B, 64, F, generator=torch.Generator().manual_seed(7)).cuda()
+            g = torch.randint(0, 10, (B,), generator=torch.Generator().manual_seed(9)).cuda()
+            for rep in range(1 if mode == "0" else 4):
+                y = eng.decoder_forward(x, lat, g)["logits"]
+                torch.cuda.synchronize()
+                if mode == "0":
+                    ref[(B, F)] = y.clone()
+                else:
+                    assert torch.equal(y, ref[(B, F)]), (B, F, rep)
