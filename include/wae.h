@@ -49,6 +49,8 @@ extern "C" {
                                same results bit for bit */
 #define WAE_GLU_WAVES4 8    /* bf16: 128-step tiles, 4 waves, two workgroups per CU instead of one 256-step / 8-wave workgroup
                                (same results bit for bit; an A/B switch per launch, not process state) */
+#define WAE_GLU_GENERIC 64   /* 16-bit dtypes: run the run-time-scheduled kernel (csrc/glu_fwd.hip) even where a static-schedule
+                               instantiation (csrc/glu_fwd_static.hip) exists for the geometry; same results bit for bit */
 
 const char* wae_version(void);
 const char* wae_last_error(void);

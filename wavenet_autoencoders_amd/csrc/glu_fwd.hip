@@ -42,22 +42,7 @@
 #define ABL(flags, bit) false
 #endif
 
-struct GluArgs {
-  const char* x_in;
-  const char* x_conv;  // operand of the dilated convolution: x_in, or dropout(x_in) in training with p > 0 (modules.py:127-128)
-  char* x_out;
-  const char* c_up;
-  char* u_out;
-  const float* zb;
-  char* z_save;
-  const char* w;
-  const float* bias_out;
-  int64_t zb_stride;
-  int64_t u_stride;  // elements per time row of u_out
-  int B, T, Rp, Ccp, Hp, ktaps, dilation, flags;
-  int nslot;  // LDS ring slots (>= 2); weight chunk q lives in slot q % nslot and is requested nslot-1 chunks ahead
-  unsigned long long* stamps;  // diagnostic only (wae_debug_set_stamps): 16 x u64 per workgroup, else null
-};
+#include "glu_fwd.hpp"
 
 // Diagnostics (tools/stamps_glu.py, tools/time_glu.py) exist only in a `make EXTRA=-DWAE_DEBUG_KNOBS` build: the product
 // library has no process-global switches (include/wae.h: every entry is re-entrant; shapes are chosen by descriptor flags).
@@ -664,6 +649,15 @@ extern "C" int wae_glu_layer_fwd_drop(const wae_glu_desc* d, const void* x_in, c
   a.u_stride = u_stride; a.B = d->B; a.T = d->T; a.Rp = d->Rp; a.Ccp = d->Ccp; a.Hp = d->Hp; a.ktaps = d->ktaps;
   a.dilation = d->dilation; a.flags = d->flags; a.stamps = g_stamps;
   hipStream_t st = as_stream(stream);
+#ifndef WAE_GLU_ABLATE
+  // the benchmarked 16-bit geometries run on their static-schedule instantiations (glu_fwd_static.hip; bit-identical results);
+  // the shape flags and WAE_GLU_GENERIC select this file's kernel
+  if (!(d->flags & (WAE_GLU_GENERIC | WAE_GLU_CG2 | WAE_GLU_WAVES4))) {
+    bool handled = false;
+    rc = wae_glu_static_launch(a, d->dtype, st, &handled);
+    if (handled || rc != WAE_OK) return rc;
+  }
+#endif
   if (d->dtype == WAE_BF16) return dispatch_np<__bf16, false>(d->Hp / 32, a, st);
   if (d->dtype == WAE_F16) return dispatch_np<f16, false>(d->Hp / 32, a, st);
   return dispatch_np<float, true>(d->Hp / 32, a, st);
