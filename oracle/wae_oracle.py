@@ -206,14 +206,19 @@ def upsample_forward(sd: SD, c: torch.Tensor, scales: Sequence[int], prefix: str
 # a6: one gated residual layer (modules.py:115-163)
 # --------------------------------------------------------------------------
 def dropout_keep(seed: int, B: int, R: int, T: int, p: float) -> torch.Tensor:
-    """The keep mask (B, R, T) of the engine's dropout (csrc/misc.hip: dropout_keep): a counter-based hash of (seed, element
+    """The keep mask (B, R, T) of the engine's dropout (csrc/misc.hip: dropout_keep): a counter-based hash of (finalised seed, element
     index in the engine's (B, T, Rp) layout, Rp = R rounded up to 128); keep iff the top 24 bits of the mix >= p * 2^24.
     The reference draws its mask from torch's RNG (modules.py:127-128: F.dropout); the engine cannot reproduce that stream, so
     parity is checked mask-for-mask: the oracle applies THIS mask where the reference applies torch's."""
     Rp = (R + 127) // 128 * 128
     e = (np.arange(B * T, dtype=np.uint64)[:, None] * np.uint64(Rp) + np.arange(R, dtype=np.uint64)[None, :])
+    M = 0xFFFFFFFFFFFFFFFF
+    z = ((seed & M) + 0x9E3779B97F4A7C15) & M               # csrc/misc.hip: dropout_key -- the seed is finalised before it meets e
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    key = z ^ (z >> 31)
     with np.errstate(over="ignore"):
-        h = (e + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)) * np.uint64(0x9E3779B97F4A7C15)
+        h = (e ^ np.uint64(key)) * np.uint64(0x9E3779B97F4A7C15)
         h ^= h >> np.uint64(32)
         h *= np.uint64(0xD6E8FEB86659FD93)
         h ^= h >> np.uint64(32)

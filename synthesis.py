@@ -31,6 +31,19 @@ def inv_preemphasis(x, coef=0.85):
     return signal.lfilter([1], [1, -coef], x)
 
 
+def postprocess_indices(idx, quantize_channels, postprocess, global_gain_scale):
+    """The tail of wavegen (synthesis.py:382-394): mu-law class ids -> inv_mulaw_quantize(., quantize_channels) ->
+    getattr(audio, postprocess) (the presets name inv_preemphasis, coefficient 0.85, audio.py:64-65) -> / global_gain_scale."""
+    y = inv_mulaw_quantize(np.asarray(idx), quantize_channels)
+    if postprocess not in ("", None, "none"):
+        if postprocess != "inv_preemphasis":
+            raise NotImplementedError(f"postprocess={postprocess!r}: audio.py offers inv_preemphasis only")
+        y = inv_preemphasis(y, 0.85)
+    if global_gain_scale > 0:
+        y = y / global_gain_scale
+    return y.astype(np.float32)
+
+
 def wavegen(eng, length, c, g, initial_value=127):
     """wavegen (synthesis.py:295-396): c (Tc, D) features, g speaker id -> float waveform in [-1, 1]."""
     device = eng.device
@@ -42,12 +55,7 @@ def wavegen(eng, length, c, g, initial_value=127):
     quant, _, _ = eng.vq_forward(lat)
     out = eng.incremental_forward(quant, gid, int(length), mode="sample", init_idx=int(initial_value))
     idx = out["idx"][0].cpu().numpy()
-    y = inv_mulaw_quantize(idx, hparams.quantize_channels)                                    # synthesis.py:382-384 uses 256
-    if hparams.postprocess not in ("", None, "none"):
-        y = inv_preemphasis(y, 0.85)                                                          # :390-391
-    if hparams.global_gain_scale > 0:
-        y = y / hparams.global_gain_scale                                                     # :393-394
-    return y.astype(np.float32)
+    return postprocess_indices(idx, hparams.quantize_channels, hparams.postprocess, hparams.global_gain_scale)
 
 
 def main(argv=None):

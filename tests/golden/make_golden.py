@@ -565,6 +565,142 @@ CFG_C5 = dict(name="c5", layers=48, stacks=4, R=512, G=512, S=512, O=256, Cc=64,
               upsample_scales=[4, 4, 8, 5], cin_pad=0)
 
 
+CFG_C2 = dict(name="c2", layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153,
+              upsample_scales=[4, 4, 4, 5], cin_pad=0)
+
+
+def gen_c2():
+    """BASELINE config C2 -- the geometry bench.py times (hps/inae_hp.json decoder dims: 24 layers / 2 stacks, R 256, G 368, S 256,
+    Cc 64, Cg 64, scales 4,4,4,5) -- one clip of 8000 samples through the reference's own WaveNet: sparse logits probe, per-step
+    log-sum-exp, sums; and ONE reference train step on that clip (teacher-forced CE with the shift of vqwae_train.py:764, autograd,
+    no clipping needed): loss and every decoder parameter's gradient (squared norm + probe values), beside the fp64 oracle's."""
+    cfg = CFG_C2
+    sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+    T = 8000
+    lat = O.hash_fill((1, cfg["Cc"], T // 320), 601, 1.2)
+    x = ((O.hash_fill((1, T), 602) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    g = torch.tensor([77])
+    wn = build_ref_wavenet(cfg)
+    wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items()})
+    wn.eval()
+    ocfg = dict(layers=24, stacks=2, upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    with torch.no_grad():
+        y = wn(xin, lat, g, False)
+        oy = O.wavenet_forward(sd, ocfg, xin, lat, g)
+    e = close(oy, y, what="C2 logits", tol=5e-5)
+    print(f"  C2 (24 layers, G 368): T={T}, max|oracle-ref| = {e:.2e}, |y|max {y.abs().max().item():.3f}")
+    ti = torch.unique(torch.cat([torch.arange(0, T, 53), torch.arange(4090, 4106), torch.arange(T - 4, T)]))
+    # one reference train step (decoder only; the reference module in train mode, dropout 0.0)
+    wn.train()
+    for p_ in wn.parameters():
+        p_.grad = None
+    y_t = wn(xin, lat, g, False)
+    crit = torch.nn.CrossEntropyLoss(reduction="none")
+    ce = crit(y_t[:, :, :-1].unsqueeze(-1), x[:, 1:].unsqueeze(-1)).mean()
+    ce.backward()
+    grads = {"wavenet." + n: (p_.grad.clone() if p_.grad is not None else torch.zeros_like(p_)) for n, p_ in wn.named_parameters()}
+    psd = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    oy64 = O.wavenet_forward(psd, ocfg, xin.double(), lat.double(), g)
+    oce = O.masked_ce_loss(oy64, x.unsqueeze(-1), torch.tensor([T]))
+    oce.backward()
+    close(oce, ce, what="C2 train loss", tol=1e-5)
+    ograds = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in psd.items()}
+    worst = max((ograds[k].float() - grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-20) for k in grads)
+    print(f"  C2 train step: loss {ce.item():.5f}, worst fp32-reference vs fp64-oracle gradient deviation {worst:.2e} of a tensor's max")
+    names = list(grads.keys())
+    pidx = {k: _probe_index(grads[k].numel()) for k in names}
+    cat = lambda d, dt: torch.cat([d[k].reshape(-1)[pidx[k]].to(dt) for k in names])   # noqa: E731
+    save("model_c2_probe", cfg=json.dumps(cfg), salt=5, lat_salt=601, x_salt=602, g=g, T=T, probe_t=ti, y_probe=y[0][:, ti],
+         y_lse=torch.logsumexp(y, 1), y_sum=y.double().sum(), y_abs_sum=y.double().abs().sum(),
+         loss=ce.detach(), names=json.dumps(names), probe_counts=np.array([len(pidx[k]) for k in names]),
+         grad_probe=cat(grads, torch.float32), grad64_probe=cat(ograds, torch.float64),
+         grad64_sq=np.array([float((ograds[k] ** 2).sum()) for k in names]),
+         grad_max=np.array([float(grads[k].abs().max()) for k in names]))
+
+
+CFG_P = dict(name="P", layers=4, stacks=2, R=32, G=48, S=32, O=64, Cc=16, Cg=8, k=3, n_speakers=5,
+             upsample_scales=[4, 4, 8, 5], encoder_hid=32, c_in=39, K=32, cin_pad=1)
+
+
+def gen_cin_pad():
+    """cin_pad = 1 (upsample.py:69-85: conv_in has k = 2*cin_pad + 1 taps and NO padding, so it eats cin_pad frames on either side;
+    vqwae_train.py:455-478 crops the features cin_pad frames wider than the audio): the reference's VQVAE with
+    upsample_params cin_pad=1 -- c_up, logits and, for the decoder alone on (B, Cc, Tc) features, logits and the input gradient."""
+    cfg = CFG_P
+    sd = O.make_state_dict(cfg, 4)
+    assert sd["wavenet.upsample_net.conv_in.weight"].shape[-1] == 3
+    B, F = 2, 16                                   # encoder: 16 frames -> 4 latent frames; conv_in leaves 2 -> T = 2 * 640
+    c = O.hash_fill((B, cfg["c_in"], F), 41, 1.7)
+    hop = int(np.prod(cfg["upsample_scales"]))
+    wn = RefWaveNet(out_channels=cfg["O"], layers=cfg["layers"], stacks=cfg["stacks"], residual_channels=cfg["R"],
+                    gate_channels=cfg["G"], skip_out_channels=cfg["S"], kernel_size=cfg["k"], dropout=0.0,
+                    cin_channels=cfg["Cc"], gin_channels=cfg["Cg"], n_speakers=cfg["n_speakers"],
+                    upsample_conditional_features=True, upsample_net="ConvInUpsampleNetwork",
+                    upsample_params=dict(upsample_scales=cfg["upsample_scales"], cin_channels=cfg["Cc"], cin_pad=1),
+                    scalar_input=False, use_speaker_embedding=True, output_distribution="Logistic", cin_pad=1)
+    model = ref_vqvae.VQVAE(c_in=cfg["c_in"], hid=cfg["Cc"], K=cfg["K"], wavenet=wn, encoder_hid=cfg["encoder_hid"])
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.eval()
+    with torch.no_grad():
+        lat = model.encoder(c)
+        quant, vq_loss, perp = model.vq(lat)
+        c_up = model.wavenet.upsample_net(quant)
+    T = c_up.shape[-1]
+    assert T == (lat.shape[-1] - 2) * hop, (T, lat.shape)
+    x = ((O.hash_fill((B, T), 42) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    g = torch.tensor([1, 3])
+    with torch.no_grad():
+        y_hat, vq2, perp2 = model(xin, c, g, False)
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=1)
+    close(O.upsample_forward(sd, quant, cfg["upsample_scales"], cin_pad=1), c_up, what="cin_pad c_up")
+    oy, ovq, operp, aux = O.vqvae_forward(sd, ocfg, xin, c, g)
+    e = close(oy, y_hat, what="cin_pad logits")
+    # decoder alone with a gradient flowing back into the (B, Cc, Tc) features through conv_in
+    feats = O.hash_fill((B, cfg["Cc"], lat.shape[-1]), 43, 1.1).requires_grad_(True)
+    y_dec = model.wavenet(xin, feats, g, False)
+    wsum = O.hash_fill(tuple(y_dec.shape), 44, 1.0)
+    (y_dec * wsum).sum().backward()
+    print(f"  cin_pad=1: T={T} from {lat.shape[-1]} latent frames, logits max|oracle-ref| = {e:.2e}")
+    save("model_P", cfg=json.dumps(cfg), salt=4, c=c, x=x.numpy(), g=g, latents=lat, quant=quant, vq_idx=aux["idx"], vq_loss=vq_loss,
+         perp=perp, c_up=c_up, y_hat=y_hat, feats=feats.detach(), y_dec_probe=y_dec.detach()[:, :, ::7], dfeats=feats.grad, w_salt=44)
+
+
+def _ref_sampler_class():
+    """The reference's PartialyRandomizedSimilarTimeLengthSampler, cut out of vqwae_train.py by its syntax tree (the file itself
+    cannot be imported: docopt / nnmnkwii / librosa / tensorboardX are absent) and executed as is."""
+    import ast
+    import random as _random
+    from torch.utils.data.sampler import Sampler
+    src = open(os.path.join(REF, "vqwae_train.py")).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "PartialyRandomizedSimilarTimeLengthSampler")
+    ns = {"Sampler": Sampler, "torch": torch, "np": np, "random": _random}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "vqwae_train.py", "exec"), ns)
+    return ns["PartialyRandomizedSimilarTimeLengthSampler"], _random
+
+
+def gen_sampler():
+    """Orders the reference's own sampler yields (three epochs each, `random.seed(1234)` first): unique lengths for N = 37, 64, 203
+    with batch sizes 8 / 4, and tied lengths (torch.sort is not stable, so only the LENGTH at every position is pinned there)."""
+    cls, rnd = _ref_sampler_class()
+    out = {}
+    cases = []
+    for i, (N, bs, tied) in enumerate(((37, 8, False), (64, 8, False), (203, 4, False), (120, 8, True))):
+        rs = np.random.RandomState(100 + i)
+        lengths = (rs.permutation(N) * 7 + 300) if not tied else rs.randint(300, 320, size=N)
+        rnd.seed(1234)
+        smp = cls(lengths.tolist(), batch_size=bs)
+        orders = np.stack([np.array([int(j) for j in smp]) for _ in range(3)])
+        assert all(sorted(o.tolist()) == list(range(N)) for o in orders)
+        out[f"lengths{i}"] = lengths.astype(np.int64)
+        out[f"orders{i}"] = orders.astype(np.int64)
+        cases.append(dict(N=N, batch_size=bs, tied=tied))
+    save("sampler_ref", cases=json.dumps(cases), **out)
+
+
+
 class _Pick:
     """Stands in for torch.distributions.OneHotCategorical inside the reference's own incremental loop (wavenet.py:335-338):
     the draw becomes reproducible -- argmax, or the inverse CDF on explicit uniforms (the oracle's and the engine's form) --
@@ -788,6 +924,12 @@ def main():
         return gen_quantizers()
     if sys.argv[1:] == ["wide"]:
         return gen_wide_probe()
+    if sys.argv[1:] == ["c2"]:
+        return gen_c2()
+    if sys.argv[1:] == ["cin_pad"]:
+        return gen_cin_pad()
+    if sys.argv[1:] == ["sampler"]:
+        return gen_sampler()
     gen_quantizers()
     gen_misc()
     gen_dmol()
@@ -807,6 +949,9 @@ def main():
     gen_ar_c4()
     gen_train_vqwae()
     gen_c5_probe()
+    gen_c2()
+    gen_cin_pad()
+    gen_sampler()
 
 
 if __name__ == "__main__":

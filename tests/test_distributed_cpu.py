@@ -45,7 +45,17 @@ def _worker(rank, world, port, q):
     gl = D.masked_loss_global(torch.tensor(3.0 * (rank + 1)), torch.tensor(float(rank + 1)))
     p = torch.full((5,), float(rank + 7))
     D.broadcast_params(p)
-    q.put((rank, ok_grad, ok_grad2, (lo, hi), sc.tolist(), float(gl), p.tolist()))
+    # variable-length presets (max_time_steps None): rank 0's shard happens to be all full-length (padded to ITS longest clip,
+    # 100 steps), rank 1's is ragged at 80 -- both must enter the mask-sum all-reduce (a per-rank decision would hang here)
+    Tr, ln = (100, torch.tensor([100, 100])) if rank == 0 else (80, torch.tensor([80, 50]))
+    scale, N = D.step_ce_scale(ln, Tr, 2, variable_length=True)
+    fixed = D.step_ce_scale(torch.tensor([64, 64]), 64, 2, variable_length=False)     # fixed crops: no collective on any rank
+    try:
+        D.step_ce_scale(torch.tensor([64, 60]), 64, 2, variable_length=False)
+        raised = False
+    except ValueError:
+        raised = True
+    q.put((rank, ok_grad, ok_grad2, (lo, hi), sc.tolist(), float(gl), p.tolist(), (scale, N, fixed, raised)))
     dist.destroy_process_group()
 
 
@@ -61,8 +71,11 @@ def test_gloo_world2_bucketed_allreduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok1, ok2, rng, sc, gl, pv in res:
+    for rank, ok1, ok2, rng, sc, gl, pv, (scale, N, fixed, raised) in res:
         assert ok1 and ok2
+        n_r = (2 * 99, 79 + 49)[rank]
+        assert N == 2 * 99 + 79 + 49 and abs(scale - n_r * 2 / N) < 1e-12
+        assert fixed == (1.0, float(2 * 2 * 63)) and raised
         assert rng == (rank * 4, rank * 4 + 4)
         assert sc == [0.5, 1.0]
         assert abs(gl - 3.0) < 1e-6          # (3*1 + 3*2) / (1 + 2)

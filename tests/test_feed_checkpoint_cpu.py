@@ -58,6 +58,24 @@ def test_sampler_is_a_length_binned_permutation():
     assert list(iter(s2)) == e1 and list(iter(s2)) == e2
 
 
+def test_sampler_reproduces_the_reference_class():
+    """Orders produced by the reference's own PartialyRandomizedSimilarTimeLengthSampler (tests/golden/make_golden.py cuts the class
+    out of vqwae_train.py:249-295 and runs it after random.seed(1234)): identical index for index over three epochs when lengths
+    are unique; with tied lengths torch.sort is not stable, so the LENGTH at every position is what is pinned."""
+    import json
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler_ref.npz"))
+    for i, case in enumerate(json.loads(str(z["cases"]))):
+        lengths, want = z[f"lengths{i}"], z[f"orders{i}"]
+        s = DT.SimilarLengthSampler(lengths, batch_size=case["batch_size"], seed=1234)
+        for ep in range(3):
+            got = np.array(list(iter(s)))
+            if case["tied"]:
+                assert np.array_equal(lengths[got], lengths[want[ep]]), (i, ep)
+                assert sorted(got.tolist()) == list(range(case["N"]))
+            else:
+                assert np.array_equal(got, want[ep]), (i, ep)
+
+
 def test_reader_drops_short_clips_and_checks_speaker_ids(dump):
     items = DT.read_index(dump, "train_no_dev", 32, n_speakers=3)
     assert all(n > 32 for _, n, _ in items) and 0 < len(items) < 53

@@ -260,3 +260,147 @@ def test_c5_shard_properties_bf16(c5):
                                   want_logits=False)["loss"])
     assert abs(lb - l32) < 2e-2 * l32, (lb, l32)
     assert np.isfinite(l0)
+
+
+# ------------------------------------------------------------------------------------------------------------------ C2
+@pytest.fixture(scope="module")
+def c2():
+    z = load_npz("model_c2_probe")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]), with_encoder=False)
+    T = int(z["T"])
+    lat = O.hash_fill((1, cfg["Cc"], T // 320), int(z["lat_salt"]), 1.2)
+    x = ((O.hash_fill((1, T), int(z["x_salt"])) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    return cfg, sd, z, x, lat
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2), ("fp16", 1e-2)])
+def test_c2_logits_against_the_reference(c2, dtype, tol):
+    """BASELINE config C2 -- the geometry the bench line is measured on (24 layers / 2 stacks, R 256, G 368, S 256, Cc 64, Cg 64,
+    scales 4,4,4,5; Hp = 192 runs the one-pass static-schedule layer kernel in the 16-bit modes) -- one 8000-sample clip against
+    the logits of the reference's own WaveNet (tests/golden/model_c2_probe.npz): 1e-3 fp32 (north star), 5e-2 bf16, 1e-2 fp16."""
+    cfg, sd, z, x, lat = c2
+    eng = _engine(cfg, sd, dtype)
+    out = eng.decoder_forward(x.cuda(), lat.cuda(), torch.from_numpy(z["g"]).cuda(), targets=x.cuda())
+    torch.cuda.synchronize()
+    y = out["logits"].cpu()[0]
+    pt = torch.from_numpy(z["probe_t"]).long()
+    assert rel_err(y[:, pt], z["y_probe"]) < tol
+    scale = float(np.abs(z["y_probe"]).max())
+    assert float((torch.logsumexp(y, 0) - torch.from_numpy(z["y_lse"])[0]).abs().max()) < tol * scale
+    assert abs(float(out["loss"]) - float(z["loss"])) < (1e-4 if dtype == "fp32" else 2e-2) * float(z["loss"])
+    if dtype == "fp32":
+        assert abs(float(y.double().sum()) - float(z["y_sum"])) < 1e-4 * float(z["y_abs_sum"])
+
+
+def test_c2_train_step_gradients_fp32(c2):
+    """One C2 clip, one train step: every decoder parameter gradient of the fp32 engine at the fixture's probes against the
+    fp64 oracle's autograd (2e-3 of the tensor's largest gradient, the bound the reference's own fp32 autograd meets with 7e-3
+    on this model) and by its norm."""
+    from wavenet_autoencoders_amd import backward as BW
+    cfg, sd, z, x, lat = c2
+    eng = _engine(cfg, sd, "fp32")
+    xs, g = x.cuda(), torch.from_numpy(z["g"]).cuda()
+    out = eng.decoder_forward(xs, lat.cuda(), g, targets=xs, train=True, want_logits=False)
+    assert abs(float(out["loss"]) - float(z["loss"])) < 1e-4 * float(z["loss"])
+    dc = BW.decoder_backward(eng, xs, xs, None, g)
+    BW.frontend_backward(eng, dc)
+    grads = BW.finish_grads(eng).cpu()
+    names = json.loads(str(z["names"]))
+    off, bad = 0, {}
+    for i, k in enumerate(names):
+        n = eng.lay.numel(k)
+        idx = np.unique(np.concatenate([np.arange(min(4, n)), (np.arange(24, dtype=np.int64) * 2654435761 + 12345) % n]))
+        assert len(idx) == z["probe_counts"][i]
+        sl = slice(off, off + len(idx))
+        off += len(idx)
+        o = eng.lay.off(k)
+        gk = grads[o:o + n]
+        gmax = float(z["grad_max"][i])
+        e64 = float((gk[idx].double() - torch.from_numpy(z["grad64_probe"][sl])).abs().max())
+        sq = float((gk.double() ** 2).sum())
+        floor = 1e-7 if k.endswith("weight_g") else 2e-8
+        if e64 > 2e-3 * gmax + floor or abs(sq - z["grad64_sq"][i]) > 6e-3 * z["grad64_sq"][i] + 1e-12:
+            bad[k] = (e64, gmax, sq, float(z["grad64_sq"][i]))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 8e-2), ("fp16", 4e-2)])
+def test_c2_train_step_gradients_16bit(c2, dtype, tol):
+    """The same step in the throughput modes (the stream-K weight-gradient launch, the static layer kernel with z saved): every
+    tensor's gradient at the probes within tol of its largest entry of the fp64 oracle's."""
+    from wavenet_autoencoders_amd import backward as BW
+    cfg, sd, z, x, lat = c2
+    eng = _engine(cfg, sd, dtype)
+    xs, g = x.cuda(), torch.from_numpy(z["g"]).cuda()
+    eng.decoder_forward(xs, lat.cuda(), g, targets=xs, train=True, want_logits=False)
+    dc = BW.decoder_backward(eng, xs, xs, None, g)
+    BW.frontend_backward(eng, dc)
+    grads = BW.finish_grads(eng).cpu()
+    names = json.loads(str(z["names"]))
+    off, bad = 0, {}
+    for i, k in enumerate(names):
+        n = eng.lay.numel(k)
+        idx = np.unique(np.concatenate([np.arange(min(4, n)), (np.arange(24, dtype=np.int64) * 2654435761 + 12345) % n]))
+        sl = slice(off, off + len(idx))
+        off += len(idx)
+        gk = grads[eng.lay.off(k):eng.lay.off(k) + n]
+        e = float((gk[idx].double() - torch.from_numpy(z["grad64_probe"][sl])).abs().max())
+        # weight_g gradients are cancelling row sums of dW * v / |v| (largest ~1e-4 here where the weight_v gradients they are formed
+        # from reach ~1e-2): their error follows the 16-bit rounding of the summands, hence the absolute floor
+        floor = 2e-5 if k.endswith("weight_g") else 1e-6
+        if e > tol * float(z["grad_max"][i]) + floor:
+            bad[k] = (e, float(z["grad_max"][i]))
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------------------ cin_pad = 1
+def test_cin_pad_one_forward_and_backward():
+    """cin_pad = 1 (upsample.py:69-85: conv_in with 2*cin_pad+1 taps and no padding; features cin_pad frames wider than the audio,
+    vqwae_train.py:455-478): VQ indices, c_up and logits of the whole model against the reference's own (model_P.npz), then one
+    train step's gradients -- conv_in's three-tap weight among them -- against autograd through the oracle."""
+    from helpers import golden_model
+    cfg, sd, ins, z, _ = golden_model("P")
+    assert cfg["cin_pad"] == 1 and sd["wavenet.upsample_net.conv_in.weight"].shape[-1] == 3
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=1)
+    eng = _engine(cfg, sd, "fp32")
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    out = eng.forward(x, c, g, targets=x)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["idx"].cpu().numpy(), z["vq_idx"])
+    assert rel_err(out["logits"].cpu(), z["y_hat"]) < 1e-3
+    T = x.shape[1]
+    assert T == (z["latents"].shape[-1] - 2) * int(np.prod(cfg["upsample_scales"]))
+    # gradients of one train step
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y_o, vq_o, _, _ = O.vqvae_forward(psd, ocfg, ins["xin"], ins["c"], ins["g"])
+    (O.masked_ce_loss(y_o, ins["x"].unsqueeze(-1), torch.full((2,), T)) + vq_o).backward()
+    eng.init_optimizer()
+    seen = {}
+    eng.train_step(x, c, g, lr=0.0, clip_thresh=-1.0, grad_hook=lambda gr: seen.update(g=gr.clone()))
+    torch.cuda.synchronize()
+    grads = seen["g"].cpu()
+    for k in ("wavenet.upsample_net.conv_in.weight", "wavenet.upsample_net.upsample.up_layers.1.weight_v", "encoder.lin.weight",
+              "vq.embedding.weight", "wavenet.conv_layers.0.conv1x1c.weight_v", "wavenet.first_conv.weight_v"):
+        gk = grads[eng.lay.off(k):eng.lay.off(k) + eng.lay.numel(k)].view(eng.lay.shapes[k])
+        assert rel_err(gk, psd[k].grad) < 2e-3, k
+
+
+def test_cin_pad_one_module_decoder_and_feature_gradient():
+    """The drop-in WaveNet with upsample_params cin_pad=1 on (B, Cc, Tc) features: logits and the gradient w.r.t. the features
+    (through conv_in's three taps) against the reference's own (model_P.npz: y_dec_probe, dfeats)."""
+    from helpers import golden_model
+    from wavenet_autoencoders_amd.wavenet_vocoder import WaveNet
+    cfg, sd, ins, z, _ = golden_model("P")
+    wn = WaveNet(out_channels=cfg["O"], layers=cfg["layers"], stacks=cfg["stacks"], residual_channels=cfg["R"],
+                 gate_channels=cfg["G"], skip_out_channels=cfg["S"], kernel_size=cfg["k"], dropout=0.0, cin_channels=cfg["Cc"],
+                 gin_channels=cfg["Cg"], n_speakers=cfg["n_speakers"], upsample_conditional_features=True,
+                 upsample_params=dict(upsample_scales=cfg["upsample_scales"], cin_channels=cfg["Cc"], cin_pad=1),
+                 use_speaker_embedding=True, cin_pad=1)
+    wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items() if k.startswith("wavenet.")})
+    wn = wn.cuda().train()
+    feats = torch.from_numpy(z["feats"]).cuda().requires_grad_(True)
+    y = wn(ins["xin"].cuda(), feats, ins["g"].cuda())
+    assert rel_err(y[:, :, ::7].detach().cpu(), z["y_dec_probe"]) < 1e-3
+    (y * O.hash_fill(tuple(y.shape), int(z["w_salt"]), 1.0).cuda()).sum().backward()
+    assert rel_err(feats.grad.cpu(), z["dfeats"]) < 2e-3

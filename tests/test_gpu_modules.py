@@ -162,6 +162,16 @@ def test_standalone_residual_conv1d_glu_against_golden(name, d):
         layer.train()
         with pytest.raises(RuntimeError):
             layer.incremental_forward(xs[:, :, :1].transpose(1, 2))
+        # the stand-alone layer has no backward: a call that expects gradients is refused, never answered with detached tensors
+        with pytest.raises(NotImplementedError):
+            layer(xs, cs, gv.cuda().expand(-1, -1, n))
+        layer.eval()
+        with pytest.raises(NotImplementedError):
+            layer(xs.clone().requires_grad_(True), cs, gv.cuda().expand(-1, -1, n))
+        with torch.no_grad():
+            layer.train()
+            layer(xs, cs, gv.cuda().expand(-1, -1, n))          # train mode without autograd is an ordinary forward (dropout 0)
+            layer.eval()
 
 
 def _t(z):
@@ -273,7 +283,7 @@ def test_backward_after_a_second_forward_raises():
 def test_masked_cross_entropy_module_on_explicit_logits(name):
     """losses.MaskedCrossEntropyLoss (vqwae_train.py:363-379) called the reference's way -- criterion(y_hat[:, :, :-1, :],
     y[:, 1:, :], mask=mask) -- runs wae_ce_logits_fwd / _bwd + wae_weighted_mean: value and d loss / d logits against the
-    vectors the reference produced (ce_<name>.npz), and IndexError for a target outside the classes."""
+    vectors the reference produced (ce_<name>.npz), and the (deferred) IndexError for a target outside the classes."""
     from wavenet_autoencoders_amd.losses import MaskedCrossEntropyLoss, sequence_mask
     cfg, sd, ins, zm, ocfg = golden_model(name)
     z = load_npz("ce_" + name)
@@ -289,5 +299,43 @@ def test_masked_cross_entropy_module_on_explicit_logits(name):
     assert rel_err(y_hat.grad.cpu()[:, :, ::29], z["dlogits_probe"]) < 1e-4
     bad = y[:, 1:, :].clone()
     bad[0, 3, 0] = cfg["O"]
+    # an out-of-range target is clamped by the kernel and flagged in a sticky device word; the IndexError nn.CrossEntropyLoss raises
+    # on the spot comes from check_target_errors() (or, at the latest, from the next loss call): no host sync per loss evaluation
+    from wavenet_autoencoders_amd.losses import check_target_errors
+    check_target_errors()                                       # the good call above left nothing behind
+    MaskedCrossEntropyLoss()(y_hat.detach().unsqueeze(-1)[:, :, :-1, :], bad, mask=mask)
     with pytest.raises(IndexError):
-        MaskedCrossEntropyLoss()(y_hat.detach().unsqueeze(-1)[:, :, :-1, :], bad, mask=mask)
+        check_target_errors()
+    MaskedCrossEntropyLoss()(y_hat.detach().unsqueeze(-1)[:, :, :-1, :], bad, mask=mask)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        MaskedCrossEntropyLoss()(y_hat.detach().unsqueeze(-1)[:, :, :-1, :], y[:, 1:, :], mask=mask)   # raised by the next call
+    check_target_errors()                                       # cleared
+
+
+def test_out_of_range_ids_raise_index_error():
+    """The reference raises IndexError on the spot for a speaker id >= n_speakers (nn.Embedding, wavenet.py:185-187) or a class id
+    outside [0, out_channels) (the one-hot encoder / CrossEntropyLoss).  The kernels clamp such ids and set a sticky flag;
+    the module API turns it into the same IndexError at the end of the call, the engine API in check_errors()."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    model, wn = _build(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    g_bad = ins["g"].clone()
+    g_bad[1] = cfg["n_speakers"] + 3
+    with torch.no_grad():
+        with pytest.raises(IndexError, match="speaker id"):
+            model(ins["xin"].cuda(), ins["c"].cuda(), g_bad.cuda(), False)
+        model(ins["xin"].cuda(), ins["c"].cuda(), ins["g"].cuda(), False)       # the flag is cleared: a good call passes again
+    eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+    eng.load_state_dict(sd)
+    eng.init_optimizer()
+    x_bad = ins["x"].clone()
+    x_bad[0, 17] = cfg["O"] + 5
+    eng.train_step(x_bad.cuda(), ins["c"].cuda(), ins["g"].cuda())
+    with pytest.raises(IndexError, match="class id"):
+        eng.check_errors()
+    eng.train_step(ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda())
+    eng.check_errors()

@@ -193,3 +193,50 @@ def test_weighted_shares_cover_the_work_list_once():
         tot = [sum((hi - lo) * w[job] for job, lo, hi in sh) for sh in shares]
         if nsl * len(items) > 4 * nshares:
             assert max(tot[:-1]) - min(tot[:-1]) <= 2.0 * max(w.values()) + 1e-9
+
+
+def test_wavenet_constructor_refuses_options_it_does_not_implement():
+    """wavenet.py:151 builds ConvInUpsampleNetwork(**upsample_params) (upsample.py:69-85).  Every option of that signature is
+    either implemented or refused: a silently ignored key would give silently different numbers."""
+    import pytest
+    from wavenet_autoencoders_amd.wavenet_vocoder import WaveNet
+    base = dict(out_channels=64, layers=4, stacks=2, residual_channels=32, gate_channels=48, skip_out_channels=32, cin_channels=16,
+                gin_channels=8, n_speakers=5, upsample_conditional_features=True, use_speaker_embedding=True)
+    up = dict(upsample_scales=[4, 4], cin_channels=16)
+    w = WaveNet(**base, upsample_params=dict(up, cin_pad=1, upsample_activation="none", mode="nearest", freq_axis_kernel_size=1))
+    assert w.geom.cin_pad == 1 and tuple(w.state_dict()["upsample_net.conv_in.weight"].shape) == (16, 16, 3)
+    assert WaveNet(**base, upsample_params=up, cin_pad=2).geom.cin_pad == 2      # no key in upsample_params: the constructor's
+    for bad, exc in ((dict(upsample_activation="ReLU"), NotImplementedError), (dict(mode="linear"), NotImplementedError),
+                     (dict(freq_axis_kernel_size=3), NotImplementedError), (dict(cin_channels=80), ValueError),
+                     (dict(typo_scales=[4]), TypeError)):
+        with pytest.raises(exc):
+            WaveNet(**base, upsample_params=dict(up, **bad))
+    with pytest.raises(TypeError):
+        WaveNet(**base, upsample_params=dict(cin_channels=16))
+    with pytest.raises(NotImplementedError):
+        WaveNet(**base, upsample_params=up, upsample_net="UpsampleNetwork")
+    with pytest.raises(NotImplementedError):
+        WaveNet(**base, upsample_params=up, kernel_size=2)
+
+
+def test_synthesis_postprocessing_closed_form():
+    """synthesis.py:382-394 after the decode: inv_mulaw_quantize(idx, 256), inv_preemphasis (audio.py:64-65: the IIR
+    y[n] = x[n] + 0.85 y[n-1]), division by global_gain_scale -- against hand-derived values."""
+    import synthesis as S
+    mu = 256.0       # wavegen passes hparams.quantize_channels = 256 as nnmnkwii's `mu` (synthesis.py:384; SURVEY 8c notes 255 elsewhere)
+    inv = lambda i: (lambda v: np.sign(v) * ((1.0 + mu) ** np.abs(v) - 1.0) / mu)(2.0 * i / mu - 1.0)   # noqa: E731  (companding formula)
+    idx = np.array([255, 0, 128, 127, 200, 31])
+    x = inv(idx.astype(np.float64))
+    assert abs(x[1] + 1.0) < 1e-12 and x[2] == 0.0 and -2e-4 < x[3] < 0 and 0.9 < x[0] < 1.0     # class 128 is exact silence at mu = 256
+    got = S.postprocess_indices(idx, 256, "inv_preemphasis", 0.55)
+    want = np.empty(6)
+    acc = 0.0
+    for n in range(6):                        # the recurrence, term by term
+        acc = x[n] + 0.85 * acc
+        want[n] = acc / 0.55
+    assert np.allclose(got, want, rtol=0, atol=1e-6)
+    # impulse response of the de-emphasis filter: 0.85^n; no post-processing / no gain leave the companded values alone
+    imp = S.inv_preemphasis(np.array([1.0, 0, 0, 0, 0]), 0.85)
+    assert np.allclose(imp, 0.85 ** np.arange(5), atol=1e-12)
+    assert np.allclose(S.postprocess_indices(idx, 256, "none", 0.0), x, atol=1e-6)
+    assert np.allclose(S.postprocess_indices(idx, 256, None, 1.0), x, atol=1e-6)

@@ -310,3 +310,53 @@ def test_vqwae_full_geometry_train_step():
         off += len(idx)
         assert float((gk[idx] - torch.from_numpy(z["grad_probe"][sl])).abs().max()) < 1e-3 * float(z["grad_max"][i]) + 1e-8, k   # weight_g gradients are cancelling sums (largest ~1e-5 where weight_v's are ~1e-3): absolute floor
         assert abs(float((gk.double() ** 2).sum()) - z["grad_sq"][i]) < 1e-3 * z["grad_sq"][i] + 1e-14, k
+
+
+def test_c2_probe_and_train_step():
+    """BASELINE config C2 (the geometry bench.py times): the oracle's logits on the 8000-sample clip against the reference's probe,
+    and its autograd of the one-clip train step against the reference's gradients."""
+    z = load_npz("model_c2_probe")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(dict(cfg), int(z["salt"]), with_encoder=False)
+    T = int(z["T"])
+    lat = O.hash_fill((1, cfg["Cc"], T // 320), int(z["lat_salt"]), 1.2)
+    x = ((O.hash_fill((1, T), int(z["x_salt"])) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    y = O.wavenet_forward(psd, ocfg, xin, lat, torch.from_numpy(z["g"]))
+    assert rel_err(y[0][:, z["probe_t"]].detach(), z["y_probe"]) < TOL
+    assert rel_err(torch.logsumexp(y.detach(), 1), z["y_lse"]) < TOL
+    ce = O.masked_ce_loss(y, x.unsqueeze(-1), torch.tensor([T]))
+    assert abs(float(ce) - float(z["loss"])) < 1e-5 * float(z["loss"])
+    ce.backward()
+    names = json.loads(str(z["names"]))
+    off = 0
+    for i, k in enumerate(names):
+        gk = psd[k].grad.reshape(-1) if psd[k].grad is not None else torch.zeros(psd[k].numel())
+        n = gk.numel()
+        idx = np.unique(np.concatenate([np.arange(min(4, n)), (np.arange(24, dtype=np.int64) * 2654435761 + 12345) % n]))
+        sl = slice(off, off + len(idx))
+        off += len(idx)
+        # fp32 autograd twice (reference and oracle sum in different orders): 2e-3 of the tensor's largest gradient
+        assert float((gk[idx] - torch.from_numpy(z["grad_probe"][sl])).abs().max()) < 2e-3 * float(z["grad_max"][i]) + 1e-8, k
+
+
+def test_cin_pad_model():
+    """cin_pad = 1 (upsample.py:69-85): conv_in with three taps and no padding; features cin_pad frames wider than the audio."""
+    z = load_npz("model_P")
+    cfg = json.loads(str(z["cfg"]))
+    sd = O.make_state_dict(cfg, int(z["salt"]))
+    c, g = torch.from_numpy(z["c"]), torch.from_numpy(z["g"])
+    x = torch.from_numpy(z["x"]).long()
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=1)
+    assert rel_err(O.upsample_forward(sd, torch.from_numpy(z["quant"]), cfg["upsample_scales"], cin_pad=1), z["c_up"]) < TOL
+    y, vq, perp, aux = O.vqvae_forward(sd, ocfg, xin, c, g)
+    assert np.array_equal(aux["idx"].numpy(), z["vq_idx"])
+    assert rel_err(y, z["y_hat"]) < TOL
+    feats = torch.from_numpy(z["feats"]).clone().requires_grad_(True)
+    yd = O.wavenet_forward(sd, ocfg, xin, feats, g)
+    assert rel_err(yd[:, :, ::7].detach(), z["y_dec_probe"]) < TOL
+    (yd * O.hash_fill(tuple(yd.shape), int(z["w_salt"]), 1.0)).sum().backward()
+    assert rel_err(feats.grad, z["dfeats"]) < 1e-4

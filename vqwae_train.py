@@ -109,7 +109,8 @@ def main(argv=None):
 
     from wavenet_autoencoders_amd.engine import WaeEngine
     geom = build_geometry(hp)
-    eng = WaeEngine(geom, dtype=args.dtype, device=device, dropout=float(hp.dropout))            # vqwae_train.py:933
+    eng = WaeEngine(geom, dtype=args.dtype, device=device, dropout=float(hp.dropout),            # vqwae_train.py:933
+                    drop_seed=0x5EED * 4099 + rank)   # replicas draw their own masks
     # reference initialisation, identical on every rank
     torch.manual_seed(1234)
     from wavenet_autoencoders_amd.wavenet_vocoder._base import ArenaModel, register_params
@@ -125,6 +126,7 @@ def main(argv=None):
         restore_parts(args.restore_parts, eng)
     if args.checkpoint:
         step, epoch, test_step = load_checkpoint(args.checkpoint, eng, args.reset_optimizer, ema=use_ema)
+    eng.drop_calls = step        # the dropout masks follow the global step: a resumed run does not replay the first steps' masks
     D.broadcast_params(eng.params)
     if not hasattr(eng, "exp_avg"):
         eng.init_optimizer(ema=use_ema)
@@ -166,7 +168,8 @@ def main(argv=None):
                 T = x.shape[1]
                 ln = None if bool((lengths == T).all()) else lengths
                 # ragged shards: the CE is normalised by the mask sum of the GLOBAL batch (vqwae_train.py:374-379 after :705)
-                ce_scale, n_glob = D.ragged_ce_scale(ln, T, x.shape[0]) if world > 1 else (1.0, None)
+                # (every rank enters the mask-sum all-reduce or none does: decided by the preset, not by this rank's shard)
+                ce_scale, n_glob = D.step_ce_scale(lengths, T, x.shape[0], variable_length=hp.max_time_steps is None)
                 res = eng.train_step(x, c, g, lengths=ln, lr=lr, eps=hp.optimizer_params.get("eps", 1e-8),
                                      weight_decay=hp.optimizer_params.get("weight_decay", 0.0), clip_thresh=hp.clip_thresh,
                                      ema_decay=hp.ema_decay, grad_sync=sync, ce_scale=ce_scale,
@@ -177,6 +180,7 @@ def main(argv=None):
                 run += torch.stack([ce + vq, vq, res.get("perp", torch.zeros((), device=device)).float()]).double()
                 nb += 1
                 if step % 10 == 0 or step == 1:
+                    eng.check_errors()          # ids the kernels had to clamp -> IndexError (the host reads scalars here anyway)
                     stats = torch.stack([ce + vq, vq, res.get("perp", torch.zeros((), device=device)).float()])
                     D.all_reduce_scalars(stats)
                     if rank == 0:
@@ -184,6 +188,7 @@ def main(argv=None):
                         print(f"step {step} loss {float(stats[0]):.4f} vq {float(stats[1]):.4f} perp {float(stats[2]):.2f} "
                               f"gnorm {float(res['grad_norm']):.3f} lr {lr:.2e} {hp.batch_size * T / dt / 1e6:.2f} Msamples/s")
                 if step % hp.checkpoint_interval == 0:
+                    eng.check_errors()          # never checkpoint weights that were trained on clamped ids
                     save_checkpoint(eng, step, epoch, args.checkpoint_dir, hp, rank, test_step, lr)
                 if step >= max_steps:
                     print("Training reached max train steps ({}). will exit".format(max_steps)) if rank == 0 else None

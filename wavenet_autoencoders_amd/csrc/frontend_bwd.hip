@@ -374,8 +374,8 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
   }
 }
 template <int K, int S, int PAD>
-static void launch_conv_bwd_tiled(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* dbias,
-                                  int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual, hipStream_t st) {
+static int launch_conv_bwd_tiled(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* dbias,
+                                 int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual, hipStream_t st) {
   if (dx) {
     constexpr int R0 = (((PAD - K + 1) % S) + S) % S;
     constexpr int TWIN = (ECB_T - 1 + K - 1 + R0) / S + 1;
@@ -383,7 +383,7 @@ static void launch_conv_bwd_tiled(const float* x, const float* w, const float* y
     const size_t a = (size_t)(Cout < ECB_CH ? Cout : ECB_CH) * TP, r = (size_t)ECB_NS * ECB_T * 33;
     const size_t lds = (a > r ? a : r) * sizeof(float);
     static WaeLdsCache cache;
-    if (wae_ensure_lds((const void*)conv_bwd_x_tiled_kernel<K, S, PAD>, cache, lds, "enc_conv_bwd") != WAE_OK) return;
+    if (int rc = wae_ensure_lds((const void*)conv_bwd_x_tiled_kernel<K, S, PAD>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
     hipLaunchKernelGGL((conv_bwd_x_tiled_kernel<K, S, PAD>), dim3((Tin + ECB_T - 1) / ECB_T, (Cin + ECB_T - 1) / ECB_T, B), dim3(256), lds,
                        st, x, w, y, dy, dx, Cin, Tin, Cout, Tout, relu, residual);
   }
@@ -392,10 +392,11 @@ static void launch_conv_bwd_tiled(const float* x, const float* w, const float* y
     constexpr int WP = (WIN + 3) & ~3;
     const size_t lds = (size_t)ECB_RT * (ECB_T * 36 + ECB_T * WP) * sizeof(float);
     static WaeLdsCache cache;
-    if (wae_ensure_lds((const void*)conv_bwd_w_tiled_kernel<K, S>, cache, lds, "enc_conv_bwd") != WAE_OK) return;
+    if (int rc = wae_ensure_lds((const void*)conv_bwd_w_tiled_kernel<K, S>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
     hipLaunchKernelGGL((conv_bwd_w_tiled_kernel<K, S>), dim3((Cout + ECB_T - 1) / ECB_T, (Cin + ECB_T - 1) / ECB_T), dim3(256), lds, st, x,
                        y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, PAD, relu, residual);
   }
+  return WAE_OK;
 }
 
 extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
@@ -406,7 +407,8 @@ extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, 
   WAE_REQUIRE(!relu || y, "enc_conv_bwd: relu needs the forward output y");
   const int Tout = (Tin + 2 * pad - k) / stride + 1;
   hipStream_t st = as_stream(stream);
-#define WAE_ECB(K_, S_, P_) launch_conv_bwd_tiled<K_, S_, P_>(x, w, y, dy, dx, dw, dbias, B, Cin, Tin, Cout, Tout, relu, residual, st)
+  int rc = WAE_OK;   // a failed LDS opt-in skips the launch: the caller must see that
+#define WAE_ECB(K_, S_, P_) rc = launch_conv_bwd_tiled<K_, S_, P_>(x, w, y, dy, dx, dw, dbias, B, Cin, Tin, Cout, Tout, relu, residual, st)
   if (k == 1 && stride == 1 && pad == 0) WAE_ECB(1, 1, 0);
   else if (k == 3 && stride == 1 && pad == 1) WAE_ECB(3, 1, 1);
   else if (k == 3 && stride == 1 && pad == 0) WAE_ECB(3, 1, 0);
@@ -421,6 +423,7 @@ extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, 
                        stride, pad, relu, residual);
   }
 #undef WAE_ECB
+  if (rc != WAE_OK) return rc;
   return wae_check_launch("enc_conv_bwd");
 }
 

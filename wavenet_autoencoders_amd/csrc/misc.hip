@@ -442,16 +442,17 @@ __global__ void __launch_bounds__(256) enc_conv_fwd_tiled_kernel(const float* __
   }
 }
 template <int K, int S>
-static void launch_enc_fwd_tiled(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Tin, int Cout,
-                                 int Tout, int pad, int relu, int residual, hipStream_t st) {
+static int launch_enc_fwd_tiled(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Tin, int Cout,
+                                int Tout, int pad, int relu, int residual, hipStream_t st) {
   constexpr int WIN = (EC_T - 1) * S + K;
   constexpr int WP = (WIN + 3) & ~3;
   const size_t a = (size_t)(Cin < EC_CH ? Cin : EC_CH) * WP, r = (size_t)EC_NS * EC_T * 33;
   const size_t lds = (a > r ? a : r) * sizeof(float);
   static WaeLdsCache cache;
-  if (wae_ensure_lds((const void*)enc_conv_fwd_tiled_kernel<K, S>, cache, lds, "enc_conv_fwd") != WAE_OK) return;
+  if (int rc = wae_ensure_lds((const void*)enc_conv_fwd_tiled_kernel<K, S>, cache, lds, "enc_conv_fwd"); rc != WAE_OK) return rc;   // y untouched: the caller must see the error
   hipLaunchKernelGGL((enc_conv_fwd_tiled_kernel<K, S>), dim3((Tout + EC_T - 1) / EC_T, (Cout + EC_T - 1) / EC_T, B), dim3(256), lds, st,
                      x, w, bias, y, Cin, Tin, Cout, Tout, pad, relu, residual);
+  return WAE_OK;
 }
 
 extern "C" int wae_enc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
@@ -463,13 +464,15 @@ extern "C" int wae_enc_conv_fwd(const float* x, const float* w, const float* bia
   const int Tout = (Tin + 2 * pad - k) / stride + 1;
   WAE_REQUIRE(Tout > 0, "enc_conv: empty output");
   hipStream_t st = as_stream(stream);
-  if (k == 1 && stride == 1) launch_enc_fwd_tiled<1, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
-  else if (k == 3 && stride == 1) launch_enc_fwd_tiled<3, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
-  else if (k == 5 && stride == 2) launch_enc_fwd_tiled<5, 2>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
-  else if (k == 5 && stride == 1) launch_enc_fwd_tiled<5, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  int rc = WAE_OK;
+  if (k == 1 && stride == 1) rc = launch_enc_fwd_tiled<1, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  else if (k == 3 && stride == 1) rc = launch_enc_fwd_tiled<3, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  else if (k == 5 && stride == 2) rc = launch_enc_fwd_tiled<5, 2>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  else if (k == 5 && stride == 1) rc = launch_enc_fwd_tiled<5, 1>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
   else   // any other shape (e.g. a wider conv_in, cin_pad > 2): the plain one-thread-per-output kernel
     hipLaunchKernelGGL(enc_conv_fwd_kernel, dim3((Tout + 63) / 64, (Cout + 3) / 4, B), dim3(256), 0, st, x, w, bias, y, B, Cin, Tin,
                        Cout, Tout, k, stride, pad, relu, residual);
+  if (rc != WAE_OK) return rc;
   return wae_check_launch("enc_conv_fwd");
 }
 
@@ -1072,25 +1075,34 @@ extern "C" int wae_masked_mean(const float* nll, const int32_t* lengths, float* 
 // forward:  xd = x * keep / (1 - p)          (xd is the conv operand of wae_glu_layer_fwd_drop and the Q operand of dW1)
 // backward: out = alpha * (g_next + acc * keep / (1 - p))    (acc = sum_taps W1_tap^T dz, wae_gemm_tm mode 0)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t e, uint32_t thr) {
-  uint64_t h = (e + seed) * 0x9E3779B97F4A7C15ull;
+// `key` = dropout_key(seed), formed on the host once per launch: the seed goes through a full 64-bit finaliser BEFORE it meets the
+// element index, so the masks of consecutive seeds (layer l and l + 1, step n and n + 1, rank r and r + 1) are unrelated.  (Round 2
+// hashed e + seed: the mask of seed + 1 was the mask of seed shifted by one element.)
+static inline uint64_t dropout_key(uint64_t seed) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t key, uint64_t e, uint32_t thr) {
+  uint64_t h = (e ^ key) * 0x9E3779B97F4A7C15ull;
   h ^= h >> 32;
   h *= 0xD6E8FEB86659FD93ull;
   h ^= h >> 32;
   return (uint32_t)(h >> 40) >= thr;
 }
 template <typename E>
-__global__ void __launch_bounds__(256) dropout_fwd_kernel(const void* __restrict__ x, void* __restrict__ xd, int64_t n, uint64_t seed,
+__global__ void __launch_bounds__(256) dropout_fwd_kernel(const void* __restrict__ x, void* __restrict__ xd, int64_t n, uint64_t key,
                                                           uint32_t thr, float scale) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    store_e<E>(xd, i, dropout_keep(seed, (uint64_t)i, thr) ? load_e<E>(x, i) * scale : 0.f);
+    store_e<E>(xd, i, dropout_keep(key, (uint64_t)i, thr) ? load_e<E>(x, i) * scale : 0.f);
 }
 template <typename E>
 __global__ void __launch_bounds__(256) dropout_bwd_kernel(const void* __restrict__ acc, const void* __restrict__ g_next,
-                                                          void* __restrict__ out, int64_t n, uint64_t seed, uint32_t thr, float scale,
+                                                          void* __restrict__ out, int64_t n, uint64_t key, uint32_t thr, float scale,
                                                           float alpha) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float a = dropout_keep(seed, (uint64_t)i, thr) ? load_e<E>(acc, i) * scale : 0.f;
+    const float a = dropout_keep(key, (uint64_t)i, thr) ? load_e<E>(acc, i) * scale : 0.f;
     store_e<E>(out, i, alpha * (load_e<E>(g_next, i) + a));
   }
 }
@@ -1105,9 +1117,9 @@ extern "C" int wae_dropout_fwd(const void* x, void* xd, int64_t n, uint64_t seed
   uint32_t thr; float scale;
   if (int rc = dropout_args(p, &thr, &scale); rc != WAE_OK) return rc;
   const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-  if (dtype == WAE_BF16) hipLaunchKernelGGL(dropout_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, seed, thr, scale);
-  else if (dtype == WAE_F16) hipLaunchKernelGGL(dropout_fwd_kernel<f16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, seed, thr, scale);
-  else hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, seed, thr, scale);
+  if (dtype == WAE_BF16) hipLaunchKernelGGL(dropout_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, dropout_key(seed), thr, scale);
+  else if (dtype == WAE_F16) hipLaunchKernelGGL(dropout_fwd_kernel<f16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, dropout_key(seed), thr, scale);
+  else hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), x, xd, n, dropout_key(seed), thr, scale);
   return wae_check_launch("dropout_fwd");
 }
 extern "C" int wae_dropout_bwd(const void* acc, const void* g_next, void* out, int64_t n, uint64_t seed, float p, float alpha,
@@ -1116,8 +1128,8 @@ extern "C" int wae_dropout_bwd(const void* acc, const void* g_next, void* out, i
   uint32_t thr; float scale;
   if (int rc = dropout_args(p, &thr, &scale); rc != WAE_OK) return rc;
   const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-  if (dtype == WAE_BF16) hipLaunchKernelGGL(dropout_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, seed, thr, scale, alpha);
-  else if (dtype == WAE_F16) hipLaunchKernelGGL(dropout_bwd_kernel<f16>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, seed, thr, scale, alpha);
-  else hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, seed, thr, scale, alpha);
+  if (dtype == WAE_BF16) hipLaunchKernelGGL(dropout_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, dropout_key(seed), thr, scale, alpha);
+  else if (dtype == WAE_F16) hipLaunchKernelGGL(dropout_bwd_kernel<f16>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, dropout_key(seed), thr, scale, alpha);
+  else hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), acc, g_next, out, n, dropout_key(seed), thr, scale, alpha);
   return wae_check_launch("dropout_bwd");
 }

@@ -184,6 +184,27 @@ def ragged_ce_scale(lengths: Optional[torch.Tensor], T: int, batch: int, group=N
     return (n_r * world / N if N > 0 else 1.0), N
 
 
+def step_ce_scale(lengths: Optional[torch.Tensor], T: int, batch: int, variable_length: bool, group=None) -> Tuple[float, Optional[float]]:
+    """The per-step CE scale of a data-parallel rank (what vqwae_train.py calls).  Whether the ranks meet in ragged_ce_scale's
+    all-reduce is decided by a GLOBAL fact -- `variable_length`: hparams.max_time_steps is None, i.e. every shard is padded to
+    its own longest clip (vqwae_train.py:455-478) -- never by what one rank observes in its own shard: the length-sorted sampler
+    can hand one rank a shard of equal-length clips while another rank's is ragged, and a collective entered by some ranks only
+    hangs the job (or pairs with the gradient all-reduce).  With variable lengths every rank enters, a full shard contributing
+    n_r = batch * (T_r - 1) with its OWN padded length T_r; with fixed-length crops no rank does, and a shard that is ragged
+    anyway is an error, not a silent local normalisation."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return 1.0, None
+    if not variable_length:
+        if lengths is not None and bool((lengths.detach().to("cpu") != T).any()):
+            raise ValueError("a fixed-length (max_time_steps) batch holds clips shorter than the crop: the global masked mean "
+                             "needs every rank in the mask-sum all-reduce; train with max_time_steps=None or drop short clips")
+        return 1.0, float(world * batch * (T - 1))
+    if lengths is None:
+        lengths = torch.full((batch,), T, dtype=torch.int64)
+    return ragged_ce_scale(lengths, T, batch, group)
+
+
 def all_reduce_scalars(values: torch.Tensor, group=None, average: bool = True) -> torch.Tensor:
     """Logged per-rank scalars (loss, vq_loss, perplexity): the reference averages the per-replica values
     (vqwae_train.py:759 `torch.mean(vq_loss), torch.mean(perp)`), so the mean over ranks reproduces it."""

@@ -255,6 +255,9 @@ class WaeEngine:
 
     def layer_drop_seed(self, call: int, layer: int) -> int:
         """64-bit seed of layer `layer`'s dropout mask in the call-th train-mode forward (csrc/misc.hip: dropout_keep)"""
+        # distinct (drop_seed, call, layer) triples give distinct seeds; the kernel finalises the seed (dropout_key) before it meets
+        # the element index, so neighbouring seeds give unrelated masks.  drop_seed should differ per data-parallel rank and
+        # drop_calls follow the global step across a resume (vqwae_train.py does both).
         return ((self.drop_seed * 0x100000001B3 + call) * 1024 + layer) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ decoder

@@ -38,6 +38,37 @@ class _MaskedMeanFn(torch.autograd.Function):
         return (mf * (g / out[1])).view(ctx.shape), None
 
 
+_ERR_WORDS = {}
+
+
+def _err_word(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _ERR_WORDS:
+        _ERR_WORDS[key] = dict(word=torch.zeros(1, dtype=torch.int32, device=device), pending=None)
+    return _ERR_WORDS[key]
+
+
+def _raise_if_flagged(err, sync):
+    """Read the sticky word once the launch that may have set it is known to be complete (sync=False: only if its event has
+    already fired -- no host wait on the hot path)."""
+    ev = err["pending"]
+    if ev is None or (not sync and not ev.query()):
+        return
+    if sync:
+        ev.synchronize()
+    err["pending"] = None
+    if int(err["word"].item()):
+        err["word"].zero_()
+        raise IndexError("Target out of bounds")              # what nn.CrossEntropyLoss raises
+
+
+def check_target_errors(device=None):
+    """Raise the IndexError of an earlier MaskedCrossEntropyLoss call whose targets left [0, C) (synchronises with that call)."""
+    for key, err in list(_ERR_WORDS.items()):
+        if device is None or key == (torch.device(device).type, torch.device(device).index):
+            _raise_if_flagged(err, sync=True)
+
+
 class _CELogitsFn(torch.autograd.Function):
     """per-position cross-entropy of (B, C, T) logits by wae_ce_logits_fwd / _bwd"""
 
@@ -48,10 +79,14 @@ class _CELogitsFn(torch.autograd.Function):
         B, C, T = lg.shape
         nll = torch.empty(B, T, dtype=torch.float32, device=lg.device)
         lse = torch.empty(B, T, dtype=torch.float32, device=lg.device)
-        err = torch.zeros(1, dtype=torch.int32, device=lg.device)
-        L.check(L.lib().wae_ce_logits_fwd(L.ptr(lg), L.ptr(tg), L.ptr(nll), L.ptr(lse), B, C, T, L.ptr(err), _stream(lg)), "ce_logits")
-        if int(err.item()):
-            raise IndexError("Target out of bounds")              # what nn.CrossEntropyLoss raises
+        # an out-of-range target: the kernel clamps it and sets a sticky per-device word; the IndexError nn.CrossEntropyLoss raises on
+        # the spot is raised by check_target_errors() -- at the latest by the NEXT loss call on that device (reading the word here
+        # every time was one host synchronisation per loss evaluation)
+        err = _err_word(lg.device)
+        _raise_if_flagged(err, sync=False)
+        L.check(L.lib().wae_ce_logits_fwd(L.ptr(lg), L.ptr(tg), L.ptr(nll), L.ptr(lse), B, C, T, L.ptr(err["word"]), _stream(lg)), "ce_logits")
+        err["pending"] = torch.cuda.Event()
+        err["pending"].record(torch.cuda.current_stream(lg.device))
         ctx.save_for_backward(lg, tg, lse)
         return nll
 

@@ -16,6 +16,7 @@ class _VQVAEFn(torch.autograd.Function):
         out = eng.forward(ids, c, gid, want_logits=True, train=train, dropout_on=model.training)
         ctx.model, ctx.ids, ctx.gid = model, ids, gid
         ctx.gen, ctx.train = getattr(eng, "fwd_gen", 0), train
+        eng.check_errors()     # IndexError for an id outside its table, like the reference's nn.Embedding (wavenet.py:185-187)
         return out["logits"], out["vq_loss"].reshape(()), out["perp"].reshape(())
 
     @staticmethod

@@ -93,6 +93,16 @@ class ResidualConv1dGLU(ArenaModel):
     # ------------------------------------------------------------------ reference API
     def forward(self, x, c=None, g=None):
         """x (B, R, T), c (B, Cc, T), g (B, Cg, T) -> (x' (B, R, T), s (B, S, T))   (modules.py:109-110)."""
+        # The stand-alone layer is an INFERENCE module here: its outputs carry no autograd graph (the reference's is an ordinary
+        # nn.Module; training the decoder goes through WaveNet / VQVAE, whose backward is the engine's).  A call that expects
+        # gradients -- an input that requires one, or train mode with trainable parameters under enabled autograd -- is refused
+        # instead of returning detached tensors that would silently train nothing.
+        if torch.is_grad_enabled():
+            wants = any(t is not None and t.requires_grad for t in (x, c, g))
+            if wants or (self.training and any(p.requires_grad for p in self.parameters())):
+                raise NotImplementedError("ResidualConv1dGLU is inference-only in this build (no backward): call it under "
+                                          "torch.no_grad() / in eval() mode with inputs that do not require gradients, or train "
+                                          "through wavenet_vocoder.WaveNet")
         with torch.no_grad():
             return self._run(x, c, g)
 

@@ -43,6 +43,7 @@ class _DecoderFn(torch.autograd.Function):
         out = eng.decoder_forward(ids, c, gid, want_logits=True, train=train, c_is_upsampled=c_is_up, gvec=gvec,
                                   dropout_on=model.training)
         ctx.gen = getattr(eng, "fwd_gen", 0)
+        eng.check_errors()     # an out-of-range class / speaker id raises IndexError here, as nn.Embedding / the one-hot encoder do
         return out["logits"]
 
     @staticmethod
@@ -94,7 +95,35 @@ class WaveNet(ArenaModel):
         self.out_channels = out_channels
         self.cin_channels = cin_channels
         self.output_distribution = output_distribution
-        scales = list(upsample_params.get("upsample_scales", [])) if upsample_conditional_features else None
+        scales = None
+        if upsample_conditional_features:
+            # the reference builds ConvInUpsampleNetwork(**upsample_params) (wavenet.py:151, upsample.py:69-85): its signature is
+            # (upsample_scales, upsample_activation="none", upsample_activation_params={}, mode="nearest",
+            # freq_axis_kernel_size=1, cin_pad=0, cin_channels=80).  An option the kernels do not implement RAISES here -- it
+            # would otherwise give silently different numbers (round-2 finding: every key but upsample_scales was dropped).
+            known = {"upsample_scales", "upsample_activation", "upsample_activation_params", "mode", "freq_axis_kernel_size",
+                     "cin_pad", "cin_channels"}
+            unknown = sorted(set(upsample_params) - known)
+            if unknown:
+                raise TypeError(f"__init__() got an unexpected keyword argument {unknown[0]!r} (upsample_params)")
+            if "upsample_scales" not in upsample_params:
+                raise TypeError("__init__() missing 1 required positional argument: 'upsample_scales' (upsample_params)")
+            if upsample_params.get("upsample_activation", "none") != "none":
+                raise NotImplementedError("upsample_activation other than 'none' is not implemented (upsample.py:44-46; no preset sets it)")
+            if upsample_params.get("mode", "nearest") != "nearest":
+                raise NotImplementedError("only nearest-neighbour stretching (Stretch2d mode='nearest', upsample.py:19-21) is implemented")
+            if int(upsample_params.get("freq_axis_kernel_size", 1)) != 1:
+                raise NotImplementedError("freq_axis_kernel_size must be 1 (a smoothing FIR along time only, upsample.py:36-40)")
+            if int(upsample_params.get("cin_channels", cin_channels)) != cin_channels:
+                raise ValueError(f"upsample_params cin_channels ({upsample_params['cin_channels']}) != cin_channels ({cin_channels}): "
+                                 "conv_in would not accept the features")
+            scales = list(upsample_params["upsample_scales"])
+            # the network's own cin_pad is the one in upsample_params (the reference ignores the constructor argument for it)
+            cin_pad = int(upsample_params.get("cin_pad", cin_pad))
+        if kernel_size != 3:
+            # kernel_size is a template constant of the layer kernels; 3 is what every preset and every parity fixture uses
+            raise NotImplementedError(f"kernel_size={kernel_size}: only the reference presets' kernel_size=3 is verified against the "
+                                      "reference; other tap counts are refused rather than run unverified")
         geom = P.Geometry(layers=layers, stacks=stacks, R=residual_channels, G=gate_channels, S=skip_out_channels,
                           O=out_channels, Cc=cin_channels, Cg=gin_channels, k=kernel_size,
                           n_speakers=n_speakers if (gin_channels > 0 and use_speaker_embedding) else None,
