@@ -51,7 +51,7 @@ AR_CFG = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3
               upsample_scales=[4, 4, 8, 5], cin_pad=0)
 
 
-def ar_leg(device, T_ar=4000, cpu=True):
+def ar_leg(device, T_ar=4000, cpu=True, full_clip=True):
     """Second half of BASELINE.json's metric: autoregressive kHz of synthesis.py's incremental_forward on one GPU, one
     utterance (config C4: hps/vqwae.json decoder, 16 kHz; a 0.25 s prefix of the 10 s clip -- the per-sample cost is
     constant), categorical sampling as in the reference (wavenet.py:300-338).  Untimed warm-up, then one timed run.
@@ -79,6 +79,25 @@ def ar_leg(device, T_ar=4000, cpu=True):
         torch.cuda.synchronize()
         out[dt] = Tg / (time.perf_counter() - t0) / 1e3
     best = "bf16" if out["bf16"] >= out["fp32"] else "fp32"
+    full = None
+    if full_clip:
+        # BASELINE.json configs[3] as named: ONE 16 kHz 10 s clip = 250 latent frames -> 160 000 samples, end to end, best dtype
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=best, device=str(device))
+        eng.load_state_dict(sd)
+        gen = torch.Generator(device="cpu").manual_seed(4321)
+        lat = torch.randn(1, 64, 250, generator=gen).to(device)
+        gid = torch.zeros(1, dtype=torch.int64, device=device)
+        eng.incremental_forward(lat[:, :, :2].contiguous(), gid, 1280, mode="sample")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = eng.incremental_forward(lat, gid, 160000, mode="sample")
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t0
+        idx = o["idx"][0]
+        full = {"samples": 160000, "seconds": dtf, "khz": 160000 / dtf / 1e3, "dtype": best, "realtime_factor": 160000 / dtf / 16000.0,
+                "distinct_classes": int(torch.unique(idx).numel()),
+                "note": "the whole 10 s clip in one persistent launch (250 latent frames x 640); the headline value above is the "
+                        "short prefix run"}
     us = 1e3 / out[best]
     wbytes = n_w * (2 if best == "bf16" else 4)
     bound_us = wbytes / (HBM_PEAK_GBS * 1e9) * 1e6
@@ -90,6 +109,8 @@ def ar_leg(device, T_ar=4000, cpu=True):
                         "note": "SURVEY 8(d): every effective weight once per sample (%d x %d B) / 8 TB/s; 20 strictly sequential "
                                 "layers + head per sample" % (n_w, 2 if best == "bf16" else 4)},
            "config": "C4: hps/vqwae.json decoder (20 layers, R=G=S=256), categorical sampling, one persistent launch"}
+    if full is not None:
+        res["full_clip"] = full
     if cpu:
         nthreads = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(nthreads)
@@ -180,6 +201,25 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def glu_kernel_name(dtype, save_z):
+    """Name of the fused layer kernel a C2 launch runs: the 16-bit modes take the static-schedule instantiation
+    (csrc/glu_fwd_static.hip), whose training launches (z saved) and inference launches are differently NAMED entry points."""
+    if dtype == "fp32":
+        return "glu_fwd_kernel"
+    return "glu_fwd_static_z_kernel" if save_z else "glu_fwd_static_kernel"
+
+
+def kernel_matches(name, profiler_name):
+    """Does a rocprofv3 kernel name belong to the kernel `name`?  (name followed by '<' or '(': glu_fwd_static_kernel must not
+    match glu_fwd_static_z_kernel; mangled names -- _Z21gemm_tn_stream_kernelI... -- match by substring.)  The last layer's
+    launch (WAE_GLU_NO_OUT: x' is dead) is a different instantiation of the same name with about 20 % less traffic; the mean over
+    a name's launches is what tools/profile_round.sh stores."""
+    for sep in ("<", "("):
+        if name + sep in profiler_name:
+            return True
+    return profiler_name.startswith("_Z") and name + "I" in profiler_name
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has not
     initialised the GPU and never will), relay its output, exit with its code."""
@@ -200,6 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--ar-short", action="store_true", help="autoregressive leg: skip the full 160 000-sample C4 clip (about 24 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ar", action="store_true", help="skip the autoregressive leg (BASELINE config C4, rank 0 only)")
     args = ap.parse_args()
@@ -279,7 +320,7 @@ def main():
         dt = float(tmax.item())
     loss_v = float(loss)
 
-    # dominant kernel: glu_fwd_kernel -- HIP events recorded on the launch stream around the 24-layer stack of
+    # dominant kernel: the fused layer kernel (glu_kernel_name) -- HIP events recorded on the launch stream around the 24-layer stack of
     # every timed step; average per launch (includes the inter-kernel gaps, so it is conservative)
     stack_ms = [a.elapsed_time(b) for a, b in ev]
     glu_ms = sum(stack_ms) / len(stack_ms) / geom.layers
@@ -291,7 +332,7 @@ def main():
     achieved_gbs = bytes_per_launch / (glu_ms * 1e-3) / 1e9
     achieved_tf = flops_per_launch / (glu_ms * 1e-3) / 1e12
     peak_tf = FP32_MFMA_PEAK_TF if args.dtype == "fp32" else MFMA_PEAK_TF      # fp16 and bf16 MFMA run at the same dense rate
-    fwd_roof = {"bound": "hbm", "kernel": "glu_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    fwd_roof = {"bound": "hbm", "kernel": glu_kernel_name(args.dtype, args.mode == "train"), "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": glu_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "mfma_achieved_tflops": achieved_tf,
                 "mfma_frac": achieved_tf / peak_tf,
@@ -299,7 +340,7 @@ def main():
     roof = fwd_roof
     extra = {}
     if args.mode == "train":
-        # The kernel with the largest share of the train step is still glu_fwd_kernel (24 launches); in training it also
+        # The kernel with the largest share of the train step is still the fused layer kernel (24 launches); in training it also
         # saves the pre-activations: SURVEY 8(d) train bytes, forward part = (2R + 2S + Cc) + G per layer and sample.
         tb = (2 * C2["R"] + 2 * C2["S"] + C2["Cc"] + C2["G"]) * es * samples
         roof = dict(fwd_roof, achieved=tb / (glu_ms * 1e-3) / 1e9, frac=tb / (glu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -326,7 +367,7 @@ def main():
 
     # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (bench.py cannot run the profiler
     # on itself).  The file carries the hash of the kernel sources it was measured on: a different build reports null.
-    traffic_src = None
+    traffic_src, traffic_doc = None, None
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
@@ -335,10 +376,11 @@ def main():
                 doc = json.load(fh)
             if doc.get("csrc_hash") == csrc_hash():
                 traffic_src = os.path.basename(fpath)
+                traffic_doc = doc
                 if args.dtype in ("bf16", "fp16") and args.mode == "train":
                     for rf in [roof] + list(extra.values()):
                         for k, v in doc["kernels"].items():
-                            if rf["kernel"] in k:
+                            if kernel_matches(rf["kernel"], k):
                                 rf["traffic"] = v["hbm_bytes_per_launch"]
                                 rf["traffic_source"] = traffic_src
                 break
@@ -392,14 +434,20 @@ def main():
             res["forward_inference"] = {
                 "metric": "teacher-forced audio samples/sec (24-layer decoder), forward + CE", "value": samples / (f_step * 1e-3),
                 "unit": "samples/s", "ms_per_step": f_step, "steps": nf,
-                "roofline": {"bound": "hbm", "kernel": "glu_fwd_kernel", "achieved": bytes_per_launch / (f_ms * 1e-3) / 1e9,
+                "roofline": {"bound": "hbm", "kernel": glu_kernel_name(args.dtype, False), "achieved": bytes_per_launch / (f_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "avg_launch_ms": f_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                             "traffic": None, "avg_launch_ms": f_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                              "mfma_frac": flops_per_launch / (f_ms * 1e-3) / 1e12 / peak_tf,
                              "note": "inference launch (no z saved): SURVEY 8(d) forward bytes (2R+2S+Cc)*e x 64000 samples; HIP "
                                      "events around the 24-layer stack"}}
+            if traffic_doc is not None and args.dtype in ("bf16", "fp16"):
+                # the inference launch is its own kernel symbol: its own PMC entry (the train-mode profile runs this leg too)
+                for k, v in traffic_doc["kernels"].items():
+                    if kernel_matches(res["forward_inference"]["roofline"]["kernel"], k):
+                        res["forward_inference"]["roofline"]["traffic"] = v["hbm_bytes_per_launch"]
+                        res["forward_inference"]["roofline"]["traffic_source"] = traffic_src
         if not args.no_ar and world == 1:
-            res["autoregressive"] = ar_leg(device, cpu=not args.no_cpu)
+            res["autoregressive"] = ar_leg(device, cpu=not args.no_cpu, full_clip=not args.ar_short)
         if not args.no_cpu and world == 1:
             cb, cpu_loss = cpu_baseline_train(sd) if args.mode == "train" else cpu_baseline(sd)
             res["cpu_baseline"] = cb

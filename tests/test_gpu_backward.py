@@ -268,19 +268,22 @@ def test_c2_full_size_backward_properties(monkeypatch):
     assert rel < 1e-5, rel
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_grad_sync_path_equals_plain_backward(dtype):
-    """Data-parallel step order: with a GradSync the layers' + head's slice of the arena goes through the sliced
-    weight-norm backward and is handed over inside decoder_backward, the rest in finish_grads.  Single process (no collective
-    runs): the gradients and the updated weights must equal those of the plain order."""
+@pytest.mark.parametrize("dtype,name", [("fp32", "A"), ("bf16", "A"), ("bf16", "B")])
+def test_grad_sync_path_equals_plain_backward(dtype, name):
+    """Data-parallel step order: with a GradSync the arena is handed to the all-reduce in THREE pieces -- the upper half
+    of the gated layers + the head in the middle of the backward sweep (the stream-K weight-gradient launch is cut into two layer
+    halves for that), the lower half at its end, the rest in finish_grads; fp32 (per-layer tile launches) hands the layers + head
+    over in one piece.  Single process (no collective runs): the hand-over order is checked, and the gradients and the updated
+    weights must equal those of the plain order."""
     from wavenet_autoencoders_amd import Geometry
     from wavenet_autoencoders_amd import backward as BW
     from wavenet_autoencoders_amd.distributed import GradSync
     from wavenet_autoencoders_amd.engine import WaeEngine
-    cfg, sd, ins, z, ocfg = golden_model("A")
+    cfg, sd, ins, z, ocfg = golden_model(name)
     x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
     lengths = torch.tensor([x.shape[1], x.shape[1] - 333])
     got = {}
+    handed = []
     for tag in ("plain", "sync"):
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
         eng.load_state_dict(sd)
@@ -291,10 +294,15 @@ def test_grad_sync_path_equals_plain_backward(dtype):
             lo, hi = BW.layer_segment(eng)
             assert 0 < lo < hi < eng.lay.total and (hi - lo) > 0.5 * eng.lay.total
             assert any(b[0] == lo for b in sync.bounds) and any(b[1] == hi for b in sync.bounds)
+            mid = BW.layer_segment_mid(eng)
+            assert lo < mid < hi and any(b[0] == mid for b in sync.bounds)
+            inner = sync.ready_range
+            sync.ready_range = lambda a, b_, inner=inner: (handed.append((a, b_)), inner(a, b_))[1]
         r = eng.train_step(x, c, g, lengths=lengths, grad_sync=sync, grad_hook=lambda gr: seen.setdefault("g", gr.clone()))
         torch.cuda.synchronize()
         if sync is not None:
             assert sync.launched == [False] * len(sync.bounds)          # finish() re-armed the buckets
+            assert handed == ([(mid, hi), (lo, mid)] if dtype == "bf16" else [(lo, hi)]), handed
         got[tag] = (seen["g"].cpu(), eng.params.cpu().clone(), float(r["loss"]), float(r["grad_norm"]))
     ga, gb = got["plain"][0], got["sync"][0]
     tol = 1e-6 if dtype == "fp32" else 1e-5            # fp32 atomics arrive in another order

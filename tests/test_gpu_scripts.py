@@ -40,8 +40,14 @@ def test_train_synthesis_and_feature_export_scripts(tmp_path):
     preset = os.path.join(ROOT, "hps", "vqwae.json")
     ck = tmp_path / "ck"
     out = _run([os.path.join(ROOT, "vqwae_train.py"), "--dump-root", str(dump), "--checkpoint-dir", str(ck), "--preset", preset,
-                "--hparams", HP, "--max-steps", "3", "--dtype", "fp32"], str(tmp_path))
+                "--hparams", HP + ",train_eval_interval=2", "--max-steps", "3", "--dtype", "fp32"], str(tmp_path))
     assert "Finished" in out and "step 1 loss" in out
+    # in-training online decoding with the averaged weights (vqwae_train.py:572-640,772-774): step 2 wrote both waveforms
+    assert "Eval at train step 2" in out and "Using averaged model for evaluation" in out
+    from scipy.io import wavfile as _wf
+    for tag in ("predicted", "target"):
+        sr_e, y_e = _wf.read(ck / "intermediate" / "train_no_dev_eval" / f"step000000002_{tag}.wav")
+        assert sr_e == 16000 and y_e.shape == (2560,) and float(np.abs(y_e.astype(np.float64)).max()) > 0
     for f in ("checkpoint_step000000003.pth", "checkpoint_latest.pth", "checkpoint_step000000003_ema.pth", "hparams.json"):
         assert (ck / f).exists(), f
     sd = torch.load(ck / "checkpoint_latest.pth", map_location="cpu")["state_dict"]

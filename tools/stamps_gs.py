@@ -53,6 +53,9 @@ for fl in (0, 2):
         names = ["prologue (tables, first requests)", "GEMM1 pass 0", "z/gate/u-store pass 0", "GEMM1 pass 1", "z/gate/u-store pass 1",
                  "GEMM2: counted wait", "GEMM2: barrier", "GEMM2: MFMAs", "GEMM2: residual + x' stores"]
         idx = [0, 1, 2, 3, 4, 5, 9, 10, 11, 8]
+        if not s[:, 4].any():            # the one-pass form (Hp = 192 at C2) has no second pass: stamps 4 and 5 are never written
+            names = names[:3] + names[5:]
+            idx = [0, 1, 2, 3, 9, 10, 11, 8]
         print(f"--- flags={fl} dilation={d}: s_memtime ticks per phase of wave 0, median / p10 / p90 over {nwg} workgroups")
         for i, nme in enumerate(names):
             v = np.sort(s[:, idx[i + 1]] - s[:, idx[i]])

@@ -76,6 +76,56 @@ def evaluate(eng, loader, device, hp):
     return [float(v) for v in stats.cpu()]
 
 
+def eval_model(eng, x, c, g, lengths, global_step, eval_dir, hp, use_ema, hop):
+    """eval_model (vqwae_train.py:572-640): online decoding of ONE random item of the batch with the AVERAGED weights when an EMA is
+    kept (clone_as_averaged_model, :353-360: the shadow replaces the parameters for the duration of the decode; the reference also
+    strips weight norm with make_generation_fast_, which changes nothing numerically): encoder + VQ on the item's features,
+    autoregressive decode of `length` samples from the silence class (mulaw_quantize(0, 255) = 127) by categorical sampling
+    (softmax=True, quantize=True), then predicted and target waveforms as 16-bit wav files named as the reference names them.
+    (The reference's wave plots are out of scope.)  Returns (predicted, target) float waveforms."""
+    import numpy as np
+    from scipy.io import wavfile
+    from wavenet_autoencoders_amd.data import inv_mulaw_quantize
+    idx = int(np.random.randint(0, x.shape[0]))
+    length = int(lengths[idx])
+    y_target = x[idx, :length].detach().cpu().numpy()
+    frames = length // hop + 2 * hp.cin_pad if eng.g.upsample_scales else length
+    ci = c[idx:idx + 1, :, :frames].contiguous().float()
+    gi = g[idx:idx + 1].contiguous() if g is not None else None
+    saved = None
+    if use_ema and getattr(eng, "shadow", None) is not None:
+        print("Using averaged model for evaluation")
+        saved = eng.params.clone()
+        eng.params.copy_(eng.shadow)
+        eng.weights_dirty = True
+    try:
+        eng.prepare_weights()
+        lat = eng.encoder_forward(ci)
+        quant, _, _ = eng.vq_forward(lat)
+        Tgen = length
+        if eng.g.upsample_scales:        # the decoder emits whole latent frames (the reference asserts the same, wavenet.py:198-200)
+            Tgen = min(length, (quant.shape[-1] - 2 * hp.cin_pad) * int(np.prod(eng.g.upsample_scales)))
+            y_target = y_target[:Tgen]
+        if eng.g.scalar_input:
+            out = eng.incremental_forward(quant, gi, Tgen, mode="sample", log_scale_min=hp.log_scale_min)
+            y_hat = out["x"][0].float().cpu().numpy()
+            y_target = y_target.astype(np.float32)
+        else:
+            out = eng.incremental_forward(quant, gi, Tgen, mode="sample", init_idx=127)
+            y_hat = inv_mulaw_quantize(out["idx"][0].cpu().numpy(), hp.quantize_channels - 1)       # :621-623 use 255
+            y_target = inv_mulaw_quantize(y_target, hp.quantize_channels - 1)
+        eng.check_errors()
+    finally:
+        if saved is not None:
+            eng.params.copy_(saved)
+            eng.weights_dirty = True
+    os.makedirs(eval_dir, exist_ok=True)
+    for tag, y in (("predicted", y_hat), ("target", y_target)):
+        pcm = np.clip(np.asarray(y, dtype=np.float64) * 32767.0, -32768, 32767).astype(np.int16)
+        wavfile.write(os.path.join(eval_dir, "step{:09d}_{}.wav".format(global_step, tag)), hp.sample_rate, pcm)
+    return y_hat, y_target
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--dump-root")
@@ -187,6 +237,10 @@ def main(argv=None):
                         dt = (time.time() - t0) / max(step - step0, 1)
                         print(f"step {step} loss {float(stats[0]):.4f} vq {float(stats[1]):.4f} perp {float(stats[2]):.2f} "
                               f"gnorm {float(res['grad_norm']):.3f} lr {lr:.2e} {hp.batch_size * T / dt / 1e6:.2f} Msamples/s")
+                if step > 0 and step % hp.train_eval_interval == 0 and rank == 0:                  # vqwae_train.py:834-836,772-774
+                    print("[train_no_dev] Eval at train step {}".format(step))
+                    eval_model(eng, x, c, g, lengths, step, os.path.join(args.checkpoint_dir, "intermediate", "train_no_dev_eval"),
+                               hp, use_ema, hop)
                 if step % hp.checkpoint_interval == 0:
                     eng.check_errors()          # never checkpoint weights that were trained on clamped ids
                     save_checkpoint(eng, step, epoch, args.checkpoint_dir, hp, rank, test_step, lr)
@@ -199,6 +253,12 @@ def main(argv=None):
                 if rank == 0:                                                         # vqwae_train.py:862-869
                     print("Step {} [train_no_dev] Loss: {} vq: {} perp {}".format(step, float(avg[0]), float(avg[1]), float(avg[2])))
             if dev_loader is not None and step < max_steps:
+                if rank == 0 and epoch % hp.test_eval_epoch_interval == 0:                            # :838-842: once per dev epoch
+                    for xd, cd, gd, ld in Prefetcher(dev_loader, device):
+                        print("[dev] Eval at train step {}".format(step))
+                        eval_model(eng, xd, cd, gd, ld, step, os.path.join(args.checkpoint_dir, "intermediate", "dev_eval"), hp,
+                                   use_ema, hop)
+                        break
                 dl, dvq, dperp = evaluate(eng, Prefetcher(dev_loader, device), device, hp)
                 test_step += len(dev_loader)
                 if rank == 0:

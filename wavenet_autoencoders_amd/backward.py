@@ -305,6 +305,36 @@ def bwd_workspace(eng, B, T):
     return ws
 
 
+def _build_stream_table(eng, ws, fw, B, T, l0, l1):
+    """The stream-K launch (csrc/gemm_tn_stream.hip) over the weight gradients of layers [l0, l1): dW1 taps, dWc + zb sums, dW_out +
+    bias of every layer of the range.  The whole stack is one launch; data-parallel steps cut it into an upper and a lower half so
+    that the upper half's slice of the gradient arena reaches the all-reduce in the middle of backward (decoder_backward)."""
+    g, sm = eng.g, eng.sm
+    es = eng.w_glu.element_size()
+    Z2 = 2 * g.Hp
+    dzs = g.layers * Z2
+    c1, co = eng.cview["c1"], eng.cview["co"]
+    ia = 1.0 / eng.grad_scale
+    stt = StreamTable(eng, B, T)
+    for l in range(l0, l1):
+        d = g.dilations[l]
+        stt.begin_group()
+        dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
+        c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
+        xl = fw["xd"][l] if "xd" in fw else fw["x"][l]      # dW1 contracts dz against the convolution's operand
+        for tap in range(g.k):
+            last = tap == g.k - 1 and not g.Ccp
+            stt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, dz_ptr, dzs, xl.data_ptr(), g.Rp,
+                    c1l + tap * g.Rp * 4, sm["ld1"])
+        if g.Ccp:
+            stt.add(Z2, g.Ccp, 0, g.Ccp, ia, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
+        has_out = l < g.layers - 1
+        stt.add(g.Rp, g.Hp, 0, g.Hp, ia, ws["gx"][l + 1].data_ptr() if has_out else 0, g.Rp,
+                fw["u"].data_ptr() + l * g.Hp * es, g.Ku, co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
+    stt.lead_jobs = g.k
+    return stt.finalize()
+
+
 def _build_tile_tables(eng, ws, fw, B, T):
     """All weight-gradient contractions of a step as two kinds of launches: one table per layer (dW1 taps, dWc + zb sums,
     dW_out + bias) and one global table (dW_skip of every layer + bias, head matrices + biases, first-conv table)."""
@@ -317,24 +347,7 @@ def _build_tile_tables(eng, ws, fw, B, T):
     ws["tt_layer"] = []
     ws["stream"] = None
     if use_stream_tn(eng):
-        stt = StreamTable(eng, B, T)
-        for l in range(g.layers):
-            d = g.dilations[l]
-            stt.begin_group()
-            dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
-            c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
-            xl = fw["xd"][l] if "xd" in fw else fw["x"][l]      # dW1 contracts dz against the convolution's operand
-            for tap in range(g.k):
-                last = tap == g.k - 1 and not g.Ccp
-                stt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, dz_ptr, dzs, xl.data_ptr(), g.Rp,
-                        c1l + tap * g.Rp * 4, sm["ld1"])
-            if g.Ccp:
-                stt.add(Z2, g.Ccp, 0, g.Ccp, ia, dz_ptr, dzs, fw["c_up"].data_ptr(), g.Ccp, c1l + g.k * g.Rp * 4, sm["ld1"])
-            has_out = l < g.layers - 1
-            stt.add(g.Rp, g.Hp, 0, g.Hp, ia, ws["gx"][l + 1].data_ptr() if has_out else 0, g.Rp,
-                    fw["u"].data_ptr() + l * g.Hp * es, g.Ku, co.data_ptr() + l * g.Rp * sm["ldo"] * 4, sm["ldo"])
-        stt.lead_jobs = g.k
-        ws["stream"] = stt.finalize()
+        ws["stream"] = _build_stream_table(eng, ws, fw, B, T, 0, g.layers)
     for l in range(g.layers if ws["stream"] is None else 0):
         d = g.dilations[l]
         tt = TileTable(eng)
@@ -376,6 +389,12 @@ def layer_segment(eng):
     last = keys.index("wavenet.last_conv_layers.3.weight_v")
     hi = lay.offsets[keys[last + 1]] if last + 1 < len(keys) else lay.total
     return lay.off("wavenet.conv_layers.0.conv.bias"), hi
+
+
+def layer_segment_mid(eng):
+    """First arena element of layer L/2: [layer_segment lo, mid) = the lower half of the gated layers, [mid, hi) = the upper half
+    and the head -- the slice a data-parallel backward hands to the all-reduce first."""
+    return eng.lay.off("wavenet.conv_layers.0.conv.bias") + (eng.g.layers // 2) * eng.lay.layer_stride
 
 
 def _wn_bwd_range(eng, lo, hi):
@@ -480,6 +499,67 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             e1.record(torch.cuda.current_stream(eng.device))
             ev.append((e0, e1))
 
+    def launch_stream(tab):
+        ev = getattr(eng, "_tn_events", None)
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(eng.device))
+        tab.launch()
+        if ev is not None:
+            e1.record(torch.cuda.current_stream(eng.device))
+            ev.append((e0, e1))
+
+    OP = P.ONES_PAD
+
+    def finish_layers(l0, l1, with_head):
+        """Scatter the dense gradient tiles of layers [l0, l1) (and of the head) into the effective-weight arena, then the zb chain
+        (conv bias + hoisted global conditioning, modules.py:148-152) of those layers.  Disjoint slots; the tables never move."""
+        key = ("scatter_jobs", l0, l1, with_head)
+        jobs = ws.get(key)
+        if jobs is None:
+            nb, ls = l1 - l0, lay.layer_stride
+
+            def sjob(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1, doff=0):
+                return L.ScatterJob(src.data_ptr() + off * 4, mp.data_ptr(), eng.d_eff.data_ptr() + doff * 4, rows * cols, ss, ds, ld, nb,
+                                    cols, unique, 0)
+            lst = [sjob(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], off=l0 * Z2 * sm["ld1"], nb=nb, ss=Z2 * sm["ld1"], ds=ls, doff=l0 * ls),
+                   sjob(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], off=l0 * g.Rp * sm["ldo"], nb=nb, ss=g.Rp * sm["ldo"], ds=ls, doff=l0 * ls),
+                   sjob(co, sm["bo"], g.Rp, OP, sm["ldo"], off=l0 * g.Rp * sm["ldo"] + g.Hp, nb=nb, ss=g.Rp * sm["ldo"], ds=ls, unique=2,
+                        doff=l0 * ls),
+                   sjob(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=nb, ss=0, ds=ls, unique=2, doff=l0 * ls)]
+            if with_head:
+                lst += [sjob(cs, sm["ws"], g.Sp, g.Ku, sm["lds"]),
+                        sjob(c3, sm["w3"], g.Op, g.Sp, sm["ldh"]),
+                        sjob(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2),
+                        sjob(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"]),
+                        sjob(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)]
+            jobs = ws[key] = (L.ScatterJob * len(lst))(*lst)
+        L.check(lib.wae_unpack_scatter_add_multi(jobs, len(jobs), st), "scatter layer and head gradients")
+        wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") + l0 * lay.layer_stride if g.Cg > 0 else -1
+        L.check(lib.wae_gproj_bwd(L.ptr(eng.eff), L.ptr(eng.d_eff), wg_off,
+                                  lay.off("wavenet.conv_layers.0.conv.bias") + l0 * lay.layer_stride, lay.layer_stride,
+                                  L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec),
+                                  ctypes.c_void_p(c1.data_ptr() + l0 * Z2 * sm["ld1"] * 4), Z2 * sm["ld1"], sm["ld1"],
+                                  g.k * g.Rp + g.Ccp, B, l1 - l0, g.G, g.Hp, max(g.Cg, 0), int(g.n_speakers or 0), st),
+                "gproj_bwd")
+
+    emb_off = lay.offsets.get("wavenet.embed_speakers.weight", 0)
+    use_gid = gid is not None and "wavenet.embed_speakers.weight" in lay.offsets
+    gid32 = gid.to(torch.int32).contiguous() if gid is not None else None
+    keep.append(gid32)
+    # ---- data parallel: where the arena is cut.  [seg_lo, seg_hi) = the gated layers + the head (backward.layer_segment); with the
+    #      stream-K launch and >= 4 layers the sweep hands over [seg_mid, seg_hi) -- the upper half of the layers and the head -- as
+    #      soon as it has passed layer L/2, and [seg_lo, seg_mid) at its end (WAE_DP_SPLIT=0: one hand-over at the end)
+    eng._grads_done = None
+    seg_lo, seg_hi = layer_segment(eng)
+    split = None
+    if grad_sync is not None and ws["stream"] is not None and g.layers >= 4 and os.environ.get("WAE_DP_SPLIT", "1") != "0":
+        split = g.layers // 2
+        seg_mid = layer_segment_mid(eng)
+        if "stream_hi" not in ws:
+            ws["stream_hi"] = _build_stream_table(eng, ws, fw, B, T, split, g.layers)
+            ws["stream_lo"] = _build_stream_table(eng, ws, fw, B, T, 0, split)
+
     k_u(g.layers - 1, g_next)
     for l in range(g.layers - 1, -1, -1):
         assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % ngx].data_ptr()
@@ -499,51 +579,33 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             if l > 0:
                 k_u(l - 1, g_cur)
         g_next = g_cur
-    if ws["stream"] is not None:          # every layer's dW1 taps, dWc + zb sums, dW_out + bias: one launch
-        ev = getattr(eng, "_tn_events", None)
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(eng.device))
-        ws["stream"].launch()
-        if ev is not None:
-            e1.record(torch.cuda.current_stream(eng.device))
-            ev.append((e0, e1))
-    # ---- scatter the dense tiles of the layers and the head into the effective-weight gradient arena -----------------------
-    def sjob(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1):
-        return L.ScatterJob(src.data_ptr() + off * 4, mp.data_ptr(), eng.d_eff.data_ptr(), rows * cols, ss, ds, ld, nb, cols, unique, 0)
-    OP = P.ONES_PAD
-    jobs = ws.get("scatter_jobs")
-    if jobs is None:           # disjoint slots: one launch (the tables and the arena never move)
-        lst = [sjob(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], nb=g.layers, ss=Z2 * sm["ld1"], ds=lay.layer_stride),
-               sjob(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride),
-               sjob(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, nb=g.layers, ss=g.Rp * sm["ldo"], ds=lay.layer_stride, unique=2),
-               sjob(cs, sm["ws"], g.Sp, g.Ku, sm["lds"]),
-               sjob(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=g.layers, ss=0, ds=lay.layer_stride, unique=2),
-               sjob(c3, sm["w3"], g.Op, g.Sp, sm["ldh"]),
-               sjob(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2),
-               sjob(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"]),
-               sjob(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)]
-        jobs = ws["scatter_jobs"] = (L.ScatterJob * len(lst))(*lst)
-    L.check(lib.wae_unpack_scatter_add_multi(jobs, len(jobs), st), "scatter layer and head gradients")
-    # ---- zb (conv bias + hoisted global conditioning) ---------------------------------------------------------------------
-    wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
-    emb_off = lay.offsets.get("wavenet.embed_speakers.weight", 0)
-    use_gid = gid is not None and "wavenet.embed_speakers.weight" in lay.offsets
-    gid32 = gid.to(torch.int32).contiguous() if gid is not None else None
-    keep.append(gid32)
-    L.check(lib.wae_gproj_bwd(L.ptr(eng.eff), L.ptr(eng.d_eff), wg_off, lay.off("wavenet.conv_layers.0.conv.bias"),
-                              lay.layer_stride, L.ptr(gid32) if use_gid else None, emb_off, L.ptr(gvec), L.ptr(c1),
-                              Z2 * sm["ld1"], sm["ld1"], g.k * g.Rp + g.Ccp, B, g.layers, g.G, g.Hp, max(g.Cg, 0),
-                              int(g.n_speakers or 0), st),
-            "gproj_bwd")
-    # ---- data parallel: the layers' + head's gradients are final -> weight-norm backward of that slice, then the all-reduce
-    #      starts on its side stream while the launches below (and the front end's backward) still run ------------------------
-    eng._grads_done = None
-    if grad_sync is not None:
-        lo, hi = layer_segment(eng)
-        _wn_bwd_range(eng, lo, hi)
-        eng._grads_done = (lo, hi)
-        grad_sync.ready_range(lo, hi)
+        if split is not None and l == split:
+            # data parallel: dz, dx-hat and the saved activations of layers [split, L) are complete -> their weight gradients now
+            # (one stream-K launch over the upper half), the head's and theirs into the arena, weight-norm backward of that slice,
+            # and the all-reduce of ~half the arena starts while the lower half of the sweep still runs
+            launch_stream(ws["stream_hi"])
+            finish_layers(split, g.layers, with_head=True)
+            _wn_bwd_range(eng, seg_mid, seg_hi)
+            grad_sync.ready_range(seg_mid, seg_hi)
+    if split is not None:
+        launch_stream(ws["stream_lo"])
+    elif ws["stream"] is not None:        # every layer's dW1 taps, dWc + zb sums, dW_out + bias: one launch
+        launch_stream(ws["stream"])
+    if split is not None:
+        finish_layers(0, split, with_head=False)
+        _wn_bwd_range(eng, seg_lo, seg_mid)
+        eng._grads_done = (seg_lo, seg_hi)
+        grad_sync.ready_range(seg_lo, seg_mid)
+    else:
+        finish_layers(0, g.layers, with_head=True)
+        # ---- data parallel without the split (too few layers, or the per-layer tile launches of fp32): the layers' + head's
+        #      gradients are final -> weight-norm backward of that slice, then the all-reduce starts on its side stream while the
+        #      launches below (and the front end's backward) still run
+        eng._grads_done = None
+        if grad_sync is not None:
+            _wn_bwd_range(eng, seg_lo, seg_hi)
+            eng._grads_done = (seg_lo, seg_hi)
+            grad_sync.ready_range(seg_lo, seg_hi)
     # ---- local-conditioning gradient over all layers at once ---------------------------------------------------------
     if g.Ccp:
         _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), dzs, dzs, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
@@ -561,6 +623,8 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
     jobs = ws.get("scatter_jobs_first")
     if jobs is None:
+        def sjob(src, mp, rows, cols, ld):
+            return L.ScatterJob(src.data_ptr(), mp.data_ptr(), eng.d_eff.data_ptr(), rows * cols, 0, 0, ld, 1, cols, 1, 0)
         lst = [sjob(ctab, sm["tab"], 1 if g.scalar_input else g.O, g.Rp, g.Rp), sjob(fb, sm["fb"], 1, g.Rp, g.Rp)]
         jobs = ws["scatter_jobs_first"] = (L.ScatterJob * len(lst))(*lst)
     L.check(lib.wae_unpack_scatter_add_multi(jobs, len(jobs), st), "scatter first-conv gradients")
@@ -568,8 +632,9 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     return ws["dc"]
 
 
-def _debug_kernels(eng, B, T, l):
-    """(du/dz launch, dx launch) of layer l as closures over the workspaces of the last train step (tools/ablate_tm.py)."""
+def _debug_kernels(eng, B, T, l, flags_u=0, flags_x=0):
+    """(du/dz launch, dx launch) of layer l as closures over the workspaces of the last train step (tools/ablate_tm.py,
+    flags_*: extra wae_tm_desc flags (L.TM_ONE_WG)."""
     g, ws, fw = eng.g, eng._ws[("bwd", B, T)], eng._ws[(B, T, True)]
     es = eng.w_glu.element_size()
     Z2 = 2 * g.Hp
@@ -579,12 +644,12 @@ def _debug_kernels(eng, B, T, l):
 
     def k_u():
         _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
-            eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2)
+            eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2, flags=flags_u)
 
     def k_x():
         srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
         _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp,
-            flags=P.TM_INTERLEAVE)
+            flags=P.TM_INTERLEAVE | flags_x)
     return k_u, k_x
 
 

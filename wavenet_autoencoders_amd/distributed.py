@@ -156,13 +156,16 @@ class GradBucketer:
 
 
 class GradSync(GradBucketer):
-    """The bucketer of a WaeEngine's gradient arena, cut at the boundaries of the slice that backward finishes first
-    (pass as train_step(grad_sync=...))."""
+    """The bucketer of a WaeEngine's gradient arena, cut at the boundaries of the slices backward finishes first -- the upper half
+    of the gated layers + the head in the middle of the sweep, the lower half at its end, first conv / embedding / upsampling /
+    encoder / codebook in finish() (pass as train_step(grad_sync=...))."""
 
     def __init__(self, eng, bucket_bytes: int = 16 << 20, group=None, timing: bool = False):
         from . import backward as BW
         BW._prepare_bwd(eng)
-        super().__init__(eng.grads, bucket_bytes, group, cuts=BW.layer_segment(eng), timing=timing)
+        # cut at the slice boundaries backward hands over: [lo, mid) lower half of the gated layers, [mid, hi) upper half + head
+        lo, hi = BW.layer_segment(eng)
+        super().__init__(eng.grads, bucket_bytes, group, cuts=(lo, BW.layer_segment_mid(eng), hi), timing=timing)
 
 
 def ragged_ce_scale(lengths: Optional[torch.Tensor], T: int, batch: int, group=None) -> Tuple[float, float]:
