@@ -35,6 +35,11 @@ def _prepare_bwd(eng):
     occ = int(os.environ.get("WAE_TM_OCC", "6"))
     eng.tm_flags_u = 0 if occ & 2 else L.TM_ONE_WG
     eng.tm_flags_x = 0 if occ & 4 else L.TM_ONE_WG
+    # A/B switch: WAE_TM_BLDS bit 0 gate-backward, bit 1 residual launches on the 8-wave shape whose operand is staged through LDS
+    # (default 0: bit-identical and measured not faster)
+    blds = int(os.environ.get("WAE_TM_BLDS", "0"))
+    eng.tm_flags_u |= L.TM_BLDS if blds & 1 else 0
+    eng.tm_flags_x |= L.TM_BLDS if blds & 2 else 0
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
     # Fusing K_X(l) with K_U(l-1) (csrc/glu_bwd.hip) measured SLOWER than the two launches at C2 (118 us vs 60 + 50 us:
