@@ -1,14 +1,16 @@
 #!/bin/bash
 # Static check of every kernel that requests operands by inline-asm loads (gload_async): emit the gfx950 ISA and scan it with
 # tools/check_asm_regs.py.  CPU only (hipcc cross-compiles).  Usage: tools/check_asm_all.sh [out.txt]
-OUT=${1:-profiles/r02_asm_load_check.txt}
+OUT=${1:-profiles/r03_asm_load_check.txt}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
 {
 echo "# tools/check_asm_all.sh: no compiler-generated instruction may touch a register between its inline-asm request and the"
 echo "# counted wait that retires it (csrc/wae_common.hpp: gload_async).  hipcc $(/opt/rocm/bin/hipcc --version | grep -o 'HIP version.*')"
-for f in glu_fwd head_fwd gemm_tm; do
+for f in glu_fwd glu_fwd_static head_fwd gemm_tm; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only $ROOT/wavenet_autoencoders_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
+  # lookahead: glu_fwd requests two chunks ahead; glu_fwd_static mixes two-chunks-ahead fragments with residual rows that are retired
+  # by the very next counted wait (text-order scanning cannot tell them apart): the always-valid lookahead 1
   la=1; [ $f = glu_fwd ] && la=3
   for k in $(grep -o "^_Z[0-9]*[a-z_]*kernelIDF16[b_][A-Za-z0-9_]*" $TMP/$f.s | sort -u); do
     python3 $ROOT/tools/check_asm_regs.py $TMP/$f.s $k $la | tail -1

@@ -49,7 +49,7 @@ def main():
     notes = 0
     nload = 0
     for i, l in enumerate(body):
-        if kinds[i] != "asm" or "global_load_dwordx4" not in l:
+        if kinds[i] != "asm" or not ("global_load_dwordx4" in l or "buffer_load_dwordx4" in l):   # (buffer form: csrc/glu_fwd_static.hip)
             continue
         nload += 1
         dst = regs_of(l.split(",")[0])
@@ -61,9 +61,9 @@ def main():
                 break                                    # a full drain retires every request
             if not t or t.startswith(";") or t.startswith(".") or kinds[j] == "marker":
                 continue
-            if kinds[j] == "asm" and ("global_load_dwordx4" in t or "s_waitcnt" in t or "ds_read" in t):
+            if kinds[j] == "asm" and ("global_load_dwordx4" in t or "buffer_load_dwordx4" in t or "s_waitcnt" in t or "ds_read" in t):
                 # other asm loads / waits / LDS reads name their own registers
-                if regs_of(t.split(",")[0]) & dst and "global_load_dwordx4" in t and j != i:
+                if regs_of(t.split(",")[0]) & dst and ("global_load_dwordx4" in t or "buffer_load_dwordx4" in t) and j != i:
                     # a second request into a pending register: benign (loads return in order, the later one wins) and, in
                     # a linear scan, usually the other arm of a branch
                     notes += 1
