@@ -37,5 +37,5 @@ if prof is not None:
 if prof is not None and int(prof[2:].abs().sum()) != 0:
     import numpy as np
     pc = prof.cpu().numpy()[2:18].view(np.uint64)
-    names = ["assemble taps", "gate rows GEMV", "publish+gather u", "x'+skip GEMV", "skip exchange", "head", "draw"]
+    names = ["gate rows GEMV + requests", "gate + x' and skip shares", "-", "all-reduce + residual + next tap", "skip exchange", "head", "draw"]
     print("  s_memtime ticks per sample (member 0):", {n: int(v // T) for n, v in zip(names, pc)})

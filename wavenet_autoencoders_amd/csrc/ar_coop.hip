@@ -12,7 +12,7 @@
 //   (identical code on identical data: every member feeds back the same sample).
 // No member ever streams a whole matrix: per layer it reads its 2*hc rows of W1 and 2 x 16-byte column packets per row of
 // W_out / W_skip.  (v1 all-gathered u and computed x' redundantly: 32 CUs pulling the same 128 KB through one L2 cost
-// 7 us per layer.)  The sums are formed by atomics in arrival order: results are reproducible to fp32 rounding, not bitwise.
+// 7 us per layer.)  The sums are formed by 64-bit integer atomics on 2^-24 fixed-point shares (arc_allreduce): bitwise reproducible.
 // Where all members run on one XCD (checked at start through agent-scope messages), the accumulators stay in that XCD's
 // L2; otherwise every access is an agent-scope atomic.  A wait that does not complete within ~1 s raises *error and every
 // member leaves: never a hung device.
@@ -196,71 +196,131 @@ __device__ __forceinline__ bool arc_gather(unsigned long long* bank, int NV, int
   return *abort_flag == 0;
 }
 
-// Sum one value per thread (n <= ARC_THREADS values) over the C members of an utterance.  Value j lives in an 8-byte granule
-// {fp32 sum, int32 count} of an L2-resident bank; use number `use` (0, 1, 2, ..) takes bank use % 3.  Thread j of every member
-//   1. adds its share to the sum, then 1 to the count (two no-return atomics of one lane to one granule: the L2 channel
-//      performs them in program order),
-//   2. polls its granule with ONE 8-byte load until count = C x (uses of this bank so far): a single-copy-atomic snapshot, so
-//      a complete count comes with the complete sum,
-//   3. (thread j of member j % C only) zeroes the sum of granule j in the bank of use + 2.
-// One L2 round trip after the last member's adds arrive -- the previous scheme (adds, wait for them, a counter, a barrier,
-// then the sums) was three dependent round trips, 5.5 of the 8.4 us per layer.  Everything is per index j: thread j sees
-// count(use) complete => every member's thread j has added for `use` => their reads of the bank of use - 1 (= use + 2) have
-// returned => the owner may zero it; and the owner's zero store is performed before its own adds of use + 1 (the vmcnt(0)
-// in front of them, long satisfied by then), hence before anybody sees count(use + 1) complete and adds for use + 2.
+// Sum one value per thread (n <= ARC_THREADS values) over the C members of an utterance.  Value j lives in ONE 8-byte granule of
+// an L2-resident bank: count * 2^48 + (sum of the shares in 2^-24 fixed point, two's complement); use number `use` (0, 1, 2, ..)
+// takes bank use % 3.  Thread j of every member
+//   1. adds 2^48 + round(share * 2^24) with one no-return 64-bit integer atomic (round 3; before: an fp32 atomic for the sum and
+//      an integer one for the count -- twice the L2 atomic work, and sums that depended on the arrival order),
+//   2. polls its granule with ONE 8-byte load until the count field (rounded: a negative sum borrows from it) reads C: a
+//      single-copy-atomic snapshot, so a complete count comes with the complete sum,
+//   3. (thread j of member j % C only) zeroes granule j in the bank of use + 2.
+// Integer addition is associative: the result does not depend on the arrival order, decoding is bit-reproducible from run to run.
+// Range: |share| < 2^22 / C (so |sum| < 2^22 and the 46-bit sum never reaches the count field's rounding bit); a share outside it
+// (or a NaN) is replaced by 0 and *error = 2 tells the host -- nobody waits for it.  Resolution 2^-24 = 6e-8 absolute per share.
+// One L2 round trip after the last member's add arrives.  Everything is per index j: thread j sees count(use) complete => every
+// member's thread j has added for `use` => their reads of the bank of use - 1 (= use + 2) have returned => the owner may zero it;
+// and the owner's zero store is performed before its own add of use + 1 (the vmcnt(0) in front of it, long satisfied by then),
+// hence before anybody sees count(use + 1) complete and adds for use + 2.
 // fast (all members on one XCD): the atomics stay in that XCD's L2; otherwise agent-scope atomics (memory side).
-// `between` runs once the adds are issued: loads it issues travel while the members wait for each other.
-template <typename F>
-__device__ __forceinline__ bool arc_allreduce(float* banks, int n, unsigned use, float mine, float& sum, int C, int m, bool fast,
-                                              int* error, int* abort_flag, F&& between) {
+// `between` runs once the add is issued: loads it issues travel while the members wait for each other.  `after(sum)` runs on
+// every thread before the closing workgroup barrier (the caller's LDS writes of its next stage).
+template <typename F, typename A>
+__device__ __forceinline__ bool arc_allreduce(float* banks, int n, unsigned use, float mine, float& sum, int C, bool owner, float lim,
+                                              bool fast, int* error, int* abort_flag, F&& between, A&& after) {
   const int tid = threadIdx.x;
-  float* gran = banks + ((int64_t)(use % ARC_NB) * n + tid) * 2;
+  unsigned long long* gran = (unsigned long long*)banks + ((use % ARC_NB) * n + tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's zero store of two uses ago has been performed
   if (tid < n) {
-    if (fast) {
-      __hip_atomic_fetch_add(gran, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add((int*)gran + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-      __hip_atomic_fetch_add(gran, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add((int*)gran + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const bool inside = fabsf(mine) < lim;     // lim = 2^22 / C; false for NaN as well
+    if (!inside) __hip_atomic_store(error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long fx = inside ? __float2ll_rn(mine * 16777216.f) : 0ll;
+    const unsigned long long add = (1ull << 48) + (unsigned long long)fx;
+    if (fast) __hip_atomic_fetch_add(gran, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_add(gran, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   between();
   sum = 0.f;
   bool bad = false;
   if (tid < n) {
-    const unsigned target = (unsigned)C * (use / ARC_NB + 1);
     int spins = 0;
     unsigned long long v;
     for (;;) {
-      v = __hip_atomic_load((unsigned long long*)gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)(v >> 32) >= target) break;
-      if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      v = __hip_atomic_load(gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)((v + (1ull << 47)) >> 48) >= (unsigned)C) break;
+      if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
         bad = true;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
-    sum = __uint_as_float((unsigned)v);
-    if (!bad && tid % C == m) {      // the owner of granule tid clears the bank of use + 2 (= the bank of use - 1)
-      float* clean = banks + ((int64_t)((use + 2) % ARC_NB) * n + tid) * 2;
-      if (fast) *(volatile float*)clean = 0.f;
-      else __hip_atomic_store(clean, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long cnt = (v + (1ull << 47)) >> 48;
+    sum = (float)(long long)(v - (cnt << 48)) * (1.f / 16777216.f);
+    if (!bad && owner) {      // the owner of granule tid (thread tid of member tid % C) clears the bank of use + 2 (= the bank of use - 1)
+      unsigned long long* clean = (unsigned long long*)banks + ((use + 2) % ARC_NB) * n + tid;
+      if (fast) *(volatile unsigned long long*)clean = 0ull;
+      else __hip_atomic_store(clean, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (bad) {
     *abort_flag = 1;
     __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  after(sum);
   arc_barrier();
   return *abort_flag == 0;
 }
+
+// all-gather of n values, one writer per value (the head's rows are split over the members): the thread that holds value idx
+// stores {use + 1, fp32 bits} into granule idx of bank use & 1, every thread polls granule tid for that sequence number.  Exact (no
+// arithmetic), one store per value instead of C atomics (round 3; before, the gather went through the all-reduce with the other
+// members adding zeros).  Two banks are enough: a member writes for use + 2 only after use + 1 completed on it, which needs every
+// member's values of use + 1, which they store after their polls of `use` returned.  Sequence numbers start at 1; the banks at 0.
+template <typename A>
+__device__ __forceinline__ bool arc_allgather(unsigned long long* banks, int n, unsigned use, bool has, int idx, float mine, bool fast,
+                                              int* error, int* abort_flag, A&& after) {
+  const int tid = threadIdx.x;
+  const unsigned seq = use + 1;
+  unsigned long long* bank = banks + (use & 1) * n;
+  if (has) {
+    const unsigned long long v = arc_pack(seq, mine);
+    if (fast) *(volatile unsigned long long*)(bank + idx) = v;
+    else __hip_atomic_store(bank + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool bad = false;
+  float got = 0.f;
+  if (tid < n) {
+    int spins = 0;
+    unsigned long long v;
+    for (;;) {
+      v = __hip_atomic_load(bank + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)v == seq) break;
+      if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+        bad = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    got = __uint_as_float((unsigned)(v >> 32));
+  }
+  if (bad) {
+    *abort_flag = 1;
+    __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  after(got);
+  arc_barrier();
+  return *abort_flag == 0;
+}
+
+// tanh(a) * sigmoid(g).  fp32 models: libm, as csrc/ar_fwd.hip.  16-bit models: hardware exp2 / rcp (absolute error ~1e-7 on values
+// whose weights carry 8 or 11 bits): the libm pair was ~300 instructions on the critical path of every layer.
+template <typename E>
+__device__ __forceinline__ float arc_gate(float a, float g) {
+  if constexpr (ET<E>::EPL == 4) {
+    return tanhf(a) * (1.f / (1.f + expf(-g)));
+  } else {
+    const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * a));      // e^{2a} = inf -> 1, = 0 -> -1
+    return th * __builtin_amdgcn_rcpf(1.f + __expf(-g));
+  }
+}
+
+__device__ __forceinline__ int arc_uni(const int* q) { return __builtin_amdgcn_readfirstlane(*q); }
 
 template <typename E>
 __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int EPL = ET<E>::EPL;
-  const int tid = threadIdx.x;
+  constexpr int NWV = ARC_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // blocks b and b + 8 share an XCD (round-robin dispatch; speed only): utterance = b % 8, member = b / 8
   const int b = blockIdx.x & 7, m = blockIdx.x >> 3;
   if (b >= p.B || m >= p.C) return;
@@ -269,33 +329,37 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   const int sc = (p.S + C - 1) / C, s0 = min(m * sc, p.S), s1 = min(s0 + sc, p.S), nsk = s1 - s0;   // head rows of this member
   const int K1 = p.ktaps * p.R + (p.Cc > 0 ? p.Cc : 0);
   const int K1p = (K1 + EPL - 1) / EPL * EPL;
-  const int Hk = (H + EPL - 1) / EPL * EPL;
   const int Sk = (p.S + EPL - 1) / EPL * EPL;
-  float* vbuf = sm;                       // K1p
-  float* xbuf = vbuf + K1p;               // R
-  float* ubuf = xbuf + p.R;               // Hk
-  float* skipb = ubuf + Hk;               // Sk   full skip vector after the exchange (also the head's h0)
+  float* uw = sm;                         // NWV x 2*EPL: each wave's own copy of u in the member's two W2 column packets
+  float* vbuf = uw + NWV * 2 * EPL;       // K1p   [history taps ; current tap ; conditioning] of the layer in flight
+  float* skipb = vbuf + K1p;              // Sk   full skip vector after the exchange (also the head's h0)
   float* hbuf = skipb + Sk;               // Sk
   float* lbuf = hbuf + Sk;                // O logits, then exp(l - max)
   float* psum = lbuf + ((p.O + 3) & ~3);  // ARC_THREADS
-  float* myskip = psum + ARC_THREADS;     // this member's gated activations of the layer (hc values)
+  float* myskip = psum + ARC_THREADS;     // this member's gated activations of the layer (hc values; wide members only)
   int* ibuf = (int*)(myskip + ((max(sc, hc) + 3) & ~3));   // [0] = current input id, [1] = abort flag, [2] = argmax
+  // the layers' dilations, ring offsets and ring cursors (row of the current sample = t mod ring length, advanced once per sample).
+  // As loads from the argument arrays inside the layer loop, dilation and offset were vector loads with a full wait each (the
+  // compiler cannot prove them invariant next to the ring stores): two L2 round trips in front of every history request.
+  int* ldil = ibuf + 8;
+  int* lroff = ldil + p.L;
+  int* lpos = lroff + p.L;
 
   float* ring = p.ring + ((int64_t)b * C + m) * p.ring_total;
   const float* zb_b = p.zb + (int64_t)b * p.L * 2 * p.Hp;
   unsigned long long* msg_b = p.msg + (int64_t)b * 2 * C * p.NV;
   const int g_pad = (p.G + 63) & ~63, w_pad = (p.R + p.S + 63) & ~63, s_pad = (p.S + 63) & ~63, o_pad = (p.O + 63) & ~63;
 
-  for (int i = tid; i < K1p; i += ARC_THREADS) vbuf[i] = 0.f;
-  for (int i = tid; i < Hk; i += ARC_THREADS) ubuf[i] = 0.f;
+  for (int i = tid; i < NWV * 2 * EPL + K1p; i += ARC_THREADS) sm[i] = 0.f;
   for (int i = tid; i < Sk; i += ARC_THREADS) { skipb[i] = 0.f; hbuf[i] = 0.f; }
   if (tid == 0) { ibuf[0] = p.n_forced > 0 ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
+  for (int i = tid; i < p.L; i += ARC_THREADS) { ldil[i] = p.dil[i]; lroff[i] = (int)p.ring_off[i]; lpos[i] = 0; }
   arc_barrier();
 
   float* xbanks = p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S, p.O);
   float* sbanks = xbanks + 2 * ARC_NB * p.R;
-  float* hbanks = sbanks + 2 * ARC_NB * p.S;       // all-gather of h1 (head rows are split over the members)
-  float* ybanks = hbanks + 2 * ARC_NB * p.S;       // all-gather of the logits
+  unsigned long long* hbanks = (unsigned long long*)(sbanks + 2 * ARC_NB * p.S);       // all-gather of h1 (2 of the 3 banks)
+  unsigned long long* ybanks = hbanks + ARC_NB * p.S;                                  // all-gather of the logits
   unsigned xuse = 0, suse = 0, huse = 0, yuse = 0;
   unsigned seq = 0;   // exchange counter (same on every member); message bank = seq & 1
   // Where all members run on ONE XCD (the usual placement: blocks b and b+8 share one), messages go through that XCD's L2:
@@ -331,211 +395,298 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
 #else
 #define ARC_TICK(i) do { } while (0)
 #endif
-  // history element i (= tap * R + ch, tap < ktaps - 1) of layer l at sample t: zero before the clip starts
+  const bool owner = tid % C == m;                  // of granule tid in the all-reduce banks (clears it)
+  const float fx_lim = 4194304.f / (float)C;
+
+  // ---- what a thread does per layer, worked out once (round 3: the layer loop ran ~2000 instructions per wave -- integer divisions
+  //      per history element, 64-bit addresses, libm, per-element range tests, scalar spills; one wave per SIMD issues them one by one,
+  //      so the instruction count WAS the layer time: 14 k clocks) ------------------------------------------------------------------
+  // history: element i = tap * R + ch (tap < ktaps - 1) of the taps; thread tid holds elements tid + k * ARC_THREADS, k < ARC_HP
+  int h_ch[ARC_HP], h_back[ARC_HP];     // channel, and how many dilations back the tap lies (0: no element)
+#pragma unroll
+  for (int k = 0; k < ARC_HP; ++k) {
+    const int i = tid + k * ARC_THREADS;
+    const bool ok = i < (p.ktaps - 1) * p.R;
+    const int tap = ok ? i / p.R : 0;
+    h_ch[k] = ok ? i - tap * p.R : 0;
+    h_back[k] = ok ? p.ktaps - 1 - tap : 0;
+  }
+  const bool hist_more = (p.ktaps - 1) * p.R > ARC_HP * ARC_THREADS;      // uniform; wide models only
+  // history element i of layer l at sample t the long way (elements beyond ARC_HP per thread): zero before the clip starts
   auto hist_load = [&](int l, int t, int i) -> float {
     const int tap = i / p.R, ch = i - tap * p.R;
-    const int d = p.dil[l];
+    const int d = ldil[l];
     const int rlen = (p.ktaps - 1) * d + 1;
     const int tt = t - (p.ktaps - 1 - tap) * d;
-    return tt >= 0 ? ring[p.ring_off[l] + (int64_t)(tt % rlen) * p.R + ch] : 0.f;
+    return tt >= 0 ? ring[lroff[l] + (tt % rlen) * p.R + ch] : 0.f;
   };
   float hist[ARC_HP];
 #pragma unroll
   for (int k = 0; k < ARC_HP; ++k) hist[k] = 0.f;   // layer 0 at t = 0: no history yet
-  // The weights a member needs for a layer -- ARC_W1P packets of its slice of one gate row, two packets of W_out row tid
-  // and of W_skip row tid -- depend on nothing computed: they are requested one layer ahead (before the all-reduce of the
-  // previous layer) and wait in registers.
-  const int gns = nch > 0 ? ARC_THREADS / (2 * nch) : 1;          // k slices per gate row
-  const int gi2 = nch > 0 ? tid % (2 * nch) : 0, gs = nch > 0 ? tid / (2 * nch) : gns;
-  const int grow = gi2 < nch ? ch0 + gi2 : H + ch0 + (gi2 - nch);
-  const int nkb1 = (K1 + EPL - 1) / EPL;
-  const int kb_a = ch0 / EPL, kb_b = nch > 0 ? (ch1 - 1) / EPL : kb_a - 1;   // W2 packets that hold this member's columns
-  f32x4 w1n[ARC_W1P], wxr[2], wsr[2];
-  auto prefetch_layer = [&](int l) {
-    const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
-    if (gs < gns) {
+  // request this thread's history elements of a layer whose ring starts at roff and whose current row is pos (of sample tq)
+  auto request_hist = [&](int d, int roff, int pos, int tq) {
+    const int rlen = (p.ktaps - 1) * d + 1;
 #pragma unroll
-      for (int u = 0; u < ARC_W1P; ++u)
-        if (gs + u * gns < nkb1) w1n[u] = *(const volatile f32x4*)(wl + ((int64_t)(gs + u * gns) * g_pad + grow) * 16);
-    }
-    const char* w2 = wl + p.w2_off;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (kb_a + q <= kb_b && tid < p.R) wxr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + tid) * 16);
-      if (kb_a + q <= kb_b && tid < p.S) wsr[q] = *(const volatile f32x4*)(w2 + ((int64_t)(kb_a + q) * w_pad + p.R + tid) * 16);
+    for (int k = 0; k < ARC_HP; ++k) {
+      const int back = h_back[k] * d;
+      int row = pos - back;
+      row += row < 0 ? rlen : 0;
+      hist[k] = (h_back[k] > 0 && tq >= back) ? ring[(unsigned)(roff + row * p.R + h_ch[k])] : 0.f;
     }
   };
-  prefetch_layer(0);
+  auto place_hist = [&](int l, int t) {
+#pragma unroll
+    for (int k = 0; k < ARC_HP; ++k)
+      if (h_back[k] > 0) vbuf[tid + k * ARC_THREADS] = hist[k];
+    if (hist_more)
+      for (int i = tid + ARC_HP * ARC_THREADS; i < (p.ktaps - 1) * p.R; i += ARC_THREADS) vbuf[i] = hist_load(l, t, i);
+  };
+  // The weights a member needs for a layer -- ARC_W1P packets of its slice of one gate row, two packets of W_out row tid
+  // and of W_skip row tid -- depend on nothing computed: they are requested one layer ahead and wait in registers.
+  const int rw = 2 * nch;
+  const bool fold = nch > 0 && (rw & (rw - 1)) == 0 && rw <= 32;          // slices of a row fold inside the wave
+  const int gns = nch > 0 ? ARC_THREADS / rw : 1;                        // k slices per gate row
+  const int gi2 = nch > 0 ? tid % rw : 0, gs = nch > 0 ? tid / rw : gns;
+  const int grow = gi2 < nch ? ch0 + gi2 : H + ch0 + (gi2 - nch);
+  const int nkb1 = (K1 + EPL - 1) / EPL;
+  const bool row_ok = nch > 0 && gs < gns;
+  const int nu = min(ARC_W1P, (nkb1 + gns - 1) / gns);                   // packets per thread (uniform)
+  const bool w1_more = nkb1 > ARC_W1P * gns;                             // uniform; long rows on few members only
+  unsigned pk_ok = 0;                                                    // bit u: packet gs + u * gns exists
+#pragma unroll
+  for (int u = 0; u < ARC_W1P; ++u) pk_ok |= (row_ok && gs + u * gns < nkb1) ? 1u << u : 0u;
+  const unsigned w1_toff = row_ok ? ((unsigned)gs * g_pad + grow) * 16u : 0u, w1_ustride = (unsigned)gns * g_pad * 16u;
+  const int kb_a = ch0 / EPL, kb_b = nch > 0 ? (ch1 - 1) / EPL : kb_a - 1;   // W2 packets that hold this member's columns
+  const int nq = min(2, kb_b - kb_a + 1);
+  const bool more_cols = kb_b > kb_a + 1;                                // uniform; few members on wide layers only
+  const unsigned w2x_toff = ((unsigned)kb_a * w_pad + tid) * 16u, w2s_toff = ((unsigned)kb_a * w_pad + p.R + tid) * 16u;
+  const int uw_slot = ch0 - kb_a * EPL + lane;                           // where gate lane `lane` puts its u in the wave's window
+  f32x4 w1n[ARC_W1P], wxr[2], wsr[2];
+#pragma unroll
+  for (int u = 0; u < ARC_W1P; ++u) w1n[u] = f32x4{0.f, 0.f, 0.f, 0.f};   // packets that do not exist stay zero
+  wxr[0] = wxr[1] = wsr[0] = wsr[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ... and so do the layer's scalars that sit on the critical path of a sample: the gate lanes' two zb values and this thread's
+  // conv1x1_out / conv1x1_skip biases (as plain loads inside the gate and behind the all-reduce they cost an L2 round trip each)
+  float zb_a = 0.f, zb_g = 0.f, b2_x = 0.f, b2_s = 0.f;
+  auto prefetch_gate = [&](int l) {
+    const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
+    const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
+    if (lane < nch) { zb_a = zbl[ch0 + lane]; zb_g = zbl[p.Hp + ch0 + lane]; }      // every wave gates for itself
+    const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
+    if (tid < p.R) b2_x = b2[tid];
+    if (tid < p.S) b2_s = b2[p.R + tid];
+#pragma unroll
+    for (int u = 0; u < ARC_W1P; ++u)
+      if (u < nu && (pk_ok >> u & 1)) w1n[u] = *(const f32x4*)(wl + u * w1_ustride + w1_toff);
+  };
+  auto prefetch_out = [&](int l) {
+    const char* w2 = p.w_layers + (int64_t)l * p.layer_stride + p.w2_off;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < nq) {
+        if (tid < p.R) wxr[q] = *(const f32x4*)(w2 + q * (w_pad * 16u) + w2x_toff);
+        if (tid < p.S) wsr[q] = *(const f32x4*)(w2 + q * (w_pad * 16u) + w2s_toff);
+      }
+  };
+  prefetch_gate(0);
+  prefetch_out(0);
+  // the head's matrices never change: where a thread's share of a row slice is one packet it lives in a register for the whole clip
+  // (before: two dependent L2 round trips per sample).  Thread -> (row tid / SL, k slice tid % SL), SL a power of two; the SL lanes
+  // of a row fold by shuffles, lane 0 of the group ends up with the row.
+  const int nkbS = (p.S + EPL - 1) / EPL;
+  const int oc = (p.O + C - 1) / C, o0 = min(m * oc, p.O), o1 = min(o0 + oc, p.O), nlo = o1 - o0;
+  auto slices = [&](int nr) { int SL = 64; while (SL > 1 && SL * nr > ARC_THREADS) SL >>= 1; return SL; };
+  const int SLh = slices(nsk), SLo = slices(nlo);
+  const int hi = tid / SLh, hsl = tid - hi * SLh, oi = tid / SLo, osl = tid - oi * SLo;
+  const bool h_reg = nkbS <= SLh, o_reg = nkbS <= SLo;
+  f32x4 hw1 = f32x4{0.f, 0.f, 0.f, 0.f}, hw2 = hw1;
+  if (h_reg && hi < nsk && hsl < nkbS) hw1 = *(const f32x4*)(p.w_head + ((int64_t)hsl * s_pad + s0 + hi) * 16);
+  if (o_reg && oi < nlo && osl < nkbS) hw2 = *(const f32x4*)(p.w_head + ((int64_t)nkbS * s_pad + (int64_t)osl * o_pad + o0 + oi) * 16);
+  const float hb1 = (hi < nsk && hsl == 0) ? p.head_bias[s0 + hi] : 0.f, hb2 = (oi < nlo && osl == 0) ? p.head_bias[p.S + o0 + oi] : 0.f;
+  // nr rows from r0 of a blocked matrix times v; the row of group i in its lane 0.  wreg: this thread's packet if the matrix is resident
+  auto rows_dot = [&](const char* W, int rows_pad, int r0, int nr, int SL, int i, int sl, bool resident, const f32x4& wreg,
+                      const float* v) -> float {
+    float acc = 0.f;
+    if (resident) {
+      float w[EPL];
+      arc_unpack<E>(wreg, w);
+      const float* vp = v + (sl < nkbS ? sl : 0) * EPL;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], vp[j], acc);
+    } else if (i < nr) {
+      for (int kb = sl; kb < nkbS; kb += SL) {
+        float w[EPL];
+        arc_load_w<E>(W + ((int64_t)kb * rows_pad + r0 + i) * 16, w);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], v[kb * EPL + j], acc);
+      }
+    }
+    for (int o = SL >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    return acc;
+  };
+  // conditioning row of sample t, element cc (requested one sample ahead)
+  auto c_load = [&](int t, int cc) -> float {
+    const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
+    return p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : (p.c_dtype == WAE_F16 ? (float)((const f16*)p.c_up)[ci] : ((const float*)p.c_up)[ci]);
+  };
+  float creg = tid < p.Cc ? c_load(0, tid) : 0.f;
+  const float fbias = tid < p.R ? p.first_bias[tid] : 0.f;
+
+  // A layer is two workgroup barriers (round 3; five before).  Thread tid keeps x[tid] in a register; behind the all-reduce it writes
+  // the next layer's current tap straight into vbuf (and into that layer's ring); the next layer's history taps -- requested right
+  // after this layer's GEMV -- are placed into vbuf after the gate; the all-reduce's own barrier is the one in front of the next GEMV.
+  // Every wave gates for itself (lanes < nch, from the four waves' partial row sums) and passes u to its own lanes through its
+  // private window of LDS, so nothing separates the gate from the x' / skip shares.
+  float xreg = 0.f;
   for (int t = 0; t < p.T; ++t) {
     const int cur = ibuf[0];
-    if (tid < p.R) xbuf[tid] = p.first_tab[(int64_t)cur * p.Rp + tid] + p.first_bias[tid];
-    for (int cc = tid; cc < p.Cc; cc += ARC_THREADS) {
-      const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + cc;
-      vbuf[p.ktaps * p.R + cc] = p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : (p.c_dtype == WAE_F16 ? (float)((const f16*)p.c_up)[ci] : ((const float*)p.c_up)[ci]);
+    {
+      const int roff0 = arc_uni(lroff), pos0 = arc_uni(lpos);
+      if (tid < p.R) {
+        xreg = p.first_tab[(int64_t)cur * p.Rp + tid] + fbias;
+        vbuf[(p.ktaps - 1) * p.R + tid] = xreg;
+        ring[(unsigned)(roff0 + pos0 * p.R + tid)] = xreg;
+      }
     }
+    // layer 0's history taps: zeros at t = 0, placed after the last gate of sample t - 1 after
+    if (tid < p.Cc) vbuf[p.ktaps * p.R + tid] = creg;
+    for (int cc = tid + ARC_THREADS; cc < p.Cc; cc += ARC_THREADS) vbuf[p.ktaps * p.R + cc] = c_load(t, cc);
+    if (tid < p.Cc && t + 1 < p.T) creg = c_load(t + 1, tid);
     float skip_part = 0.f;   // this member's contribution to skip row tid, summed over the layers (the skip path is linear)
     arc_barrier();
 
     for (int l = 0; l < p.L; ++l) {
-      const int d = p.dil[l];
-      const int rlen = (p.ktaps - 1) * d + 1;
-      float* rl = ring + p.ring_off[l];
-      // current tap from xbuf (and into the ring); history taps were requested one layer ago (hist[])
-      for (int i = tid, k = 0; i < p.ktaps * p.R; i += ARC_THREADS, ++k) {
-        const int tap = i / p.R, ch = i - tap * p.R;
-        float v;
-        if (tap == p.ktaps - 1) {
-          v = xbuf[ch];
-          rl[(int64_t)(t % rlen) * p.R + ch] = v;
-        } else {
-          v = k < ARC_HP ? hist[k] : hist_load(l, t, i);
-        }
-        vbuf[i] = v;
-      }
-      {   // request the history rows of the next layer (or of layer 0 of the next sample): they do not depend on this one
-        const int ln = l + 1 < p.L ? l + 1 : 0, tn = l + 1 < p.L ? t : t + 1;
-#pragma unroll
-        for (int k = 0; k < ARC_HP; ++k) {
-          const int i = tid + k * ARC_THREADS;
-          hist[k] = i < (p.ktaps - 1) * p.R ? hist_load(ln, tn, i) : 0.f;
-        }
-      }
-      arc_barrier();
-      ARC_TICK(0);
-      const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
       // ---- this member's gate rows: tanh rows [ch0, ch1), sigmoid rows H + [ch0, ch1) ------------------------------
-      if (gs < gns) {
+      {
         float acc = 0.f;
 #pragma unroll
         for (int u = 0; u < ARC_W1P; ++u)
-          if (gs + u * gns < nkb1) {
+          if (u < nu) {
             float w[EPL];
             arc_unpack<E>(w1n[u], w);
+            const float* vp = vbuf + ((pk_ok >> u & 1) ? (gs + u * gns) * EPL : 0);
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], vbuf[(gs + u * gns) * EPL + j], acc);
+            for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], vp[j], acc);
           }
-        if (gs + ARC_W1P * gns < nkb1)   // longer rows than the prefetched packets cover
-          acc += arc_dot<E, 8>(wl + (int64_t)grow * 16, (int64_t)g_pad * 16, gs + ARC_W1P * gns, gns, nkb1, vbuf);
+        if (w1_more && row_ok && gs + ARC_W1P * gns < nkb1)   // longer rows than the prefetched packets cover
+          acc += arc_dot<E, 8>(p.w_layers + (int64_t)l * p.layer_stride + (int64_t)grow * 16, (int64_t)g_pad * 16, gs + ARC_W1P * gns,
+                               gns, nkb1, vbuf);
         // slices of one row sit 2*nch lanes apart: fold them inside the wave when that is a power of two (<= 32),
         // so that only one partial per wave and row goes through LDS
-        const int rw = 2 * nch;
-        if ((rw & (rw - 1)) == 0 && rw <= 32) {
+        if (fold) {
           for (int o = 32; o >= rw; o >>= 1) acc += __shfl_xor(acc, o, 64);
-          if ((tid & 63) < rw) psum[(tid >> 6) * rw + gi2] = acc;
-        } else {
+          if (lane < rw) psum[wv * rw + gi2] = acc;
+        } else if (row_ok) {
           psum[gs * rw + gi2] = acc;
         }
       }
+      // the gate weights and scalars of the next layer (of layer 0 of the next sample) and its history rows: nothing computed
+      // goes into them, the registers they replace were consumed just above
+      const int ln = l + 1 < p.L ? l + 1 : 0, tn = l + 1 < p.L ? t : t + 1;
+      const float za = zb_a, zg = zb_g, bx = b2_x, bs = b2_s;
+      const int dN = arc_uni(ldil + ln), roffN = arc_uni(lroff + ln);
+      int posN = arc_uni(lpos + ln);
+      if (ln == 0) posN = posN + 1 == (p.ktaps - 1) * dN + 1 ? 0 : posN + 1;
+      prefetch_gate(ln);
+      request_hist(dN, roffN, posN, tn);
       arc_barrier();
-      ARC_TICK(1);
-      // ---- gate: u of this member's channels ----------------------------------------------------------------------------
-      const char* w2 = wl + p.w2_off;
-      if (tid < nch) {
-        const int ns = gns;
-        const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
-        float a = zbl[ch0 + tid], g = zbl[p.Hp + ch0 + tid];
-        const int rw = 2 * nch;
-        const int nparts = ((rw & (rw - 1)) == 0 && rw <= 32) ? ARC_THREADS / 64 : ns;
-        for (int s = 0; s < nparts; ++s) { a += psum[s * rw + tid]; g += psum[s * rw + nch + tid]; }
-        myskip[tid] = tanhf(a) * (1.f / (1.f + expf(-g)));
+      ARC_TICK(0);
+      // ---- gate: u of this member's channels, in every wave ----------------------------------------------------------------
+      if (lane < nch) {
+        float a = za, g = zg;
+        const int nparts = fold ? NWV : gns;
+        for (int s = 0; s < nparts; ++s) { a += psum[s * rw + lane]; g += psum[s * rw + nch + lane]; }
+        const float u = arc_gate<E>(a, g);
+        if (uw_slot < 2 * EPL) uw[wv * 2 * EPL + uw_slot] = u;
+        if (more_cols && wv == 0) myskip[lane] = u;
       }
-      arc_barrier();
-      // ---- this member's share of x' = W_out u and of skip += W_skip u: columns [ch0, ch1) only ----------------------------
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own window: program order is enough
+      place_hist(ln, tn);     // the GEMV that read vbuf is a barrier back; the rows were requested then
+      // ---- this member's share of x' = W_out u and of skip += W_skip u: columns [ch0, ch1) only; u is zero outside them --------
       float px = 0.f;
       {
         float ps = 0.f;
+        const float* ue = uw + wv * 2 * EPL;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          if (kb_a + q <= kb_b) {
+          if (q < nq) {
             float wx[EPL], ws[EPL];
             arc_unpack<E>(wxr[q], wx);
             arc_unpack<E>(wsr[q], ws);
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
-              const int ch = (kb_a + q) * EPL + e;
+              px = fmaf(wx[e], ue[q * EPL + e], px);
+              ps = fmaf(ws[e], ue[q * EPL + e], ps);
+            }
+          }
+        if (more_cols) {      // more than two packets of columns per member (few members, wide layers)
+          arc_barrier();
+          const char* w2 = p.w_layers + (int64_t)l * p.layer_stride + p.w2_off;
+          for (int kb = kb_a + 2; kb <= kb_b; ++kb) {
+            float wx[EPL], ws[EPL];
+            if (tid < p.R) arc_load_w<E>(w2 + ((int64_t)kb * w_pad + tid) * 16, wx);
+            if (tid < p.S) arc_load_w<E>(w2 + ((int64_t)kb * w_pad + p.R + tid) * 16, ws);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int ch = kb * EPL + e;
               if (ch >= ch0 && ch < ch1) {
-                const float u = myskip[ch - ch0];
-                px = fmaf(wx[e], u, px);
-                ps = fmaf(ws[e], u, ps);
+                if (tid < p.R) px = fmaf(wx[e], myskip[ch - ch0], px);
+                if (tid < p.S) ps = fmaf(ws[e], myskip[ch - ch0], ps);
               }
             }
           }
-        for (int kb = kb_a + 2; kb <= kb_b; ++kb) {   // more than two packets of columns per member (few members, wide layers)
-          float wx[EPL], ws[EPL];
-          if (tid < p.R) arc_load_w<E>(w2 + ((int64_t)kb * w_pad + tid) * 16, wx);
-          if (tid < p.S) arc_load_w<E>(w2 + ((int64_t)kb * w_pad + p.R + tid) * 16, ws);
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const int ch = kb * EPL + e;
-            if (ch >= ch0 && ch < ch1) {
-              if (tid < p.R) px = fmaf(wx[e], myskip[ch - ch0], px);
-              if (tid < p.S) ps = fmaf(ws[e], myskip[ch - ch0], ps);
-            }
-          }
         }
-        const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
-        if (tid < p.S) skip_part += ps + (m == 0 ? b2[p.R + tid] : 0.f);   // the bias once: member 0
+        if (tid < p.S) skip_part += ps + (m == 0 ? bs : 0.f);   // the bias once: member 0
       }
-      ARC_TICK(2);
-      // ---- all-reduce x' over the members, then residual (modules.py:157-162) -------------------------------------------------
+      ARC_TICK(1);
+      // ---- all-reduce x' over the members, then residual (modules.py:157-162) and the next layer's current tap -----------------
       {
         float sum;
-        if (!arc_allreduce(xbanks, p.R, xuse++, px, sum, C, m, fast, p.error, &ibuf[1],
-                           [&]() { prefetch_layer(l + 1 < p.L ? l + 1 : 0); }))
+        if (!arc_allreduce(xbanks, p.R, xuse++, px, sum, C, owner, fx_lim, fast, p.error, &ibuf[1],
+                           [&]() { prefetch_out(ln); },
+                           [&](float tot) {
+                             xreg = (tot + bx + xreg) * 0.70710678118654752440f;
+                             if (l + 1 < p.L && tid < p.R) {
+                               vbuf[(p.ktaps - 1) * p.R + tid] = xreg;
+                               ring[(unsigned)(roffN + posN * p.R + tid)] = xreg;
+                             }
+                           }))
           return;
-        const float* b2 = p.bias2 + (int64_t)l * (p.R + p.S);
-        if (tid < p.R) xbuf[tid] = (sum + b2[tid] + xbuf[tid]) * 0.70710678118654752440f;
       }
-      arc_barrier();
       ARC_TICK(3);
     }
     // ---- all-reduce the skip vector (once per sample), then head + draw on every member ---------------------------------
     {
       float sum;
-      if (!arc_allreduce(sbanks, p.S, suse++, skip_part, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
-      if (tid < p.S) skipb[tid] = fmaxf(sum * p.scale, 0.f);
-      arc_barrier();
+      if (!arc_allreduce(sbanks, p.S, suse++, skip_part, sum, C, owner, fx_lim, fast, p.error, &ibuf[1], []() {},
+                         [&](float tot) {
+                           if (tid < p.S) skipb[tid] = fmaxf(tot * p.scale, 0.f);
+                           for (int i = tid; i < p.L; i += ARC_THREADS) {      // every ring's cursor moves on to sample t + 1
+                             const int nx = lpos[i] + 1;
+                             lpos[i] = nx == (p.ktaps - 1) * ldil[i] + 1 ? 0 : nx;
+                           }
+                         }))
+        return;
     }
     ARC_TICK(4);
     // ---- head (wavenet.py:209-214), its rows split over the members: member m computes rows [s0, s1) of h1 and [o0, o1) of
     //      the logits (every member streaming both matrices -- 256 KB per sample through one L2 -- took 24 us per sample), the
-    //      vectors are all-gathered through the all-reduce (the other members add zeros: exact), the draw runs on every member
+    //      vectors are all-gathered (one store per row by the lane that holds it), the draw runs on every member
     {
-      const int nkb = (p.S + EPL - 1) / EPL;
-      // nr rows from r0 of a blocked matrix times v: thread -> (row tid / SL, k slice tid % SL); the slices of a row are SL
-      // adjacent lanes of one wave and fold by shuffles; rowres[i] = dot of row r0 + i
-      auto rows_dot = [&](const char* W, int rows_pad, int r0, int nr, const float* v, float* rowres) {
-        int SL = 64;
-        while (SL > 1 && SL * nr > ARC_THREADS) SL >>= 1;
-        const int i = tid / SL, sl = tid - i * SL;
-        float acc = 0.f;
-        if (i < nr)
-          for (int kb = sl; kb < nkb; kb += SL) {
-            float w[EPL];
-            arc_load_w<E>(W + ((int64_t)kb * rows_pad + r0 + i) * 16, w);
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) acc = fmaf(w[j], v[kb * EPL + j], acc);
-          }
-        for (int o = SL >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (i < nr && sl == 0) rowres[i] = acc;
-      };
-      const int oc = (p.O + C - 1) / C, o0 = min(m * oc, p.O), o1 = min(o0 + oc, p.O);
-      float sum;
-      rows_dot(p.w_head, s_pad, s0, nsk, skipb, psum);
-      arc_barrier();
-      const float mine_h = (tid >= s0 && tid < s1) ? fmaxf(psum[tid - s0] + p.head_bias[tid], 0.f) : 0.f;
-      if (!arc_allreduce(hbanks, p.S, huse++, mine_h, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
-      if (tid < p.S) hbuf[tid] = sum;
-      arc_barrier();
-      rows_dot(p.w_head + (int64_t)nkb * s_pad * 16, o_pad, o0, o1 - o0, hbuf, psum);
-      arc_barrier();
-      const float mine_y = (tid >= o0 && tid < o1) ? psum[tid - o0] + p.head_bias[p.S + tid] : 0.f;
-      if (!arc_allreduce(ybanks, p.O, yuse++, mine_y, sum, C, m, fast, p.error, &ibuf[1], []() {})) return;
-      if (tid < p.O) {
-        lbuf[tid] = sum;
-        if (p.out_logits && m == 0) p.out_logits[((int64_t)b * p.O + tid) * p.T + t] = sum;
-      }
-      arc_barrier();
+      const float r1 = rows_dot(p.w_head, s_pad, s0, nsk, SLh, hi, hsl, h_reg, hw1, skipb);
+      if (!arc_allgather(hbanks, p.S, huse++, hi < nsk && hsl == 0, s0 + hi, fmaxf(r1 + hb1, 0.f), fast, p.error, &ibuf[1],
+                         [&](float v) { if (tid < p.S) hbuf[tid] = v; }))
+        return;
+      const float r2 = rows_dot(p.w_head + (int64_t)nkbS * s_pad * 16, o_pad, o0, nlo, SLo, oi, osl, o_reg, hw2, hbuf);
+      if (!arc_allgather(ybanks, p.O, yuse++, oi < nlo && osl == 0, o0 + oi, r2 + hb2, fast, p.error, &ibuf[1],
+                         [&](float v) {
+                           if (tid < p.O) {
+                             lbuf[tid] = v;
+                             if (p.out_logits && m == 0) p.out_logits[((int64_t)b * p.O + tid) * p.T + t] = v;
+                           }
+                         }))
+        return;
     }
     ARC_TICK(5);
     // ---- next input (wavenet.py:300-338): same arithmetic and summation order as csrc/ar_fwd.hip; the exponentials are
@@ -685,7 +836,8 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   const int epl = wae_is16(d->dtype) ? 8 : 4;
   auto ru = [](int x, int mm) { return (x + mm - 1) / mm * mm; };
   const size_t lds = sizeof(float) * (size_t)(ru(d->ktaps * d->R + (d->Cc > 0 ? d->Cc : 0), epl) + d->R + ru(H, epl) +
-                                              2 * ru(d->S, epl) + ru(d->O, 4) + ARC_THREADS + ru(hc > sc ? hc : sc, 4) + 8);
+                                              2 * ru(d->S, epl) + ru(d->O, 4) + ARC_THREADS + ru(hc > sc ? hc : sc, 4) + 8 + 3 * d->L + 64);
+  WAE_REQUIRE(ring_total < (int64_t)1 << 31, "ar_generate_coop: ring_total %lld does not fit 32-bit offsets", (long long)ring_total);
   hipStream_t st = as_stream(stream);
   // the message banks must start with sequence numbers no exchange will use (0): the caller zeroes msg and error
   if (d->dtype == WAE_BF16) {
