@@ -36,13 +36,20 @@ def c4():
     return cfg, sd, z
 
 
-@pytest.mark.parametrize("coop", ["1", "0"])
+def _set_ar_path(monkeypatch, coop):
+    """'1': the cooperative kernel (this geometry: the one with the sizes as constants), 'generic': the any-shape cooperative
+    kernel on the same geometry, '0': one CU per utterance"""
+    monkeypatch.setenv("WAE_AR_COOP", "0" if coop == "0" else "1")
+    monkeypatch.setenv("WAE_AR_COOP_GENERIC", "1" if coop == "generic" else "0")
+
+
+@pytest.mark.parametrize("coop", ["1", "generic", "0"])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
 def test_c4_teacher_forced_logits(c4, dtype, tol, coop, monkeypatch):
     """Teacher-forced incremental decode over 2560 samples == the reference's incremental_forward(test_inputs) at the probe
     steps (every 13th + the steps around both wraps of the d = 512 rings), and the log-sum-exp of EVERY step."""
     cfg, sd, z = c4
-    monkeypatch.setenv("WAE_AR_COOP", coop)
+    _set_ar_path(monkeypatch, coop)
     eng = _engine(cfg, sd, dtype)
     T = z["x"].shape[1]
     x = torch.from_numpy(z["x"].astype(np.int64)).cuda()
@@ -73,10 +80,30 @@ def _check_rollout(got, want, margin, thresh, what):
     return first
 
 
-@pytest.mark.parametrize("coop", ["1", "0"])
+@pytest.mark.parametrize("coop", ["1", "generic"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_c4_cooperative_decode_is_bitwise_reproducible(c4, dtype, coop, monkeypatch):
+    """The members' shares are added in a fixed order (csrc/ar_coop.hip: arc_allsum / arc_allsum2), not by atomics in arrival order:
+    two runs give the same bits, logits and drawn samples alike."""
+    cfg, sd, z = c4
+    _set_ar_path(monkeypatch, coop)
+    eng = _engine(cfg, sd, dtype)
+    T = z["x"].shape[1]
+    lat, g = torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda()
+    uni = torch.rand(1, T, generator=torch.Generator().manual_seed(5)).cuda()
+    runs = []
+    for _ in range(2):
+        out = eng.incremental_forward(lat, g, T, mode="sample", init_idx=127, uniforms=uni, want_logits=True)
+        torch.cuda.synchronize()
+        runs.append((out["idx"].cpu().clone(), out["logits"].cpu().clone()))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize("coop", ["1", "generic", "0"])
 def test_c4_greedy_rollout_fp32(c4, coop, monkeypatch):
     cfg, sd, z = c4
-    monkeypatch.setenv("WAE_AR_COOP", coop)
+    _set_ar_path(monkeypatch, coop)
     eng = _engine(cfg, sd, "fp32")
     T = z["x"].shape[1]
     lat, g = torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda()

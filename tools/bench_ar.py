@@ -36,6 +36,7 @@ if prof is not None:
     print(f"  cooperative path: same-XCD exchange = {f & 1}, XCC id of member 0 / last member = {(f >> 4) & 15} / {(f >> 8) & 15}")
 if prof is not None and int(prof[2:].abs().sum()) != 0:
     import numpy as np
-    pc = prof.cpu().numpy()[2:18].view(np.uint64)
-    names = ["gate rows GEMV + requests", "gate + x' and skip shares", "-", "all-reduce + residual + next tap", "skip exchange", "head", "draw"]
+    pc = prof.cpu().numpy()[2:30].view(np.uint64)
+    names = ["barrier after the GEMV", "gate + x' and skip shares", "-", "residual, next taps + barrier", "skip exchange", "head", "draw",
+             "gate rows GEMV", "-", "-", "exchange: stores + requests (weights, scalars, history)", "exchange: polling passes + sum"]
     print("  s_memtime ticks per sample (member 0):", {n: int(v // T) for n, v in zip(names, pc)})

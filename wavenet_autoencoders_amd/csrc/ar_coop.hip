@@ -6,13 +6,13 @@
 // share an XCD and its L2) split each layer by gate channels:
 //   member m:  z[rows of its channels] = W1[rows] . [x taps ; c] + zb   ->   u[its channels] = tanh(a) * sigmoid(b)
 //   member m:  its share of x' and of the skip row sums:  W_out[:, its channels] u,  W_skip[:, its channels] u
-//   all-reduce of the x' shares (fp32 atomic adds into an L2 accumulator + a counter; 1 per layer), residual on every
+//   all-reduce of the x' shares (every member stores its shares, every member reads and adds all of them; 1 per layer), residual on every
 //   member (each keeps its own copy of the history rings); the skip shares are summed over the layers locally (the skip
 //   path is linear) and all-reduced ONCE per sample; the head and the draw of the next input then run redundantly
 //   (identical code on identical data: every member feeds back the same sample).
 // No member ever streams a whole matrix: per layer it reads its 2*hc rows of W1 and 2 x 16-byte column packets per row of
 // W_out / W_skip.  (v1 all-gathered u and computed x' redundantly: 32 CUs pulling the same 128 KB through one L2 cost
-// 7 us per layer.)  The sums are formed by 64-bit integer atomics on 2^-24 fixed-point shares (arc_allreduce): bitwise reproducible.
+// 7 us per layer.)  The sums are formed in member order from one stored share per member (arc_allsum): bitwise reproducible.
 // Where all members run on one XCD (checked at start through agent-scope messages), the accumulators stay in that XCD's
 // L2; otherwise every access is an agent-scope atomic.  A wait that does not complete within ~1 s raises *error and every
 // member leaves: never a hung device.
@@ -21,8 +21,10 @@
 #define ARC_THREADS 256
 #define ARC_HP 4      // history elements a thread prefetches per layer: (ktaps-1)*R <= ARC_HP * ARC_THREADS is the fast case
 #define ARC_W1P 8      // W1 packets of a gate row slice a thread holds (fp32: K1/4/32 slices = 6.5 at hps/vqwae.json)
-#define ARC_NB 3       // accumulator banks of the all-reduce (see arc_allreduce)
-#define ARC_ACC_FLOATS(R, S, O) (2 * ARC_NB * ((R) + 2 * (S) + (O)) + 32)   // {sum, count} granules: 3 banks each of R, S, S, O
+#define ARC_CMAX 32     // cooperating workgroups per utterance, at most
+// 8-byte {sequence number, fp32} granules: 2 banks of S and of O (arc_allgather), 2 banks x ARC_CMAX members of R and of S (arc_allsum,
+// round 1 of arc_allsum2), 2 banks of R and of S (round 2 of arc_allsum2)
+#define ARC_ACC_FLOATS(R, S, O) (4 * ((S) + (O)) + 4 * ARC_CMAX * ((R) + (S)) + 4 * ((R) + (S)) + 32)
 
 struct ArcArgs {
   int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp, C;
@@ -49,7 +51,7 @@ struct ArcArgs {
   float* out_logits;
   unsigned long long* msg;   // (B, 2 banks, C, NV) {seq, value} granules
   int NV;                    // values per member and exchange = max(channels per member, skip rows per member)
-  float* acc;                // (B, ARC_ACC_FLOATS(R, S)): 3 banks of R and of S {sum, count} granules, zeroed
+  float* acc;                // (B, ARC_ACC_FLOATS(R, S, O)) exchange granules, zeroed
   int* error;
 };
 
@@ -196,65 +198,68 @@ __device__ __forceinline__ bool arc_gather(unsigned long long* bank, int NV, int
   return *abort_flag == 0;
 }
 
-// Sum one value per thread (n <= ARC_THREADS values) over the C members of an utterance.  Value j lives in ONE 8-byte granule of
-// an L2-resident bank: count * 2^48 + (sum of the shares in 2^-24 fixed point, two's complement); use number `use` (0, 1, 2, ..)
-// takes bank use % 3.  Thread j of every member
-//   1. adds 2^48 + round(share * 2^24) with one no-return 64-bit integer atomic (round 3; before: an fp32 atomic for the sum and
-//      an integer one for the count -- twice the L2 atomic work, and sums that depended on the arrival order),
-//   2. polls its granule with ONE 8-byte load until the count field (rounded: a negative sum borrows from it) reads C: a
-//      single-copy-atomic snapshot, so a complete count comes with the complete sum,
-//   3. (thread j of member j % C only) zeroes granule j in the bank of use + 2.
-// Integer addition is associative: the result does not depend on the arrival order, decoding is bit-reproducible from run to run.
-// Range: |share| < 2^22 / C (so |sum| < 2^22 and the 46-bit sum never reaches the count field's rounding bit); a share outside it
-// (or a NaN) is replaced by 0 and *error = 2 tells the host -- nobody waits for it.  Resolution 2^-24 = 6e-8 absolute per share.
-// One L2 round trip after the last member's add arrives.  Everything is per index j: thread j sees count(use) complete => every
-// member's thread j has added for `use` => their reads of the bank of use - 1 (= use + 2) have returned => the owner may zero it;
-// and the owner's zero store is performed before its own add of use + 1 (the vmcnt(0) in front of it, long satisfied by then),
-// hence before anybody sees count(use + 1) complete and adds for use + 2.
-// fast (all members on one XCD): the atomics stay in that XCD's L2; otherwise agent-scope atomics (memory side).
-// `between` runs once the add is issued: loads it issues travel while the members wait for each other.  `after(sum)` runs on
-// every thread before the closing workgroup barrier (the caller's LDS writes of its next stage).
-template <typename F, typename A>
-__device__ __forceinline__ bool arc_allreduce(float* banks, int n, unsigned use, float mine, float& sum, int C, bool owner, float lim,
-                                              bool fast, int* error, int* abort_flag, F&& between, A&& after) {
+#ifdef WAE_ARC_PROFILE
+#define ARC_TICK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc[i] += n_ - pt; pt = n_; } while (0)
+#else
+#define ARC_TICK(i) do { } while (0)
+#endif
+struct ArcNoTick { __device__ __forceinline__ void operator()(int) const {} };
+
+// Sum one value per thread (n <= ARC_THREADS values) over the C members of an utterance, without atomics (round 3): member m stores {use + 1, fp32 bits} of its share j into
+// granule [m][j] of bank use & 1; thread j of every member then requests the C granules [0..C)[j] at once, re-requests the stale ones
+// until all carry the sequence number, and adds the values in member order: exact fp32, the same bits on every member and every
+// run.  (Rounds 1-2 added the shares into one {sum, count} granule per value with L2 atomics: 32 members serialise in the L2's
+// atomic unit -- 6 k of the 12 k clocks per layer -- and the sums depended on the arrival order.)  Two banks suffice (see
+// arc_allgather).  `between` runs once the stores are issued: what it requests travels while the members wait for each other;
+// `after(sum)` runs on every thread before the closing workgroup barrier (the caller's LDS writes of its next stage).
+// NM > 0: the member count as a constant (straight-line requests, one min-reduction as the freshness test: a granule carries seq or
+// an older number); NM = 0: any C <= ARC_CMAX.  One wave per SIMD issues a VALU instruction every 5 clocks and an L2 hit returns in
+// ~240 (tools/clk_probe.hip): the instructions of a polling pass, not the round trip, are what a pass costs -- keep them few.
+template <int NM, typename F, typename A, typename K = ArcNoTick>
+__device__ __forceinline__ bool arc_allsum(unsigned long long* banks, int n, unsigned use, float mine, int C, int m, bool fast,
+                                           int* error, int* abort_flag, F&& between, A&& after, K&& tick = K()) {
   const int tid = threadIdx.x;
-  unsigned long long* gran = (unsigned long long*)banks + ((use % ARC_NB) * n + tid);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's zero store of two uses ago has been performed
+  const unsigned seq = use + 1;
+  unsigned long long* bank = banks + (size_t)(use & 1) * C * n;
   if (tid < n) {
-    const bool inside = fabsf(mine) < lim;     // lim = 2^22 / C; false for NaN as well
-    if (!inside) __hip_atomic_store(error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long fx = inside ? __float2ll_rn(mine * 16777216.f) : 0ll;
-    const unsigned long long add = (1ull << 48) + (unsigned long long)fx;
-    if (fast) __hip_atomic_fetch_add(gran, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_fetch_add(gran, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = arc_pack(seq, mine);
+    if (fast) *(volatile unsigned long long*)(bank + (size_t)m * n + (unsigned)tid) = v;
+    else __hip_atomic_store(bank + (size_t)m * n + (unsigned)tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   between();
-  sum = 0.f;
+  tick(1);
+  float sum = 0.f;
   bool bad = false;
   if (tid < n) {
+    constexpr int NV = NM > 0 ? NM : ARC_CMAX;
+    unsigned long long v[NV];
     int spins = 0;
-    unsigned long long v;
     for (;;) {
-      v = __hip_atomic_load(gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)((v + (1ull << 47)) >> 48) >= (unsigned)C) break;
-      if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+      unsigned mn = seq;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (NM > 0 || i < C) v[i] = __hip_atomic_load(bank + (size_t)i * n + (unsigned)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (NM > 0 || i < C) mn = min(mn, (unsigned)v[i]);
+      if (mn == seq) break;
+      if (++spins > (1 << 20) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
         bad = true;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
-    const unsigned long long cnt = (v + (1ull << 47)) >> 48;
-    sum = (float)(long long)(v - (cnt << 48)) * (1.f / 16777216.f);
-    if (!bad && owner) {      // the owner of granule tid (thread tid of member tid % C) clears the bank of use + 2 (= the bank of use - 1)
-      unsigned long long* clean = (unsigned long long*)banks + ((use + 2) % ARC_NB) * n + tid;
-      if (fast) *(volatile unsigned long long*)clean = 0ull;
-      else __hip_atomic_store(clean, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    float part[4] = {0.f, 0.f, 0.f, 0.f};      // member i into part[i % 4]: a fixed order, four short chains
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (NM > 0 || i < C) part[i & 3] += __uint_as_float((unsigned)(v[i] >> 32));
+    sum = (part[0] + part[1]) + (part[2] + part[3]);
   }
   if (bad) {
     *abort_flag = 1;
     __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  tick(2);
   after(sum);
   arc_barrier();
   return *abort_flag == 0;
@@ -313,6 +318,100 @@ __device__ __forceinline__ float arc_gate(float a, float g) {
   }
 }
 
+// ---- next input (wavenet.py:300-338) from the logits in lbuf: ibuf[0] <- the class fed back, out_idx[t] <- the class produced --------
+__device__ __forceinline__ void arc_draw(const ArcArgs& p, float* lbuf, float* psum, int* ibuf, int b, int m, int t) {
+  const int tid = threadIdx.x;
+  // same arithmetic and summation order as csrc/ar_fwd.hip; the exponentials are evaluated by all threads, the order-dependent
+  // sums by one
+  // argmax with the first maximal index (as the serial scan of csrc/ar_fwd.hip)
+  {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < p.O; i += ARC_THREADS)
+      if (lbuf[i] > bv) { bv = lbuf[i]; bi = i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_down(bv, o, 64);
+      const int oi = __shfl_down(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { psum[2 * (tid >> 6)] = bv; ((int*)psum)[2 * (tid >> 6) + 1] = bi; }
+    arc_barrier();
+    if (tid == 0) {
+      for (int w = 1; w < ARC_THREADS / 64; ++w) {
+        const float ov = psum[2 * w];
+        const int oi = ((int*)psum)[2 * w + 1];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      psum[16] = bv;
+      ibuf[2] = bi;
+    }
+    arc_barrier();
+  }
+  int produced_par = -1;
+  if (p.mode == 2 && p.O <= ARC_THREADS) {
+    // softmax in fp32 (F.softmax), then inverse CDF over a double cumulative sum (numpy's choice, wavenet.py:331), all in
+    // parallel: block sum for the denominator, block scan for the cumulative sums, block count of the sums below u * total
+    const float mx = psum[16];
+    const float e = tid < p.O ? expf(lbuf[tid] - mx) : 0.f;
+    float sden = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sden += __shfl_down(sden, o, 64);
+    if ((tid & 63) == 0) psum[32 + (tid >> 6)] = sden;
+    arc_barrier();
+    float den = 0.f;
+    for (int w = 0; w < ARC_THREADS / 64; ++w) den += psum[32 + w];
+    double c = tid < p.O ? (double)(e / den) : 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(c, o, 64);
+      if ((tid & 63) >= o) c += up;
+    }
+    double* dsum = (double*)(psum + 40);
+    if ((tid & 63) == 63) dsum[tid >> 6] = c;
+    arc_barrier();
+    double base = 0.0, tot = 0.0;
+    for (int w = 0; w < ARC_THREADS / 64; ++w) {
+      if (w < (tid >> 6)) base += dsum[w];
+      tot += dsum[w];
+    }
+    c += base;
+    const double thr = (double)p.uniforms[(int64_t)b * p.T + t] * tot;
+    const unsigned long long below = __ballot(tid < p.O && c < thr);
+    if ((tid & 63) == 0) ((int*)psum)[56 + (tid >> 6)] = __popcll(below);
+    arc_barrier();
+    int cnt = 0;
+    for (int w = 0; w < ARC_THREADS / 64; ++w) cnt += ((int*)psum)[56 + w];
+    produced_par = min(cnt, p.O - 1);
+  } else if (p.mode == 2) {
+    const float mx = psum[16];
+    for (int i = tid; i < p.O; i += ARC_THREADS) lbuf[i] = expf(lbuf[i] - mx);
+    arc_barrier();
+  }
+  if (tid == 0) {
+    int produced = ibuf[2];
+    if (p.mode == 2 && produced_par >= 0) {
+      produced = produced_par;
+    } else if (p.mode == 2) {
+      float den = 0.f;
+      for (int i = 0; i < p.O; ++i) den += lbuf[i];
+      double tot = 0.0;
+      for (int i = 0; i < p.O; ++i) tot += (double)(lbuf[i] / den);
+      const double thr = (double)p.uniforms[(int64_t)b * p.T + t] * tot;
+      double c = 0.0;
+      int cnt = 0;
+      for (int i = 0; i < p.O; ++i) {
+        c += (double)(lbuf[i] / den);
+        if (c < thr) ++cnt;
+      }
+      produced = min(cnt, p.O - 1);
+    }
+    if (m == 0) p.out_idx[(int64_t)b * p.T + t] = produced;
+    ibuf[0] = t + 1 < p.n_forced ? p.inputs[(int64_t)b * p.T + t + 1] : produced;
+  }
+  arc_barrier();
+}
+
 __device__ __forceinline__ int arc_uni(const int* q) { return __builtin_amdgcn_readfirstlane(*q); }
 
 template <typename E>
@@ -356,10 +455,10 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   for (int i = tid; i < p.L; i += ARC_THREADS) { ldil[i] = p.dil[i]; lroff[i] = (int)p.ring_off[i]; lpos[i] = 0; }
   arc_barrier();
 
-  float* xbanks = p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S, p.O);
-  float* sbanks = xbanks + 2 * ARC_NB * p.R;
-  unsigned long long* hbanks = (unsigned long long*)(sbanks + 2 * ARC_NB * p.S);       // all-gather of h1 (2 of the 3 banks)
-  unsigned long long* ybanks = hbanks + ARC_NB * p.S;                                  // all-gather of the logits
+  unsigned long long* hbanks = (unsigned long long*)(p.acc + (int64_t)b * ARC_ACC_FLOATS(p.R, p.S, p.O));   // all-gather of h1 (head rows are split over the members)
+  unsigned long long* ybanks = hbanks + 2 * p.S;                                       // all-gather of the logits
+  unsigned long long* xsum = ybanks + 2 * p.O;                                         // arc_allsum: 2 banks x C members x R
+  unsigned long long* ssum = xsum + 2 * ARC_CMAX * p.R;                                //             2 banks x C members x S
   unsigned xuse = 0, suse = 0, huse = 0, yuse = 0;
   unsigned seq = 0;   // exchange counter (same on every member); message bank = seq & 1
   // Where all members run on ONE XCD (the usual placement: blocks b and b+8 share one), messages go through that XCD's L2:
@@ -383,20 +482,15 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
     bool same = true;
     for (int i = 1; i < C; ++i) same = same && ids[i] == ids[0];
     if (tid == 0 && m == 0 && b == 0) p.error[1] = 0x1000 | (same ? 1 : 0) | ((int)ids[0] << 4) | ((int)ids[C - 1] << 8);
-#ifdef WAE_ARC_PROFILE
-    if (tid < C && m == 0 && b == 0) p.error[20 + tid] = (int)ids[tid];
-#endif
     arc_barrier();
     fast = same;
   }
 #ifdef WAE_ARC_PROFILE
-  unsigned long long pc[8] = {}, pt = __builtin_amdgcn_s_memtime();
+  unsigned long long pc[14] = {}, pt = __builtin_amdgcn_s_memtime();
 #define ARC_TICK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc[i] += n_ - pt; pt = n_; } while (0)
 #else
 #define ARC_TICK(i) do { } while (0)
 #endif
-  const bool owner = tid % C == m;                  // of granule tid in the all-reduce banks (clears it)
-  const float fx_lim = 4194304.f / (float)C;
 
   // ---- what a thread does per layer, worked out once (round 3: the layer loop ran ~2000 instructions per wave -- integer divisions
   //      per history element, 64-bit addresses, libm, per-element range tests, scalar spills; one wave per SIMD issues them one by one,
@@ -580,20 +674,12 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
           psum[gs * rw + gi2] = acc;
         }
       }
-      // the gate weights and scalars of the next layer (of layer 0 of the next sample) and its history rows: nothing computed
-      // goes into them, the registers they replace were consumed just above
-      const int ln = l + 1 < p.L ? l + 1 : 0, tn = l + 1 < p.L ? t : t + 1;
-      const float za = zb_a, zg = zb_g, bx = b2_x, bs = b2_s;
-      const int dN = arc_uni(ldil + ln), roffN = arc_uni(lroff + ln);
-      int posN = arc_uni(lpos + ln);
-      if (ln == 0) posN = posN + 1 == (p.ktaps - 1) * dN + 1 ? 0 : posN + 1;
-      prefetch_gate(ln);
-      request_hist(dN, roffN, posN, tn);
+      ARC_TICK(7);
       arc_barrier();
       ARC_TICK(0);
       // ---- gate: u of this member's channels, in every wave ----------------------------------------------------------------
       if (lane < nch) {
-        float a = za, g = zg;
+        float a = zb_a, g = zb_g;
         const int nparts = fold ? NWV : gns;
         for (int s = 0; s < nparts; ++s) { a += psum[s * rw + lane]; g += psum[s * rw + nch + lane]; }
         const float u = arc_gate<E>(a, g);
@@ -602,7 +688,6 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own window: program order is enough
-      place_hist(ln, tn);     // the GEMV that read vbuf is a barrier back; the rows were requested then
       // ---- this member's share of x' = W_out u and of skip += W_skip u: columns [ch0, ch1) only; u is zero outside them --------
       float px = 0.f;
       {
@@ -637,29 +722,43 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
             }
           }
         }
-        if (tid < p.S) skip_part += ps + (m == 0 ? bs : 0.f);   // the bias once: member 0
+        if (tid < p.S) skip_part += ps + (m == 0 ? b2_s : 0.f);   // the bias once: member 0
       }
       ARC_TICK(1);
-      // ---- all-reduce x' over the members, then residual (modules.py:157-162) and the next layer's current tap -----------------
+      // ---- sum x' over the members, then residual (modules.py:157-162) and the next layer's taps ----------------------------------
+      // Between this member's stores and its requests for everybody's shares sit the requests that depend on nothing computed: the
+      // next layer's (layer 0's of the next sample) weights, scalars and history rows.  Their issue time covers the store -> L2 ->
+      // load latency of the exchange, so the first polling pass usually finds every share; the history rows return in front of the
+      // shares (loads return in order) and go into vbuf with the new current tap.
       {
-        float sum;
-        if (!arc_allreduce(xbanks, p.R, xuse++, px, sum, C, owner, fx_lim, fast, p.error, &ibuf[1],
-                           [&]() { prefetch_out(ln); },
-                           [&](float tot) {
-                             xreg = (tot + bx + xreg) * 0.70710678118654752440f;
-                             if (l + 1 < p.L && tid < p.R) {
-                               vbuf[(p.ktaps - 1) * p.R + tid] = xreg;
-                               ring[(unsigned)(roffN + posN * p.R + tid)] = xreg;
-                             }
-                           }))
+        const int ln = l + 1 < p.L ? l + 1 : 0, tn = l + 1 < p.L ? t : t + 1;
+        const float bx = b2_x;
+        const int dN = arc_uni(ldil + ln), roffN = arc_uni(lroff + ln);
+        int posN = arc_uni(lpos + ln);
+        if (ln == 0) posN = posN + 1 == (p.ktaps - 1) * dN + 1 ? 0 : posN + 1;
+        auto x_between = [&]() {
+          prefetch_out(ln);
+          prefetch_gate(ln);
+          request_hist(dN, roffN, posN, tn);
+        };
+        auto x_after = [&](float tot) {
+          xreg = (tot + bx + xreg) * 0.70710678118654752440f;
+          if (l + 1 < p.L && tid < p.R) {
+            vbuf[(p.ktaps - 1) * p.R + tid] = xreg;
+            ring[(unsigned)(roffN + posN * p.R + tid)] = xreg;
+          }
+          place_hist(ln, tn);
+        };
+        auto x_tick = [&](int i) { ARC_TICK(9 + i); };
+        if (!(C == 32 ? arc_allsum<32>(xsum, p.R, xuse++, px, C, m, fast, p.error, &ibuf[1], x_between, x_after, x_tick)
+                      : arc_allsum<0>(xsum, p.R, xuse++, px, C, m, fast, p.error, &ibuf[1], x_between, x_after, x_tick)))
           return;
       }
       ARC_TICK(3);
     }
     // ---- all-reduce the skip vector (once per sample), then head + draw on every member ---------------------------------
     {
-      float sum;
-      if (!arc_allreduce(sbanks, p.S, suse++, skip_part, sum, C, owner, fx_lim, fast, p.error, &ibuf[1], []() {},
+      if (!arc_allsum<0>(ssum, p.S, suse++, skip_part, C, m, fast, p.error, &ibuf[1], []() {},
                          [&](float tot) {
                            if (tid < p.S) skipb[tid] = fmaxf(tot * p.scale, 0.f);
                            for (int i = tid; i < p.L; i += ARC_THREADS) {      // every ring's cursor moves on to sample t + 1
@@ -689,103 +788,385 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
         return;
     }
     ARC_TICK(5);
-    // ---- next input (wavenet.py:300-338): same arithmetic and summation order as csrc/ar_fwd.hip; the exponentials are
-    //      evaluated by all threads, the order-dependent sums by one ---------------------------------------------------------
-    // argmax with the first maximal index (as the serial scan of csrc/ar_fwd.hip)
-    {
-      float bv = -INFINITY;
-      int bi = 0x7fffffff;
-      for (int i = tid; i < p.O; i += ARC_THREADS)
-        if (lbuf[i] > bv) { bv = lbuf[i]; bi = i; }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_down(bv, o, 64);
-        const int oi = __shfl_down(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      if ((tid & 63) == 0) { psum[2 * (tid >> 6)] = bv; ((int*)psum)[2 * (tid >> 6) + 1] = bi; }
-      arc_barrier();
-      if (tid == 0) {
-        for (int w = 1; w < ARC_THREADS / 64; ++w) {
-          const float ov = psum[2 * w];
-          const int oi = ((int*)psum)[2 * w + 1];
-          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        psum[16] = bv;
-        ibuf[2] = bi;
-      }
-      arc_barrier();
-    }
-    int produced_par = -1;
-    if (p.mode == 2 && p.O <= ARC_THREADS) {
-      // softmax in fp32 (F.softmax), then inverse CDF over a double cumulative sum (numpy's choice, wavenet.py:331), all in
-      // parallel: block sum for the denominator, block scan for the cumulative sums, block count of the sums below u * total
-      const float mx = psum[16];
-      const float e = tid < p.O ? expf(lbuf[tid] - mx) : 0.f;
-      float sden = e;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sden += __shfl_down(sden, o, 64);
-      if ((tid & 63) == 0) psum[32 + (tid >> 6)] = sden;
-      arc_barrier();
-      float den = 0.f;
-      for (int w = 0; w < ARC_THREADS / 64; ++w) den += psum[32 + w];
-      double c = tid < p.O ? (double)(e / den) : 0.0;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const double up = __shfl_up(c, o, 64);
-        if ((tid & 63) >= o) c += up;
-      }
-      double* dsum = (double*)(psum + 40);
-      if ((tid & 63) == 63) dsum[tid >> 6] = c;
-      arc_barrier();
-      double base = 0.0, tot = 0.0;
-      for (int w = 0; w < ARC_THREADS / 64; ++w) {
-        if (w < (tid >> 6)) base += dsum[w];
-        tot += dsum[w];
-      }
-      c += base;
-      const double thr = (double)p.uniforms[(int64_t)b * p.T + t] * tot;
-      const unsigned long long below = __ballot(tid < p.O && c < thr);
-      if ((tid & 63) == 0) ((int*)psum)[56 + (tid >> 6)] = __popcll(below);
-      arc_barrier();
-      int cnt = 0;
-      for (int w = 0; w < ARC_THREADS / 64; ++w) cnt += ((int*)psum)[56 + w];
-      produced_par = min(cnt, p.O - 1);
-    } else if (p.mode == 2) {
-      const float mx = psum[16];
-      for (int i = tid; i < p.O; i += ARC_THREADS) lbuf[i] = expf(lbuf[i] - mx);
-      arc_barrier();
-    }
-    if (tid == 0) {
-      int produced = ibuf[2];
-      if (p.mode == 2 && produced_par >= 0) {
-        produced = produced_par;
-      } else if (p.mode == 2) {
-        float den = 0.f;
-        for (int i = 0; i < p.O; ++i) den += lbuf[i];
-        double tot = 0.0;
-        for (int i = 0; i < p.O; ++i) tot += (double)(lbuf[i] / den);
-        const double thr = (double)p.uniforms[(int64_t)b * p.T + t] * tot;
-        double c = 0.0;
-        int cnt = 0;
-        for (int i = 0; i < p.O; ++i) {
-          c += (double)(lbuf[i] / den);
-          if (c < thr) ++cnt;
-        }
-        produced = min(cnt, p.O - 1);
-      }
-      if (m == 0) p.out_idx[(int64_t)b * p.T + t] = produced;
-      ibuf[0] = t + 1 < p.n_forced ? p.inputs[(int64_t)b * p.T + t + 1] : produced;
-    }
-    arc_barrier();
+    arc_draw(p, lbuf, psum, ibuf, b, m, t);
     ARC_TICK(6);
   }
 #ifdef WAE_ARC_PROFILE
   if (tid == 0 && b == 0 && m == 0) {
     unsigned long long* o = (unsigned long long*)(p.error + 2);
-    for (int i = 0; i < 8; ++i) o[i] = pc[i];
+    for (int i = 0; i < 14; ++i) o[i] = pc[i];
   }
 #endif
+}
+
+// ==== the reference's own geometry (hps/vqwae.json: 256 residual / skip / output channels, 256 gate rows, 3 taps) on 32 members =====
+// ar_coop_kernel above takes any shape; its layer loop keeps ~150 uniform values and ~300 vector registers alive (459 scalar spills,
+// 132 values parked in AGPRs), and one wave per SIMD issues one VALU instruction per 5 clocks (tools/clk_probe.hip): at 12 k clocks per
+// layer the instruction count was the layer time.  With the sizes as constants a layer is ~350 instructions per wave:
+//   GEMV     lane -> (k slice 8 wv + lane % 8, gate row lane / 8): NU weight packets (registers, requested a layer ahead) x 2 LDS reads x
+//            packed FMAs; the 8 slices of a row inside a wave fold by 3 DPP adds; one partial per wave and row through LDS; barrier
+//   gate     every lane gates channel lane % 4 of the member (8 LDS reads); u reaches the other lanes as DPP quad broadcasts inside the
+//            4 + 4 FMAs of the x' and skip shares -- no LDS, no barrier
+//   exchange arc_allsum2; between its stores and its requests: the next layer's weights, scalars and history rows (addresses = a
+//            per-thread offset + a per-layer base; the ring rows of every layer for this sample are tabulated once per sample)
+//   after    residual, the next layer's three taps into vbuf, its current tap into its ring; barrier
+// The rings are zeroed at start (4 MB per member, once per clip), so "before the clip starts" needs no test.
+template <int CTRL>
+__device__ __forceinline__ float arc_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over aligned groups of 8 lanes / 32 lanes; every lane of the group gets it
+__device__ __forceinline__ float arc_fold8(float x) {
+  x += arc_dpp<0xB1>(x);      // quad_perm [1,0,3,2]
+  x += arc_dpp<0x4E>(x);      // quad_perm [2,3,0,1]
+  x += arc_dpp<0x141>(x);     // row_half_mirror
+  return x;
+}
+__device__ __forceinline__ float arc_fold32(float x) {
+  x = arc_fold8(x);
+  x += arc_dpp<0x140>(x);     // row_mirror
+  x += __shfl_xor(x, 16, 64);
+  return x;
+}
+
+// The same sum for 256 values on 32 members in two rounds (reduce-scatter + all-gather; the fast kernel).  arc_allsum has every member
+// read every member's shares: 64 KB per member and layer, 2 MB per layer through one XCD's L2 at ~1 KB per clock -- the 2 k clocks that
+// its polling pass could not get under.  Here member d owns values 8d .. 8d+7:
+//   round 1  thread (d = tid / 8, c = tid % 8) stores its share of value 8d + c into granule [d][m][c] of bank use & 1 (64 contiguous
+//            bytes per destination); thread (c = tid / 32, src = tid % 32) of member d polls granule [d][src][c]; the 32 sources of a
+//            value are 32 adjacent lanes: fold by DPP (a fixed tree)
+//   round 2  lane src = 0 stores the total into granule 8d + c of a 256-granule bank; thread tid of every member polls granule tid
+// 4 KB per member and layer, one request per thread and round; every member reads the same totals.  Two banks per round suffice (as in
+// arc_allgather; a member's round-2 read of `use` precedes its round-1 store of use + 1).
+template <typename F, typename A, typename K = ArcNoTick>
+__device__ __forceinline__ bool arc_allsum2(unsigned long long* banks1, unsigned long long* banks2, unsigned use, float mine, int m, bool fast,
+                                            int* error, int* abort_flag, F&& between, A&& after, K&& tick = K()) {
+  constexpr int C = 32, NC = 8;
+  const int tid = threadIdx.x;
+  const unsigned seq = use + 1;
+  unsigned long long* b1 = banks1 + (size_t)(use & 1) * C * C * NC;
+  unsigned long long* b2 = banks2 + (size_t)(use & 1) * C * NC;
+  auto put = [&](unsigned long long* q, float x) {
+    const unsigned long long v = arc_pack(seq, x);
+    if (fast) *(volatile unsigned long long*)q = v;
+    else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  bool bad = false;
+  auto get = [&](const unsigned long long* q) -> float {
+    int spins = 0;
+    unsigned long long v;
+    for (;;) {
+      v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)v == seq) break;
+      if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+        bad = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return __uint_as_float((unsigned)(v >> 32));
+  };
+  put(b1 + (unsigned)(((tid >> 3) * C + m) * NC + (tid & 7)), mine);
+  between();
+  tick(1);
+  const float part = get(b1 + (unsigned)((m * C + (tid & 31)) * NC + (tid >> 5)));
+  const float tot = arc_fold32(part);
+  if ((tid & 31) == 0) put(b2 + (unsigned)(NC * m + (tid >> 5)), tot);
+  const float sum = get(b2 + (unsigned)tid);
+  if (bad) {
+    *abort_flag = 1;
+    __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  tick(2);
+  after(sum);
+  arc_barrier();
+  return *abort_flag == 0;
+}
+
+// the 4 weights of a W2 row that multiply a member's 4 channels: half a 16-byte packet of 16-bit elements, a whole one of fp32
+template <typename E> struct ArcW2;
+template <> struct ArcW2<float> {
+  using raw = f32x4;
+  static constexpr int BYTES = 16;
+  static __device__ __forceinline__ void unpack(const raw& r, float (&w)[4]) { w[0] = r.x; w[1] = r.y; w[2] = r.z; w[3] = r.w; }
+};
+template <> struct ArcW2<__bf16> {
+  using raw = uint2;
+  static constexpr int BYTES = 8;
+  static __device__ __forceinline__ void unpack(const raw& r, float (&w)[4]) {
+    w[0] = __uint_as_float(r.x << 16); w[1] = __uint_as_float(r.x & 0xffff0000u);
+    w[2] = __uint_as_float(r.y << 16); w[3] = __uint_as_float(r.y & 0xffff0000u);
+  }
+};
+template <> struct ArcW2<f16> {
+  using raw = uint2;
+  static constexpr int BYTES = 8;
+  static __device__ __forceinline__ void unpack(const raw& r, float (&w)[4]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 v = __builtin_bit_cast(h4, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (float)v[i];
+  }
+};
+
+// dot of one 16-byte weight packet with EPL floats in LDS, two chains (packed FMAs)
+template <typename E>
+__device__ __forceinline__ void arc_packet_fma(const f32x4& raw, const float* v, float& a0, float& a1) {
+  constexpr int EPL = ET<E>::EPL;
+  float w[EPL];
+  arc_unpack<E>(raw, w);
+  const f32x4 v0 = *(const f32x4*)v;
+  a0 = fmaf(w[0], v0.x, a0); a1 = fmaf(w[1], v0.y, a1); a0 = fmaf(w[2], v0.z, a0); a1 = fmaf(w[3], v0.w, a1);
+  if constexpr (EPL == 8) {
+    const f32x4 v1 = *(const f32x4*)(v + 4);
+    a0 = fmaf(w[4], v1.x, a0); a1 = fmaf(w[5], v1.y, a1); a0 = fmaf(w[6], v1.z, a0); a1 = fmaf(w[7], v1.w, a1);
+  }
+}
+
+template <typename E, int NU>
+__global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int EPL = ET<E>::EPL, R = 256, S = 256, O = 256, H = 128, C = 32, NCH = 4;
+  constexpr int G_PAD = 256, W_PAD = 512, S_PAD = 256, O_PAD = 256;
+  constexpr int NKS = S / EPL, NPK = NKS / 32;       // head: k packets per row, packets per thread (32 k slices per row)
+  static_assert(ARC_THREADS == 256 && NPK >= 1, "geometry");
+  using W2 = ArcW2<E>;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x & 7, m = blockIdx.x >> 3;      // blocks b and b + 8 share an XCD
+  if (b >= p.B) return;
+  const int L = p.L, Cc = p.Cc > 0 ? p.Cc : 0;
+  const int nkb1 = (3 * R + Cc + EPL - 1) / EPL, K1p = nkb1 * EPL;
+  const int ch0 = m * NCH;
+  float* zer = sm;                        // 8 zeros: what a packet that does not exist is multiplied with
+  float* vbuf = sm + 32;                  // K1p   [tap t-2d ; tap t-d ; current tap ; conditioning] of the layer in flight
+  float* skipb = vbuf + K1p;              // S
+  float* hbuf = skipb + S;                // S
+  float* lbuf = hbuf + S;                 // O
+  float* psum = lbuf + O;                 // ARC_THREADS
+  int* ibuf = (int*)(psum + ARC_THREADS);  // [0] = current input id, [1] = abort flag, [2] = argmax
+  int4* ltab = (int4*)(ibuf + 8);         // L + 1: ring offsets {tap t-2d, tap t-d, current row} of every layer for this sample;
+                                          // entry L = layer 0 for the next sample
+  int* ldil = (int*)(ltab + L + 1);
+  int* lroff = ldil + L;
+  int* lpos = lroff + L;                  // current row of every ring = t mod (2d + 1)
+
+  float* ring = p.ring + ((int64_t)b * C + m) * p.ring_total;
+  unsigned long long* msg_b = p.msg + (int64_t)b * 2 * C * p.NV;
+  for (int i = tid; i < 32 + K1p + 2 * S; i += ARC_THREADS) sm[i] = 0.f;
+  if (tid == 0) { ibuf[0] = p.n_forced > 0 ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
+  for (int i = tid; i < L; i += ARC_THREADS) { ldil[i] = p.dil[i]; lroff[i] = (int)p.ring_off[i]; lpos[i] = 0; }
+  {
+    f32x4* r4 = (f32x4*)ring;
+    for (int64_t i = tid; i < p.ring_total / 4; i += ARC_THREADS) r4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = p.ring_total / 4 * 4 + tid; i < p.ring_total; i += ARC_THREADS) ring[i] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  arc_barrier();
+  auto tab_entry = [&](int l, int pos) -> int4 {
+    const int d = ldil[l], rlen = 2 * d + 1, ro = lroff[l];
+    int r1 = pos - d, r0 = pos - 2 * d;
+    r1 += r1 < 0 ? rlen : 0;
+    r0 += r0 < 0 ? rlen : 0;
+    return int4{ro + r0 * R, ro + r1 * R, ro + pos * R, 0};
+  };
+  for (int i = tid; i < L; i += ARC_THREADS) ltab[i] = tab_entry(i, 0);
+  if (tid == 0) ltab[L] = tab_entry(0, 1);
+
+  unsigned long long* hbanks = (unsigned long long*)(p.acc + (int64_t)b * ARC_ACC_FLOATS(R, S, O));
+  unsigned long long* ybanks = hbanks + 2 * S;
+  unsigned long long* xsum = ybanks + 2 * O;
+  unsigned long long* ssum = xsum + 2 * ARC_CMAX * R;
+  unsigned long long* xtot = ssum + 2 * ARC_CMAX * S;      // round 2 of arc_allsum2
+  unsigned long long* stot = xtot + 2 * R;
+  unsigned xuse = 0, suse = 0, huse = 0, yuse = 0;
+  bool fast = false;      // all members on one XCD: see ar_coop_kernel
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    unsigned long long* bank = msg_b + (int64_t)1 * C * p.NV;
+    if (tid == 0) __hip_atomic_store(bank + m * p.NV, arc_pack(1u, (float)xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float* ids = psum;
+    if (!arc_gather(bank, p.NV, C, 1, C, 1u, p.error, &ibuf[1], [&](int i, float v) { ids[i] = v; })) return;
+    bool same = true;
+    for (int i = 1; i < C; ++i) same = same && ids[i] == ids[0];
+    if (tid == 0 && m == 0 && b == 0) p.error[1] = 0x1000 | (same ? 1 : 0) | ((int)ids[0] << 4) | ((int)ids[C - 1] << 8);
+    arc_barrier();
+    fast = same;
+  }
+#ifdef WAE_ARC_PROFILE
+  unsigned long long pc[14] = {}, pt = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- per-thread constants ---------------------------------------------------------------------------------------------------------
+  const int ks = wv * 8 + (lane & 7), gr = lane >> 3;                     // k slice (of 32) and gate row (of 8) in the GEMV
+  const int grow = gr < NCH ? ch0 + gr : H + ch0 + (gr - NCH);
+  unsigned w1off[NU];                                                     // byte offset of packet u in a layer's W1
+#pragma unroll
+  for (int u = 0; u < NU; ++u) w1off[u] = (unsigned)(((ks + 32 * u < nkb1 ? ks + 32 * u : ks) * G_PAD + grow) * 16);
+  const float* vb = vbuf + ks * EPL;                                      // packet u multiplies vb[u * 32 * EPL ..]
+  const float* vlast = ks + 32 * (NU - 1) < nkb1 ? vb + (NU - 1) * 32 * EPL : zer;
+  const int kb_a = EPL == 8 ? m >> 1 : m;
+  const unsigned w2sub = EPL == 8 ? (unsigned)(m & 1) * 8u : 0u;
+  const unsigned w2xoff = (unsigned)((kb_a * W_PAD + tid) * 16) + w2sub, w2soff = (unsigned)((kb_a * W_PAD + R + tid) * 16) + w2sub;
+  const int gch = ch0 + (lane & 3);                                       // the channel this lane gates
+  const float* zb_b = p.zb + (int64_t)b * L * 2 * p.Hp;
+  f32x4 w1n[NU];
+  typename W2::raw wxr, wsr;
+  float zb_a, zb_g, b2_x, h0 = 0.f, h1 = 0.f;
+  int4 te;                                                                // ltab entry of the layer whose taps are being fetched
+  auto prefetch = [&](int l, int tab) {                                   // layer l's weights and scalars; ring rows of ltab[tab]
+    const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) w1n[u] = *(const f32x4*)(wl + w1off[u]);
+    wxr = *(const typename W2::raw*)(wl + p.w2_off + w2xoff);
+    wsr = *(const typename W2::raw*)(wl + p.w2_off + w2soff);
+    const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
+    zb_a = zbl[gch];
+    zb_g = zbl[p.Hp + gch];
+    b2_x = p.bias2[(int64_t)l * (R + S) + tid];
+    te = ltab[tab];
+    h0 = ring[(unsigned)(te.x + tid)];
+    h1 = ring[(unsigned)(te.y + tid)];
+  };
+  // the head's rows of this member: 8 of h1, 8 of the logits; thread -> (row tid / 32, k slice tid % 32); resident for the clip
+  const int hi = tid >> 5, hsl = tid & 31;
+  f32x4 hw1[NPK], hw2[NPK];
+#pragma unroll
+  for (int j = 0; j < NPK; ++j) {
+    hw1[j] = *(const f32x4*)(p.w_head + ((int64_t)(hsl + 32 * j) * S_PAD + 8 * m + hi) * 16);
+    hw2[j] = *(const f32x4*)(p.w_head + ((int64_t)NKS * S_PAD + (int64_t)(hsl + 32 * j) * O_PAD + 8 * m + hi) * 16);
+  }
+  const float hb1 = p.head_bias[8 * m + hi], hb2 = p.head_bias[S + 8 * m + hi];
+  float sbias = 0.f;                      // conv1x1_skip biases of all layers: once, on member 0 (the skip path is linear)
+  if (m == 0)
+    for (int l = 0; l < L; ++l) sbias += p.bias2[(int64_t)l * (R + S) + R + tid];
+  auto c_load = [&](int t) -> float {
+    const int64_t ci = ((int64_t)b * p.T + t) * p.Ccp + tid;
+    return p.c_dtype == WAE_BF16 ? (float)((const __bf16*)p.c_up)[ci] : (p.c_dtype == WAE_F16 ? (float)((const f16*)p.c_up)[ci] : ((const float*)p.c_up)[ci]);
+  };
+  float creg = tid < Cc ? c_load(0) : 0.f;
+  const float fbias = p.first_bias[tid];
+  prefetch(0, 0);
+  arc_barrier();      // ltab
+
+  float xreg = 0.f;
+  for (int t = 0; t < p.T; ++t) {
+    const int cur = ibuf[0];
+    xreg = p.first_tab[(int64_t)cur * p.Rp + tid] + fbias;
+    vbuf[2 * R + tid] = xreg;
+    ring[(unsigned)(ltab[0].z + tid)] = xreg;
+    if (tid < Cc) vbuf[3 * R + tid] = creg;
+    if (tid < Cc && t + 1 < p.T) creg = c_load(t + 1);
+    float skip_part = sbias;
+    arc_barrier();
+
+    for (int l = 0; l < L; ++l) {
+      // ---- this member's 8 gate rows ---------------------------------------------------------------------------------------------
+      {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU - 1; ++u) arc_packet_fma<E>(w1n[u], vb + u * 32 * EPL, a0, a1);
+        arc_packet_fma<E>(w1n[NU - 1], vlast, a0, a1);
+        const float acc = arc_fold8(a0 + a1);
+        if ((lane & 7) == 0) psum[wv * 8 + gr] = acc;
+      }
+      ARC_TICK(7);
+      arc_barrier();
+      ARC_TICK(0);
+      // ---- gate (every lane: channel lane % 4), then this member's shares of x' and of the skip sum ------------------------------
+      float px, ps;
+      {
+        float a = zb_a, g = zb_g;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += psum[w * 8 + (lane & 3)]; g += psum[w * 8 + NCH + (lane & 3)]; }
+        const float ug = arc_gate<E>(a, g);
+        float wx[4], ws[4];
+        W2::unpack(wxr, wx);
+        W2::unpack(wsr, ws);
+        const float u0 = arc_dpp<0x00>(ug), u1 = arc_dpp<0x55>(ug), u2 = arc_dpp<0xAA>(ug), u3 = arc_dpp<0xFF>(ug);
+        px = fmaf(wx[3], u3, fmaf(wx[2], u2, fmaf(wx[1], u1, wx[0] * u0)));
+        ps = fmaf(ws[3], u3, fmaf(ws[2], u2, fmaf(ws[1], u1, ws[0] * u0)));
+        skip_part += ps;
+      }
+      ARC_TICK(1);
+      // ---- sum x' over the members; between the stores and the requests: everything the next layer needs that is not computed ------
+      {
+        const float bx = b2_x;
+        const int ln = l + 1 < L ? l + 1 : 0;
+        if (!arc_allsum2(xsum, xtot, xuse++, px, m, fast, p.error, &ibuf[1],
+                            [&]() { prefetch(ln, l + 1); },
+                            [&](float tot) {
+                              xreg = (tot + bx + xreg) * 0.70710678118654752440f;
+                              if (l + 1 < L) {
+                                vbuf[2 * R + tid] = xreg;
+                                ring[(unsigned)(te.z + tid)] = xreg;
+                              }
+                              vbuf[tid] = h0;
+                              vbuf[R + tid] = h1;
+                            },
+                            [&](int i) { ARC_TICK(9 + i); }))
+          return;
+      }
+      ARC_TICK(3);
+    }
+    // ---- the skip sum over the members (once per sample); every ring's cursor moves on ---------------------------------------------
+    if (!arc_allsum2(ssum, stot, suse++, skip_part, m, fast, p.error, &ibuf[1], []() {},
+                        [&](float tot) {
+                          skipb[tid] = fmaxf(tot * p.scale, 0.f);
+                          for (int i = tid; i < L; i += ARC_THREADS) {
+                            const int rlen = 2 * ldil[i] + 1;
+                            int np = lpos[i] + 1;
+                            np = np == rlen ? 0 : np;
+                            lpos[i] = np;
+                            ltab[i] = tab_entry(i, np);
+                            if (i == 0) ltab[L] = tab_entry(0, np + 1 == rlen ? 0 : np + 1);
+                          }
+                        }))
+      return;
+    ARC_TICK(4);
+    // ---- head (wavenet.py:209-214): rows 8m .. 8m+7 of h1 and of the logits on this member, all-gathered ---------------------------
+    {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NPK; ++j) arc_packet_fma<E>(hw1[j], skipb + (hsl + 32 * j) * EPL, a0, a1);
+      const float r1 = arc_fold32(a0 + a1);
+      if (!arc_allgather(hbanks, S, huse++, hsl == 0, 8 * m + hi, fmaxf(r1 + hb1, 0.f), fast, p.error, &ibuf[1],
+                         [&](float v) { hbuf[tid] = v; }))
+        return;
+      a0 = 0.f; a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NPK; ++j) arc_packet_fma<E>(hw2[j], hbuf + (hsl + 32 * j) * EPL, a0, a1);
+      const float r2 = arc_fold32(a0 + a1);
+      if (!arc_allgather(ybanks, O, yuse++, hsl == 0, 8 * m + hi, r2 + hb2, fast, p.error, &ibuf[1],
+                         [&](float v) {
+                           lbuf[tid] = v;
+                           if (p.out_logits && m == 0) p.out_logits[((int64_t)b * O + tid) * p.T + t] = v;
+                         }))
+        return;
+    }
+    ARC_TICK(5);
+    arc_draw(p, lbuf, psum, ibuf, b, m, t);
+    ARC_TICK(6);
+  }
+#ifdef WAE_ARC_PROFILE
+  if (tid == 0 && b == 0 && m == 0) {
+    unsigned long long* o = (unsigned long long*)(p.error + 2);
+    for (int i = 0; i < 14; ++i) o[i] = pc[i];
+  }
+#endif
+}
+
+template <typename E, int NU>
+static void launch_arc_fast(const ArcArgs& a, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+}
+
+// WAE_AR_COOP_GENERIC=1 in the environment: the any-shape kernel also on the reference's geometry (A/B, tests)
+static int flags_env() {
+  const char* e = getenv("WAE_AR_COOP_GENERIC");
+  return e && e[0] == '1' ? 1 : 0;
 }
 
 extern "C" int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d) {
@@ -810,7 +1191,7 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
                   out_idx && msg && acc && error, "ar_generate_coop: null pointer argument");
   WAE_REQUIRE(wae_dtype_ok(d->dtype), "ar_generate_coop: bad dtype");
   WAE_REQUIRE(d->B > 0 && d->B <= 8, "ar_generate_coop: 1..8 utterances per launch (one XCD each); use wae_ar_generate for more");
-  WAE_REQUIRE(C >= 1 && C <= 32, "ar_generate_coop: 1..32 cooperating workgroups per utterance");
+  WAE_REQUIRE(C >= 1 && C <= ARC_CMAX, "ar_generate_coop: 1..%d cooperating workgroups per utterance", ARC_CMAX);
   WAE_REQUIRE(d->T > 0 && d->L > 0 && d->R > 0 && d->R <= ARC_THREADS && d->G > 0 && d->G % 2 == 0 && d->S > 0 &&
                   d->S <= ARC_THREADS && d->O > 0 && d->O <= ARC_THREADS,
               "ar_generate_coop: bad sizes (R, S, O <= %d)", ARC_THREADS);
@@ -840,6 +1221,23 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   WAE_REQUIRE(ring_total < (int64_t)1 << 31, "ar_generate_coop: ring_total %lld does not fit 32-bit offsets", (long long)ring_total);
   hipStream_t st = as_stream(stream);
   // the message banks must start with sequence numbers no exchange will use (0): the caller zeroes msg and error
+  // the reference's own geometry on 32 members: the kernel with the sizes as constants (NU = W1 packets per GEMV thread)
+  const int nu = ((3 * d->R + (d->Cc > 0 ? d->Cc : 0) + epl - 1) / epl + 31) / 32;
+  const bool fast_shape = C == 32 && d->R == 256 && d->S == 256 && d->O == 256 && d->G == 256 && d->ktaps == 3 && d->Cc <= 256 &&
+                          ring_total % 4 == 0 && !(flags_env() & 1);
+  if (fast_shape) {
+    const size_t lds_f = sizeof(float) * (size_t)(32 + 4 * nu * 32 * epl / 4 + 4 * 256 + 8 + 4 * (d->L + 1) + 3 * d->L + epl);
+    bool done = true;
+    if (d->dtype == WAE_BF16 && nu == 3) launch_arc_fast<__bf16, 3>(a, lds_f, st);
+    else if (d->dtype == WAE_BF16 && nu == 4) launch_arc_fast<__bf16, 4>(a, lds_f, st);
+    else if (d->dtype == WAE_F16 && nu == 3) launch_arc_fast<f16, 3>(a, lds_f, st);
+    else if (d->dtype == WAE_F16 && nu == 4) launch_arc_fast<f16, 4>(a, lds_f, st);
+    else if (d->dtype == WAE_F32 && nu == 6) launch_arc_fast<float, 6>(a, lds_f, st);
+    else if (d->dtype == WAE_F32 && nu == 7) launch_arc_fast<float, 7>(a, lds_f, st);
+    else if (d->dtype == WAE_F32 && nu == 8) launch_arc_fast<float, 8>(a, lds_f, st);
+    else done = false;
+    if (done) return wae_check_launch("ar_generate_coop");
+  }
   if (d->dtype == WAE_BF16) {
     (void)hipFuncSetAttribute((const void*)ar_coop_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ar_coop_kernel<__bf16>, dim3(8 * C), dim3(ARC_THREADS), lds, st, a);

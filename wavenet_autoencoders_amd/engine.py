@@ -536,11 +536,7 @@ class WaeEngine:
                                              L.ptr(out_idx), L.ptr(logits), L.ptr(msg), L.ptr(acc), L.ptr(err), st),
                     "ar_generate_coop")
             self._ar_profile = err
-            code = int(err[0].item())  # synchronises: generation is a blocking call for its callers anyway
-            if code == 2:
-                raise L.WaeError("ar_generate_coop: a partial sum left the all-reduce's fixed-point range (|share| >= 2^22 / C, or not "
-                                 "finite): the decoder's activations have diverged")
-            if code != 0:
+            if int(err[0].item()) != 0:  # synchronises: generation is a blocking call for its callers anyway
                 raise L.WaeError("ar_generate_coop: an exchange between the cooperating workgroups timed out")
         else:
             L.check(lib.wae_ar_generate(ctypes.byref(d), L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring), self.ar_ring_total,
