@@ -30,6 +30,14 @@ __global__ void pp(unsigned long long* slot, unsigned long long* out, int iters)
       else if (LD == 4) { v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_s_sleep(4); }
       else if (LD == 6) { v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_s_sleep(16); }
       else if (LD == 7) { v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_s_sleep(64); }
+      else if (LD == 9) {     // scalar load, glc: past the scalar cache, from L2 (uniform address: every lane polls lane 0's granule)
+        const unsigned long long* q = slot + (1 - me) * 64;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n s_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q) : "memory");
+      }
+      else if (LD == 10) { asm volatile("global_load_dwordx2 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(theirs) : "memory"); }
+      else if (LD == 11) { asm volatile("global_load_dwordx2 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(theirs) : "memory"); }
+      else if (LD == 12) { asm volatile("buffer_inv sc0\n global_load_dwordx2 %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(theirs) : "memory"); }
+      else if (LD == 13) { asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(theirs) : "memory"); }
       else if (LD == 8) { __builtin_amdgcn_s_sleep(8); v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       else { v = __hip_atomic_load(theirs + (spins & 1) * 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     } while ((unsigned)v != (unsigned)i && ++spins < 20000);      // bounded: a variant that never becomes visible must not hang the box
@@ -71,6 +79,11 @@ int main() {
   run<0, 2>("plain store, system-scope load (sc0 sc1)", slot, out);
   run<0, 3>("plain store, buffer_inv sc1 + plain load", slot, out);
   run<0, 4>("plain store, sc1 load + s_sleep 4 between polls", slot, out);
+  run<0, 9>("plain store, scalar load glc", slot, out);
+  run<0, 10>("plain store, vector load nt", slot, out);
+  run<0, 11>("plain store, vector load sc0 (asm)", slot, out);
+  run<0, 12>("plain store, buffer_inv sc0 + plain load", slot, out);
+  run<0, 13>("plain store, vector load sc0 sc1 nt", slot, out);
   run<0, 6>("plain store, sc1 load + s_sleep 16", slot, out);
   run<0, 7>("plain store, sc1 load + s_sleep 64", slot, out);
   run<0, 8>("plain store, s_sleep 8 + sc1 load (sleep first)", slot, out);
