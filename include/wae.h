@@ -314,8 +314,10 @@ int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilations, const
  * sample through `acc` (B x wae_ar_coop_acc_floats(d) floats), `msg` ((B, 2, C, NV) 8-byte granules, NV =
  * wae_ar_coop_msg_values(d, C)) carries the start-up handshake; each member keeps its own copy of the history rings:
  * ring is (B, C, ring_total).  B <= 8, C <= 32, R, S and O <= 256.  The caller zeroes msg, acc and error (>= 64 ints) before
- * the launch; error[0] != 0 afterwards means a wait timed out (the output is then invalid).  Sums are formed by fp32
- * atomics in arrival order: reproducible to rounding, not bitwise. */
+ * the launch; error[0] != 0 afterwards means a wait timed out (the output is then invalid).  No atomics: every share is one
+ * stored {sequence number, fp32} granule and the members add them in a fixed order -- results are bitwise reproducible.  The
+ * reference's geometry (R = G = S = O = 256, 3 taps, Cc <= 256) on C = 32 runs a kernel with those sizes as constants
+ * (WAE_AR_COOP_GENERIC=1 in the environment keeps the any-shape kernel); both zero-fill / overwrite `ring` themselves. */
 int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d);
 int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C);
 int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
