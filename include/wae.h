@@ -326,6 +326,18 @@ int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilatio
                          const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
                          const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
                          uint64_t* msg, float* acc, int32_t* error, void* stream);
+/* The same call with one more operand for the reference's geometry on 32 members: w_fused = (L, G, Hp) row-major in the model's element
+ * type, row block l = sqrt(.5) * W1_cur[l] . W_out[l-1] (the current-tap columns of layer l's dilated convolution times the previous
+ * layer's conv1x1_out; block 0 unused) -- formed once per weight update by the caller (a plain matrix product).  Because
+ * z_l = W1_cur[l] x_l + .. and x_l = sqrt(.5) (W_out[l-1] u_{l-1} + b_{l-1} + x_{l-1}), a member's 4 channels of u_{l-1} give its share of
+ * all gate rows of layer l directly: ONE reduce-scatter per layer stays on the critical path instead of the all-reduce's two hand-overs
+ * (csrc/ar_coop.hip: FUSED).  w_fused = NULL, or any other geometry: exactly wae_ar_generate_coop. */
+int wae_ar_generate_coop_fused(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                         int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                         const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                         const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                         const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                         uint64_t* msg, float* acc, int32_t* error, const void* w_fused, void* stream);
 
 /* ---- backward data path of the gated stack: C[t][M] = sum_s W_s . X_s[t + shift_s] on time-major operands ----
  * (autograd of modules.py:115-163; see csrc/gemm_tm.hip).  mode 0: out (t, M) = acc.  mode 1 (residual):

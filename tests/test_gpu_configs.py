@@ -37,13 +37,15 @@ def c4():
 
 
 def _set_ar_path(monkeypatch, coop):
-    """'1': the cooperative kernel (this geometry: the one with the sizes as constants), 'generic': the any-shape cooperative
-    kernel on the same geometry, '0': one CU per utterance"""
+    """'1': the cooperative kernel (this geometry: the one with the sizes as constants), 'fused': the same with one hand-over per layer
+    (wae_ar_generate_coop_fused with the host-formed W1_cur . W_out products), 'generic': the any-shape cooperative kernel on the same
+    geometry, '0': one CU per utterance"""
     monkeypatch.setenv("WAE_AR_COOP", "0" if coop == "0" else "1")
     monkeypatch.setenv("WAE_AR_COOP_GENERIC", "1" if coop == "generic" else "0")
+    monkeypatch.setenv("WAE_AR_FUSED", "1" if coop == "fused" else "0")
 
 
-@pytest.mark.parametrize("coop", ["1", "generic", "0"])
+@pytest.mark.parametrize("coop", ["1", "fused", "generic", "0"])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
 def test_c4_teacher_forced_logits(c4, dtype, tol, coop, monkeypatch):
     """Teacher-forced incremental decode over 2560 samples == the reference's incremental_forward(test_inputs) at the probe
@@ -80,7 +82,7 @@ def _check_rollout(got, want, margin, thresh, what):
     return first
 
 
-@pytest.mark.parametrize("coop", ["1", "generic"])
+@pytest.mark.parametrize("coop", ["1", "fused", "generic"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_c4_cooperative_decode_is_bitwise_reproducible(c4, dtype, coop, monkeypatch):
     """The members' shares are added in a fixed order (csrc/ar_coop.hip: arc_allsum / arc_allsum2), not by atomics in arrival order:
@@ -100,7 +102,7 @@ def test_c4_cooperative_decode_is_bitwise_reproducible(c4, dtype, coop, monkeypa
     assert torch.equal(runs[0][1], runs[1][1])
 
 
-@pytest.mark.parametrize("coop", ["1", "generic", "0"])
+@pytest.mark.parametrize("coop", ["1", "fused", "generic", "0"])
 def test_c4_greedy_rollout_fp32(c4, coop, monkeypatch):
     cfg, sd, z = c4
     _set_ar_path(monkeypatch, coop)

@@ -38,5 +38,5 @@ if prof is not None and int(prof[2:].abs().sum()) != 0:
     import numpy as np
     pc = prof.cpu().numpy()[2:30].view(np.uint64)
     names = ["barrier after the GEMV", "gate + x' and skip shares", "-", "residual, next taps + barrier", "skip exchange", "head", "draw",
-             "gate rows GEMV", "-", "-", "exchange: stores + requests (weights, scalars, history)", "exchange: polling passes + sum"]
+             "gate rows GEMV", "fused: x round-2 poll", "fused: vbuf writes + barrier", "exchange: stores + requests (weights, scalars, history)", "exchange: polling passes + sum"]
     print("  s_memtime ticks per sample (member 0):", {n: int(v // T) for n, v in zip(names, pc)})

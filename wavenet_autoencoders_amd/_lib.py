@@ -121,6 +121,8 @@ SIGNATURES = {
     "wae_ar_coop_acc_floats": (c_i64, [ctypes.POINTER(ArDesc)]),
     "wae_ar_generate_coop": (c_i32, [ctypes.POINTER(ArDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7
                              + [c_i32] + [c_vp] * 8),
+    "wae_ar_generate_coop_fused": (c_i32, [ctypes.POINTER(ArDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64] + [c_vp] * 7
+                                   + [c_i32] + [c_vp] * 9),
     "wae_ce_logits_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_ce_logits_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "wae_weighted_mean": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),

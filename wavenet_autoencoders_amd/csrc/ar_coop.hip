@@ -23,8 +23,8 @@
 #define ARC_W1P 8      // W1 packets of a gate row slice a thread holds (fp32: K1/4/32 slices = 6.5 at hps/vqwae.json)
 #define ARC_CMAX 32     // cooperating workgroups per utterance, at most
 // 8-byte {sequence number, fp32} granules: 2 banks of S and of O (arc_allgather), 2 banks x ARC_CMAX members of R and of S (arc_allsum,
-// round 1 of arc_allsum2), 2 banks of R and of S (round 2 of arc_allsum2)
-#define ARC_ACC_FLOATS(R, S, O) (4 * ((S) + (O)) + 4 * ARC_CMAX * ((R) + (S)) + 4 * ((R) + (S)) + 32)
+// round 1 of arc_allsum2), 2 banks of R and of S (round 2 of arc_allsum2), 2 banks x ARC_CMAX members of R (the fused kernel's second stream)
+#define ARC_ACC_FLOATS(R, S, O) (4 * ((S) + (O)) + 4 * ARC_CMAX * ((R) + (S)) + 4 * ((R) + (S)) + 4 * ARC_CMAX * (R) + 32)
 
 struct ArcArgs {
   int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp, C;
@@ -41,6 +41,7 @@ struct ArcArgs {
   const float* first_bias;
   const char* w_head;
   const float* head_bias;
+  const char* w_fused;       // (L, G, H) row-major, element type of the model: sqrt(.5) W1_cur[l] . W_out[l-1] (row 0 unused), or null
   const char* c_up;
   int c_dtype;
   const int32_t* inputs;
@@ -160,6 +161,13 @@ __device__ __forceinline__ void arc_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// One 8-byte store that stays in the XCD's L2 (members on one XCD).  Not `*(volatile T*)p = v`: hipcc follows a volatile store with
+// s_waitcnt vmcnt(0) -- the wave then sits out the store's acknowledgement (~500 clocks, tools/store_probe.hip) and every load it has
+// in flight, on the critical path of each exchange (round 3: two such stores per layer cost the fused kernel 1 k clocks per layer).
+__device__ __forceinline__ void arc_store64(unsigned long long* q, unsigned long long v) {
+  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ unsigned long long arc_pack(unsigned seq, float v) {
   return ((unsigned long long)__float_as_uint(v) << 32) | seq;
 }
@@ -223,7 +231,7 @@ __device__ __forceinline__ bool arc_allsum(unsigned long long* banks, int n, uns
   unsigned long long* bank = banks + (size_t)(use & 1) * C * n;
   if (tid < n) {
     const unsigned long long v = arc_pack(seq, mine);
-    if (fast) *(volatile unsigned long long*)(bank + (size_t)m * n + (unsigned)tid) = v;
+    if (fast) arc_store64(bank + (size_t)m * n + (unsigned)tid, v);
     else __hip_atomic_store(bank + (size_t)m * n + (unsigned)tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   between();
@@ -278,7 +286,7 @@ __device__ __forceinline__ bool arc_allgather(unsigned long long* banks, int n, 
   unsigned long long* bank = banks + (use & 1) * n;
   if (has) {
     const unsigned long long v = arc_pack(seq, mine);
-    if (fast) *(volatile unsigned long long*)(bank + idx) = v;
+    if (fast) arc_store64(bank + idx, v);
     else __hip_atomic_store(bank + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   bool bad = false;
@@ -467,7 +475,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_kernel(ArcArgs p) {
   // XCC ids once, through the always-valid agent-scope path, and all reach the same verdict.
   bool fast = false;
   auto publish = [&](unsigned long long* slot, unsigned long long v) {
-    if (fast) *(volatile unsigned long long*)slot = v;
+    if (fast) arc_store64(slot, v);
     else __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   {
@@ -858,7 +866,7 @@ __device__ __forceinline__ bool arc_allsum2(unsigned long long* banks1, unsigned
   unsigned long long* b2 = banks2 + (size_t)(use & 1) * C * NC;
   auto put = [&](unsigned long long* q, float x) {
     const unsigned long long v = arc_pack(seq, x);
-    if (fast) *(volatile unsigned long long*)q = v;
+    if (fast) arc_store64(q, v);
     else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   bool bad = false;
@@ -934,7 +942,7 @@ __device__ __forceinline__ void arc_packet_fma(const f32x4& raw, const float* v,
   }
 }
 
-template <typename E, int NU>
+template <typename E, int NU, bool FUSED>
 __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int EPL = ET<E>::EPL, R = 256, S = 256, O = 256, H = 128, C = 32, NCH = 4;
@@ -989,6 +997,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   unsigned long long* ssum = xsum + 2 * ARC_CMAX * R;
   unsigned long long* xtot = ssum + 2 * ARC_CMAX * S;      // round 2 of arc_allsum2
   unsigned long long* stot = xtot + 2 * R;
+  [[maybe_unused]] unsigned long long* xsh = stot + 2 * S;  // FUSED: round 1 of the lazy x' sum (xsum carries the gate-row shares)
   unsigned xuse = 0, suse = 0, huse = 0, yuse = 0;
   bool fast = false;      // all members on one XCD: see ar_coop_kernel
   {
@@ -1081,6 +1090,176 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   hist_part(hp0, hp1);
 
   float xreg = 0.f;
+  if constexpr (FUSED) {
+    // ==== ONE hand-over per layer on the critical path ==============================================================================
+    // z_{l+1} = W1_cur x_{l+1} + (history, conditioning, zb)  and  x_{l+1} = sqrt(.5) (W_out u_l + b_l + x_l), hence
+    //   z_{l+1} = M_{l+1} u_l + [ W1_cur sqrt(.5) (b_l + x_l) + history + conditioning + zb ],   M_{l+1} = sqrt(.5) W1_cur^{l+1} W_out^l
+    // (p.w_fused, formed once by the host).  A member's u_l (4 channels) gives its share of ALL 256 gate rows of layer l + 1 by 4 FMAs
+    // per thread; ONE reduce-scatter hands every member the sums of its 8 rows -> gate -> u_{l+1}.  The bracket needs x_l on every
+    // member, but not u_l: x_l's own sum (started a layer earlier, with u_{l-1}) travels as a second, lazy stream -- round 1 beside the
+    // gate-row shares, round 2 published at the end of one window and read in the next -- and the bracket (current-tap packet on
+    // sqrt(.5)(b_l + x_l), history packets) is contracted while the gate-row shares are in flight.  arc_allsum2's two hand-overs per
+    // layer become one; the rings still receive every x_l (history of later samples).
+    const float rs = 0.70710678118654752440f;
+    float* zrow = sm + 16;                       // sums of this member's 8 gate rows (M u part) of the layer about to be gated
+    unsigned ex = 0;                             // exchanges so far (one per layer l < L - 1 of every sample)
+    bool bad = false;
+    auto put = [&](unsigned long long* q, unsigned seq, float x) {
+      const unsigned long long v = arc_pack(seq, x);
+      if (fast) arc_store64(q, v);
+      else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto get = [&](const unsigned long long* q, unsigned seq) -> float {
+      int spins = 0;
+      unsigned long long v;
+      for (;;) {
+        v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)v == seq) break;
+        if (++spins > (1 << 21) || ((spins & 255) == 255 && __hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+          bad = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      return __uint_as_float((unsigned)(v >> 32));
+    };
+    typename W2::raw wmr;                        // M_{l+1}[row tid, this member's 4 channels]
+    auto load_wm = [&](int l) {                  // (layer l's matrix: used when layer l - 1 has been gated)
+      if (l < L) wmr = *(const typename W2::raw*)(p.w_fused + (((int64_t)l * 256 + tid) * H + ch0) * (int64_t)sizeof(E));
+    };
+    load_wm(1);
+    // gate row tid of the next layer belongs to member (tid % 128) / 4, as its row 4 (tid / 128) + tid % 4
+    const unsigned zdst = (unsigned)(((((tid & 127) >> 2) * C + m) * 8) + ((tid >> 7) * 4 + (tid & 3)));
+    const unsigned xdst = (unsigned)(((tid >> 3) * C + m) * 8 + (tid & 7));          // x' value tid belongs to member tid / 8
+    const unsigned mysrc = (unsigned)((m * C + (tid & 31)) * 8 + (tid >> 5));        // what thread (row tid / 32, source tid % 32) collects
+    float bprev = 0.f;
+    for (int t = 0; t < p.T; ++t) {
+      const int cur = ibuf[0];
+      xreg = p.first_tab[(int64_t)cur * p.Rp + tid] + fbias;                          // x_0: local
+      vbuf[2 * R + tid] = xreg;
+      ring[(unsigned)(ltab[0].z + tid)] = xreg;
+      if (tid < Cc && t + 1 < p.T) creg = c_load(t + 1);
+      if (tid < 8) zrow[tid] = 0.f;                                                   // layer 0: no M u part
+      float skip_part = sbias;
+      arc_barrier();
+      {
+        float a0 = hp0, a1 = hp1;
+        arc_static_for<CUR0, CUR0 + PT>([&](auto uc) { packet_at(uc, a0, a1); });
+        const float acc = arc_fold8(a0 + a1);
+        if ((lane & 7) == 0) psum[wv * 8 + gr] = acc;
+      }
+      arc_barrier();
+      for (int l = 0; l < L; ++l) {
+        // ---- gate of layer l, shares ------------------------------------------------------------------------------------------------
+        float a = zb_a + zrow[lane & 3], g = zb_g + zrow[NCH + (lane & 3)];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += psum[w * 8 + (lane & 3)]; g += psum[w * 8 + NCH + (lane & 3)]; }
+        const float ug = arc_gate<E>(a, g);
+        const float u0 = arc_dpp<0x00>(ug), u1 = arc_dpp<0x55>(ug), u2 = arc_dpp<0xAA>(ug), u3 = arc_dpp<0xFF>(ug);
+        float wx[4], ws[4];
+        W2::unpack(wsr, ws);
+        skip_part += fmaf(ws[3], u3, fmaf(ws[2], u2, fmaf(ws[1], u1, ws[0] * u0)));
+        ARC_TICK(1);
+        if (l + 1 < L) {
+          float wm[4];
+          W2::unpack(wxr, wx);
+          W2::unpack(wmr, wm);
+          const float px = fmaf(wx[3], u3, fmaf(wx[2], u2, fmaf(wx[1], u1, wx[0] * u0)));
+          const float pm = fmaf(wm[3], u3, fmaf(wm[2], u2, fmaf(wm[1], u1, wm[0] * u0)));
+          const unsigned seq = ex + 1, bank = ex & 1;
+          unsigned long long* zb1 = xsum + (size_t)bank * C * C * 8;
+          unsigned long long* xb1 = xsh + (size_t)bank * C * C * 8;
+          put(zb1 + zdst, seq, pm);
+          put(xb1 + xdst, seq, px);
+          // ---- the window: everything layer l + 1 needs that does not depend on u_l ---------------------------------------------------
+          const float bl = b2_x;                   // b_l
+          const int tz = te.z;                     // current ring row of layer l
+          prefetch(l + 1, l + 1);                  // layer l + 1: weights, scalars, history rows (ring rows of ltab[l + 1])
+          load_wm(l + 2);
+          ARC_TICK(10);
+          if (l >= 1) {                            // x_l: the lazy stream's round 2 of the previous exchange
+            const float tot = get(xtot + (size_t)((ex - 1) & 1) * 256 + tid, ex);
+            xreg = (tot + bprev + xreg) * rs;
+            ring[(unsigned)(tz + tid)] = xreg;
+          }
+          ARC_TICK(8);
+          vbuf[2 * R + tid] = (bl + xreg) * rs;    // what W1_cur of layer l + 1 multiplies beside M u
+          vbuf[tid] = h0;
+          vbuf[R + tid] = h1;
+          arc_barrier();
+          ARC_TICK(9);
+          {
+            hist_part(hp0, hp1);
+            float a0 = hp0, a1 = hp1;
+            arc_static_for<CUR0, CUR0 + PT>([&](auto uc) { packet_at(uc, a0, a1); });
+            const float acc = arc_fold8(a0 + a1);
+            if ((lane & 7) == 0) psum[wv * 8 + gr] = acc;
+          }
+          ARC_TICK(7);
+          const float zt = arc_fold32(get(zb1 + mysrc, seq));
+          if ((tid & 31) == 0) zrow[tid >> 5] = zt;
+          ARC_TICK(11);
+          const float xt = arc_fold32(get(xb1 + mysrc, seq));
+          if ((tid & 31) == 0) put(xtot + (size_t)bank * 256 + 8 * m + (tid >> 5), seq, xt);
+          bprev = bl;
+          ++ex;
+          if (bad) { ibuf[1] = 1; __hip_atomic_store(p.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          arc_barrier();
+          if (ibuf[1]) return;
+          ARC_TICK(3);
+        } else if (L >= 2) {                       // x_{L-1}: into its ring only (the last layer's x' is dead, wavenet.py:205-207)
+          const float tot = get(xtot + (size_t)((ex - 1) & 1) * 256 + tid, ex);
+          ring[(unsigned)(te.z + tid)] = (tot + bprev + xreg) * rs;
+        }
+      }
+      // ---- the skip sum (once per sample); in its waits: layer 0 of the next sample ----------------------------------------------------
+      if (!arc_allsum2(ssum, stot, suse++, skip_part, m, fast, p.error, &ibuf[1],
+                       [&]() { prefetch(0, L); load_wm(1); },
+                       [&]() {
+                         vbuf[tid] = h0;
+                         vbuf[R + tid] = h1;
+                         if (tid < Cc) vbuf[3 * R + tid] = creg;
+                         arc_barrier();
+                         hist_part(hp0, hp1);
+                       },
+                       [&](float tot) {
+                         skipb[tid] = fmaxf(tot * p.scale, 0.f);
+                         for (int i = tid; i < L; i += ARC_THREADS) {
+                           const int rlen = 2 * ldil[i] + 1;
+                           int np = lpos[i] + 1;
+                           np = np == rlen ? 0 : np;
+                           lpos[i] = np;
+                           ltab[i] = tab_entry(i, np);
+                           if (i == 0) ltab[L] = tab_entry(0, np + 1 == rlen ? 0 : np + 1);
+                         }
+                       }))
+        return;
+      if (bad) return;
+      ARC_TICK(4);
+      {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPK; ++j) arc_packet_fma<E>(hw1[j], skipb + (hsl + 32 * j) * EPL, a0, a1);
+        const float r1 = arc_fold32(a0 + a1);
+        if (!arc_allgather(hbanks, S, huse++, hsl == 0, 8 * m + hi, fmaxf(r1 + hb1, 0.f), fast, p.error, &ibuf[1],
+                           [&](float v) { hbuf[tid] = v; }))
+          return;
+        a0 = 0.f; a1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPK; ++j) arc_packet_fma<E>(hw2[j], hbuf + (hsl + 32 * j) * EPL, a0, a1);
+        const float r2 = arc_fold32(a0 + a1);
+        if (!arc_allgather(ybanks, O, yuse++, hsl == 0, 8 * m + hi, r2 + hb2, fast, p.error, &ibuf[1],
+                           [&](float v) {
+                             lbuf[tid] = v;
+                             if (p.out_logits && m == 0) p.out_logits[((int64_t)b * O + tid) * p.T + t] = v;
+                           }))
+          return;
+      }
+      ARC_TICK(5);
+      arc_draw(p, lbuf, psum, ibuf, b, m, t);
+      ARC_TICK(6);
+    }
+  } else
   for (int t = 0; t < p.T; ++t) {
     const int cur = ibuf[0];
     xreg = p.first_tab[(int64_t)cur * p.Rp + tid] + fbias;
@@ -1191,8 +1370,13 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
 
 template <typename E, int NU>
 static void launch_arc_fast(const ArcArgs& a, size_t lds, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+  if (a.w_fused) {
+    (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, true>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, false>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+  }
 }
 
 // WAE_AR_COOP_GENERIC=1 in the environment: the any-shape kernel also on the reference's geometry (A/B, tests)
@@ -1213,12 +1397,12 @@ extern "C" int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C) {
   return hc > sc ? hc : sc;
 }
 
-extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
-                                    int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
-                                    const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
-                                    const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
-                                    const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
-                                    uint64_t* msg, float* acc, int32_t* error, void* stream) {
+static int ar_generate_coop_impl(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                                 int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                                 const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                                 const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                                 const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                                 uint64_t* msg, float* acc, int32_t* error, const void* w_fused, void* stream) {
   WAE_REQUIRE(d && dilations && ring_off && ring && w_layers && bias2 && zb && first_tab && first_bias && w_head && head_bias &&
                   out_idx && msg && acc && error, "ar_generate_coop: null pointer argument");
   WAE_REQUIRE(wae_dtype_ok(d->dtype), "ar_generate_coop: bad dtype");
@@ -1243,6 +1427,7 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   a.ring_off = ring_off; a.ring = ring; a.ring_total = ring_total; a.w_layers = (const char*)w_layers;
   a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
   a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
+  a.w_fused = nullptr;
   a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
   a.n_forced = inputs ? (d->n_forced > 0 && d->n_forced < d->T ? d->n_forced : d->T) : 0;
   a.out_logits = out_logits; a.msg = (unsigned long long*)msg; a.NV = hc > sc ? hc : sc; a.acc = acc; a.error = error;
@@ -1258,6 +1443,7 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
   const bool fast_shape = C == 32 && d->R == 256 && d->S == 256 && d->O == 256 && d->G == 256 && d->ktaps == 3 && d->Cc <= 256 &&
                           ring_total % 4 == 0 && !(flags_env() & 1);
   if (fast_shape) {
+    a.w_fused = d->L >= 2 ? (const char*)w_fused : nullptr;     // the one-hand-over-per-layer kernel (else: ar_coop_fast_kernel's two)
     const size_t lds_f = sizeof(float) * (size_t)(32 + 4 * nu * 32 * epl / 4 + 4 * 256 + 8 + 4 * (d->L + 1) + 3 * d->L + epl);
     bool done = true;
     if (d->dtype == WAE_BF16 && nu == 3) launch_arc_fast<__bf16, 3>(a, lds_f, st);
@@ -1281,4 +1467,26 @@ extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32
     hipLaunchKernelGGL(ar_coop_kernel<float>, dim3(8 * C), dim3(ARC_THREADS), lds, st, a);
   }
   return wae_check_launch("ar_generate_coop");
+}
+
+extern "C" int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                                    int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                                    const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                                    const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                                    const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                                    uint64_t* msg, float* acc, int32_t* error, void* stream) {
+  return ar_generate_coop_impl(d, C, dilations, ring_off, ring, ring_total, w_layers, layer_stride_bytes, w2_off_bytes, bias2, zb, first_tab,
+                               first_bias, w_head, head_bias, c_up, c_dtype, inputs, uniforms, out_idx, out_logits, msg, acc, error, nullptr,
+                               stream);
+}
+
+extern "C" int wae_ar_generate_coop_fused(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
+                                          int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
+                                          const float* bias2, const float* zb, const float* first_tab, const float* first_bias,
+                                          const void* w_head, const float* head_bias, const void* c_up, int32_t c_dtype,
+                                          const int32_t* inputs, const float* uniforms, int32_t* out_idx, float* out_logits,
+                                          uint64_t* msg, float* acc, int32_t* error, const void* w_fused, void* stream) {
+  return ar_generate_coop_impl(d, C, dilations, ring_off, ring, ring_total, w_layers, layer_stride_bytes, w2_off_bytes, bias2, zb, first_tab,
+                               first_bias, w_head, head_bias, c_up, c_dtype, inputs, uniforms, out_idx, out_logits, msg, acc, error, w_fused,
+                               stream);
 }

@@ -423,7 +423,31 @@ class WaeEngine:
                                     self.dt, st), "pack AR head")
         L.check(lib.wae_pack_gather(L.ptr(self.eff), L.ptr(self.m_ar_hb), L.ptr(self.ar_hb), g.S + g.O, 1, 0, 0, L.WAE_F32, st),
                 "pack AR head bias")
+        self.ar_wm = self._pack_ar_fused()
         self._ar_packed = True
+
+    def _pack_ar_fused(self):
+        """include/wae.h: wae_ar_generate_coop_fused.  M_l = sqrt(.5) W1_cur[l] W_out[l-1] for the reference's own geometry (the one the
+        cooperative kernel has with its sizes as constants), from the packed decode weights: one small matrix product per layer, once per
+        weight update -- like make_generation_fast_ (wavenet.py:358-364) it is preparation, not the decode path.  Opt-in (WAE_AR_FUSED=1):
+        with the exchange's stores no longer waiting for their acknowledgement a hand-over costs ~1.3 k clocks, and the fused layer's
+        longer window (its requests miss L2: 11.7 MB of weights cycle through a 4-MB L2 every sample) measures 19 kHz against 22.7."""
+        g = self.g
+        if not (g.R == 256 and g.S == 256 and g.O == 256 and g.G == 256 and g.k == 3 and g.layers >= 2 and not g.scalar_input
+                and os.environ.get("WAE_AR_FUSED", "0") == "1"):
+            return None
+        epl = 4 if self.dt == L.WAE_F32 else 8
+        K1 = 3 * g.R + max(g.Cc, 0)
+        nkb1, nkbh = (K1 + epl - 1) // epl, (g.H + epl - 1) // epl
+        g_pad, w_pad = (g.G + 63) // 64 * 64, (g.R + g.S + 63) // 64 * 64
+        w = self.ar_w.view(g.layers, self.ar_layer_elems).float()
+        w1 = w[:, :nkb1 * g_pad * epl].view(g.layers, nkb1, g_pad, epl)                       # [l][k / epl][row][k % epl]
+        w1c = w1[:, 2 * g.R // epl:3 * g.R // epl, :g.G].permute(0, 2, 1, 3).reshape(g.layers, g.G, g.R)      # current tap
+        w2 = w[:, self.ar_w2_off:self.ar_w2_off + nkbh * w_pad * epl].view(g.layers, nkbh, w_pad, epl)
+        wout = w2[:, :, :g.R].permute(0, 2, 1, 3).reshape(g.layers, g.R, nkbh * epl)[:, :, :g.H]
+        wm = torch.zeros(g.layers, g.G, g.H, dtype=torch.float32, device=self.device)
+        wm[1:] = math.sqrt(0.5) * torch.bmm(w1c[1:], wout[:-1])
+        return wm.to(self.tdtype).contiguous()
 
     def incremental_forward(self, c: Optional[torch.Tensor], gid: Optional[torch.Tensor], T: int, mode: str = "sample",
                             test_inputs: Optional[torch.Tensor] = None, uniforms: Optional[torch.Tensor] = None,
@@ -529,11 +553,12 @@ class WaeEngine:
             msg = torch.zeros(B * 2 * C * nv, dtype=torch.int64, device=dev)
             acc = torch.zeros(B * lib.wae_ar_coop_acc_floats(ctypes.byref(d)), dtype=torch.float32, device=dev)
             err = torch.zeros(64, dtype=torch.int32, device=dev)   # [0] = time-out flag; the rest: profile counters of a -DWAE_ARC_PROFILE build
-            L.check(lib.wae_ar_generate_coop(ctypes.byref(d), C, L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring),
-                                             self.ar_ring_total, L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es,
-                                             L.ptr(self.ar_b2), L.ptr(zb), L.ptr(self.first_tab), L.ptr(self.first_bias),
-                                             L.ptr(self.ar_wh), L.ptr(self.ar_hb), L.ptr(c_up), self.dt, L.ptr(inputs), L.ptr(uni),
-                                             L.ptr(out_idx), L.ptr(logits), L.ptr(msg), L.ptr(acc), L.ptr(err), st),
+            L.check(lib.wae_ar_generate_coop_fused(ctypes.byref(d), C, L.ptr(self.ar_dil), L.ptr(self.ar_ring_off), L.ptr(ring),
+                                                   self.ar_ring_total, L.ptr(self.ar_w), self.ar_layer_elems * es, self.ar_w2_off * es,
+                                                   L.ptr(self.ar_b2), L.ptr(zb), L.ptr(self.first_tab), L.ptr(self.first_bias),
+                                                   L.ptr(self.ar_wh), L.ptr(self.ar_hb), L.ptr(c_up), self.dt, L.ptr(inputs),
+                                                   L.ptr(uni), L.ptr(out_idx), L.ptr(logits), L.ptr(msg), L.ptr(acc), L.ptr(err),
+                                                   L.ptr(getattr(self, "ar_wm", None)), st),
                     "ar_generate_coop")
             self._ar_profile = err
             if int(err[0].item()) != 0:  # synchronises: generation is a blocking call for its callers anyway
