@@ -19,6 +19,7 @@ __global__ void pp(unsigned long long* slot, unsigned long long* out, int iters)
       else if (ST == 3) { *(volatile unsigned long long*)mine = v; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       else if (ST == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n" :: "v"(mine), "v"(v) : "memory");
       else if (ST == 5) asm volatile("global_store_dwordx2 %0, %1, off nt\n" :: "v"(mine), "v"(v) : "memory");
+      else if (ST == 6) asm volatile("global_store_dwordx2 %0, %1, off\n" :: "v"(mine), "v"(v) : "memory");   // plain, no wait
     }
     unsigned long long v;
     int spins = 0;
@@ -50,6 +51,7 @@ __global__ void pp(unsigned long long* slot, unsigned long long* out, int iters)
       else if (ST == 3) { *(volatile unsigned long long*)mine = w; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       else if (ST == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n" :: "v"(mine), "v"(w) : "memory");
       else if (ST == 5) asm volatile("global_store_dwordx2 %0, %1, off nt\n" :: "v"(mine), "v"(w) : "memory");
+      else if (ST == 6) asm volatile("global_store_dwordx2 %0, %1, off\n" :: "v"(mine), "v"(w) : "memory");
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -74,6 +76,9 @@ int main() {
   run<3, 0>("plain store + s_waitcnt vmcnt(0), sc1 load", slot, out);
   run<4, 0>("store sc0 sc1, sc1 load", slot, out);
   run<5, 0>("store nt, sc1 load", slot, out);
+  run<6, 0>("asm store without the compiler's wait, sc1 load", slot, out);
+  run<6, 9>("asm store without the compiler's wait, scalar load glc", slot, out);
+  run<6, 4>("asm store without the compiler's wait, sc1 load + s_sleep 4", slot, out);
   run<0, 1>("plain store, poll by agent-scope atomic add 0 (RMW in L2)", slot, out);
   run<2, 1>("atomic exchange, poll by agent-scope atomic add 0", slot, out);
   run<0, 2>("plain store, system-scope load (sc0 sc1)", slot, out);
