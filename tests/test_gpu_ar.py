@@ -115,3 +115,34 @@ def test_dense_feedback_and_partial_teacher_forcing(name, dtype, tol):
     assert rel_err(raw.cpu(), z["raw"]) < tol
     assert rel_err(part.cpu(), z["part"]) < tol
     assert abs(float(soft[:, :, -1].sum()) - soft.shape[0]) < 1e-3        # rows are probabilities
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 1e-5), ("fp16", 1e-5)])
+@pytest.mark.parametrize("cc", [0, 64, 128, 256])
+def test_constant_size_cooperative_kernel_every_packet_count(cc, dtype, tol, monkeypatch):
+    """csrc/ar_coop.hip: ar_coop_fast_kernel<E, NU> is instantiated per number of gate-row packets a thread holds (3 / 4 for 16-bit
+    elements, 6 / 7 / 8 for fp32 -- a function of the conditioning width).  Every instantiation, and its one-hand-over-per-layer variant
+    (wae_ar_generate_coop_fused), against the one-CU kernel on the same teacher-forced inputs: the cooperative sums are exact fp32 in a
+    fixed order, so only the summation order differs (1e-7); the fused variant multiplies by host-formed, rounded products."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=6, stacks=2, R=256, G=256, S=256, O=256, Cc=cc, Cg=32, k=3, n_speakers=7, upsample_scales=None, cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=3, with_encoder=False)
+    T = 700
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randint(0, 256, (2, T), generator=gen).cuda()
+    c = torch.randn(2, cc, T, generator=gen).cuda() if cc > 0 else None
+    gid = torch.tensor([1, 4]).cuda()
+
+    def run(coop, fused):
+        monkeypatch.setenv("WAE_AR_COOP", coop)
+        monkeypatch.setenv("WAE_AR_FUSED", fused)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        out = eng.incremental_forward(c, gid, T, mode="logits", test_inputs=x, c_is_upsampled=True)
+        torch.cuda.synchronize()
+        return out["logits"].float().cpu()
+
+    one_cu = run("0", "0")
+    assert rel_err(run("1", "0"), one_cu) < tol
+    assert rel_err(run("1", "1"), one_cu) < (1e-5 if dtype == "fp32" else (2e-3 if dtype == "bf16" else 3e-4))
