@@ -462,6 +462,35 @@ int wae_gemm_tn_stream(int32_t dtype /* WAE_BF16 or WAE_F16 */, const wae_ts_job
                        const int32_t* team_seg_dev, int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T,
                        int32_t* pace, int32_t window, int32_t pace_from, void* stream);
 
+/* ---- the same launch on a static schedule (csrc/gemm_tn_static.hip; 16-bit operands; round 4) -----------------------
+ * Replaces the autograd of modules.py:134-136 (dilated conv: kind TAPS, one job per tap), :141-145 (conv1x1c + the per-clip
+ * sums of dz that feed the conv bias and conv1x1g: kind COND) and :157-160 (conv1x1_out AND conv1x1_skip, which contract the
+ * same gated activations u: kind OUTSKIP, C0[h][r] += sum u[t][h] Ghat[t][r], C1[h][s] += sum u[t][h] dS[t][s], Cb[r] += sum
+ * Ghat[t][r]) for geometries that fit one region: m_valid <= 384 (TAPS / COND) or 192 (OUTSKIP), n0_valid, n1_valid <= 256
+ * (COND: <= 64), B <= 32, every operand clip below 2^30 bytes.  Teams, segments and slab numbering as wae_gemm_tn_stream.
+ * Rows outside a clip (a tap's causal shift, T % 32 != 0) are zero-filled by the hardware through per-clip buffer
+ * descriptors; OUTSKIP's outputs are TRANSPOSED relative to the reference's weight layout (rows = gated channel h). */
+enum { WAE_TQ_TAPS = 0, WAE_TQ_COND = 1, WAE_TQ_OUTSKIP = 2 };
+typedef struct wae_tq_job {
+  const void* P;
+  const void* Q0;
+  const void* Q1;
+  float* C0;
+  float* C1;
+  float* Cb;
+  int64_t p_stride, q0_stride, q1_stride, ldc0, ldc1;
+  int32_t m_valid, n0_valid, n1_valid;
+  int32_t shift;
+  int32_t ones_col;   /* COND: column of clip 0's sums in C0 (a multiple of 32, >= n0_valid); clip b adds into ones_col + b */
+  int32_t kind;
+  float alpha;
+  int32_t pad_;
+} wae_tq_job;
+/* stamps: NULL, or (diagnostic builds, -DWAE_TQ_STAMPS) nwg x 16 x 4 int64 zeroed by the caller */
+int wae_gemm_tn_static(int32_t dtype /* WAE_BF16 or WAE_F16 */, const wae_tq_job* jobs_dev, const wae_ts_seg* segs_dev,
+                       const int32_t* team_seg_dev, int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T,
+                       int64_t* stamps, void* stream);
+
 /* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
  * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).
  * conv block: dpre = dy * [relu ? (y - (residual ? x : 0)) > 0 : 1]; dx (or NULL), dw +=, dbias += (or NULL).

@@ -49,6 +49,15 @@ class TsJob(ctypes.Structure):           # include/wae.h: wae_ts_job (device arr
                 ("m_valid", c_i32), ("n_valid", c_i32), ("shift", c_i32), ("ones_col", c_i32), ("alpha", c_f32), ("pad_", c_i32)]
 
 
+class TqJob(ctypes.Structure):           # include/wae.h: wae_tq_job (device array element of wae_gemm_tn_static)
+    _fields_ = [("P", c_vp), ("Q0", c_vp), ("Q1", c_vp), ("C0", c_vp), ("C1", c_vp), ("Cb", c_vp), ("p_stride", c_i64),
+                ("q0_stride", c_i64), ("q1_stride", c_i64), ("ldc0", c_i64), ("ldc1", c_i64), ("m_valid", c_i32), ("n0_valid", c_i32),
+                ("n1_valid", c_i32), ("shift", c_i32), ("ones_col", c_i32), ("kind", c_i32), ("alpha", c_f32), ("pad_", c_i32)]
+
+
+TQ_TAPS, TQ_COND, TQ_OUTSKIP = 0, 1, 2
+
+
 class TsSeg(ctypes.Structure):           # include/wae.h: wae_ts_seg
     _fields_ = [("job", c_i32), ("slab_begin", c_i32), ("slab_end", c_i32)]
 
@@ -108,6 +117,7 @@ SIGNATURES = {
     "wae_glu_bwd_fused_supported": (c_i32, [c_i32, c_i32]),
     "wae_glu_bwd_fused": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wae_gemm_tn_stream": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    "wae_gemm_tn_static": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_sum_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_head_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_dmol_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),

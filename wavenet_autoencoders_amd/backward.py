@@ -65,6 +65,10 @@ def _prepare_bwd(eng):
     # dense weight-gradient tiles (fp32), one allocation so a single memset clears them
     sizes = dict(c1=g.layers * 2 * g.Hp * sm["ld1"], co=g.layers * g.Rp * sm["ldo"], cs=g.Sp * sm["lds"],
                  c3=g.Op * sm["ldh"], c1h=g.Sp * sm["ldh"], ctab=P._ru(g.O, 128) * g.Rp, fb=g.Rp)
+    if static_tn_geometry(eng):
+        # wae_gemm_tn_static (kind OUTSKIP) writes dW_out / dW_skip of a layer transposed: rows = gated channel, and the out bias
+        # as one more row; the skip bias (column sums of dS, the same for every layer) comes from a small tile job
+        sizes.update(coT=g.layers * sm["ldoT_rows"] * g.Rp, csT=g.layers * g.Hp * g.Sp, cbs=g.Sp * P.ONES_PAD)
     total = sum(sizes.values())
     eng.cbuf = torch.zeros(total, dtype=torch.float32, device=dev)
     eng.cview, off = {}, 0
@@ -282,6 +286,79 @@ class StreamTable:
                 "gemm_tn_stream")
 
 
+def static_tn_geometry(eng):
+    """The static-schedule weight-gradient launch (csrc/gemm_tn_static.hip) covers geometries whose layer fits one region per job
+    kind: dz (2 Hp <= 384 columns) x x (Rp <= 256), dz x [c (Ccp = 64) | ones], u (Hp <= 192) x [Ghat (Rp) | dS (Sp <= 256)].
+    WAE_TN_STATIC=0 keeps the any-shape kernel (csrc/gemm_tn_stream.hip)."""
+    g = eng.g
+    if int(os.environ.get("WAE_TN_PACE", "0")) > 0 or os.environ.get("WAE_TN_SHARES", "teams") != "teams":
+        return False                  # the opt-in schedules (pacing, equal-time shares) belong to the any-shape kernel
+    return (eng.dt in (L.WAE_BF16, L.WAE_F16) and os.environ.get("WAE_TN_STATIC", "1") != "0" and 2 * g.Hp <= 384 and g.Rp <= 256
+            and g.Sp <= 256 and g.Hp <= 192 and g.Ccp == 64)
+
+
+def static_tn_shape(eng, B, T):
+    """... and shapes it can address: one ones column per clip inside one 32-column tile, every operand clip below 2^30 bytes
+    (the per-clip buffer descriptors carry 32-bit offsets; rows before a clip wrap to offsets beyond num_records)."""
+    g = eng.g
+    widest = max(g.layers * 2 * g.Hp, g.Ku, g.Rp, g.Sp, g.Ccp) * 2            # bytes per time row of the widest operand array
+    reach = T + (g.k - 1) * max(g.dilations) + 32
+    return static_tn_geometry(eng) and use_stream_tn(eng) and B <= 32 and reach * widest < (1 << 30)
+
+
+class StaticStreamTable:
+    """Host builder for wae_gemm_tn_static: per layer one job per dilated-conv tap (TAPS), one for conv1x1c + the per-clip sums of
+    dz (COND) and one for conv1x1_out + conv1x1_skip (OUTSKIP).  Teams and segments as StreamTable."""
+    KT = 32
+
+    def __init__(self, eng, B, T):
+        self.eng, self.B, self.T = eng, B, T
+        self.groups = []
+
+    def begin_group(self):
+        self.groups.append([])
+
+    def add(self, **kw):
+        f = dict(P=None, Q0=None, Q1=None, C0=None, C1=None, Cb=None, p_stride=0, q0_stride=0, q1_stride=0, ldc0=0, ldc1=0,
+                 m_valid=0, n0_valid=0, n1_valid=0, shift=0, ones_col=-1, kind=0, alpha=1.0, pad_=0)
+        f.update(kw)
+        assert f["shift"] <= 0 and f["m_valid"] % 8 == 0 and f["n0_valid"] % 8 == 0 and f["n1_valid"] % 8 == 0
+        self.groups[-1].append(L.TqJob(*[f[n] for n, _ in L.TqJob._fields_]))
+
+    def finalize(self):
+        eng, B, T = self.eng, self.B, self.T
+        gs = len(self.groups[0])
+        assert all(len(g) == gs for g in self.groups), "every layer must contribute the same list of jobs"
+        ncu = torch.cuda.get_device_properties(eng.device).multi_processor_count
+        spc = (T + self.KT - 1) // self.KT
+        segs, team_seg = [], [0]
+        self.team_size = gs
+        self.nteams = max(1, ncu // gs)
+        self.nwg = ncu if ncu % 8 == 0 and ncu >= self.nteams * gs else self.nteams * gs
+        total = len(self.groups) * B * spc
+        for t in range(self.nteams):
+            lo, hi = total * t // self.nteams, total * (t + 1) // self.nteams
+            while lo < hi:
+                grp = lo // (B * spc)
+                end = min(hi, (grp + 1) * B * spc)
+                segs.append(L.TsSeg(grp * gs, lo - grp * B * spc, end - grp * B * spc))
+                lo = end
+            team_seg.append(len(segs))
+        jobs = [j for g in self.groups for j in g]
+        dev = eng.device
+        self.jobs_dev = torch.frombuffer(bytearray(bytes((L.TqJob * len(jobs))(*jobs))), dtype=torch.uint8).to(dev)
+        self.segs_dev = torch.frombuffer(bytearray(bytes((L.TsSeg * len(segs))(*segs))), dtype=torch.uint8).to(dev)
+        self.team_seg_dev = torch.tensor(team_seg, dtype=torch.int32, device=dev)
+        self.stamps = None          # diagnostic builds (-DWAE_TQ_STAMPS): an int64 [nwg][8] tensor, zeroed before the launch
+        self.window = 0             # (no pacing on this path)
+        return self
+
+    def launch(self):
+        eng = self.eng
+        L.check(eng.lib.wae_gemm_tn_static(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
+                                           self.team_size, self.nwg, self.B, self.T, L.ptr(self.stamps), eng.stream()), "gemm_tn_static")
+
+
 def use_stream_tn(eng):
     """bf16 runs take every layer's weight gradients in one wae_gemm_tn_stream launch after the backward sweep (needs the
     residual-stream gradient of every layer kept); fp32 (the parity mode) keeps one wae_gemm_tn_tiles launch per layer."""
@@ -320,6 +397,28 @@ def _build_stream_table(eng, ws, fw, B, T, l0, l1):
     dzs = g.layers * Z2
     c1, co = eng.cview["c1"], eng.cview["co"]
     ia = 1.0 / eng.grad_scale
+    if static_tn_shape(eng, B, T):
+        coT, csT = eng.cview["coT"], eng.cview["csT"]
+        rows = sm["ldoT_rows"]
+        stt = StaticStreamTable(eng, B, T)
+        for l in range(l0, l1):
+            d = g.dilations[l]
+            stt.begin_group()
+            dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
+            c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
+            xl = fw["xd"][l] if "xd" in fw else fw["x"][l]      # dW1 contracts dz against the convolution's operand
+            for tap in range(g.k):
+                stt.add(kind=L.TQ_TAPS, P=dz_ptr, p_stride=dzs, m_valid=Z2, Q0=xl.data_ptr(), q0_stride=g.Rp, n0_valid=g.Rp,
+                        shift=-(g.k - 1 - tap) * d, C0=c1l + tap * g.Rp * 4, ldc0=sm["ld1"], alpha=ia)
+            stt.add(kind=L.TQ_COND, P=dz_ptr, p_stride=dzs, m_valid=Z2, Q0=fw["c_up"].data_ptr(), q0_stride=g.Ccp, n0_valid=g.Ccp,
+                    ones_col=g.Ccp, C0=c1l + g.k * g.Rp * 4, ldc0=sm["ld1"], alpha=ia)
+            has_out = l < g.layers - 1       # the last layer's x' is dead (wavenet.py:205-207): no conv1x1_out gradient
+            coTl = coT.data_ptr() + l * rows * g.Rp * 4
+            stt.add(kind=L.TQ_OUTSKIP, P=fw["u"].data_ptr() + l * g.Hp * es, p_stride=g.Ku, m_valid=g.Hp,
+                    Q0=ws["gx"][l + 1].data_ptr() if has_out else None, q0_stride=g.Rp, n0_valid=g.Rp if has_out else 0,
+                    Q1=ws["dskip"].data_ptr(), q1_stride=g.Sp, n1_valid=g.Sp, C0=coTl, ldc0=g.Rp,
+                    C1=csT.data_ptr() + l * g.Hp * g.Sp * 4, ldc1=g.Sp, Cb=(coTl + g.Hp * g.Rp * 4) if has_out else None, alpha=ia)
+        return stt.finalize()
     stt = StreamTable(eng, B, T)
     for l in range(l0, l1):
         d = g.dilations[l]
@@ -374,7 +473,10 @@ def _build_tile_tables(eng, ws, fw, B, T):
     c3, c1h, cs, ctab = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"], eng.cview["ctab"]
     tt.add(g.Op, g.Sp, 0, g.Sp, ia, ws["dy"].data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
     tt.add(g.Sp, g.Sp, 0, g.Sp, ia, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
-    tt.add(g.Sp, g.Ku, 0, g.Ku, ia, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
+    if static_tn_shape(eng, B, T):    # dW_skip of every layer rides in the static stream launch; what is left is the skip bias
+        tt.add(g.Sp, 0, 0, 0, ia, ws["dskip"].data_ptr(), g.Sp, ws["dskip"].data_ptr(), g.Sp, eng.cview["cbs"].data_ptr(), P.ONES_PAD)
+    else:
+        tt.add(g.Sp, g.Ku, 0, g.Ku, ia, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
     ws["tt_head"] = tt.finalize(B)
     tt = TileTable(eng)
     g0 = ws["gx"][0]                                    # dxhat_0 lands in gx[0 % 2]
@@ -521,20 +623,29 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         (conv bias + hoisted global conditioning, modules.py:148-152) of those layers.  Disjoint slots; the tables never move."""
         key = ("scatter_jobs", l0, l1, with_head)
         jobs = ws.get(key)
+        static = isinstance(ws["stream"], StaticStreamTable)
         if jobs is None:
             nb, ls = l1 - l0, lay.layer_stride
 
             def sjob(src, mp, rows, cols, ld, off=0, nb=1, ss=0, ds=0, unique=1, doff=0):
                 return L.ScatterJob(src.data_ptr() + off * 4, mp.data_ptr(), eng.d_eff.data_ptr() + doff * 4, rows * cols, ss, ds, ld, nb,
                                     cols, unique, 0)
-            lst = [sjob(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], off=l0 * Z2 * sm["ld1"], nb=nb, ss=Z2 * sm["ld1"], ds=ls, doff=l0 * ls),
-                   sjob(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], off=l0 * g.Rp * sm["ldo"], nb=nb, ss=g.Rp * sm["ldo"], ds=ls, doff=l0 * ls),
-                   sjob(co, sm["bo"], g.Rp, OP, sm["ldo"], off=l0 * g.Rp * sm["ldo"] + g.Hp, nb=nb, ss=g.Rp * sm["ldo"], ds=ls, unique=2,
-                        doff=l0 * ls),
-                   sjob(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=nb, ss=0, ds=ls, unique=2, doff=l0 * ls)]
+            lst = [sjob(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"], off=l0 * Z2 * sm["ld1"], nb=nb, ss=Z2 * sm["ld1"], ds=ls, doff=l0 * ls)]
+            if static:      # transposed dW_out (+ its bias row) and dW_skip blocks of the static stream launch, per layer
+                coT, csT, cbs, rows = eng.cview["coT"], eng.cview["csT"], eng.cview["cbs"], sm["ldoT_rows"]
+                lst += [sjob(coT, sm["woT"], g.Hp, g.Rp, g.Rp, off=l0 * rows * g.Rp, nb=nb, ss=rows * g.Rp, ds=ls, doff=l0 * ls),
+                        sjob(coT, sm["boT"], 1, g.Rp, g.Rp, off=l0 * rows * g.Rp + g.Hp * g.Rp, nb=nb, ss=rows * g.Rp, ds=ls, doff=l0 * ls),
+                        sjob(csT, sm["wsT"], g.Hp, g.Sp, g.Sp, off=l0 * g.Hp * g.Sp, nb=nb, ss=g.Hp * g.Sp, ds=ls, doff=l0 * ls),
+                        sjob(cbs, sm["bs"], g.Sp, OP, OP, nb=nb, ss=0, ds=ls, unique=2, doff=l0 * ls)]
+            else:
+                lst += [sjob(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], off=l0 * g.Rp * sm["ldo"], nb=nb, ss=g.Rp * sm["ldo"], ds=ls, doff=l0 * ls),
+                        sjob(co, sm["bo"], g.Rp, OP, sm["ldo"], off=l0 * g.Rp * sm["ldo"] + g.Hp, nb=nb, ss=g.Rp * sm["ldo"], ds=ls, unique=2,
+                             doff=l0 * ls),
+                        sjob(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, nb=nb, ss=0, ds=ls, unique=2, doff=l0 * ls)]
             if with_head:
-                lst += [sjob(cs, sm["ws"], g.Sp, g.Ku, sm["lds"]),
-                        sjob(c3, sm["w3"], g.Op, g.Sp, sm["ldh"]),
+                if not static:
+                    lst.append(sjob(cs, sm["ws"], g.Sp, g.Ku, sm["lds"]))
+                lst += [sjob(c3, sm["w3"], g.Op, g.Sp, sm["ldh"]),
                         sjob(c3, sm["b3"], g.Op, OP, sm["ldh"], off=g.Sp, unique=2),
                         sjob(c1h, sm["w1h"], g.Sp, g.Sp, sm["ldh"]),
                         sjob(c1h, sm["b1h"], g.Sp, OP, sm["ldh"], off=g.Sp, unique=2)]

@@ -551,6 +551,15 @@ def grad_scatter_maps(g: Geometry, lay: ParamLayout) -> dict:
     bs = lay.off("wavenet.conv_layers.0.conv1x1_skip.bias")
     rowb = np.arange(g.Sp)[:, None] + ones
     out["bs"] = np.where(rowb < g.S, bs + rowb, -1).astype(np.int32).reshape(-1)   # (Sp, ONES_PAD) ones columns, layer 0
+    # The static weight-gradient launch (csrc/gemm_tn_static.hip, kind OUTSKIP) writes dW_out and dW_skip of a layer TRANSPOSED --
+    # rows = gated channel h (Hp of them), columns = residual / skip channel -- and the out bias as ONE row behind the Hp rows.
+    hrow, rcol = np.meshgrid(np.arange(g.Hp), np.arange(g.Rp), indexing="ij")
+    out["woT"] = np.where((rcol < g.R) & (hrow < g.H), wo + rcol * g.H + hrow, -1).astype(np.int32).reshape(-1)
+    rr = np.arange(g.Rp)
+    out["boT"] = np.where(rr < g.R, bo + rr, -1).astype(np.int32)
+    out["ldoT_rows"] = g.Hp + 8               # rows of a layer's block: Hp weight rows, the bias row, padding
+    hrow, scol = np.meshgrid(np.arange(g.Hp), np.arange(g.Sp), indexing="ij")
+    out["wsT"] = np.where((scol < g.S) & (hrow < g.H), ws + scol * g.H + hrow, -1).astype(np.int32).reshape(-1)   # layer 0
     # head
     ldh = g.Sp + ONES_PAD
     row, col = np.meshgrid(np.arange(g.Op), np.arange(g.Sp), indexing="ij")
