@@ -486,10 +486,16 @@ typedef struct wae_tq_job {
   float alpha;
   int32_t pad_;
 } wae_tq_job;
-/* stamps: NULL, or (diagnostic builds, -DWAE_TQ_STAMPS) nwg x 16 x 4 int64 zeroed by the caller */
+/* stamps: NULL, or (diagnostic builds, -DWAE_TQ_STAMPS) nwg x 16 x 4 int64 zeroed by the caller.
+ * pace: nteams uint32, ZEROED by the caller before every launch (or NULL / window <= 0: no pacing): every tap member adds its
+ * request progress (in 32-row slabs; a team's share must stay below 1000 slabs) to its 10-bit field, and every TAPS / COND member
+ * requests no more than `window` slabs beyond the slowest other tap member, so that the dz half-slabs four jobs of a layer share
+ * are fetched from HBM once and found in the XCD's L2 by the others (window_cond: the bound of the COND member; negative = it stays
+ * that many slabs behind the slowest tap).  Timing only: results do not depend on it, and a wait that
+ * does not end switches it off. */
 int wae_gemm_tn_static(int32_t dtype /* WAE_BF16 or WAE_F16 */, const wae_tq_job* jobs_dev, const wae_ts_seg* segs_dev,
                        const int32_t* team_seg_dev, int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T,
-                       int64_t* stamps, void* stream);
+                       int64_t* stamps, uint32_t* pace, int32_t window, int32_t window_cond, int32_t ntaps, void* stream);
 
 /* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
  * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).

@@ -153,7 +153,8 @@ def test_stream_weight_gradients_match_per_layer_tiles(name, lengths, monkeypatc
     assert not bad, bad
 
 
-@pytest.mark.parametrize("env", [{"WAE_TN_PACE": "2"}, {"WAE_TN_PACE": "8", "WAE_TN_PACE_FROM": "1"}, {"WAE_TN_SHARES": "weighted"}])
+@pytest.mark.parametrize("env", [{"WAE_TN_PACE": "2"}, {"WAE_TN_PACE": "8", "WAE_TN_PACE_FROM": "1"}, {"WAE_TN_SHARES": "weighted"},
+                                 {"WAE_TQ_PACE": "2"}, {"WAE_TQ_PACE": "6", "WAE_TQ_PACE_COND": "-2"}])
 def test_stream_schedules_do_not_change_the_gradients(env, monkeypatch):
     """The opt-in schedules of the one weight-gradient launch (narrow jobs paced against the taps; equal-time shares instead of
     teams) are timing devices: same operands, same fp32 sums, only the arrival order of the atomics differs (1e-6 of the range)."""
@@ -166,7 +167,7 @@ def test_stream_schedules_do_not_change_the_gradients(env, monkeypatch):
     ln = torch.tensor([1280, 1280 - 137])
     got = []
     for e in ({}, env):
-        for k in ("WAE_TN_PACE", "WAE_TN_PACE_FROM", "WAE_TN_SHARES"):
+        for k in ("WAE_TN_PACE", "WAE_TN_PACE_FROM", "WAE_TN_SHARES", "WAE_TQ_PACE", "WAE_TQ_PACE_COND"):
             monkeypatch.delenv(k, raising=False)
         for k, v in e.items():
             monkeypatch.setenv(k, v)
@@ -175,7 +176,10 @@ def test_stream_schedules_do_not_change_the_gradients(env, monkeypatch):
         eng.decoder_forward(x, c_up, g, targets=x, lengths=ln.cuda(), train=True, c_is_upsampled=True, want_logits=False)
         BW.decoder_backward(eng, x, x, ln, g)
         st = BW.bwd_workspace(eng, *x.shape)["stream"]
-        assert st is not None and (st.window > 0) == ("WAE_TN_PACE" in e) and (st.team_size == 1) == ("WAE_TN_SHARES" in e)
+        if not e or "WAE_TQ_PACE" in e:   # the default: the static-schedule launch (csrc/gemm_tn_static.hip); WAE_TQ_PACE = its team pacing
+            assert isinstance(st, BW.StaticStreamTable) and (st.window > 0) == ("WAE_TQ_PACE" in e)
+        else:          # the other opt-in schedules belong to the any-shape kernel (csrc/gemm_tn_stream.hip)
+            assert isinstance(st, BW.StreamTable) and (st.window > 0) == ("WAE_TN_PACE" in e) and (st.team_size == 1) == ("WAE_TN_SHARES" in e)
         got.append(BW.finish_grads(eng).clone())
         torch.cuda.synchronize()
     err, ref = float((got[0] - got[1]).abs().max()), float(got[0].abs().max())

@@ -39,10 +39,14 @@ def main(lib):
     e1.record()
     torch.cuda.synchronize()
     s = st.stamps.cpu().numpy().reshape(-1, 16, 4)
-    member = np.arange(st.nwg)
-    if st.nwg % 8 == 0:
-        member = ((member & 7) * (st.nwg >> 3) + (member >> 3))
-    member = member % st.team_size
+    bid = np.arange(st.nwg)
+    if st.nwg % 8 == 0:      # the kernel's team map: whole teams inside an XCD, the XCDs' leftover workgroups form the last teams
+        per, ts = st.nwg >> 3, st.team_size
+        xcd, slot = bid & 7, bid >> 3
+        whole, rest = per // ts, per % ts
+        member = np.where(slot < whole * ts, slot % ts, (xcd * rest + slot - whole * ts) % ts)
+    else:
+        member = bid % st.team_size
     ok = s[:, 0, 3] > 0
     life_t, life_w = s[:, 15, 0].astype(np.float64), s[:, 15, 1].astype(np.float64)
     mhz = life_t[ok] / (life_w[ok] / 100.0)

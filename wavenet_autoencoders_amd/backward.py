@@ -349,14 +349,24 @@ class StaticStreamTable:
         self.jobs_dev = torch.frombuffer(bytearray(bytes((L.TqJob * len(jobs))(*jobs))), dtype=torch.uint8).to(dev)
         self.segs_dev = torch.frombuffer(bytearray(bytes((L.TsSeg * len(segs))(*segs))), dtype=torch.uint8).to(dev)
         self.team_seg_dev = torch.tensor(team_seg, dtype=torch.int32, device=dev)
-        self.stamps = None          # diagnostic builds (-DWAE_TQ_STAMPS): an int64 [nwg][8] tensor, zeroed before the launch
-        self.window = 0             # (no pacing on this path)
+        self.stamps = None          # diagnostic builds (-DWAE_TQ_STAMPS): an int64 [nwg][16][4] tensor, zeroed before the launch
+        # team pacing (csrc/gemm_tn_static.hip): one 32-bit word of request positions per team (three 10-bit fields, in slabs), zeroed
+        # before every launch; a team's share must stay below 1000 slabs.  WAE_TQ_PACE=<slabs>, 0 = off
+        self.ntaps = gs - 2
+        self.window = int(os.environ.get("WAE_TQ_PACE", "0"))
+        self.window_cond = int(os.environ.get("WAE_TQ_PACE_COND", str(self.window)))
+        if self.ntaps > 3 or total // self.nteams + 2 >= 1000:
+            self.window = 0
+        self.pace = torch.zeros(self.nteams, dtype=torch.int32, device=dev)
         return self
 
     def launch(self):
         eng = self.eng
+        if self.window > 0:
+            self.pace.zero_()
         L.check(eng.lib.wae_gemm_tn_static(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
-                                           self.team_size, self.nwg, self.B, self.T, L.ptr(self.stamps), eng.stream()), "gemm_tn_static")
+                                           self.team_size, self.nwg, self.B, self.T, L.ptr(self.stamps), L.ptr(self.pace), self.window,
+                                           self.window_cond, self.ntaps, eng.stream()), "gemm_tn_static")
 
 
 def use_stream_tn(eng):

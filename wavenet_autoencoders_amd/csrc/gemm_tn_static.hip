@@ -84,6 +84,12 @@ struct TqArgs {
   int nteams, team_size;
   int B, T, spc;
   long long* stamps;   // WAE_TQ_STAMPS builds: [workgroup][16][4]
+  unsigned* pace;             // [nteams] words of three 10-bit request positions (the tap members, in 32-row slabs), zeroed by the caller; or null
+  int window;                 // a paced member requests at most `window` slabs beyond the slowest other tap member (0: no pacing)
+  int ntaps;                  // members [0, ntaps) are the taps, member ntaps is COND
+  int window_cond;            // the same bound for COND (may be negative: stay that many slabs BEHIND the slowest tap, where every dz
+                              // half-slab it asks for is already in L2)
+  int dump_off;               // byte offset of a 1-KiB LDS area behind the rings (the pacing wave's filler requests land there)
 };
 
 enum { TQ_TAPS = 0, TQ_COND = 1, TQ_OUTSKIP = 2 };
@@ -107,7 +113,8 @@ template <int KIND> struct TqDer {
 
 // ---- the register bank -----------------------------------------------------------------------------------------------------------
 // v10        the offset of the request being issued
-// v[11:13]   per lane and piece: row * stride + column bytes inside a half-slab, or TQ_OOB      (set once per segment)
+// v[11:13]   per lane and piece: row * stride + column bytes inside a half-slab, or TQ_OOB      (set once per segment); the wave
+//            that paces its workgroup has one piece (v11); v12 carries its pacing atomic's data, v13 the team's word as last returned
 // v14, v15   per lane: LDS addresses of the A / B fragments being READ (they run over the ring with the slot of the next half-slab)
 // v[16:143]  the wave's accumulator tiles, tile k at v[16 + 16 k : 31 + 16 k]   (2 x 4 layout: k = 4 i + j; COND: k = 0, 1, ones)
 // v[144:167] operand fragments: A0 v[144:147], A1 v[148:151], B0..B3 v[152:167]   (COND: A0, B0, B1, ones = v[160:163])
@@ -345,8 +352,97 @@ struct TqState {
   unsigned dma_dst;                   // LDS address of this wave's first piece in the ring slot of the next request
   int rd_slot;                        // ring slot the fragments are being read from
   int cc_b, cc_run;                   // COND: clip of the contraction cursor / half-slabs left in it
+  // team pacing (the wave that carries it: tq_run<..., PACE>)
+  int rq_pos, pos_inc;                // absolute position of the next request in the team's list of half-slabs / its step (0 once dead)
+  int window;
 };
-
+// Team pacing.  The members of a team stream the same time range of one layer, and four of them read the same dz half-slabs -- but an
+// XCD's 4 MiB L2 is shared by six teams and holds about ten half-slabs of everything a team streams, while unpaced members drift
+// apart by hundreds (COND has a third of the taps' MFMA work and runs ahead; the taps drift at random): every member then fetches
+// its own copy from HBM, and HBM bytes are what bounds this launch (requests alone: 1.17 ms of 1.5).  A team has ONE 32-bit word:
+// three 10-bit fields, the request positions of the tap members in units of 32-row slabs.  Once per half-slab a paced member's
+// wave 11 issues one returning atomic add on it -- a tap adds its progress to its field, COND adds zero -- and so learns the
+// others' positions; the returned word is looked at a few half-slabs later, when the counted wait at the loop top has retired it,
+// and the wave holds its workgroup in front of the barrier while its cursor is more than `window` slabs ahead of the slowest OTHER
+// tap.  The atomic takes the place of a request in the wave's operation count (wave 11 has one piece fewer than the variant it
+// runs) and lives in the two registers that piece would use: v12 data, v13 the returned word.  Timing only: results never depend
+// on it; the slowest member never waits; a member first publishes, then waits; a wait that does not end switches pacing off.
+struct TqPace {
+  unsigned* word;   // the team's word, or null
+  int shift;        // 10 * member for a tap, -1 for COND (reads only)
+  int pub;          // position (slabs) last published by this member
+  int ntaps;
+  int next;         // request position (half-slabs) at which the next atomic is due
+  unsigned dump;    // LDS address of a 1-KiB area nobody reads: where the filler request of the other half-slabs lands
+  int dbg_holds, dbg_spins, dbg_timeouts, dbg_pos, dbg_word, dbg_tword, dbg_tpub;   // diagnostics (written to `stamps` when passed)
+};
+#define TQ_PACE_INF 1023
+__device__ __forceinline__ void tq_pace_init_ret() { asm volatile("v_mov_b32 v13, -1" : : : TQ_BANK); }   // nobody is behind, until the first word arrives
+// one returning add of this member's unpublished progress: v13 <- the word before it.  ONE lane adds (a wave-wide atomic is 64
+// adds): exec = 1 around it; v_readfirstlane reads lane 0 under full exec.
+template <bool SYNC>
+__device__ __forceinline__ void tq_pace_add(TqPace& pc, int pos_slabs) {
+  int delta = pos_slabs - pc.pub;
+  delta = __builtin_amdgcn_readfirstlane((delta > 0 && pc.shift >= 0) ? delta : 0);
+  pc.pub += delta;
+  const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)delta << (pc.shift >= 0 ? pc.shift : 0));
+  unsigned long long save;
+  if constexpr (SYNC)
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 v10, 0\n\tv_mov_b32 v12, %1\n\t"
+                 "global_atomic_add v13, v10, v12, %2 sc0\n\ts_waitcnt vmcnt(0)\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(d), "s"(pc.word) : TQ_BANK);
+  else
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 v10, 0\n\tv_mov_b32 v12, %1\n\t"
+                 "global_atomic_add v13, v10, v12, %2 sc0\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(d), "s"(pc.word) : TQ_BANK);
+}
+// Every TQ_PACE_EVERY-th half-slab only: a returning atomic stays in the wave's in-order queue for ~2.3 us under this launch's
+// traffic, longer than the ~2 us the counted wait at the loop top gives it -- one per half-slab cost 0.5 ms of 1.5.  The half-slabs
+// in between fill the operation slot with a request whose every lane is out of range: zeros into the dump area, no memory traffic.
+#define TQ_PACE_EVERY 4
+__device__ __forceinline__ void tq_pace_step(TqPace& pc, int pos) {
+  if (pos >= pc.next) {
+    pc.next = pos + TQ_PACE_EVERY;
+    tq_pace_add<false>(pc, pos >> 1);
+  } else {
+    const tq_i32x4 none = {0, 0, 0, 0x00020000};   // num_records 0: everything is out of range
+    asm volatile("s_mov_b32 m0, %1\n\tv_mov_b32 v10, 0\n\tbuffer_load_dwordx4 v10, %0, 0 offen lds" : : "s"(none), "s"(pc.dump) : "m0", TQ_BANK);
+  }
+}
+__device__ __forceinline__ int tq_pace_lead(TqPace& pc) {   // slowest OTHER tap's position in the word last returned to v13
+  unsigned w;
+  asm volatile("v_readfirstlane_b32 %0, v13" : "=s"(w) : : TQ_BANK);
+  // (a member's own field lags its cursor -- by the atomics in flight, and by a whole clip head right after the cursor has skipped
+  //  one -- and a member that holds does not publish: a lead that includes the own field can wait for itself for ever)
+  const int me = pc.shift >= 0 ? pc.shift / 10 : -1;
+  int lead = TQ_PACE_INF;
+  if (me != 0) lead = min(lead, (int)(w & 1023u));
+  if (pc.ntaps > 1 && me != 1) lead = min(lead, (int)((w >> 10) & 1023u));
+  if (pc.ntaps > 2 && me != 2) lead = min(lead, (int)((w >> 20) & 1023u));
+  pc.dbg_word = (int)w;
+  return lead;
+}
+__device__ __forceinline__ void tq_pace_hold(TqPace& pc, int pos_slabs, int& window) {
+  int lead = tq_pace_lead(pc);
+  if (pos_slabs - lead <= window) return;
+  ++pc.dbg_holds;
+  // slow path (this wave is waiting anyway; vmcnt(0) only makes the counted waits that follow stricter): first make the own
+  // position visible -- the members this one waits for may be waiting for it --, then poll (with the atomic, not a load: a load,
+  // even sc1, is served by this XCD's L2)
+  tq_pace_add<true>(pc, pos_slabs);
+  lead = tq_pace_lead(pc);
+  int spins = 0;
+  while (pos_slabs - lead > window) {
+    ++pc.dbg_spins;
+    __builtin_amdgcn_s_sleep(8);
+    tq_pace_add<true>(pc, pos_slabs);
+    lead = tq_pace_lead(pc);
+    if (++spins > 4096) {   // ~10 ms: give up pacing, never hang
+      window = 0x7fffffff; ++pc.dbg_timeouts; pc.dbg_pos = pos_slabs; pc.dbg_tword = pc.dbg_word; pc.dbg_tpub = pc.pub;
+      break;
+    }
+  }
+}
 template <int KIND>
 __device__ __forceinline__ void tq_rq_next_run(TqState<KIND>& st, const TqArgs& p, const TqJob* jp, int wave, int b, int t_start, int run) {
   using Dr = TqDer<KIND>;
@@ -374,23 +470,28 @@ template <int KIND>
 __device__ __forceinline__ void tq_rq_boundary(TqState<KIND>& st, const TqArgs& p, const TqJob* jp, int wave) {
   if (st.rq_total > 0) {   // the run of the request cursor has ended: the next clip ...
     ++st.rq_b;
+    st.rq_pos += 2 * p.spc - st.per_clip;   // the skipped slabs at the head of the next clip
     tq_rq_next_run<KIND>(st, p, jp, wave, st.rq_b, p.spc * 32 - (st.per_clip >> 1) * 32, min(st.rq_total, st.per_clip));
   } else {                 // ... or the dead state behind the segment's end: every lane out of range (zeros into the ring), forever
 #pragma unroll
     for (int j = 0; j < TqState<KIND>::PMAX; ++j) { st.ro[j] = TQ_DEAD; st.inc[j] = 0; }
     st.rq_run = 0x7fffffff;
+    st.pos_inc = 0;
   }
 }
 // timing-only ablations (tools/ablate_tq.sh; results are wrong when any bit is set): 1 no requests, 2 no MFMA / fragment streams
 #ifndef WAE_TQ_ABL
 #define WAE_TQ_ABL 0
 #endif
-template <int KIND, int NPW, int J0 = 0, int J1 = 3>
-__device__ __forceinline__ void tq_request_some(TqState<KIND>& st) {   // pieces [J0, min(J1, NPW)) of the half-slab under the request cursor
+// pieces [J0, min(J1, NPW)) of the half-slab under the request cursor; PACE: the wave's last operation is the pacing atomic
+template <int KIND, int NPW, bool PACE, int J0 = 0, int J1 = 3>
+__device__ __forceinline__ void tq_request_some(TqState<KIND>& st, TqPace& pc) {
   if constexpr (WAE_TQ_ABL & 1) return;
-  if constexpr (J0 <= 0 && 0 < J1 && NPW > 0) tq_request<0>(st.srd[0], st.ro[0], st.dma_dst);
-  if constexpr (J0 <= 1 && 1 < J1 && NPW > 1) tq_request<1>(st.srd[1], st.ro[1], st.dma_dst + TQ_NW * 1024);
-  if constexpr (J0 <= 2 && 2 < J1 && NPW > 2) tq_request<2>(st.srd[2], st.ro[2], st.dma_dst + 2 * TQ_NW * 1024);
+  constexpr int NR = PACE ? NPW - 1 : NPW;   // real requests
+  if constexpr (J0 <= 0 && 0 < J1 && NR > 0) tq_request<0>(st.srd[0], st.ro[0], st.dma_dst);
+  if constexpr (J0 <= 1 && 1 < J1 && NR > 1) tq_request<1>(st.srd[1], st.ro[1], st.dma_dst + TQ_NW * 1024);
+  if constexpr (J0 <= 2 && 2 < J1 && NR > 2) tq_request<2>(st.srd[2], st.ro[2], st.dma_dst + 2 * TQ_NW * 1024);
+  if constexpr (PACE && J0 <= NPW - 1 && NPW - 1 < J1) tq_pace_step(pc, st.rq_pos);
 }
 template <int KIND>
 __device__ __forceinline__ void tq_step_slots(TqState<KIND>& st, unsigned ring_end) {   // behind a half-slab's requests
@@ -398,12 +499,13 @@ __device__ __forceinline__ void tq_step_slots(TqState<KIND>& st, unsigned ring_e
 #pragma unroll
   for (int j = 0; j < TqState<KIND>::PMAX; ++j) st.ro[j] += st.inc[j];
   st.dma_dst = st.dma_dst + SLOT >= ring_end ? st.dma_dst - (NS - 1) * SLOT : st.dma_dst + SLOT;
+  st.rq_pos += st.pos_inc;
 }
 
 // NPW: pieces of this wave per half-slab; MODE 0: no valid tile (requests and barriers only), 1: contracts, 2: contracts + column
 // sums.  One instantiation per combination: no wave-uniform branch around the asm streams inside the loop.
-template <typename E, int KIND, int NPW, int MODE>
-__device__ __forceinline__ void tq_run(TqState<KIND>& st, const TqArgs& p, const TqJob* jp, unsigned ring_end, int wave, int lane, int nh) {
+template <typename E, int KIND, int NPW, int MODE, bool PACE = false>
+__device__ __forceinline__ void tq_run(TqState<KIND>& st, TqPace& pc, const TqArgs& p, const TqJob* jp, unsigned ring_end, int wave, int lane, int nh) {
   using G = TqGeo<KIND>;
   using Dr = TqDer<KIND>;
   constexpr bool F16 = ET<E>::DT == WAE_F16;
@@ -412,9 +514,10 @@ __device__ __forceinline__ void tq_run(TqState<KIND>& st, const TqArgs& p, const
   constexpr bool active = MODE > 0 && !(WAE_TQ_ABL & 2), bias_wave = MODE == 2;
   float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;   // MODE 2: column sums of Q0 (per lane: 8 of the 16 k of every half-slab)
   // ---- prologue: half-slabs 0 .. D-1 requested, the first one visible, its fragments requested -------------------------------
+  if constexpr (PACE) tq_pace_init_ret();
 #pragma unroll 1
   for (int h = 0; h < D; ++h) {
-    tq_request_some<KIND, NPW>(st);
+    tq_request_some<KIND, NPW, PACE>(st, pc);
     tq_step_slots<KIND>(st, ring_end);
     if (--st.rq_run == 0) tq_rq_boundary<KIND>(st, p, jp, wave);
   }
@@ -445,6 +548,7 @@ __device__ __forceinline__ void tq_run(TqState<KIND>& st, const TqArgs& p, const
       const long long s0 = tq_clock();
 #endif
       tq_wait_vm<(D - 2) * NPW>();   // this wave's pieces of the next half-slab have landed; the younger D - 2 stay in flight
+      if constexpr (PACE) tq_pace_hold(pc, st.rq_pos >> 1, st.window);
 #ifdef WAE_TQ_STAMPS
       const long long s1 = tq_clock();
 #endif
@@ -454,16 +558,30 @@ __device__ __forceinline__ void tq_run(TqState<KIND>& st, const TqArgs& p, const
 #endif
       if constexpr (KIND == TQ_COND) {
         if constexpr (active) tq_c1<F16, QP>();
-        tq_request_some<KIND, NPW>(st);
+        tq_request_some<KIND, NPW, PACE>(st, pc);
         if constexpr (active) tq_c2<F16, PP>();
       } else {
+#if defined(WAE_TQ_REQ) && WAE_TQ_REQ == 1      // experiment: every request behind the wave's last MFMA
         if constexpr (active) tq_s1<F16>();
-        tq_request_some<KIND, NPW, 0, 1>(st);
         if constexpr (active) tq_s2<F16, PP>();
-        tq_request_some<KIND, NPW, 1, 2>(st);
         if constexpr (active) tq_s3<F16, QP, bias_wave>(bs0, bs1);
-        tq_request_some<KIND, NPW, 2, 3>(st);
         if constexpr (active) tq_s4<F16, PP, QP, bias_wave>(bs2, bs3);
+        tq_request_some<KIND, NPW, PACE>(st, pc);
+#elif defined(WAE_TQ_REQ) && WAE_TQ_REQ == 2    // experiment: every request in front of the wave's first MFMA
+        tq_request_some<KIND, NPW, PACE>(st, pc);
+        if constexpr (active) tq_s1<F16>();
+        if constexpr (active) tq_s2<F16, PP>();
+        if constexpr (active) tq_s3<F16, QP, bias_wave>(bs0, bs1);
+        if constexpr (active) tq_s4<F16, PP, QP, bias_wave>(bs2, bs3);
+#else
+        if constexpr (active) tq_s1<F16>();
+        tq_request_some<KIND, NPW, PACE, 0, 1>(st, pc);
+        if constexpr (active) tq_s2<F16, PP>();
+        tq_request_some<KIND, NPW, PACE, 1, 2>(st, pc);
+        if constexpr (active) tq_s3<F16, QP, bias_wave>(bs0, bs1);
+        tq_request_some<KIND, NPW, PACE, 2, 3>(st, pc);
+        if constexpr (active) tq_s4<F16, PP, QP, bias_wave>(bs2, bs3);
+#endif
       }
       tq_step_slots<KIND>(st, ring_end);
       const bool wrap = st.rd_slot + 1 == NS;
@@ -524,7 +642,7 @@ __device__ __forceinline__ void tq_flush_tile(float* C, int ldc, int row0, int c
 
 template <typename E, int KIND>
 __device__ __forceinline__ void tq_segment(const TqArgs& p, const TqJob* jp, const int slab_begin, const int slab_end, char* smem,
-                                           const unsigned lds0, const int wave) {
+                                           const unsigned lds0, const int wave, TqPace& pc, const int pos_base) {
   using G = TqGeo<KIND>;
   using Dr = TqDer<KIND>;
   constexpr bool F16 = ET<E>::DT == WAE_F16;
@@ -600,14 +718,25 @@ __device__ __forceinline__ void tq_segment(const TqArgs& p, const TqJob* jp, con
   st.cc_b = first_b; st.cc_run = first_run;   // COND: the clip whose column the ones operand feeds
   if constexpr (KIND == TQ_COND) tq_set_ones((lane & 31) == st.cc_b ? ONES : 0u);
 
-  if (npw == PMAX) {
-    if (!active) tq_run<E, KIND, PMAX, 0>(st, p, jp, ring_end, wave, lane, nh);
-    else if (KIND == TQ_OUTSKIP && bias_wave) tq_run<E, KIND, PMAX, (KIND == TQ_OUTSKIP ? 2 : 1)>(st, p, jp, ring_end, wave, lane, nh);
-    else tq_run<E, KIND, PMAX, 1>(st, p, jp, ring_end, wave, lane, nh);
+  st.rq_pos = pos_base + 2 * (first_b * p.spc + (first_t >> 5) - slab_begin);
+  st.pos_inc = 1;
+  st.window = KIND == TQ_COND ? p.window_cond : p.window;
+  // the wave that paces its workgroup against the team: wave 11, which in TAPS / COND has one piece fewer than PMAX -- the pacing
+  // atomic fills the free slot of the PMAX variant's operation count
+  const bool pacer = KIND != TQ_OUTSKIP && PMAX == 2 && pc.word != nullptr && wave == TQ_NW - 1 && npw == PMAX - 1;
+  if (pacer) {
+    if constexpr (KIND != TQ_OUTSKIP) {
+      if (!active) tq_run<E, KIND, PMAX, 0, true>(st, pc, p, jp, ring_end, wave, lane, nh);
+      else tq_run<E, KIND, PMAX, 1, true>(st, pc, p, jp, ring_end, wave, lane, nh);
+    }
+  } else if (npw == PMAX) {
+    if (!active) tq_run<E, KIND, PMAX, 0>(st, pc, p, jp, ring_end, wave, lane, nh);
+    else if (KIND == TQ_OUTSKIP && bias_wave) tq_run<E, KIND, PMAX, (KIND == TQ_OUTSKIP ? 2 : 1)>(st, pc, p, jp, ring_end, wave, lane, nh);
+    else tq_run<E, KIND, PMAX, 1>(st, pc, p, jp, ring_end, wave, lane, nh);
   } else {
-    if (!active) tq_run<E, KIND, PMAX - 1, 0>(st, p, jp, ring_end, wave, lane, nh);
-    else if (KIND == TQ_OUTSKIP && bias_wave) tq_run<E, KIND, PMAX - 1, (KIND == TQ_OUTSKIP ? 2 : 1)>(st, p, jp, ring_end, wave, lane, nh);
-    else tq_run<E, KIND, PMAX - 1, 1>(st, p, jp, ring_end, wave, lane, nh);
+    if (!active) tq_run<E, KIND, PMAX - 1, 0>(st, pc, p, jp, ring_end, wave, lane, nh);
+    else if (KIND == TQ_OUTSKIP && bias_wave) tq_run<E, KIND, PMAX - 1, (KIND == TQ_OUTSKIP ? 2 : 1)>(st, pc, p, jp, ring_end, wave, lane, nh);
+    else tq_run<E, KIND, PMAX - 1, 1>(st, pc, p, jp, ring_end, wave, lane, nh);
   }
 
   // the fragments requested for the half-slab behind the last one, and the zero-fill requests behind the segment's end
@@ -650,17 +779,41 @@ gemm_tn_static_kernel(TqArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
-  // teams: see csrc/gemm_tn_stream.hip (members of a team land in ONE XCD; speed only)
-  int logical = blockIdx.x;
-  if ((gridDim.x & 7) == 0) logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int team = logical / p.team_size, member = logical - team * p.team_size;
+  // Teams.  Workgroups are dealt round-robin over the 8 XCDs in launch order (speed only, never correctness): workgroup b runs on
+  // XCD b & 7 as that XCD's (b >> 3)-th workgroup.  A team's members share operands through their XCD's L2, so a team is built from
+  // workgroups of ONE XCD: per XCD floor(32 / team_size) whole teams; the XCDs' leftover workgroups (2 each at team_size 5) form
+  // the last few teams across XCDs -- they do their share of the work, without the sharing.
+  int team, member;
+  bool one_xcd = false;   // the team's members share an L2
+  if ((gridDim.x & 7) == 0) {
+    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int whole = per_xcd / p.team_size, rest = per_xcd - whole * p.team_size;
+    if (slot < whole * p.team_size) {
+      team = xcd * whole + slot / p.team_size;
+      member = slot % p.team_size;
+      one_xcd = true;
+    } else {
+      const int left = xcd * rest + (slot - whole * p.team_size);
+      team = 8 * whole + left / p.team_size;
+      member = left % p.team_size;
+    }
+  } else {
+    team = blockIdx.x / p.team_size;
+    member = blockIdx.x - team * p.team_size;
+  }
   if (team >= p.nteams) return;
+  long long k_w0 = 0;   // diagnostics: start of this workgroup's life (100 MHz ticks), read only when the caller passes `stamps`
+  if (p.stamps) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k_w0) : : "memory");
 #ifdef WAE_TQ_STAMPS
   const long long k_t0 = tq_clock();
-  long long k_w0;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k_w0) : : "memory");
 #endif
   const int seg_b = p.team_seg[team], seg_e = p.team_seg[team + 1];
+  TqPace pc;
+  pc.word = (p.pace != nullptr && p.window > 0 && one_xcd && member <= p.ntaps && p.ntaps <= 3) ? p.pace + team : nullptr;
+  pc.shift = member < p.ntaps ? 10 * member : -1; pc.pub = 0; pc.ntaps = p.ntaps; pc.next = 0;
+  pc.dump = lds0 + (unsigned)p.dump_off;
+  pc.dbg_holds = pc.dbg_spins = pc.dbg_timeouts = pc.dbg_pos = pc.dbg_word = pc.dbg_tword = pc.dbg_tpub = 0;
+  int pos_base = 0;   // positions of the team's list of half-slabs: segments back to back, 2 per 32-row slab
 #pragma unroll 1
   for (int si = seg_b; si < seg_e; ++si) {
     const int* q = (const int*)(p.segs + si);
@@ -668,11 +821,30 @@ gemm_tn_static_kernel(TqArgs p) {
     const TqJob* jp = p.jobs + job0 + member;
     const int* jq = (const int*)jp;
     const int m_valid = tq_ldw(jq, 22), kind = tq_ldw(jq, 27);
-    if (m_valid <= 0) continue;   // null job
-    if (kind == TQ_TAPS) tq_segment<E, TQ_TAPS>(p, jp, slab_begin, slab_end, smem, lds0, wave);
-    else if (kind == TQ_COND) tq_segment<E, TQ_COND>(p, jp, slab_begin, slab_end, smem, lds0, wave);
-    else tq_segment<E, TQ_OUTSKIP>(p, jp, slab_begin, slab_end, smem, lds0, wave);
+    if (m_valid <= 0) { pos_base += 2 * (slab_end - slab_begin); continue; }   // null job
+    if (kind == TQ_TAPS) tq_segment<E, TQ_TAPS>(p, jp, slab_begin, slab_end, smem, lds0, wave, pc, pos_base);
+    else if (kind == TQ_COND) tq_segment<E, TQ_COND>(p, jp, slab_begin, slab_end, smem, lds0, wave, pc, pos_base);
+    else tq_segment<E, TQ_OUTSKIP>(p, jp, slab_begin, slab_end, smem, lds0, wave, pc, pos_base);
+    pos_base += 2 * (slab_end - slab_begin);
   }
+  // this member is done: its field goes to "infinitely far ahead" (nobody waits for it any more)
+  if (pc.word != nullptr && threadIdx.x == (TQ_NW - 1) * 64) {
+    if (pc.shift >= 0) __hip_atomic_fetch_add(pc.word, (unsigned)(TQ_PACE_INF - pc.pub) << pc.shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef WAE_TQ_STAMPS
+    if (p.stamps) {   // pacing diagnostics of this workgroup: [holds, spins, time-outs, position / published at the last time-out, word then]
+      long long* o = p.stamps + (long long)blockIdx.x * 8;
+      o[0] = pc.dbg_holds; o[1] = pc.dbg_spins; o[2] = pc.dbg_timeouts; o[3] = ((long long)pc.dbg_pos << 32) | (unsigned)pc.dbg_tpub; o[4] = (unsigned)pc.dbg_tword;
+    }
+#endif
+  }
+#ifndef WAE_TQ_STAMPS
+  if (p.stamps && threadIdx.x == 0) {   // [.., team, member, life in 10-ns ticks] of EVERY workgroup (tools/pace_debug.py)
+    long long* o = p.stamps + (long long)blockIdx.x * 8;
+    long long w1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1) : : "memory");
+    o[5] = team; o[6] = member; o[7] = w1 - k_w0;
+  }
+#endif
 #ifdef WAE_TQ_STAMPS
   if (p.stamps && threadIdx.x == 0) {
     long long* o = p.stamps + ((long long)blockIdx.x * 16 + 15) * 4;
@@ -685,7 +857,8 @@ gemm_tn_static_kernel(TqArgs p) {
 }
 
 extern "C" int wae_gemm_tn_static(int32_t dtype, const wae_tq_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
-                                  int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, int64_t* stamps, void* stream) {
+                                  int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, int64_t* stamps, uint32_t* pace,
+                                  int32_t window, int32_t window_cond, int32_t ntaps, void* stream) {
   WAE_REQUIRE(dtype == WAE_BF16 || dtype == WAE_F16, "gemm_tn_static: 16-bit operands only");
   WAE_REQUIRE(jobs_dev && segs_dev && team_seg_dev && nteams > 0 && team_size > 0 && nwg >= nteams * team_size && B > 0 && T > 0,
               "gemm_tn_static: bad arguments");
@@ -699,9 +872,16 @@ extern "C" int wae_gemm_tn_static(int32_t dtype, const wae_tq_job* jobs_dev, con
   a.nteams = nteams; a.team_size = team_size;
   a.B = B; a.T = T; a.spc = (T + 31) / 32;
   a.stamps = (long long*)stamps;
+  a.pace = window > 0 ? (unsigned*)pace : nullptr;
+  a.window = window;
+  a.window_cond = window_cond;
+  a.ntaps = ntaps;
   constexpr size_t lds_taps = (size_t)TqGeo<TQ_TAPS>::NS * TqDer<TQ_TAPS>::SLOT, lds_cond = (size_t)TqGeo<TQ_COND>::NS * TqDer<TQ_COND>::SLOT,
                    lds_os = (size_t)TqGeo<TQ_OUTSKIP>::NS * TqDer<TQ_OUTSKIP>::SLOT;
-  constexpr size_t lds = lds_taps > lds_os ? (lds_taps > lds_cond ? lds_taps : lds_cond) : (lds_os > lds_cond ? lds_os : lds_cond);
+  constexpr size_t lds_ring = lds_taps > lds_os ? (lds_taps > lds_cond ? lds_taps : lds_cond) : (lds_os > lds_cond ? lds_os : lds_cond);
+  constexpr size_t lds = lds_ring + 1024;   // + the dump area of the pacing wave's filler requests
+  static_assert(lds <= 160 * 1024, "LDS");
+  a.dump_off = (int)lds_ring;
   auto go = [&](auto kernel) -> int {
     static WaeLdsCache lds_cache;
     if (int rc = wae_ensure_lds((const void*)kernel, lds_cache, lds, "gemm_tn_static"); rc != WAE_OK) return rc;
