@@ -146,3 +146,38 @@ def test_constant_size_cooperative_kernel_every_packet_count(cc, dtype, tol, mon
     one_cu = run("0", "0")
     assert rel_err(run("1", "0"), one_cu) < tol
     assert rel_err(run("1", "1"), one_cu) < (1e-5 if dtype == "fp32" else (2e-3 if dtype == "bf16" else 3e-4))
+
+
+def test_decode_weights_follow_every_parameter_update():
+    """The decode weights are a derivative of the parameters (make_generation_fast_, wavenet.py:358-364): a decode after a train step
+    -- or after an averaged-weights swap and its restore, as vqwae_train.py's eval_model does -- must run on the weights of THAT
+    moment.  (Round 3 repacked them only at the first decode; every later in-training evaluation used the first one's weights.)"""
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    z = load_npz("ar_A")
+    eng = _engine(cfg, sd, "fp32")
+    eng.init_optimizer()
+    c_up = torch.from_numpy(z["c_up"]).cuda()
+    Tar = c_up.shape[-1]
+    x, g = ins["x"][:, :Tar].cuda(), ins["g"].cuda()
+
+    def decode(e):
+        out = e.incremental_forward(c_up, g, Tar, mode="logits", test_inputs=x, c_is_upsampled=True)
+        torch.cuda.synchronize()
+        return out["logits"].cpu()
+
+    first = decode(eng)
+    eng.train_step(ins["x"].cuda(), ins["c"].cuda(), g, lengths=None, lr=1e-2)
+    second = decode(eng)
+    fresh = _engine(cfg, eng.state_dict(), "fp32")
+    assert rel_err(second, decode(fresh)) < 1e-6                 # the decode after the step = a fresh pack of the updated weights
+    assert rel_err(second, first) > 1e-4                         # ... and the step did move them
+    # the averaged-weights swap of eval_model and its restore
+    saved = eng.params.clone()
+    eng.params.copy_(eng.shadow)
+    eng.weights_dirty = True
+    ema = decode(eng)
+    eng.params.copy_(saved)
+    eng.weights_dirty = True
+    assert rel_err(decode(eng), second) < 1e-6                   # restored: back to the trained weights, not the shadow's pack
+    shadow_eng = _engine(cfg, {k: v for k, v in zip(eng.lay.offsets, [eng.shadow[eng.lay.off(k):eng.lay.off(k) + eng.lay.numel(k)].view(eng.lay.shapes[k]) for k in eng.lay.offsets])}, "fp32")
+    assert rel_err(ema, decode(shadow_eng)) < 1e-6

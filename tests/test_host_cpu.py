@@ -205,7 +205,10 @@ def test_wavenet_constructor_refuses_options_it_does_not_implement():
     up = dict(upsample_scales=[4, 4], cin_channels=16)
     w = WaveNet(**base, upsample_params=dict(up, cin_pad=1, upsample_activation="none", mode="nearest", freq_axis_kernel_size=1))
     assert w.geom.cin_pad == 1 and tuple(w.state_dict()["upsample_net.conv_in.weight"].shape) == (16, 16, 3)
-    assert WaveNet(**base, upsample_params=up, cin_pad=2).geom.cin_pad == 2      # no key in upsample_params: the constructor's
+    # no key in upsample_params: ConvInUpsampleNetwork's own default 0 (upsample.py:72) -- the reference never hands WaveNet's
+    # cin_pad argument to the network (wavenet.py:151)
+    w0 = WaveNet(**base, upsample_params=up, cin_pad=2)
+    assert w0.geom.cin_pad == 0 and tuple(w0.state_dict()["upsample_net.conv_in.weight"].shape) == (16, 16, 1)
     for bad, exc in ((dict(upsample_activation="ReLU"), NotImplementedError), (dict(mode="linear"), NotImplementedError),
                      (dict(freq_axis_kernel_size=3), NotImplementedError), (dict(cin_channels=80), ValueError),
                      (dict(typo_scales=[4]), TypeError)):

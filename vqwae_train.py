@@ -253,11 +253,14 @@ def main(argv=None):
                 if rank == 0:                                                         # vqwae_train.py:862-869
                     print("Step {} [train_no_dev] Loss: {} vq: {} perp {}".format(step, float(avg[0]), float(avg[1]), float(avg[2])))
             if dev_loader is not None and step < max_steps:
-                if rank == 0 and epoch % hp.test_eval_epoch_interval == 0:                            # :838-842: once per dev epoch
+                if epoch % hp.test_eval_epoch_interval == 0:                                          # :838-842: once per dev epoch
+                    # EVERY rank draws this pass of the dev loader (its shuffle comes from one stateful generator that must stay
+                    # identical on all ranks: evaluate() below slices the same permutation); rank 0 alone decodes
                     for xd, cd, gd, ld in Prefetcher(dev_loader, device):
-                        print("[dev] Eval at train step {}".format(step))
-                        eval_model(eng, xd, cd, gd, ld, step, os.path.join(args.checkpoint_dir, "intermediate", "dev_eval"), hp,
-                                   use_ema, hop)
+                        if rank == 0:
+                            print("[dev] Eval at train step {}".format(step))
+                            eval_model(eng, xd, cd, gd, ld, step, os.path.join(args.checkpoint_dir, "intermediate", "dev_eval"), hp,
+                                       use_ema, hop)
                         break
                 dl, dvq, dperp = evaluate(eng, Prefetcher(dev_loader, device), device, hp)
                 test_step += len(dev_loader)

@@ -127,6 +127,14 @@ class CropBatcher:
         self.train, self.n_classes = train, n_classes
         self.pad_class = int(mulaw_quantize(0, n_classes - 1)) if pad_class is None else pad_class     # vqwae_train.py:509
         lengths = [n for _, n, _ in items]
+        if world > 1 and self.frames is not None and any(n < self.frames for n in lengths):
+            # Fixed-length data-parallel steps normalise the CE by world * batch * (T - 1) without a collective
+            # (distributed.step_ce_scale); a clip shorter than the crop would make ONE rank's shard ragged.  Every rank sees the
+            # whole index, so every rank fails here, together and before the first step -- not one rank mid-run with the others
+            # parked in the gradient all-reduce.  (The reference's collate keeps such clips; train with max_time_steps=None.)
+            short = sum(1 for n in lengths if n < self.frames)
+            raise ValueError(f"{short} of {len(lengths)} clips are shorter than max_time_steps ({self.frames} frames): with "
+                             "world > 1 drop them from the index or train with max_time_steps=None")
         self.sampler = SimilarLengthSampler(lengths, batch_size, seed=seed) if train else None
         self.order_rng = random.Random(seed + 1)        # dev shuffle: identical on every rank
         self.crop_rng = np.random.default_rng(seed + 7919 * (rank + 1))   # crops: a rank's own stream

@@ -94,8 +94,32 @@ class WaeEngine:
         self.w_head = torch.zeros(self.m_hw.numel(), dtype=self.tdtype, device=dev)
         self.b_head = torch.zeros(2 * g.Sp + g.Op, dtype=torch.float32, device=dev)   # [sum skip bias | b1 | b3]
         self._ws: Dict[tuple, dict] = {}
-        self.weights_dirty = True
+        self._param_gen, self._prep_gen, self._ar_gen = 1, 0, -1
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)      # sticky WAE_ERR_* bits set by the kernels (include/wae.h)
+
+    # Parameter generations.  Everything derived from the parameters -- the weight-normed arena and the fragment-packed buffers
+    # (prepare_weights), the matrix-vector layout of the autoregressive kernels (pack_ar_weights) -- remembers the generation it was
+    # made from.  `weights_dirty = True` (train_step, load_state_dict, the drop-in modules' parameter aliases, an EMA swap) starts a new
+    # generation; a stale derivative is rebuilt where it is next needed.  (Round 3 kept two independent booleans: the decode weights
+    # packed at the first in-training evaluation were reused by every later one.)
+    @property
+    def weights_dirty(self) -> bool:
+        return self._prep_gen != self._param_gen
+
+    @weights_dirty.setter
+    def weights_dirty(self, dirty: bool):
+        if dirty:
+            self._param_gen += 1
+        else:
+            self._prep_gen = self._param_gen
+
+    @property
+    def _ar_packed(self) -> bool:
+        return self._ar_gen == self._param_gen
+
+    @_ar_packed.setter
+    def _ar_packed(self, ok: bool):
+        self._ar_gen = self._param_gen if ok else -1
 
     def check_errors(self):
         """Turn the kernels' sticky id-range flags into the IndexError the reference raises on the spot (nn.Embedding for a

@@ -41,31 +41,51 @@ class _MaskedMeanFn(torch.autograd.Function):
 _ERR_WORDS = {}
 
 
+def _dev_key(device):
+    device = torch.device(device)
+    return (device.type, device.index if device.index is not None else torch.cuda.current_device())
+
+
 def _err_word(device):
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = _dev_key(device)
     if key not in _ERR_WORDS:
-        _ERR_WORDS[key] = dict(word=torch.zeros(1, dtype=torch.int32, device=device), pending=None)
+        _ERR_WORDS[key] = dict(word=torch.zeros(1, dtype=torch.int32, device=device), pending=None,
+                               host=torch.zeros(1, dtype=torch.int32).pin_memory())
     return _ERR_WORDS[key]
 
 
+def _arm(err, stream):
+    """Behind a launch that may set the sticky word: an asynchronous copy of it to pinned host memory, then an event.  Once the
+    event has fired the HOST copy is current -- reading it needs no device synchronisation (an `.item()` on the device word would
+    block the host until everything queued on that stream, the model forward included, has finished)."""
+    err["host"].copy_(err["word"], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    err["pending"] = ev
+
+
 def _raise_if_flagged(err, sync):
-    """Read the sticky word once the launch that may have set it is known to be complete (sync=False: only if its event has
-    already fired -- no host wait on the hot path)."""
+    """Look at the host copy of the sticky word once the launch that may have set it is known to be complete (sync=False: only if
+    its event has already fired -- no host wait on the hot path)."""
     ev = err["pending"]
     if ev is None or (not sync and not ev.query()):
         return
     if sync:
         ev.synchronize()
     err["pending"] = None
-    if int(err["word"].item()):
+    if int(err["host"][0]):
         err["word"].zero_()
+        err["host"].zero_()
         raise IndexError("Target out of bounds")              # what nn.CrossEntropyLoss raises
 
 
 def check_target_errors(device=None):
-    """Raise the IndexError of an earlier MaskedCrossEntropyLoss call whose targets left [0, C) (synchronises with that call)."""
+    """Raise the IndexError of an earlier MaskedCrossEntropyLoss call whose targets left [0, C) (synchronises with that call).
+    Contract: nn.CrossEntropyLoss raises on the spot; here the kernel clamps the target, computes on, and the error surfaces at the
+    next loss call or backward on that device, or when this function is called (call it before trusting the last loss of a run)."""
+    want = None if device is None else _dev_key(device)
     for key, err in list(_ERR_WORDS.items()):
-        if device is None or key == (torch.device(device).type, torch.device(device).index):
+        if want is None or key == want:
             _raise_if_flagged(err, sync=True)
 
 
@@ -85,14 +105,14 @@ class _CELogitsFn(torch.autograd.Function):
         err = _err_word(lg.device)
         _raise_if_flagged(err, sync=False)
         L.check(L.lib().wae_ce_logits_fwd(L.ptr(lg), L.ptr(tg), L.ptr(nll), L.ptr(lse), B, C, T, L.ptr(err["word"]), _stream(lg)), "ce_logits")
-        err["pending"] = torch.cuda.Event()
-        err["pending"].record(torch.cuda.current_stream(lg.device))
+        _arm(err, torch.cuda.current_stream(lg.device))
         ctx.save_for_backward(lg, tg, lse)
         return nll
 
     @staticmethod
     def backward(ctx, dnll):
         lg, tg, lse = ctx.saved_tensors
+        _raise_if_flagged(_err_word(lg.device), sync=False)      # a gradient of clamped targets is not handed on silently if known by now
         B, C, T = lg.shape
         w = dnll.contiguous().float()
         dl = torch.empty_like(lg)

@@ -119,7 +119,8 @@ class WaveNet(ArenaModel):
                                  "conv_in would not accept the features")
             scales = list(upsample_params["upsample_scales"])
             # the network's own cin_pad is the one in upsample_params (the reference ignores the constructor argument for it)
-            cin_pad = int(upsample_params.get("cin_pad", cin_pad))
+            # -- ConvInUpsampleNetwork(**upsample_params) defaults it to 0 when the key is absent (upsample.py:72)
+            cin_pad = int(upsample_params.get("cin_pad", 0))
         if kernel_size != 3:
             # kernel_size is a template constant of the layer kernels; 3 is what every preset and every parity fixture uses
             raise NotImplementedError(f"kernel_size={kernel_size}: only the reference presets' kernel_size=3 is verified against the "
