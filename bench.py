@@ -111,6 +111,25 @@ def ar_leg(device, T_ar=4000, cpu=True, full_clip=True):
            "config": "C4: hps/vqwae.json decoder (20 layers, R=G=S=256), categorical sampling, one persistent launch"}
     if full is not None:
         res["full_clip"] = full
+    # "Replicas only" (the layer chain of one sample is strictly sequential, utterances are independent): aggregate kHz of a
+    # batch of utterances on ONE GPU -- 8 utterances on the cooperative kernel (one XCD each), 256 on the one-CU kernel (one CU each)
+    batched = {}
+    for nb, Tb in ((8, 1280), (256, 640)):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=best, device=str(device))
+        eng.load_state_dict(sd)
+        gen = torch.Generator(device="cpu").manual_seed(99 + nb)
+        lat = torch.randn(nb, 64, Tb // 640, generator=gen).to(device)
+        gid = torch.arange(nb, dtype=torch.int64, device=device) % cfg["n_speakers"]
+        eng.incremental_forward(lat, gid, Tb, mode="sample")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.incremental_forward(lat, gid, Tb, mode="sample")
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        batched["%d_utterances" % nb] = {"aggregate_khz": nb * Tb / dtb / 1e3, "khz_per_utterance": Tb / dtb / 1e3, "samples_each": Tb,
+                                         "kernel": "ar_coop_fast_kernel (32 CUs of one XCD per utterance)" if nb <= 8 else
+                                                   "ar_kernel (one CU per utterance)", "dtype": best}
+    res["batched"] = batched
     if cpu:
         nthreads = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(nthreads)
@@ -214,6 +233,10 @@ def kernel_matches(name, profiler_name):
     match glu_fwd_static_z_kernel; mangled names -- _Z21gemm_tn_stream_kernelI... -- match by substring.)  The last layer's
     launch (WAE_GLU_NO_OUT: x' is dead) is a different instantiation of the same name with about 20 % less traffic; the mean over
     a name's launches is what tools/profile_round.sh stores."""
+    if name.startswith("gemm_tm_kernel:"):     # "gemm_tm_kernel:<MODE>": the per-layer backward launches are instantiations of ONE kernel
+        import re                               # template, told apart by its MODE argument (mangled: gemm_tm_kernelI<E>Li<NT>ELi<MODE>E...)
+        m = re.search(r"gemm_tm_kernelI\w+?Li(\d+)ELi(\d+)E", profiler_name) or re.search(r"gemm_tm_kernel<[^,]+, *(\d+), *(\d+)", profiler_name)
+        return bool(m) and m.group(2) == name.split(":")[1]
     for sep in ("<", "("):
         if name + sep in profiler_name:
             return True
@@ -302,6 +325,7 @@ def main():
             return out["loss"]
         eng._layer_events = ev if record else None
         eng._tn_events = ev_tn if record else None
+        eng._tm_events = ev_tm if record else None
         return eng.train_step(xi, lat, g, lengths=None, grad_sync=gsync)["loss"]
 
     def sync():
@@ -309,6 +333,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ev_tm = {"gate": [], "res": []}
     for _ in range(args.warmup):
         step()
     sync()
@@ -343,29 +368,62 @@ def main():
     roof = fwd_roof
     extra = {}
     if args.mode == "train":
-        # The kernel with the largest share of the train step is still the fused layer kernel (24 launches); in training it also
-        # saves the pre-activations: SURVEY 8(d) train bytes, forward part = (2R + 2S + Cc) + G per layer and sample.
+        # Training launch of the fused layer kernel: it also saves the pre-activations -- SURVEY 8(d) train bytes, forward part =
+        # (2R + 2S + Cc) + G per layer and sample.
         tb = (2 * C2["R"] + 2 * C2["S"] + C2["Cc"] + C2["G"]) * es * samples
-        roof = dict(fwd_roof, achieved=tb / (glu_ms * 1e-3) / 1e9, frac=tb / (glu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    algorithmic_bytes_per_launch=tb,
-                    note="training forward of one layer: SURVEY 8(d) (2R+2S+Cc+G)*e x 64000 samples (z saved for backward); "
-                         "HIP events around the 24-layer stack")
+        glu_roof = dict(fwd_roof, achieved=tb / (glu_ms * 1e-3) / 1e9, frac=tb / (glu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        algorithmic_bytes_per_launch=tb, ms_per_step=glu_ms * geom.layers,
+                        note="training forward of one layer: SURVEY 8(d) (2R+2S+Cc+G)*e x 64000 samples (z saved for backward); "
+                             "HIP events around the 24-layer stack")
+        families = {"glu_fwd_z": glu_roof}
         if ev_tn:
-            # weight gradients: bf16 = ONE gemm_tn_stream_kernel launch for all layers, fp32 = one gemm_tn_kernel per layer.
-            # algorithmic bytes = the operands each layer must read once: dz (G), x (R), c (Cc), dxhat (R), u (H)
+            # weight gradients: 16-bit = ONE launch for all layers (gemm_tn_static_kernel: dW1 taps, dWc + zb sums, dW_out AND dW_skip
+            # + the out bias), fp32 = one gemm_tn_kernel per layer.  Algorithmic bytes = the operands each layer must read once: dz
+            # (G), x (R), c (Cc), dx-hat (R), u (H); dS (S) is the same array for every layer: once per launch.
             nl = geom.layers if len(ev_tn) // args.steps == 1 else 1
             tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn)
-            tn_bytes = nl * (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) * es * samples
-            tn_flops = nl * 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H) * samples
+            static = nl > 1 and os.environ.get("WAE_TN_STATIC", "1") != "0"
+            tn_bytes = (nl * (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) + (C2["S"] if static else 0)) * es * samples
+            tn_flops = nl * 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H + (C2["S"] * H if static else 0)) * samples
             tn_gbs = tn_bytes / (tn_ms * 1e-3) / 1e9
-            extra["roofline_wgrad"] = {
-                "bound": "hbm", "kernel": "gemm_tn_stream_kernel" if nl > 1 else "gemm_tn_kernel", "achieved": tn_gbs,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tn_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": tn_ms,
+            families["wgrad"] = extra["roofline_wgrad"] = {
+                "bound": "hbm", "kernel": ("gemm_tn_static_kernel" if static else "gemm_tn_stream_kernel") if nl > 1 else "gemm_tn_kernel",
+                "achieved": tn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tn_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": tn_ms,
+                "ms_per_step": tn_ms * (1 if nl > 1 else geom.layers),
                 "algorithmic_bytes_per_launch": tn_bytes, "mfma_achieved_tflops": tn_flops / (tn_ms * 1e-3) / 1e12,
                 "mfma_frac": tn_flops / (tn_ms * 1e-3) / 1e12 / peak_tf,
-                "note": "weight gradients of %d layer(s) per launch (dW1 taps, dWc, dW_out); operands read once = "
-                        "(G+2R+Cc+H)*e per sample and layer" % nl}
+                "note": "weight gradients of %d layer(s) per launch (dW1 taps, dWc, dW_out%s); operands read once = (G+2R+Cc+H)*e per "
+                        "sample and layer%s" % (nl, ", dW_skip" if static else "", " + S*e per sample" if static else "")}
+        for kind, mode_id, kb, kf, what in (
+                ("gate", 2, (C2["R"] + C2["S"] + 2 * C2["G"]) * es, 2 * H * (C2["R"] + C2["S"]),
+                 "du/dz of one layer: reads dx-hat (R), dskip (S), the saved pre-activations (G), writes dz (G)"),
+                ("res", 1, (C2["G"] + 2 * C2["R"]) * es, 2 * C2["R"] * C2["G"] * C2["k"],
+                 "dx-hat of one layer: reads dz (G; three taps of the same rows) and dx-hat of the layer above (R), writes R")):
+            if ev_tm[kind]:
+                k_ms = sum(a.elapsed_time(b) for a, b in ev_tm[kind]) / len(ev_tm[kind])
+                per_step = len(ev_tm[kind]) / args.steps
+                gbs = kb * samples / (k_ms * 1e-3) / 1e9
+                families[kind] = extra["roofline_" + ("gate_bwd" if kind == "gate" else "residual_bwd")] = {
+                    "bound": "hbm", "kernel": "gemm_tm_kernel:%d" % mode_id, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k_ms, "ms_per_step": k_ms * per_step,
+                    "algorithmic_bytes_per_launch": kb * samples, "mfma_achieved_tflops": kf * samples / (k_ms * 1e-3) / 1e12,
+                    "mfma_frac": kf * samples / (k_ms * 1e-3) / 1e12 / peak_tf,
+                    "note": what + " -- the bytes this launch itself has to move; HIP events around every launch"}
+        # `roofline` = the launch family with the largest share of the timed step (HIP events on the launch stream decide, not a comment)
+        top = max(families, key=lambda k: families[k]["ms_per_step"])
+        roof = dict(families[top], family=top,
+                    family_ms_per_step={k: round(v["ms_per_step"], 4) for k, v in families.items()})
+        extra["roofline_glu_fwd_z"] = glu_roof
+        # the whole step against SURVEY 8(d): per sample and layer (5R + 3S + 2G + 4Cc)*e train bytes (+ head), 3 x forward FLOPs
+        step_bytes = (geom.layers * (5 * C2["R"] + 3 * C2["S"] + 2 * C2["G"] + 4 * C2["Cc"]) * es + (C2["S"] + 0) * es + 5) * samples
+        fwd_flops = (geom.layers * 2 * (C2["G"] * C2["R"] * C2["k"] + C2["G"] * C2["Cc"] + H * C2["R"] + H * C2["S"])
+                     + 2 * (C2["S"] * C2["S"] + C2["S"] * C2["O"])) * samples
+        step_s = dt / args.steps
+        extra["roofline_step"] = {"hbm_frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS, "mfma_frac": 3 * fwd_flops / step_s / 1e12 / peak_tf,
+                                  "algorithmic_bytes_per_step": step_bytes, "algorithmic_flops_per_step": 3 * fwd_flops,
+                                  "note": "SURVEY 8(d): train bytes (5R+3S+2G+4Cc)*e per sample and layer + head, 3 x forward FLOPs, over ms_per_step"}
     fwd_bytes_per_sample = geom.layers * (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es + (C2["S"] + 0) * es + 4 + 1
+    fwd_bytes_whole = geom.layers * (2 * C2["R"] + 2 * C2["S"] + C2["Cc"]) * es + (C2["S"] + C2["O"]) * es + 1      # 53 249 B (bf16)
     value = world * samples * args.steps / dt
 
     # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (bench.py cannot run the profiler
@@ -381,7 +439,7 @@ def main():
                 traffic_src = os.path.basename(fpath)
                 traffic_doc = doc
                 if args.dtype in ("bf16", "fp16") and args.mode == "train":
-                    for rf in [roof] + list(extra.values()):
+                    for rf in [roof] + [v for v in extra.values() if "kernel" in v]:
                         for k, v in doc["kernels"].items():
                             if kernel_matches(rf["kernel"], k):
                                 rf["traffic"] = v["hbm_bytes_per_launch"]
@@ -421,14 +479,16 @@ def main():
             # the same stack in inference (no z saved, no backward): the north star states its roofline target on this launch
             ev_f = []
             nf = max(3, min(10, args.steps))
+            # weight norm + packing run when the parameters change (WaeEngine tracks their generation), not per pass: an inference
+            # pass over unchanged weights is the reference after make_generation_fast_ (wavenet.py:358-364).  The TRAINING forward
+            # above recomputes them every step, like the reference's weight-norm hooks.
+            eng.prepare_weights()
             for i in range(2 + nf):
-                eng.prepare_weights()
                 eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False, layer_events=ev_f if i >= 2 else None)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(nf):
-                eng.prepare_weights()
                 eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False)
             e1.record()
             torch.cuda.synchronize()
@@ -437,6 +497,12 @@ def main():
             res["forward_inference"] = {
                 "metric": "teacher-forced audio samples/sec (24-layer decoder), forward + CE", "value": samples / (f_step * 1e-3),
                 "unit": "samples/s", "ms_per_step": f_step, "steps": nf,
+                "roofline_whole": {"bound": "hbm", "achieved": fwd_bytes_whole * samples / (f_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": fwd_bytes_whole * samples / (f_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_sample": fwd_bytes_whole,
+                                   "note": "the whole inference forward (upsample, speaker projection, first conv, 24 layers, head, fused CE; "
+                                           "weights prepared once) on SURVEY 8(d)'s forward bytes per sample; BASELINE.md derives the 30 % "
+                                           "target (<= 1.42 ms) from this figure"},
                 "roofline": {"bound": "hbm", "kernel": glu_kernel_name(args.dtype, False), "achieved": bytes_per_launch / (f_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "traffic": None, "avg_launch_ms": f_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

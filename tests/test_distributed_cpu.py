@@ -163,3 +163,42 @@ def test_gloo_world2_ragged_step_equals_the_global_batch():
         assert N == float(torch.clamp(lengths - 1, min=0).sum())
         assert np.abs(flat - want).max() < 2e-5 * np.abs(want).max()
     assert np.array_equal(res[0][1], res[1][1])     # both ranks hold the same reduced arena
+
+
+def _timing_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from wavenet_autoencoders_amd import distributed as D
+    D.init_from_env("gloo")
+    g = torch.ones(200_000, dtype=torch.float32) * (rank + 1)
+    b = D.GradBucketer(g, bucket_bytes=1 << 20, timing=True)
+    dist.barrier()
+    if rank == 1:
+        time.sleep(0.3)          # a slow peer: rank 0's collective cannot complete before rank 1 enters it
+    t0 = time.perf_counter()
+    b.ready(0)                   # hand the whole arena over
+    b.finish()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    comm_ms, wait_ms = b.collect_timing()
+    q.put((rank, comm_ms, wait_ms, wall_ms, float(g[0])))
+    dist.destroy_process_group()
+
+
+def test_reported_allreduce_time_covers_the_collective():
+    """The `allreduce.ms` bench.py reports must be first hand-over -> last collective DONE, not the gap between hand-over points:
+    with a peer that enters 0.3 s late, the fast rank's figure has to include the wait for it."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, comm0, wait0, wall0, v0), (r1, comm1, wait1, wall1, v1) = res
+    assert v0 == v1 == 1.5
+    assert comm0 >= 250.0 and comm0 <= wall0 + 1.0, (comm0, wall0)     # rank 0 waited for the slow peer, and says so
+    assert wait0 >= 250.0

@@ -584,18 +584,29 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     ck = 64 if eng.dt in (L.WAE_BF16, L.WAE_F16) else 32
     us_off = (g.Rp // ck) * g.NP * 4 * 1024   # bytes: the W_skip chunks follow the W_out chunks in the mode-2 stream
 
+    tm_ev = getattr(eng, "_tm_events", None)   # bench.py: {"gate": [(e0, e1), ...], "res": [...]} -- HIP events around every launch
+
+    def timed(kind, fn):
+        if tm_ev is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(eng.device))
+        fn()
+        e1.record(torch.cuda.current_stream(eng.device))
+        tm_ev[kind].append((e0, e1))
+
     def k_u(l, gn):                            # du -> dz of layer l
-        _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
-            eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2,
-            flags=eng.tm_flags_u)
+        timed("gate", lambda: _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
+                                  eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2,
+                                  flags=eng.tm_flags_u))
 
     seeds = getattr(eng, "_drop_seeds", None)   # set by the train-mode forward when dropout is active
 
     def k_x(l, gn, gc):                        # dx-hat of layer l
         srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
         if seeds is None:
-            _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp, gn.data_ptr(), g.Rp,
-                flags=P.TM_INTERLEAVE | eng.tm_flags_x)
+            timed("res", lambda: _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp,
+                                     gn.data_ptr(), g.Rp, flags=P.TM_INTERLEAVE | eng.tm_flags_x))
         else:
             # dropout: the tap contraction alone (mode 0), then out = sqrt(.5) * (g_next + keep * acc / (1 - p)) with the mask
             # the forward applied to this layer's convolution operand

@@ -54,8 +54,13 @@ class GradBucketer:
     it: backward.layer_segment) is a whole number of buckets.  `ready_range(lo, hi)` launches every not-yet-launched
     bucket inside [lo, hi) on the side stream -- adjacent ones as ONE collective: xGMI rings are per-link bound and reach
     their bandwidth on large messages -- `ready(lo)` is ready_range(lo, end); `finish()` launches the rest, waits, and
-    scales by 1/world.  With timing=True the collectives are bracketed by events: `last_comm_ms` (first launch -> last
-    collective done, on the side stream) and `last_wait_ms` (how long the compute stream stood still in finish())."""
+    scales by 1/world.  With timing=True the collectives are bracketed: `last_comm_ms` (first hand-over -> last collective DONE)
+    and `last_wait_ms` (how long the compute stream stood still in finish()).  On a GPU both brackets are events on the side
+    stream: ProcessGroupNCCL runs a collective on a stream of its own, which first waits for the stream that was current at the
+    call (the side stream: the start event) and which a work handle's wait() makes the THEN-current stream wait for -- so the
+    handles are waited for under the side stream before the end event is recorded there, and the compute stream then waits for
+    the side stream.  (Round 3 waited on the compute stream and recorded the end event on a side stream the collectives never
+    ran on: it measured the gap between hand-overs.)  CPU tensors (gloo, the tests): host wall clock around the same points."""
 
     def __init__(self, grads: torch.Tensor, bucket_bytes: int = 16 << 20, group=None, cuts=(), timing: bool = False):
         assert grads.dim() == 1 and grads.dtype == torch.float32
@@ -72,7 +77,9 @@ class GradBucketer:
         self.handles = []
         self.comm_stream = torch.cuda.Stream(grads.device) if grads.is_cuda else None
         self.timing = timing and grads.is_cuda
+        self.timing_host = timing and not grads.is_cuda
         self._ev = []
+        self._t0 = None
         self.last_comm_ms = self.last_wait_ms = 0.0
         self.n_collectives = 0
 
@@ -95,6 +102,9 @@ class GradBucketer:
                     self._ev.append(e)
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            if self.timing_host and self._t0 is None:
+                import time
+                self._t0 = time.perf_counter()
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _launch_runs(self, idx):
@@ -126,14 +136,24 @@ class GradBucketer:
         if self.timing and self.world > 1:
             w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             w0.record(torch.cuda.current_stream(dev))
-        for h in self.handles:
-            h.wait()
         if self.comm_stream is not None:
-            if self.timing and self._ev:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record(self.comm_stream)
-                self._ev.append(e)
+            with torch.cuda.stream(self.comm_stream):
+                for h in self.handles:      # the SIDE stream waits for the collectives' own streams ...
+                    h.wait()
+                if self.timing and self._ev:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(self.comm_stream)   # ... so this event fires when the last collective is done
+                    self._ev.append(e)
             torch.cuda.current_stream(dev).wait_stream(self.comm_stream)
+        else:
+            import time
+            tw0 = time.perf_counter()
+            for h in self.handles:
+                h.wait()
+            if self.timing_host and self._t0 is not None:
+                t1 = time.perf_counter()
+                self.last_comm_ms, self.last_wait_ms = (t1 - self._t0) * 1e3, (t1 - tw0) * 1e3
+            self._t0 = None
         if self.world > 1:
             self.grads.mul_(1.0 / self.world)
             if self.timing:
@@ -147,7 +167,7 @@ class GradBucketer:
         """(comm_ms, wait_ms) of the last finished step; synchronises the events (call outside the timed region)."""
         p = getattr(self, "_pending", None)
         if p is None:
-            return 0.0, 0.0
+            return (self.last_comm_ms, self.last_wait_ms) if self.timing_host else (0.0, 0.0)
         ev, (w0, w1) = p
         w1.synchronize()
         self.last_comm_ms = ev[0].elapsed_time(ev[-1]) if len(ev) == 2 else 0.0
