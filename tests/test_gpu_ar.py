@@ -181,3 +181,61 @@ def test_decode_weights_follow_every_parameter_update():
     assert rel_err(decode(eng), second) < 1e-6                   # restored: back to the trained weights, not the shadow's pack
     shadow_eng = _engine(cfg, {k: v for k, v in zip(eng.lay.offsets, [eng.shadow[eng.lay.off(k):eng.lay.off(k) + eng.lay.numel(k)].view(eng.lay.shapes[k]) for k in eng.lay.offsets])}, "fp32")
     assert rel_err(ema, decode(shadow_eng)) < 1e-6
+
+
+def test_long_decode_40960_steps_against_the_oracle(monkeypatch):
+    """The benchmarked autoregressive clip is 160 000 steps; parity elsewhere stops at 2 560.  Here: 40 960 teacher-forced steps of the
+    synthesis geometry (C4: 20 layers, 256 channels, dilations to 512 -- every history ring wraps 40 times or more, the cooperative
+    exchange's sequence numbers and banks 800 000 times) on the cooperative kernel in fp32 and bf16 and on the one-CU kernel, against
+    the oracle on the same inputs at EVERY step.  The oracle side is its batch forward: teacher-forced incremental decoding and the
+    batch forward are the same function (wavenet.py:218-346 vs :164-216; pinned step by step on the reference's own roll-outs in
+    tests/test_gpu_configs.py and, for the first 1 024 steps of this very input, against the oracle's incremental loop below).  A
+    free-running sampled decode of the same length is bitwise reproducible."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5], cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=11, with_encoder=False)
+    ocfg = dict(layers=20, stacks=2, upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    T = 64 * 640
+    x = ((O.hash_fill((1, T), 901) * 0.5 + 0.5) * 256).long().clamp(0, 255)         # hash-filled class ids
+    lat = O.hash_fill((1, 64, 64), 902)
+    gid = torch.tensor([5])
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        # teacher forcing feeds test_inputs[:, t] at step t (wavenet.py:300-301): the batch forward on the same sequence
+        xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+        want = O.wavenet_forward(sd, ocfg, xin, lat, gid)[0]                        # (O, T)
+        c_up = O.upsample_forward(sd, lat, cfg["upsample_scales"])[:, :, :1024].contiguous()
+        init = torch.zeros(1, 256, 1)
+        init[:, 127, 0] = 1
+        inc = O.incremental_forward(sd, ocfg, c_up, gid, 1024, initial_input=init, mode="logits",
+                                    test_inputs=torch.nn.functional.one_hot(x[:, :1024], 256).float().transpose(1, 2).contiguous())
+        inc = inc["logits"] if isinstance(inc, dict) else inc
+    assert rel_err(torch.as_tensor(inc)[0][:, :1024], want[:, :1024]) < 1e-4         # the oracle's loop == the oracle's batch forward
+
+    def decode(dtype, coop, mode="logits", **kw):
+        monkeypatch.setenv("WAE_AR_COOP", coop)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        out = eng.incremental_forward(lat.cuda(), gid.cuda(), T, mode=mode, init_idx=127, **kw)
+        torch.cuda.synchronize()
+        return out
+
+    scale = float(want.abs().max())
+    lse_w = torch.logsumexp(want, 0)
+    coop32 = decode("fp32", "1", test_inputs=x.cuda())["logits"].cpu()[0]
+    assert float((coop32 - want).abs().max()) < 1e-3 * scale                         # every logit of every one of the 40 960 steps
+    assert float((torch.logsumexp(coop32, 0) - lse_w).abs().max()) < 1e-3 * scale
+    # the last 4 096 steps on their own: an error that grows with the step count would show here first
+    assert float((coop32[:, -4096:] - want[:, -4096:]).abs().max()) < 1e-3 * scale
+    one_cu = decode("fp32", "0", test_inputs=x.cuda())["logits"].cpu()[0]
+    assert float((one_cu - want).abs().max()) < 1e-3 * scale
+    assert float((one_cu - coop32).abs().max()) < 1e-5 * scale                       # same fp32 arithmetic, another summation order
+    coop16 = decode("bf16", "1", test_inputs=x.cuda())["logits"].float().cpu()[0]
+    assert float((coop16 - want).abs().max()) < 5e-2 * scale
+    assert float((coop16[:, -4096:] - want[:, -4096:]).abs().max()) < 5e-2 * scale
+    # free-running, sampled, 40 960 steps, twice: the same bits
+    uni = torch.rand(1, T, generator=torch.Generator().manual_seed(17)).cuda()
+    a = decode("bf16", "1", mode="sample", uniforms=uni)["idx"].cpu()
+    b = decode("bf16", "1", mode="sample", uniforms=uni)["idx"].cpu()
+    assert torch.equal(a, b) and int(torch.unique(a).numel()) > 200
