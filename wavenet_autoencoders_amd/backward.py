@@ -769,6 +769,74 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     return ws["dc"]
 
 
+
+def layer_backward(eng, B, T, gx_hat, ds, gvec):
+    """Backward of ONE ResidualConv1dGLU layer (an engine of geometry layers == 1, wavenet_vocoder.modules.ResidualConv1dGLU) -- the
+    autograd of modules.py:115-163 from the same kernels the stack uses, last train-mode forward of that (B, T):
+        dz  = gate'(z) * (W_out^T gx_hat + W_skip^T ds)                   (wae_gemm_tm GATE_BWD)
+        dx  = gx_hat + sum_tap W1_tap^T dz[t + (k-1-tap) d]               (wae_gemm_tm RESIDUAL, alpha 1: the true gradient)
+        dc  = Wc^T dz                                                     (wae_gemm_tm PLAIN)
+        dW1, dWc, per-clip sums of dz, dW_out + bias, dW_skip + bias      (wae_gemm_tn_tiles), gproj / weight-norm backward
+    gx_hat (B,T,Rp) = sqrt(.5) * d loss / d x' (x' = (conv1x1_out(u) + x) sqrt(.5)), ds (B,T,Sp) = d loss / d s, both in the engine's
+    storage dtype (times eng.grad_scale for fp16).  Fills eng.grads (finish_grads) and returns (dx (B,T,Rp), dc (B,T,Ccp) | None)."""
+    _prepare_bwd(eng)
+    g, lib, lay, st, sm = eng.g, eng.lib, eng.lay, eng.stream(), eng.sm
+    assert g.layers == 1
+    fw = eng._ws[(B, T, True)]
+    es = eng.w_glu.element_size()
+    Z2 = 2 * g.Hp
+    key = ("lbwd", B, T)
+    ws = eng._ws.get(key)
+    ia = 1.0 / eng.grad_scale
+    c1, co, cs = eng.cview["c1"], eng.cview["co"], eng.cview["cs"]
+    if ws is None:
+        dev, td = eng.device, eng.tdtype
+        ws = dict(dz=torch.zeros(B, T, Z2, dtype=td, device=dev), gx=torch.zeros(B, T, g.Rp, dtype=td, device=dev),
+                  gn=torch.zeros(B, T, g.Rp, dtype=td, device=dev), dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
+                  dc=torch.zeros(B, T, max(g.Ccp, 64), dtype=td, device=dev))
+        d = g.dilations[0]
+        tt = TileTable(eng)
+        for tap in range(g.k):
+            last = tap == g.k - 1 and not g.Ccp
+            tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, ws["dz"].data_ptr(), Z2, fw["x"][0].data_ptr(), g.Rp,
+                   c1.data_ptr() + tap * g.Rp * 4, sm["ld1"])
+        if g.Ccp:
+            tt.add(Z2, g.Ccp, 0, g.Ccp, ia, ws["dz"].data_ptr(), Z2, fw["c_up"].data_ptr(), g.Ccp, c1.data_ptr() + g.k * g.Rp * 4, sm["ld1"])
+        tt.add(g.Rp, g.Hp, 0, g.Hp, ia, ws["gn"].data_ptr(), g.Rp, fw["u"].data_ptr(), g.Ku, co.data_ptr(), sm["ldo"])
+        tt.add(g.Sp, g.Ku, 0, g.Ku, ia, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
+        ws["tt"] = tt.finalize(B)
+        eng._ws[key] = ws
+    ws["gn"].copy_(gx_hat)
+    ws["dskip"].copy_(ds)
+    pack_bwd_weights(eng)
+    eng.d_eff.zero_()
+    eng.cbuf.zero_()
+    _tm(eng, B, T, g.Hp, 2, 1.0, [(ws["gn"].data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)], eng.w_bu.data_ptr(),
+        ws["dz"].data_ptr(), Z2, fw["z"][0].data_ptr(), Z2, flags=eng.tm_flags_u)
+    ws["tt"].launch(B, T)
+    srcs = [(ws["dz"].data_ptr(), Z2, Z2, (g.k - 1 - tap) * g.dilations[0]) for tap in range(g.k)]
+    _tm(eng, B, T, g.Rp, 1, 1.0, srcs, eng.w_bx.data_ptr(), ws["gx"].data_ptr(), g.Rp, ws["gn"].data_ptr(), g.Rp,
+        flags=P.TM_INTERLEAVE | eng.tm_flags_x)
+    if g.Ccp:
+        _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), Z2, Z2, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
+    OP = P.ONES_PAD
+    jobs = ws.get("scatter")
+    if jobs is None:
+        def sjob(src, mp, rows, cols, ld, off=0, unique=1):
+            return L.ScatterJob(src.data_ptr() + off * 4, mp.data_ptr(), eng.d_eff.data_ptr(), rows * cols, 0, 0, ld, 1, cols, unique, 0)
+        lst = [sjob(c1, sm["w1"], Z2, sm["ncol1"], sm["ld1"]), sjob(co, sm["wo"], g.Rp, g.Hp, sm["ldo"]),
+               sjob(co, sm["bo"], g.Rp, OP, sm["ldo"], off=g.Hp, unique=2), sjob(cs, sm["ws"], g.Sp, g.Ku, sm["lds"]),
+               sjob(cs, sm["bs"], g.Sp, OP, sm["lds"], off=g.Ku, unique=2)]
+        jobs = ws["scatter"] = (L.ScatterJob * len(lst))(*lst)
+    L.check(lib.wae_unpack_scatter_add_multi(jobs, len(jobs), st), "scatter layer gradients")
+    wg_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if (g.Cg > 0 and gvec is not None) else -1
+    L.check(lib.wae_gproj_bwd(L.ptr(eng.eff), L.ptr(eng.d_eff), wg_off, lay.off("wavenet.conv_layers.0.conv.bias"), lay.layer_stride,
+                              None, 0, L.ptr(gvec), L.ptr(c1), Z2 * sm["ld1"], sm["ld1"], g.k * g.Rp + g.Ccp, B, 1, g.G, g.Hp,
+                              max(g.Cg, 0), 0, st), "gproj_bwd")
+    eng._grads_done = None
+    finish_grads(eng)
+    return ws["gx"], (ws["dc"] if g.Ccp else None)
+
 def _debug_kernels(eng, B, T, l, flags_u=0, flags_x=0):
     """(du/dz launch, dx launch) of layer l as closures over the workspaces of the last train step (tools/ablate_tm.py,
     flags_*: extra wae_tm_desc flags (L.TM_ONE_WG)."""

@@ -1,6 +1,8 @@
 """``wavenet_vocoder.modules.ResidualConv1dGLU`` (reference modules.py:71-169) as a stand-alone layer on the fused HIP
-kernel.  Inference only: training goes through ``WaveNet`` (its autograd Function owns the whole stack)."""
+kernel, forward and backward (the reference's is an ordinary autograd module; here an autograd Function drives the kernels the
+stack's backward uses: backward.layer_backward)."""
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -10,13 +12,54 @@ from .. import packing as P
 from ._base import ArenaModel
 
 
+class _LayerFn(torch.autograd.Function):
+    """(x', s) = layer(x, c, g) with gradients for x, c and every parameter (g: a constant-over-time feature vector, no gradient)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, c, g, *params):
+        xo, so = mod._run(x, c, g, train=True)
+        eng = mod._engine
+        eng.fwd_gen = getattr(eng, "fwd_gen", 0) + 1           # the saved activations now belong to THIS forward
+        ctx.mod, ctx.gen, ctx.shape, ctx.has_c = mod, eng.fwd_gen, tuple(x.shape), c is not None
+        ctx.gvec = mod._keep[1]
+        return xo, so
+
+    @staticmethod
+    def backward(ctx, dxo, dso):
+        from .. import backward as BW
+        mod = ctx.mod
+        eng = mod._engine
+        if getattr(eng, "fwd_gen", 0) != ctx.gen:
+            raise RuntimeError("backward through a forward whose saved activations were overwritten by a later training-mode forward "
+                               "of the same layer: call backward before the next forward")
+        gm, lib, st = eng.g, eng.lib, eng.stream()
+        B, R, T = ctx.shape
+        dev = dxo.device if dxo is not None else dso.device
+        gx = torch.zeros(B, T, gm.Rp, dtype=eng.tdtype, device=dev)
+        ds = torch.zeros(B, T, gm.Sp, dtype=eng.tdtype, device=dev)
+        if dxo is not None:   # x' = (conv1x1_out(u) + x) sqrt(.5): the kernels take sqrt(.5) * d loss / d x' (backward.py: "hat")
+            L.check(lib.wae_to_btc(L.ptr((dxo.float() * (math.sqrt(0.5) * eng.grad_scale)).contiguous()), L.ptr(gx), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc dx'")
+        if dso is not None:
+            L.check(lib.wae_to_btc(L.ptr((dso.float() * eng.grad_scale).contiguous()), L.ptr(ds), B, gm.S, T, gm.Sp, eng.dt, st), "to_btc ds")
+        dx_btc, dc_btc = BW.layer_backward(eng, B, T, gx, ds, ctx.gvec)
+        dx = torch.empty(B, gm.R, T, dtype=torch.float32, device=dev)
+        L.check(lib.wae_from_btc_scaled(L.ptr(dx_btc), L.ptr(dx), B, gm.R, T, gm.Rp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc dx")
+        dc = None
+        if ctx.has_c and dc_btc is not None:
+            dc = torch.empty(B, gm.Cc, T, dtype=torch.float32, device=dev)
+            L.check(lib.wae_from_btc_scaled(L.ptr(dc_btc), L.ptr(dc), B, gm.Cc, T, gm.Ccp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc dc")
+        _, views = mod._grad_views(eng)
+        return (None, dx, dc, None) + tuple(v.clone() for v in views)
+
+
 class ResidualConv1dGLU(ArenaModel):
     """x' , s = layer(x, c, g):  z = conv_dilated(x) + conv1x1c(c) + conv1x1g(g); u = tanh(z_a) * sigmoid(z_b);
     s = conv1x1_skip(u); x' = (conv1x1_out(u) + x) * sqrt(.5)   (modules.py:115-163).
 
     Same constructor as the reference (modules.py:71-75).  Supported: causal=True, bias=True (what the reference's WaveNet builds,
     wavenet.py:127-134), any dropout in eval mode and dropout 0 in train mode, global features constant over time (the reference expands one
-    speaker vector, wavenet.py:185-194)."""
+    speaker vector, wavenet.py:185-194).  Trainable: gradients for x, c and every parameter (weight_g / weight_v / bias of conv,
+    conv1x1c, conv1x1g, conv1x1_out, conv1x1_skip) through ``_LayerFn``."""
 
     def __init__(self, residual_channels, gate_channels, kernel_size, skip_out_channels=None, cin_channels=-1, gin_channels=-1,
                  dropout=1 - 0.95, padding=None, dilation=1, causal=True, bias=True, *args, **kwargs):
@@ -37,7 +80,7 @@ class ResidualConv1dGLU(ArenaModel):
         self._skip_w = None
 
     # ------------------------------------------------------------------ kernels
-    def _run(self, x, c, g):
+    def _run(self, x, c, g, train=False):
         if self.training and self.dropout > 0:
             raise NotImplementedError(f"training-mode forward with dropout={self.dropout} is not implemented (every preset uses 0.0; "
                                       "eval mode is exact for any value): pass dropout=0.0 or call .eval()")
@@ -46,7 +89,7 @@ class ResidualConv1dGLU(ArenaModel):
         B, R, T = x.shape
         assert R == gm.R, f"x has {R} channels, the layer {gm.R}"
         eng.prepare_weights()
-        ws = eng.workspace(B, T, False)
+        ws = eng.workspace(B, T, train)
         L.check(lib.wae_to_btc(L.ptr(x.contiguous().float()), L.ptr(ws["x"][0]), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc x")
         if gm.Ccp:
             if c is None or c.shape[-1] != T:
@@ -63,9 +106,10 @@ class ResidualConv1dGLU(ArenaModel):
                                   st),
                 "gproj")
         ws["u"].zero_()
-        d = L.GluDesc(eng.dt, B, T, gm.Rp, gm.Ccp, gm.Hp, gm.k, self.dilation, 0)
+        d = L.GluDesc(eng.dt, B, T, gm.Rp, gm.Ccp, gm.Hp, gm.k, self.dilation, L.GLU_SAVE_Z if train else 0)
         L.check(lib.wae_glu_layer_fwd(ctypes.byref(d), L.ptr(ws["x"][0]), L.ptr(ws["x"][1]), L.ptr(ws["c_up"]), L.ptr(ws["u"]), gm.Ku,
-                                      L.ptr(ws["zb"]), 2 * gm.Hp, None, L.ptr(eng.w_glu), L.ptr(eng.b_glu), st), "glu layer")
+                                      L.ptr(ws["zb"]), 2 * gm.Hp, L.ptr(ws["z"][0]) if train else None, L.ptr(eng.w_glu), L.ptr(eng.b_glu),
+                                      st), "glu layer")
         # skip output: s = W_skip u + b as one time-major GEMM over the layer's gated activations
         if self._skip_w is None or self._skip_w[0] is not eng:
             lay = eng.lay
@@ -93,16 +137,14 @@ class ResidualConv1dGLU(ArenaModel):
     # ------------------------------------------------------------------ reference API
     def forward(self, x, c=None, g=None):
         """x (B, R, T), c (B, Cc, T), g (B, Cg, T) -> (x' (B, R, T), s (B, S, T))   (modules.py:109-110)."""
-        # The stand-alone layer is an INFERENCE module here: its outputs carry no autograd graph (the reference's is an ordinary
-        # nn.Module; training the decoder goes through WaveNet / VQVAE, whose backward is the engine's).  A call that expects
-        # gradients -- an input that requires one, or train mode with trainable parameters under enabled autograd -- is refused
-        # instead of returning detached tensors that would silently train nothing.
         if torch.is_grad_enabled():
-            wants = any(t is not None and t.requires_grad for t in (x, c, g))
-            if wants or (self.training and any(p.requires_grad for p in self.parameters())):
-                raise NotImplementedError("ResidualConv1dGLU is inference-only in this build (no backward): call it under "
-                                          "torch.no_grad() / in eval() mode with inputs that do not require gradients, or train "
-                                          "through wavenet_vocoder.WaveNet")
+            params = [p for _, p in sorted(((n, p) for n, p in self.named_parameters()), key=lambda kv: self._pnames.index(kv[0]))]
+            wants = any(t is not None and t.requires_grad for t in (x, c)) or any(p.requires_grad for p in params)
+            if g is not None and g.requires_grad:
+                raise NotImplementedError("no gradient with respect to the global features g (a constant-over-time vector here); "
+                                          "detach it, or train through wavenet_vocoder.WaveNet (speaker embedding)")
+            if wants:
+                return _LayerFn.apply(self, x, c, g, *params)
         with torch.no_grad():
             return self._run(x, c, g)
 
