@@ -57,7 +57,8 @@ const char* wae_last_error(void);
 
 /* ---- K14 weight norm (modules.py:18, upsample.py:44): w = g * v / ||v|| per output row --------------
  * Parameters live in one flat fp32 arena.  eff <- copy of params, then for every weight-normed row r:
- * eff[v_off[r] .. +cols[r]) = params[g_off[r]] * v / ||v||.  Tables are int64 device arrays of nrows. */
+ * eff[v_off[r] .. +cols[r]) = params[g_off[r]] * v / ||v||.  Tables are int64 device arrays of nrows, rows SORTED by v_off and
+ * not overlapping (the kernels copy what lies between consecutive rows through instead of copying the whole arena first). */
 int wae_weight_norm_fwd(const float* params, float* eff, int64_t n_params, const int64_t* v_off,
                         const int64_t* g_off, const int32_t* cols, int32_t nrows, void* stream);
 /* backward: given d_eff (grad wrt effective weights, same layout) accumulate into grads:
@@ -164,6 +165,11 @@ int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int64_t bias_o
  * table (1,Rp). */
 int wae_first_conv_fwd(const int32_t* idx, const float* xs, const float* table, const float* bias, void* x0,
                        int64_t BT, int32_t Rp, int32_t O, int32_t dtype, int32_t* err, void* stream);
+
+/* One-hot rows of the class ids: out (n, width) dtype, out[i][ids[i]] = 1 (ids outside [0, width): a zero row).  The operand that
+ * turns the first conv's weight gradient (autograd of wavenet.py:203: dW[:, class] = sum of dx0 rows whose input is `class`) into a
+ * P^T Q contraction of wae_gemm_tn_static. */
+int wae_onehot_rows(const int32_t* ids, void* out, int64_t n, int32_t width, int32_t dtype, void* stream);
 
 /* Ids that index tables (class ids -> first-conv table / targets, speaker ids -> embedding rows): the reference raises
  * IndexError (nn.Embedding, wavenet.py:185-190; one-hot encoding, vqwae_train.py:511).  The kernels clamp an id outside its

@@ -306,6 +306,15 @@ def static_tn_shape(eng, B, T):
     return static_tn_geometry(eng) and use_stream_tn(eng) and B <= 32 and reach * widest < (1 << 30)
 
 
+def static_head(eng, B, T):
+    """The head's weight gradients (dW3 = dy^T h1, dW1 = dh1^T h0, their biases = column sums of dy / dh1) and -- class-id input -- the
+    first conv's (onehot^T dx0) ride in the static launch as one more group of jobs when they fit its regions (P <= 384 columns,
+    Q <= 256) and a layer has at least five jobs (k >= 3); otherwise they stay on the 128 x 128 tile launches (csrc/gemm_tn.hip)."""
+    g = eng.g
+    return (static_tn_shape(eng, B, T) and not eng.wide_head and g.k >= 3 and g.Op <= 384 and g.Sp <= 256 and P._ru(g.O, 128) <= 384
+            and os.environ.get("WAE_TN_STATIC_HEAD", "1") != "0")
+
+
 class StaticStreamTable:
     """Host builder for wae_gemm_tn_static: per layer one job per dilated-conv tap (TAPS), one for conv1x1c + the per-clip sums of
     dz (COND) and one for conv1x1_out + conv1x1_skip (OUTSKIP).  Teams and segments as StreamTable."""
@@ -390,6 +399,8 @@ def bwd_workspace(eng, B, T):
                   dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
                   dc=torch.zeros(B, T, max(g.Ccp, 64), dtype=td, device=dev),
                   ids=torch.zeros(B, T, dtype=torch.int32, device=dev),
+                  onehot=(torch.zeros(B, T, P._ru(g.O, 128), dtype=td, device=dev)
+                          if static_head(eng, B, T) and not g.scalar_input else None),
                   # scalar input (first_conv is a 1x1 on one channel): operand [x | 1 | 0 ...] of its weight/bias gradient
                   xs1=torch.zeros(B, T, 64, dtype=td, device=dev) if g.scalar_input else None)
         _build_tile_tables(eng, ws, eng._ws[(B, T, True)], B, T)
@@ -424,10 +435,42 @@ def _build_stream_table(eng, ws, fw, B, T, l0, l1):
                     ones_col=g.Ccp, C0=c1l + g.k * g.Rp * 4, ldc0=sm["ld1"], alpha=ia)
             has_out = l < g.layers - 1       # the last layer's x' is dead (wavenet.py:205-207): no conv1x1_out gradient
             coTl = coT.data_ptr() + l * rows * g.Rp * 4
-            stt.add(kind=L.TQ_OUTSKIP, P=fw["u"].data_ptr() + l * g.Hp * es, p_stride=g.Ku, m_valid=g.Hp,
-                    Q0=ws["gx"][l + 1].data_ptr() if has_out else None, q0_stride=g.Rp, n0_valid=g.Rp if has_out else 0,
-                    Q1=ws["dskip"].data_ptr(), q1_stride=g.Sp, n1_valid=g.Sp, C0=coTl, ldc0=g.Rp,
-                    C1=csT.data_ptr() + l * g.Hp * g.Sp * 4, ldc1=g.Sp, Cb=(coTl + g.Hp * g.Rp * 4) if has_out else None, alpha=ia)
+            csTl = csT.data_ptr() + l * g.Hp * g.Sp * 4
+            if has_out:
+                stt.add(kind=L.TQ_OUTSKIP, P=fw["u"].data_ptr() + l * g.Hp * es, p_stride=g.Ku, m_valid=g.Hp,
+                        Q0=ws["gx"][l + 1].data_ptr(), q0_stride=g.Rp, n0_valid=g.Rp, Q1=ws["dskip"].data_ptr(), q1_stride=g.Sp,
+                        n1_valid=g.Sp, C0=coTl, ldc0=g.Rp, C1=csTl, ldc1=g.Sp, Cb=coTl + g.Hp * g.Rp * 4, alpha=ia)
+            else:
+                # ... which frees the job's first operand: dS takes its place, and the column sums the kernel forms of that operand
+                # are the skip bias gradient (the same for every layer, modules.py:157-160)
+                stt.add(kind=L.TQ_OUTSKIP, P=fw["u"].data_ptr() + l * g.Hp * es, p_stride=g.Ku, m_valid=g.Hp,
+                        Q0=ws["dskip"].data_ptr(), q0_stride=g.Sp, n0_valid=g.Sp, C0=csTl, ldc0=g.Sp,
+                        Cb=eng.cview["cbs"].data_ptr(), alpha=ia)
+        if static_head(eng, B, T):
+            gs = g.k + 2
+            first = None
+            if not g.scalar_input and l0 == 0:
+                W1 = P._ru(g.O, 128)
+                first = dict(kind=L.TQ_TAPS, P=ws["onehot"].data_ptr(), p_stride=W1, m_valid=W1, Q0=ws["gx"][0].data_ptr(),
+                             q0_stride=g.Rp, n0_valid=g.Rp, C0=eng.cview["ctab"].data_ptr(), ldc0=g.Rp, alpha=ia / RS)
+            if l1 == g.layers:
+                # the head: two contractions and two column-sum jobs (kind COND without a Q operand: per-clip sums of P's columns,
+                # the layout the ones columns of the tile launches had); the first conv's takes the free third slot
+                c3, c1h = eng.cview["c3"].data_ptr(), eng.cview["c1h"].data_ptr()
+                dy, dh1 = ws["dy"].data_ptr(), ws["dh1"].data_ptr()
+                grp = [dict(kind=L.TQ_TAPS, P=dy, p_stride=g.Op, m_valid=g.Op, Q0=fw["h1"].data_ptr(), q0_stride=g.Sp, n0_valid=g.Sp,
+                            C0=c3, ldc0=sm["ldh"], alpha=ia),
+                       dict(kind=L.TQ_TAPS, P=dh1, p_stride=g.Sp, m_valid=g.Sp, Q0=fw["h0"].data_ptr(), q0_stride=g.Sp, n0_valid=g.Sp,
+                            C0=c1h, ldc0=sm["ldh"], alpha=ia)]
+                grp += [first or {}] + [{}] * (gs - 5)
+                grp += [dict(kind=L.TQ_COND, P=dy, p_stride=g.Op, m_valid=g.Op, ones_col=g.Sp, C0=c3, ldc0=sm["ldh"], alpha=ia),
+                        dict(kind=L.TQ_COND, P=dh1, p_stride=g.Sp, m_valid=g.Sp, ones_col=g.Sp, C0=c1h, ldc0=sm["ldh"], alpha=ia)]
+            else:
+                grp = ([first] + [{}] * (gs - 1)) if first else []
+            if grp:
+                stt.begin_group()
+                for j in grp:
+                    stt.add(**j)
         return stt.finalize()
     stt = StreamTable(eng, B, T)
     for l in range(l0, l1):
@@ -481,13 +524,16 @@ def _build_tile_tables(eng, ws, fw, B, T):
         ws["tt_layer"].append(tt.finalize(B))
     tt = TileTable(eng)
     c3, c1h, cs, ctab = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"], eng.cview["ctab"]
-    tt.add(g.Op, g.Sp, 0, g.Sp, ia, ws["dy"].data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
-    tt.add(g.Sp, g.Sp, 0, g.Sp, ia, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
-    if static_tn_shape(eng, B, T):    # dW_skip of every layer rides in the static stream launch; what is left is the skip bias
-        tt.add(g.Sp, 0, 0, 0, ia, ws["dskip"].data_ptr(), g.Sp, ws["dskip"].data_ptr(), g.Sp, eng.cview["cbs"].data_ptr(), P.ONES_PAD)
-    else:
+    ws["tt_head"] = ws["tt_first"] = None
+    if not static_head(eng, B, T):
+        tt.add(g.Op, g.Sp, 0, g.Sp, ia, ws["dy"].data_ptr(), g.Op, fw["h1"].data_ptr(), g.Sp, c3.data_ptr(), sm["ldh"])
+        tt.add(g.Sp, g.Sp, 0, g.Sp, ia, ws["dh1"].data_ptr(), g.Sp, fw["h0"].data_ptr(), g.Sp, c1h.data_ptr(), sm["ldh"])
+    if not static_tn_shape(eng, B, T):    # (static: dW_skip of every layer and the skip bias ride in the stream launch)
         tt.add(g.Sp, g.Ku, 0, g.Ku, ia, ws["dskip"].data_ptr(), g.Sp, fw["u"].data_ptr(), g.Ku, cs.data_ptr(), sm["lds"])
-    ws["tt_head"] = tt.finalize(B)
+    if tt.tiles:
+        ws["tt_head"] = tt.finalize(B)
+    if static_head(eng, B, T) and not g.scalar_input:
+        return
     tt = TileTable(eng)
     g0 = ws["gx"][0]                                    # dxhat_0 lands in gx[0 % 2]
     if g.scalar_input:     # rows 0 / 1 of the tile = d weight / d bias:  sum_t [x[t] | 1] (x) dx0[t]
@@ -573,7 +619,10 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         if ext_dy is not None:
             ws["dy"].copy_(ext_dy)                # the tile table points at ws["dy"]
     c3, c1h, cs = eng.cview["c3"], eng.cview["c1h"], eng.cview["cs"]
-    ws["tt_head"].launch(B, T)
+    if ws["tt_head"] is not None:
+        ws["tt_head"].launch(B, T)
+    if ws["onehot"] is not None:        # operand of the first conv's weight gradient (a job of the stream launch)
+        L.check(lib.wae_onehot_rows(L.ptr(xi), L.ptr(ws["onehot"]), B * T, ws["onehot"].shape[-1], eng.dt, st), "onehot_rows")
 
     # ---- gated stack, last layer first ---------------------------------------------------------------------------
     Z2 = 2 * g.Hp
@@ -657,7 +706,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
                 lst += [sjob(coT, sm["woT"], g.Hp, g.Rp, g.Rp, off=l0 * rows * g.Rp, nb=nb, ss=rows * g.Rp, ds=ls, doff=l0 * ls),
                         sjob(coT, sm["boT"], 1, g.Rp, g.Rp, off=l0 * rows * g.Rp + g.Hp * g.Rp, nb=nb, ss=rows * g.Rp, ds=ls, doff=l0 * ls),
                         sjob(csT, sm["wsT"], g.Hp, g.Sp, g.Sp, off=l0 * g.Hp * g.Sp, nb=nb, ss=g.Hp * g.Sp, ds=ls, doff=l0 * ls),
-                        sjob(cbs, sm["bs"], g.Sp, OP, OP, nb=nb, ss=0, ds=ls, unique=2, doff=l0 * ls)]
+                        sjob(cbs, sm["bsT"], 1, g.Sp, g.Sp, nb=nb, ss=0, ds=ls, doff=l0 * ls)]
             else:
                 lst += [sjob(co, sm["wo"], g.Rp, g.Hp, sm["ldo"], off=l0 * g.Rp * sm["ldo"], nb=nb, ss=g.Rp * sm["ldo"], ds=ls, doff=l0 * ls),
                         sjob(co, sm["bo"], g.Rp, OP, sm["ldo"], off=l0 * g.Rp * sm["ldo"] + g.Hp, nb=nb, ss=g.Rp * sm["ldo"], ds=ls, unique=2,
@@ -755,8 +804,9 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         ws["tt_first"].launch(B, T)
         fb.copy_(ctab[g.Rp:2 * g.Rp])            # row 1: bias gradient; row 0 (weight) is scattered below
     else:
-        ws["ids"].copy_(xi)
-        ws["tt_first"].launch(B, T)
+        if ws["tt_first"] is not None:
+            ws["ids"].copy_(xi)
+            ws["tt_first"].launch(B, T)
         L.check(lib.wae_sum_rows(L.ptr(ctab), 0, g.Rp, g.O, g.Rp, g.Rp, L.ptr(fb), st), "first bias grad")
     jobs = ws.get("scatter_jobs_first")
     if jobs is None:

@@ -667,7 +667,8 @@ __device__ __forceinline__ void tq_segment(const TqArgs& p, const TqJob* jp, con
   int first_b, first_t, first_run;
   {
     const TqJobS jb = tq_load_job(jp);
-    active = wm < jb.m_valid && wnl < tq_sel3(qsub, jb.n0_valid, jb.n1_valid, 0);
+    // (COND: a wave's third tile -- the per-clip sums of its 32 P columns -- is always wanted: n0_valid = 0 makes a column-sum job)
+    active = wm < jb.m_valid && (KIND == TQ_COND || wnl < tq_sel3(qsub, jb.n0_valid, jb.n1_valid, 0));
 #ifdef WAE_TQ_NOBIAS   // timing experiment: no column sums (the out bias gradient is then missing)
     bias_wave = false;
 #else

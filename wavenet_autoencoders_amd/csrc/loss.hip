@@ -134,8 +134,19 @@ extern "C" int wae_dmol_sample(const float* y, const float* u_mix, const float* 
 //                           shadow -= (1-decay)*(shadow - p)
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) grad_sqnorm_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ acc) {
+  // four 16-byte loads in flight per thread (one at a time ran at 1.3 TB/s: 31 us for the 42 MB arena of C2)
   double s = 0.0;
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (; i + 3 * stride + 3 < n; i += 4 * stride) {
+    const f32x4 a = *(const f32x4*)(g + i), b = *(const f32x4*)(g + i + stride), c = *(const f32x4*)(g + i + 2 * stride),
+                d = *(const f32x4*)(g + i + 3 * stride);
+    s += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    s += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
+    s += (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)c.w * c.w;
+    s += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
+  }
+  for (; i < n; i += stride) {
     if (i + 3 < n) {
       const f32x4 v = *(const f32x4*)(g + i);
       s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -189,7 +200,7 @@ extern "C" int wae_clip_adam_ema(float* params, const float* grads, float* exp_a
     wae_set_error("clip_adam_ema: memset failed");
     return WAE_EHIP;
   }
-  const int grid = (int)((n + 1023) / 1024 > 2048 ? 2048 : (n + 1023) / 1024);
+  const int grid = (int)((n + 1023) / 1024 > 1024 ? 1024 : (n + 1023) / 1024);
   hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, st, grads, n, scratch);
   // scalars are formed in double on the host exactly as torch.optim.Adam forms them, then rounded once to fp32
   const double bc1 = 1.0 - pow(beta1, (double)step);

@@ -46,64 +46,180 @@ template <>
 __device__ __forceinline__ float load_e<f16>(const void* p, int64_t i) { return (float)((const f16*)p)[i]; }
 
 // ---------------------------------------------------------------------------------------------------
-// weight norm: one wave per weight row (modules.py:18: w = g * v / ||v||, norm over all dims but 0)
+// weight norm: one wave per weight row (modules.py:18: w = g * v / ||v||, norm over all dims but 0).
+// Rows are sorted by v_off and do not overlap; everything between them (biases, the g scalars, embeddings) is copied through by the
+// wave of the row in front of the gap (wave "-1" takes the head of the range), so the arena is touched once -- the first form copied
+// the whole arena with hipMemcpyAsync and then rewrote ~99 % of it.  Rows of up to 1024 aligned floats stay in registers between
+// the norm and the scale (four 16-byte loads in flight per lane).
 // ---------------------------------------------------------------------------------------------------
+#define WN_GAPS 1
+#define WN_ROWS 2
+// What these launches cost is latency, not bytes: 40 000 rows of 64..768 floats, each a table lookup, a read and a write that depend
+// on one another, against ~2.5 us per trip to HBM.  One row per wave keeps 256 B..3 KiB in flight per wave -- with the chip's 8192
+// resident waves that is ~0.8 TB/s (72 us for the arena of C2).  So a row belongs to a 16-lane GROUP (four rows per wave, 16 per
+// workgroup), every lane issues all its 16-byte loads (up to 16: rows of up to 1024 floats) before the first use, and the norm is a
+// 4-step butterfly inside the group.
+#define WN_KMAX 16
+__device__ __forceinline__ bool wn_vec_ok(const float* a, const float* b, const float* c, int n) {
+  return n >= 4 && n <= 64 * WN_KMAX && (n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+// the whole workgroup copies [a, b): four loads in flight per thread (the largest gap of C2 -- the speaker embedding and the upsampling
+// network, 14 000 floats -- copied by ONE 16-lane group, a load and a store per trip, was a 160-us tail on a 30-us launch)
+__device__ __forceinline__ void wn_block_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t a, int64_t b) {
+  for (int64_t i = a + threadIdx.x; i < b; i += 1024) {
+    const int64_t i1 = i + 256, i2 = i + 512, i3 = i + 768;
+    const float x0 = src[i], x1 = i1 < b ? src[i1] : 0.f, x2 = i2 < b ? src[i2] : 0.f, x3 = i3 < b ? src[i3] : 0.f;
+    dst[i] = x0;
+    if (i1 < b) dst[i1] = x1;
+    if (i2 < b) dst[i2] = x2;
+    if (i3 < b) dst[i3] = x3;
+  }
+}
+__device__ __forceinline__ float wn_dot(const f32x4& a, const f32x4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float wn_group_sum(float x) {   // over the 16 lanes of a group
+  x += __shfl_xor(x, 1);
+  x += __shfl_xor(x, 2);
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 8);
+  return x;
+}
+
 __global__ void __launch_bounds__(256) weight_norm_fwd_kernel(const float* __restrict__ params, float* __restrict__ eff,
                                                               const int64_t* __restrict__ v_off,
                                                               const int64_t* __restrict__ g_off,
-                                                              const int32_t* __restrict__ cols, int nrows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= nrows) return;
-  const float* v = params + v_off[row];
-  const int n = cols[row];
+                                                              const int32_t* __restrict__ cols, int nrows, int64_t lo, int64_t hi) {
+  __shared__ int64_t s_ga[16], s_gb[16];
+  const int grp = threadIdx.x >> 4;
+  const int row = blockIdx.x * 16 + grp - 1;   // -1: the head of the range
+  const int l = threadIdx.x & 15;
+  if (nrows == 0) { if (blockIdx.x == 0) wn_block_copy(params, eff, lo, hi); return; }
+  const int rc = min(max(row, 0), nrows - 1), rn = min(row + 1, nrows - 1);
+  const int64_t vo = v_off[rc], von = v_off[rn], go = g_off[rc];
+  const int n = cols[rc];
+  // what lies between this row and the next (biases, g, embeddings) passes through unchanged: the workgroup copies its 16 gaps together
+  if (l == 0) {
+    const bool live = row < nrows;
+    s_ga[grp] = live ? (row < 0 ? lo : vo + n) : 0;
+    s_gb[grp] = live ? (row + 1 < nrows ? von : hi) : 0;
+  }
+  __syncthreads();
+  for (int k = 0; k < 16; ++k)
+    if (s_gb[k] > s_ga[k]) wn_block_copy(params, eff, s_ga[k], s_gb[k]);
+  if (row < 0 || row >= nrows) return;
+  const float* v = params + vo;
+  float* w = eff + vo;
+  const float gsc = params[go];
+  if (wn_vec_ok(v, w, v, n)) {
+    f32x4 r[WN_KMAX];
+#pragma unroll
+    for (int k = 0; k < WN_KMAX; ++k)
+      if (k * 64 < n) r[k] = *(const f32x4*)(v + min((l + 16 * k) * 4, n - 4));
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < WN_KMAX; ++k)
+      if (k * 64 < n) ss += (l + 16 * k) * 4 < n ? wn_dot(r[k], r[k]) : 0.f;
+    ss = wn_group_sum(ss);
+    const float sc = gsc / sqrtf(ss);
+#pragma unroll
+    for (int k = 0; k < WN_KMAX; ++k)
+      if ((l + 16 * k) * 4 < n) *(f32x4*)(w + (l + 16 * k) * 4) = r[k] * sc;
+    return;
+  }
   float ss = 0.f;
-  for (int i = lane; i < n; i += 64) ss += v[i] * v[i];
-  ss = wave_sum(ss);
-  const float sc = params[g_off[row]] / sqrtf(ss);
-  float* w = eff + v_off[row];
-  for (int i = lane; i < n; i += 64) w[i] = v[i] * sc;
+  for (int i = l; i < n; i += 16) ss += v[i] * v[i];
+  ss = wn_group_sum(ss);
+  const float sc = gsc / sqrtf(ss);
+  for (int i = l; i < n; i += 16) w[i] = v[i] * sc;
 }
 
 extern "C" int wae_weight_norm_fwd(const float* params, float* eff, int64_t n_params, const int64_t* v_off,
                                    const int64_t* g_off, const int32_t* cols, int32_t nrows, void* stream) {
-  WAE_REQUIRE(params && eff && n_params > 0, "weight_norm_fwd: null arena");
-  hipStream_t st = as_stream(stream);
-  if (hipMemcpyAsync(eff, params, n_params * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-    wae_set_error("weight_norm_fwd: arena copy failed");
-    return WAE_EHIP;
-  }
-  if (nrows > 0) {
-    WAE_REQUIRE(v_off && g_off && cols, "weight_norm_fwd: null tables");
-    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, params, eff, v_off, g_off,
-                       cols, nrows);
-  }
+  WAE_REQUIRE(params && eff && n_params > 0 && nrows >= 0, "weight_norm_fwd: null arena");
+  WAE_REQUIRE(nrows == 0 || (v_off && g_off && cols), "weight_norm_fwd: null tables");
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((nrows + 1 + 15) / 16), dim3(256), 0, as_stream(stream), params, eff, v_off, g_off, cols,
+                     nrows, (int64_t)0, n_params);
   return wae_check_launch("weight_norm_fwd");
 }
 
+// phase WN_GAPS: grads = d_eff on everything between the rows (this also passes over the g slots, which phase WN_ROWS -- a later
+// launch on the same stream -- then overwrites with the gradient of g).  One LANE per row boundary looks its gap up; the wave
+// then copies the (few: ~5 per layer) non-empty ones together.
 __global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __restrict__ params,
                                                               const float* __restrict__ d_eff, float* __restrict__ grads,
                                                               const int64_t* __restrict__ v_off,
                                                               const int64_t* __restrict__ g_off,
-                                                              const int32_t* __restrict__ cols, int nrows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+                                                              const int32_t* __restrict__ cols, int nrows, int64_t lo, int64_t hi,
+                                                              int phase) {
+  if (phase == WN_GAPS) {
+    const int row = blockIdx.x * 256 + threadIdx.x - 1;
+    int64_t ga = 0, gb = 0;
+    if (row < nrows) {
+      if (nrows == 0) { ga = lo; gb = hi; }
+      else {
+        const int rc = max(row, 0), rn = min(row + 1, nrows - 1);
+        ga = row < 0 ? lo : v_off[rc] + cols[rc];
+        gb = row + 1 < nrows ? v_off[rn] : hi;
+      }
+    }
+    __shared__ int64_t s_a[256], s_b[256];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (gb > ga) {
+      const int k = atomicAdd(&s_n, 1);
+      s_a[k] = ga;
+      s_b[k] = gb;
+    }
+    __syncthreads();
+    for (int k = 0; k < s_n; ++k) wn_block_copy(d_eff, grads, s_a[k], s_b[k]);
+    return;
+  }
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
   if (row >= nrows) return;
-  const float* v = params + v_off[row];
-  const float* dw = d_eff + v_off[row];
+  const int64_t vo = v_off[row], go = g_off[row];
   const int n = cols[row];
+  const float* v = params + vo;
+  const float* dw = d_eff + vo;
+  float* gv = grads + vo;
+  const float g = params[go];
+  if (wn_vec_ok(v, dw, gv, n)) {
+    f32x4 rv[WN_KMAX], rd[WN_KMAX];
+#pragma unroll
+    for (int k = 0; k < WN_KMAX; ++k)
+      if (k * 64 < n) {
+        const int i = min((l + 16 * k) * 4, n - 4);
+        rv[k] = *(const f32x4*)(v + i);
+        rd[k] = *(const f32x4*)(dw + i);
+      }
+    float ss = 0.f, dv = 0.f;
+#pragma unroll
+    for (int k = 0; k < WN_KMAX; ++k)
+      if (k * 64 < n) {
+        const bool on = (l + 16 * k) * 4 < n;
+        ss += on ? wn_dot(rv[k], rv[k]) : 0.f;
+        dv += on ? wn_dot(rv[k], rd[k]) : 0.f;
+      }
+    ss = wn_group_sum(ss);
+    dv = wn_group_sum(dv);
+    const float inv = 1.0f / sqrtf(ss);
+    const float gi = g * inv, c2 = dv * inv * inv;
+#pragma unroll
+    for (int k = 0; k < WN_KMAX; ++k)
+      if ((l + 16 * k) * 4 < n) *(f32x4*)(gv + (l + 16 * k) * 4) = (rd[k] - rv[k] * c2) * gi;
+    if (l == 0) grads[go] = dv * inv;
+    return;
+  }
   float ss = 0.f, dv = 0.f;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = l; i < n; i += 16) {
     ss += v[i] * v[i];
     dv += v[i] * dw[i];
   }
-  ss = wave_sum(ss);
-  dv = wave_sum(dv);
-  const float g = params[g_off[row]];
+  ss = wn_group_sum(ss);
+  dv = wn_group_sum(dv);
   const float inv = 1.0f / sqrtf(ss);
-  float* gv = grads + v_off[row];
-  for (int i = lane; i < n; i += 64) gv[i] = g * inv * (dw[i] - v[i] * dv * inv * inv);
-  if (lane == 0) grads[g_off[row]] = dv * inv;
+  for (int i = l; i < n; i += 16) gv[i] = g * inv * (dw[i] - v[i] * dv * inv * inv);
+  if (l == 0) grads[go] = dv * inv;
 }
 
 extern "C" int wae_weight_norm_bwd_range(const float* params, const float* d_eff, float* grads, int64_t lo, int64_t hi,
@@ -111,15 +227,17 @@ extern "C" int wae_weight_norm_bwd_range(const float* params, const float* d_eff
                                          int32_t row_hi, void* stream) {
   WAE_REQUIRE(params && d_eff && grads && lo >= 0 && hi > lo, "weight_norm_bwd: bad arena range");
   WAE_REQUIRE(row_lo >= 0 && row_hi >= row_lo, "weight_norm_bwd: bad row range");
+  WAE_REQUIRE(row_hi == row_lo || (v_off && g_off && cols), "weight_norm_bwd: null tables");
   hipStream_t st = as_stream(stream);
-  if (hipMemcpyAsync(grads + lo, d_eff + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-    wae_set_error("weight_norm_bwd: arena copy failed");
-    return WAE_EHIP;
-  }
   const int nrows = row_hi - row_lo;
+  const int64_t* vo = nrows ? v_off + row_lo : v_off;
+  const int64_t* go = nrows ? g_off + row_lo : g_off;
+  const int32_t* co = nrows ? cols + row_lo : cols;
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 1 + 255) / 256), dim3(256), 0, st, params, d_eff, grads, vo, go, co, nrows, lo,
+                     hi, WN_GAPS);
   if (nrows > 0)
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, params, d_eff, grads, v_off + row_lo,
-                       g_off + row_lo, cols + row_lo, nrows);
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 15) / 16), dim3(256), 0, st, params, d_eff, grads, vo, go, co, nrows, lo, hi,
+                       WN_ROWS);
   return wae_check_launch("weight_norm_bwd");
 }
 
@@ -770,6 +888,8 @@ extern "C" int wae_check_ids(const int32_t* ids, int64_t n, int32_t lo, int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// zb[b][l][:] = conv bias + conv1x1g(g_b) (modules.py:148-152 hoisted out of the time loop).  Block = (layer, clip, 32 gate rows);
+// eight lanes share a row and walk its Cg weights 32 bytes at a time (one thread per row walked Cg dependent strided loads: 21 us).
 __global__ void __launch_bounds__(256) gproj_fwd_kernel(const float* __restrict__ eff, int64_t wg_off, int64_t bias_off,
                                                         int64_t layer_stride, const int32_t* __restrict__ gid,
                                                         int64_t emb_off, const float* __restrict__ gvec,
@@ -782,17 +902,18 @@ __global__ void __launch_bounds__(256) gproj_fwd_kernel(const float* __restrict_
   const int sp = gid ? checked_id(gid[b], n_speakers, err, WAE_ERR_SPEAKER_ID) : 0;
   const float* gv = gid ? eff + emb_off + (int64_t)sp * Cg : (gvec ? gvec + (int64_t)b * Cg : nullptr);
   float* o = zb + ((int64_t)b * L + l) * 2 * Hp;
-  for (int r = threadIdx.x; r < 2 * Hp; r += 256) {
-    const int half = r >= Hp, i = r - half * Hp;
-    float acc = 0.f;
-    if (i < H) {
-      const int ch = half * H + i;
-      acc = bs[ch];
-      if (wg && gv)
-        for (int c = 0; c < Cg; ++c) acc = fmaf(wg[(int64_t)ch * Cg + c], gv[c], acc);
-    }
-    o[r] = acc;
+  const int r = blockIdx.z * 32 + (threadIdx.x >> 3), cs = threadIdx.x & 7;
+  const int half = r >= Hp, i = r - half * Hp;
+  const bool live = r < 2 * Hp && i < H;
+  float acc = 0.f;
+  if (live && wg && gv) {
+    const float* wr = wg + (int64_t)(half * H + i) * Cg;
+    for (int c = cs; c < Cg; c += 8) acc = fmaf(wr[c], gv[c], acc);
   }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (cs == 0 && r < 2 * Hp) o[r] = live ? acc + bs[half * H + i] : 0.f;
 }
 
 extern "C" int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off, int64_t layer_stride, const int32_t* gid,
@@ -800,57 +921,75 @@ extern "C" int wae_gproj_fwd(const float* eff, int64_t wg_off, int64_t bias_off,
                              int32_t Cg, int32_t n_speakers, int32_t* err, void* stream) {
   WAE_REQUIRE(eff && zb && B > 0 && L > 0 && G > 0 && G % 2 == 0 && Hp >= G / 2, "gproj: bad arguments");
   WAE_REQUIRE(!gid || n_speakers > 0, "gproj: speaker ids need the size of the embedding table");
-  hipLaunchKernelGGL(gproj_fwd_kernel, dim3(L, B), dim3(256), 0, as_stream(stream), eff, wg_off, bias_off, layer_stride,
-                     gid, emb_off, gvec, zb, L, G, Hp, Cg, n_speakers, err);
+  hipLaunchKernelGGL(gproj_fwd_kernel, dim3(L, B, (2 * Hp + 31) / 32), dim3(256), 0, as_stream(stream), eff, wg_off, bias_off,
+                     layer_stride, gid, emb_off, gvec, zb, L, G, Hp, Cg, n_speakers, err);
   return wae_check_launch("gproj_fwd");
 }
 
 // backward of gproj: the per-clip column sums of dz (the "ones columns" of the dW1 tile of wae_gemm_tn) are the
 // gradient of zb[b][l][:]; chain into the conv bias, conv1x1g and the speaker embedding (modules.py:148-152).
+// Block = (layer, 32 gate rows).  The block's 32 x B sums and the B conditioning vectors are staged in LDS once (the first form
+// re-read both -- and the speaker id -- from global memory inside the B x Cg loops: 45 us of dependent loads per step).
+#define GPROJ_BMAX 32
 __global__ void __launch_bounds__(256) gproj_bwd_kernel(const float* __restrict__ eff, float* __restrict__ d_eff, int64_t wg_off,
                                                         int64_t bias_off, int64_t layer_stride, const int32_t* __restrict__ gid,
                                                         int64_t emb_off, const float* __restrict__ gvec,
                                                         const float* __restrict__ c1, int64_t c_layer_stride, int64_t ld,
-                                                        int ones_col, int B, int G, int Hp, int Cg, int n_speakers) {
+                                                        int ones_col, int B0, int B, int G, int Hp, int Cg, int n_speakers) {
+  extern __shared__ float gp_lds[];
+  float* s_cl = gp_lds;                      // [32][GPROJ_BMAX]
+  float* s_e = gp_lds + 32 * GPROJ_BMAX;     // [nb][Cg]
+  __shared__ int s_sp[GPROJ_BMAX];
   const int l = blockIdx.x;
   const int H = G / 2;
   const float* cl = c1 + (int64_t)l * c_layer_stride + ones_col;
-  // phase 1: blockIdx.y owns 32 gate rows; thread = (row, feature slice): bias gradient and the row of dWg
+  const bool proj = wg_off >= 0 && Cg > 0;
+  const int nb = min(B - B0, GPROJ_BMAX);
+  for (int e = threadIdx.x; e < 32 * nb; e += 256) {
+    const int rr = e / nb, b = e - rr * nb, r = blockIdx.y * 32 + rr;
+    s_cl[rr * GPROJ_BMAX + b] = r < 2 * Hp ? cl[(int64_t)r * ld + B0 + b] : 0.f;
+  }
+  if (gid && threadIdx.x < nb) s_sp[threadIdx.x] = checked_id(gid[B0 + threadIdx.x], n_speakers, nullptr, 0);
+  __syncthreads();
+  if (proj)
+    for (int e = threadIdx.x; e < nb * Cg; e += 256) {
+      const int b = e / Cg, c = e - b * Cg;
+      s_e[e] = gid ? eff[emb_off + (int64_t)s_sp[b] * Cg + c] : gvec[(int64_t)(B0 + b) * Cg + c];
+    }
+  __syncthreads();
+  // phase 1: thread = (row, feature slice): bias gradient and the row of dWg
   {
-    const int r = blockIdx.y * 32 + (threadIdx.x >> 3), cs = threadIdx.x & 7;
+    const int rr = threadIdx.x >> 3, r = blockIdx.y * 32 + rr, cs = threadIdx.x & 7;
     const int half = r >= Hp, i = r - half * Hp;
     if (r < 2 * Hp && i < H) {
       const int ch = half * H + i;
       if (cs == 0) {
         float sb = 0.f;
-        for (int b = 0; b < B; ++b) sb += cl[(int64_t)r * ld + b];
+        for (int b = 0; b < nb; ++b) sb += s_cl[rr * GPROJ_BMAX + b];
         d_eff[bias_off + (int64_t)l * layer_stride + ch] += sb;       // this (layer,row) slot is touched by one thread only
       }
-      if (wg_off >= 0 && Cg > 0) {
+      if (proj) {
         float* dwg = d_eff + wg_off + (int64_t)l * layer_stride + (int64_t)ch * Cg;
         for (int c = cs; c < Cg; c += 8) {
           float a = 0.f;
-          for (int b = 0; b < B; ++b) {
-            const float e = gid ? eff[emb_off + (int64_t)checked_id(gid[b], n_speakers, nullptr, 0) * Cg + c] : gvec[(int64_t)b * Cg + c];
-            a = fmaf(cl[(int64_t)r * ld + b], e, a);
-          }
+          for (int b = 0; b < nb; ++b) a = fmaf(s_cl[rr * GPROJ_BMAX + b], s_e[b * Cg + c], a);
           dwg[c] += a;
         }
       }
     }
   }
   // phase 2: embedding rows: thread per (clip, feature) reduces over THIS block's 32 gate rows -> one atomic each
-  // (one block per layer walking all 2Hp rows serially took 0.24 ms per step)
-  if (gid && wg_off >= 0 && Cg > 0) {
-    for (int e = threadIdx.x; e < B * Cg; e += 256) {
-      const int b = e / Cg, c = e % Cg;
+  if (gid && proj) {
+    for (int e = threadIdx.x; e < nb * Cg; e += 256) {
+      const int b = e / Cg, c = e - b * Cg;
       float a = 0.f;
-      for (int r = blockIdx.y * 32; r < min(blockIdx.y * 32 + 32, 2 * Hp); ++r) {
+      for (int rr = 0; rr < 32; ++rr) {
+        const int r = blockIdx.y * 32 + rr;
         const int half = r >= Hp, i = r - half * Hp;
-        if (i >= H) continue;
-        a = fmaf(cl[(int64_t)r * ld + b], eff[wg_off + (int64_t)l * layer_stride + (int64_t)(half * H + i) * Cg + c], a);
+        if (r >= 2 * Hp || i >= H) continue;
+        a = fmaf(s_cl[rr * GPROJ_BMAX + b], eff[wg_off + (int64_t)l * layer_stride + (int64_t)(half * H + i) * Cg + c], a);
       }
-      atomicAdd(d_eff + emb_off + (int64_t)checked_id(gid[b], n_speakers, nullptr, 0) * Cg + c, a);
+      atomicAdd(d_eff + emb_off + (int64_t)s_sp[b] * Cg + c, a);
     }
   }
 }
@@ -860,8 +999,13 @@ extern "C" int wae_gproj_bwd(const float* eff, float* d_eff, int64_t wg_off, int
                              int32_t n_speakers, void* stream) {
   WAE_REQUIRE(eff && d_eff && c1 && B > 0 && L > 0 && G > 0 && G % 2 == 0, "gproj_bwd: bad arguments");
   WAE_REQUIRE(!gid || n_speakers > 0, "gproj_bwd: speaker ids need the size of the embedding table");
-  hipLaunchKernelGGL(gproj_bwd_kernel, dim3(L, (2 * Hp + 31) / 32), dim3(256), 0, as_stream(stream), eff, d_eff, (gid || gvec) ? wg_off : -1, bias_off,
-                     layer_stride, gid, emb_off, gvec, c1, c_layer_stride, ld, ones_col, B, G, Hp, Cg, n_speakers);
+  const int64_t wg = (gid || gvec) ? wg_off : -1;
+  const size_t lds = (32 * GPROJ_BMAX + (size_t)GPROJ_BMAX * (Cg > 0 ? Cg : 0)) * sizeof(float);
+  WAE_REQUIRE(lds <= 64 * 1024, "gproj_bwd: Cg = %d too wide for the staged form", Cg);
+  for (int b0 = 0; b0 < B; b0 += GPROJ_BMAX) {   // clips in groups of 32 (the sums of a group stay in LDS)
+    hipLaunchKernelGGL(gproj_bwd_kernel, dim3(L, (2 * Hp + 31) / 32), dim3(256), lds, as_stream(stream), eff, d_eff, wg, bias_off,
+                       layer_stride, gid, emb_off, gvec, c1, c_layer_stride, ld, ones_col, b0, B, G, Hp, Cg, n_speakers);
+  }
   return wae_check_launch("gproj_bwd");
 }
 
@@ -941,6 +1085,34 @@ extern "C" int wae_first_conv_fwd(const int32_t* idx, const float* xs, const flo
   else
     hipLaunchKernelGGL(first_conv_kernel<float>, grid, dim3(256), 0, as_stream(stream), idx, xs, table, bias, x0, BT, Rp, O, err);
   return wae_check_launch("first_conv_fwd");
+}
+
+// one-hot rows of the class ids, (n, width) in the storage dtype: the first conv's weight gradient sum_t onehot(id[t]) (x) dx0[t]
+// (autograd of wavenet.py:203) then is one more P^T Q contraction of the weight-gradient launch (csrc/gemm_tn_static.hip).  An id
+// outside [0, width) gives a zero row (the forward has flagged it).  thread = 8 columns of one row, one 16-byte store.
+template <typename E>
+__global__ void __launch_bounds__(256) onehot_rows_kernel(const int32_t* __restrict__ ids, E* __restrict__ out, int64_t n, int width) {
+  const int tpr = width >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * tpr) return;
+  const int64_t row = i / tpr;
+  const int c0 = (int)(i - row * tpr) * 8;
+  const int id = ids[row];
+  E v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (E)(c0 + k == id ? 1.0f : 0.0f);
+  E* o = out + row * width + c0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = v[k];
+}
+extern "C" int wae_onehot_rows(const int32_t* ids, void* out, int64_t n, int32_t width, int32_t dtype, void* stream) {
+  WAE_REQUIRE(ids && out && n > 0 && width > 0 && width % 8 == 0 && wae_dtype_ok(dtype), "onehot_rows: bad arguments");
+  const int64_t threads = n * (width / 8);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (dtype == WAE_BF16) hipLaunchKernelGGL(onehot_rows_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), ids, (__bf16*)out, n, width);
+  else if (dtype == WAE_F16) hipLaunchKernelGGL(onehot_rows_kernel<f16>, grid, dim3(256), 0, as_stream(stream), ids, (f16*)out, n, width);
+  else hipLaunchKernelGGL(onehot_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), ids, (float*)out, n, width);
+  return wae_check_launch("onehot_rows");
 }
 
 // ---------------------------------------------------------------------------------------------------

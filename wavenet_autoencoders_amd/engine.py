@@ -668,6 +668,11 @@ class WaeEngine:
         if not hasattr(self, "exp_avg"):
             self.init_optimizer()
         self.prepare_weights()
+        # one int32 copy of the ids for forward, targets and backward (each of them converts what it is handed: four 5-us launches)
+        if not self.g.scalar_input and x.dtype != torch.int32:
+            x = x.to(self.device, torch.int32).contiguous()
+        if gid is not None and gid.dtype != torch.int32:
+            gid = gid.to(self.device, torch.int32).contiguous()
         if self.g.scalar_input:
             fwd = self.forward if self.g.has_encoder else self.decoder_forward
             out = fwd(x, c, gid, targets=None, lengths=None, want_logits=True, train=True)

@@ -560,6 +560,8 @@ def grad_scatter_maps(g: Geometry, lay: ParamLayout) -> dict:
     out["ldoT_rows"] = g.Hp + 8               # rows of a layer's block: Hp weight rows, the bias row, padding
     hrow, scol = np.meshgrid(np.arange(g.Hp), np.arange(g.Sp), indexing="ij")
     out["wsT"] = np.where((scol < g.S) & (hrow < g.H), ws + scol * g.H + hrow, -1).astype(np.int32).reshape(-1)   # layer 0
+    ss_ = np.arange(g.Sp)
+    out["bsT"] = np.where(ss_ < g.S, bs + ss_, -1).astype(np.int32)          # skip bias from a plain (Sp,) vector of sums, layer 0
     # head
     ldh = g.Sp + ONES_PAD
     row, col = np.meshgrid(np.arange(g.Op), np.arange(g.Sp), indexing="ij")
