@@ -231,6 +231,13 @@ typedef struct wae_head_desc {
 } wae_head_desc;
 int wae_head_fwd(const wae_head_desc* d, const void* u, const void* w_packed, const float* bias, float* logits,
                  const int32_t* target, float* nll, float* lse, void* h0_save, void* h1_save, void* stream);
+
+/* The second half of wae_head_fwd -- GEMM 1, GEMM 2, logits and / or the fused cross-entropy (wavenet.py:208-214,
+ * vqwae_train.py:363-379,:764) -- from a stored h0 = relu(sqrt(1/L) (sum_l b_skip_l + W_skip u)) (B,T,Sp) dtype, for callers that ran
+ * the skip contraction as a wae_gemm_tm launch (mode 3, the first Ku/CK chunks of the same packed stream as its weights).  w_tail =
+ * w_packed + (Ku / CK) * (Sp / 32) * 4096 bytes (CK = 64 for 16-bit, 32 for fp32); bias as in wae_head_fwd (first Sp entries unread). */
+int wae_head_fwd_from_h0(const wae_head_desc* d, const void* h0, const void* w_tail, const float* bias, float* logits,
+                         const int32_t* target, float* nll, float* lse, void* h1_save, void* stream);
 /* backward of the head down to dskip (csrc/head_bwd.hip).  CE mode (ext_dy == NULL): logits are recomputed from h1,
  * dy = (softmax - onehot(target[t+1])) * [t < len-1] * inv_count with the forward's lse (B,T); DMoL mode: ext_dy
  * (B,T,Op) dtype is the loss gradient.  Outputs, all time-major dtype: dy_out (B,T,Op), dh1_out (B,T,Sp) (pre-ReLU

@@ -328,3 +328,24 @@ def test_glu_barrier_on_every_second_chunk_is_bitwise_identical(R, G, monkeypatc
                     ref[(B, F)] = y.clone()
                 else:
                     assert torch.equal(y, ref[(B, F)]), (B, F, rep)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_split_head_agrees_with_the_one_kernel_head(name, dtype, monkeypatch):
+    """16-bit engines run the head's skip contraction as a wae_gemm_tm launch (mode 3) and the rest through wae_head_fwd_from_h0; the
+    one-kernel wae_head_fwd (WAE_HEAD_SPLIT=0) is the same arithmetic with the skip-bias sum added before instead of after the
+    contraction: logits within 1e-2 of the logit range, the loss within 2e-3, and both within tolerance of the oracle."""
+    cfg, sd, ins, z, ocfg = golden_model(name)
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    outs = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("WAE_HEAD_SPLIT", split)
+        eng = _engine(cfg, sd, dtype)
+        assert eng.split_head == (split == "1")
+        out = eng.forward(x, c, g, targets=x, lengths=None)
+        torch.cuda.synchronize()
+        outs.append((out["logits"].float().cpu(), float(out["loss"])))
+        assert rel_err(outs[-1][0], z["y_hat"]) < BF16_TOL
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-2
+    assert abs(outs[0][1] - outs[1][1]) < 2e-3

@@ -110,6 +110,7 @@ SIGNATURES = {
     "wae_dropout_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_uint64, c_f32, c_f32, c_i32, c_vp]),
     "wae_glu_packed_bytes": (c_i64, [ctypes.POINTER(GluDesc)]),
     "wae_head_fwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 10),
+    "wae_head_fwd_from_h0": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 9),
     "wae_head_bwd": (c_i32, [ctypes.POINTER(HeadDesc)] + [c_vp] * 7 + [c_f32] + [c_vp] * 5),
     "wae_head_bwd_packed_bytes": (c_i64, [ctypes.POINTER(HeadDesc)]),
     "wae_gemm_tm": (c_i32, [ctypes.POINTER(TmDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),

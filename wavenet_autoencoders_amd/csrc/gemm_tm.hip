@@ -575,7 +575,7 @@ static int launch_tm_blds(const TmArgs& a, int nslices, hipStream_t st) {
 template <typename E, int NT, int MODE>
 static int launch_tm(const TmArgs& a, int nslices, hipStream_t st) {
   // opt-in (WAE_TM_BLDS): bit-identical, measured NOT faster than the two-workgroup register-operand shape
-  if constexpr (sizeof(E) == 2 && NT % 2 == 0 && NT >= 4 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL)) {
+  if constexpr (sizeof(E) == 2 && NT % 2 == 0 && NT >= 4 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_BIAS_RELU)) {
     if ((a.flags & WAE_TM_BLDS) && !(a.flags & WAE_TM_ONE_WG)) return launch_tm_blds<E, NT, MODE>(a, nslices, st);
   }
   if constexpr (sizeof(E) == 2 && NT % 2 == 0 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD || MODE == TM_BIAS_RELU)) {

@@ -26,7 +26,9 @@ struct HeadArgs {
   float scale;
 };
 
-template <typename E, int NT>
+// FROM_H0: GEMM 0 ran as its own launch (wae_gemm_tm, mode BIAS_RELU: two workgroups per CU hide the long K loop's memory trips
+// behind each other, which this kernel's one workgroup per CU cannot); p.u then is h0 (B,T,Sp) and p.w starts at GEMM 1's chunks.
+template <typename E, int NT, bool FROM_H0 = false>
 __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   using T_ = ET<E>;
   using frag = typename T_::frag;
@@ -49,7 +51,7 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   const bool tvalid = t < p.T;
   const int rows_valid = min(max(p.T - t0w, 0), 32);
 
-  const int nq0 = p.Ku / T_::CK;
+  const int nq0 = FROM_H0 ? 0 : p.Ku / T_::CK;
   const int nq2 = (p.Op >> 5) / MT2;
   const int nq_total = nq0 + NQ1 + nq2;
   const char* urow = p.u + ((int64_t)b * p.T + (tvalid ? t : 0)) * p.Ku * ES + h * 16;
@@ -66,6 +68,23 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   // go through a 3-slot ring two chunks ahead, the VMEM issue of a chunk is spread over its MFMAs, and the wait at the top
   // of chunk q is counted: it leaves B(q+2) and DMA(q+1) in flight.
   f32x16 acc[NT];
+  frag uf[NKB];
+  if constexpr (FROM_H0) {
+    dma_chunk(p.w, smem, CHB, wave, lane);
+    // h0 rows of this wave's 32 time columns -> accumulator layout (coalesced rows through the staging tile) -> operand fragments
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    if (rows_valid > 0) stage_load_tiles<E, NT>(stg, acc, p.u + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      frag tmp[KBU];
+      acc_to_frags(acc[m], tmp);
+#pragma unroll
+      for (int s = 0; s < KBU; ++s) uf[m * KBU + s] = tmp[s];
+    }
+  } else {
 #pragma unroll
   for (int m = 0; m < NT; ++m) init_rows(acc[m], p.bias + 32 * m, h);
   {
@@ -119,7 +138,6 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   }
 
   // ---- h0 = relu(skips * scale) -> operand fragments (+ optional save) ------------------------------------
-  frag uf[NKB];
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
 #pragma unroll
@@ -131,6 +149,7 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   }
   if (p.h0_save && rows_valid > 0)
     stage_store_tiles<E, NT>(stg, acc, p.h0_save + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
+  }
 
   // ---- GEMM 1: h1 = relu(b1 + W1 . h0); all NT output tiles stay in registers --------------------------------
 #pragma unroll
@@ -218,14 +237,14 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   }
 }
 
-template <typename E, int NT>
+template <typename E, int NT, bool FROM_H0 = false>
 static int launch_head(const HeadArgs& a, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
   const size_t lds = 3 * CHB + 4 * STG_BYTES + (size_t)(2 * a.Sp + a.Op) * 4;
   static WaeLdsCache lds_cache;
-  if (int rc = wae_ensure_lds((const void*)head_fwd_kernel<E, NT>, lds_cache, lds, "head_fwd"); rc != WAE_OK) return rc;
+  if (int rc = wae_ensure_lds((const void*)head_fwd_kernel<E, NT, FROM_H0>, lds_cache, lds, "head_fwd"); rc != WAE_OK) return rc;
   const int tiles = (a.T + 127) / 128;
-  hipLaunchKernelGGL((head_fwd_kernel<E, NT>), dim3(a.B * tiles), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((head_fwd_kernel<E, NT, FROM_H0>), dim3(a.B * tiles), dim3(256), lds, st, a);
   return wae_check_launch("head_fwd");
 }
 
@@ -262,4 +281,24 @@ extern "C" int wae_head_fwd(const wae_head_desc* d, const void* u, const void* w
   if (d->dtype == WAE_BF16) return nt == 4 ? launch_head<__bf16, 4>(a, st) : launch_head<__bf16, 8>(a, st);
   if (d->dtype == WAE_F16) return nt == 4 ? launch_head<f16, 4>(a, st) : launch_head<f16, 8>(a, st);
   return nt == 4 ? launch_head<float, 4>(a, st) : launch_head<float, 8>(a, st);
+}
+
+// GEMM 1, GEMM 2 and the fused cross-entropy from a stored h0 = relu(sqrt(1/L) * skips) (B,T,Sp): the second half of wae_head_fwd for
+// callers that ran the skip contraction as a wae_gemm_tm launch (mode 3).  w_tail = the packed stream from GEMM 1's first chunk on
+// (w_packed + (Ku / CK) * (Sp / 32) * 4096 bytes); bias as in wae_head_fwd (its first Sp entries are not read).
+extern "C" int wae_head_fwd_from_h0(const wae_head_desc* d, const void* h0, const void* w_tail, const float* bias, float* logits,
+                                    const int32_t* target, float* nll, float* lse, void* h1_save, void* stream) {
+  int rc = head_validate(d);
+  if (rc != WAE_OK) return rc;
+  WAE_REQUIRE(h0 && w_tail && bias, "head_from_h0: null pointer argument");
+  WAE_REQUIRE(logits || (target && nll), "head_from_h0: nothing to produce (logits and nll both null)");
+  HeadArgs a;
+  a.u = (const char*)h0; a.w = (const char*)w_tail; a.bias = bias; a.logits = logits; a.target = target; a.nll = nll; a.lse = lse;
+  a.h0_save = nullptr; a.h1_save = (char*)h1_save; a.B = d->B; a.T = d->T; a.Ku = 0; a.Sp = d->Sp; a.Op = d->Op;
+  a.O = d->O; a.scale = d->scale;
+  hipStream_t st = as_stream(stream);
+  const int nt = d->Sp / 32;
+  if (d->dtype == WAE_BF16) return nt == 4 ? launch_head<__bf16, 4, true>(a, st) : launch_head<__bf16, 8, true>(a, st);
+  if (d->dtype == WAE_F16) return nt == 4 ? launch_head<f16, 4, true>(a, st) : launch_head<f16, 8, true>(a, st);
+  return nt == 4 ? launch_head<float, 4, true>(a, st) : launch_head<float, 8, true>(a, st);
 }

@@ -75,6 +75,9 @@ class WaeEngine:
         self.m_tab, self.m_fb = up(tab), up(fb)
         # head: register-chained kernels up to 256 skip channels; wider heads as separate GEMM launches (csrc/gemm_tm.hip)
         self.wide_head = P.head_is_wide(g)
+        # 16-bit dtypes: GEMM 0 of the head as its own wae_gemm_tm launch (decoder_forward); WAE_HEAD_SPLIT=0 keeps the one-kernel head
+        self.split_head = (not self.wide_head and self.dt in (L.WAE_BF16, L.WAE_F16) and g.Sp in (128, 256)
+                           and os.environ.get("WAE_HEAD_SPLIT", "1") != "0")
         if self.wide_head:
             hm = P.head_wide_maps(g, self.lay, self.dt)
             self.m_hwide = {k: up(v) for k, v in hm.items()}
@@ -205,8 +208,9 @@ class WaeEngine:
                 if self.dropout > 0:       # dropout(x_l): operand of layer l's convolution and of its weight gradient
                     ws["xd"] = [torch.empty(B, T, g.Rp, dtype=td, device=dev) for _ in range(g.layers)]
                 ws["lse"] = torch.zeros(B, T, dtype=torch.float32, device=dev)
-            if train or self.wide_head:       # the wide head passes h0 / h1 through HBM in inference too
+            if train or self.wide_head or self.split_head:   # the wide / split head pass h0 (and h1) through HBM in inference too
                 ws["h0"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
+            if train or self.wide_head:
                 ws["h1"] = torch.empty(B, T, g.Sp, dtype=td, device=dev)
             self._ws[key] = ws
         return ws
@@ -381,6 +385,19 @@ class WaeEngine:
             L.check(lib.wae_check_ids(L.ptr(tg), B * T, 0, g.O, L.ptr(self.err), L.ERR_TARGET_ID, st), "check targets")
         if self.wide_head:
             self._head_fwd_wide(ws, B, T, logits, tg, train)
+        elif self.split_head:
+            # the skip contraction (K = Ku: 72 chunks at C2, its operand 590 MB of u) as a wae_gemm_tm launch -- two workgroups per CU,
+            # 125 us against the ~200 us the same loop takes inside the head kernel's one workgroup per CU -- then the rest from h0
+            from . import backward as BW
+            es = self.w_head.element_size()
+            BW._tm(self, B, T, g.Sp, 3, math.sqrt(1.0 / g.layers), [(ws["u"].data_ptr(), g.Ku, g.Ku, 0)], self.w_head.data_ptr(),
+                   ws["h0"].data_ptr(), g.Sp, self.b_head.data_ptr(), 0, flags=int(os.environ.get("WAE_HEAD_TM_FLAGS", "0")))
+            ck = 64 if es == 2 else 32
+            tail = self.w_head.data_ptr() + (g.Ku // ck) * (g.Sp // 32) * 4096
+            L.check(lib.wae_head_fwd_from_h0(ctypes.byref(hd), L.ptr(ws["h0"]), ctypes.c_void_p(tail), L.ptr(self.b_head), L.ptr(logits),
+                                             L.ptr(tg), L.ptr(ws["nll"]) if tg is not None else None,
+                                             L.ptr(ws["lse"]) if (train and tg is not None) else None,
+                                             L.ptr(ws["h1"]) if train else None, st), "head (from h0)")
         else:
             L.check(lib.wae_head_fwd(ctypes.byref(hd), L.ptr(ws["u"]), L.ptr(self.w_head), L.ptr(self.b_head), L.ptr(logits),
                                      L.ptr(tg), L.ptr(ws["nll"]) if tg is not None else None,
