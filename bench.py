@@ -319,7 +319,7 @@ def main():
 
     def step(record=False):
         if args.mode == "forward":
-            eng.prepare_weights()
+            # (weight norm + fragment packing run inside decoder_forward only when a parameter changed since the last pack: never here)
             out = eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False,
                                       layer_events=ev if record else None)
             return out["loss"]

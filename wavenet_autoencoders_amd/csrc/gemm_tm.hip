@@ -342,9 +342,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) gemm_tm_kernel(TmArgs p) {
       }
       // past the end the last chunk is requested again (into the slot / group nobody reads): the wait count never changes
       const int qd = min(q + 1, nq - 1);
+      const char* buf = smem + (q & 1) * CHB + lane * 16;
+      // (the same requests spread between the chunk's MFMAs -- weight pieces first, then the operand fragments, as the 8-wave shape
+      //  issues them -- measured 0.4-1 % SLOWER over the train step, round 4: profiles/EXPERIMENT_LOG.md)
       if (!TM_ABL(2)) dma_chunk(wbase + (int64_t)qd * CHB, smem + ((q + 1) & 1) * CHB, CHB, wave, lane);
       request_B(min(q + 2, nq - 1), Gl, kl);
-      const char* buf = smem + (q & 1) * CHB + lane * 16;
       if (!TM_ABL(4)) gemm_chunk<4 * NT, NT, 4>(buf, Gc, acc);
       else asm volatile("" : "+v"(Gc[0]), "+v"(Gc[1]), "+v"(Gc[2]), "+v"(Gc[3]));
     };
