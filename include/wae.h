@@ -482,7 +482,13 @@ int wae_gemm_tn_stream(int32_t dtype /* WAE_BF16 or WAE_F16 */, const wae_ts_job
  * Ghat[t][r]) for geometries that fit one region: m_valid <= 384 (TAPS / COND) or 192 (OUTSKIP), n0_valid, n1_valid <= 256
  * (COND: <= 64), B <= 32, every operand clip below 2^30 bytes.  Teams, segments and slab numbering as wae_gemm_tn_stream.
  * Rows outside a clip (a tap's causal shift, T % 32 != 0) are zero-filled by the hardware through per-clip buffer
- * descriptors; OUTSKIP's outputs are TRANSPOSED relative to the reference's weight layout (rows = gated channel h). */
+ * descriptors; OUTSKIP's outputs are TRANSPOSED relative to the reference's weight layout (rows = gated channel h).
+ * The same kinds carry the rest of the step's weight gradients (one more group of jobs; backward.py: static_head): the head's
+ * 1x1 convolutions (wavenet.py:136-141) as TAPS jobs with shift 0 (P = dy, Q0 = h1; P = dh1, Q0 = h0), their biases as COND jobs
+ * WITHOUT a Q operand (Q0 = NULL, n0_valid = 0: only the per-clip column sums of P, at ones_col), first_conv (wavenet.py:119-122,
+ * 203) as a TAPS job whose P is the one-hot operand of wae_onehot_rows, and -- the last layer's conv1x1_out gradient being dead
+ * (wavenet.py:205-207) -- dS as Q0 of that layer's OUTSKIP job, whose Cb then is the skip bias gradient.  A record with
+ * m_valid <= 0 is a null job (its team member skips the segment). */
 enum { WAE_TQ_TAPS = 0, WAE_TQ_COND = 1, WAE_TQ_OUTSKIP = 2 };
 typedef struct wae_tq_job {
   const void* P;
