@@ -47,13 +47,10 @@ __device__ __forceinline__ float load_e<f16>(const void* p, int64_t i) { return 
 
 // ---------------------------------------------------------------------------------------------------
 // weight norm: one wave per weight row (modules.py:18: w = g * v / ||v||, norm over all dims but 0).
-// Rows are sorted by v_off and do not overlap; everything between them (biases, the g scalars, embeddings) is copied through by the
-// wave of the row in front of the gap (wave "-1" takes the head of the range), so the arena is touched once -- the first form copied
-// the whole arena with hipMemcpyAsync and then rewrote ~99 % of it.  Rows of up to 1024 aligned floats stay in registers between
-// the norm and the scale (four 16-byte loads in flight per lane).
+// Rows are sorted by v_off and do not overlap.  Two launches, the arena touched once (the first form copied the whole arena with
+// hipMemcpyAsync and then rewrote ~99 % of it): weight_norm_gaps_kernel passes everything BETWEEN the rows through (biases, the g
+// scalars, embeddings, un-normed tensors), the row kernel does the rows.
 // ---------------------------------------------------------------------------------------------------
-#define WN_GAPS 1
-#define WN_ROWS 2
 // What these launches cost is latency, not bytes: 40 000 rows of 64..768 floats, each a table lookup, a read and a write that depend
 // on one another, against ~2.5 us per trip to HBM.  One row per wave keeps 256 B..3 KiB in flight per wave -- with the chip's 8192
 // resident waves that is ~0.8 TB/s (72 us for the arena of C2).  So a row belongs to a 16-lane GROUP (four rows per wave, 16 per
@@ -84,28 +81,54 @@ __device__ __forceinline__ float wn_group_sum(float x) {   // over the 16 lanes 
   return x;
 }
 
+// dst = src on everything between the rows (biases, the g scalars, embeddings, whole un-normed tensors: the encoder's convolutions and the
+// codebook are plain parameters -- gaps of up to a few hundred thousand floats).  blockIdx.x: 256 row boundaries, one per thread
+// (boundary -1 = the head of the range); blockIdx.y: which 4096-float pieces of this block's gaps it copies (piece c, c + gridDim.y, ..).
+#define WN_GAP_PIECE 4096
+#define WN_GAP_Y 64
+__global__ void __launch_bounds__(256) weight_norm_gaps_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               const int64_t* __restrict__ v_off, const int32_t* __restrict__ cols,
+                                                               int nrows, int64_t lo, int64_t hi) {
+  __shared__ int64_t s_a[256], s_b[256];
+  __shared__ int s_n;
+  const int row = blockIdx.x * 256 + threadIdx.x - 1;
+  int64_t ga = 0, gb = 0;
+  if (row < nrows) {
+    if (nrows == 0) { ga = lo; gb = hi; }
+    else {
+      const int rc = max(row, 0), rn = min(row + 1, nrows - 1);
+      ga = row < 0 ? lo : v_off[rc] + cols[rc];
+      gb = row + 1 < nrows ? v_off[rn] : hi;
+    }
+  }
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  if (gb > ga) {
+    const int k = atomicAdd(&s_n, 1);
+    s_a[k] = ga;
+    s_b[k] = gb;
+  }
+  __syncthreads();
+  for (int k = 0; k < s_n; ++k) {
+    const int64_t a = s_a[k], b = s_b[k];
+    for (int64_t p0 = a + (int64_t)blockIdx.y * WN_GAP_PIECE; p0 < b; p0 += (int64_t)gridDim.y * WN_GAP_PIECE)
+      wn_block_copy(src, dst, p0, min(b, p0 + WN_GAP_PIECE));
+  }
+}
+static void wn_launch_gaps(const float* src, float* dst, const int64_t* v_off, const int32_t* cols, int nrows, int64_t lo, int64_t hi,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(weight_norm_gaps_kernel, dim3((nrows + 1 + 255) / 256, WN_GAP_Y), dim3(256), 0, st, src, dst, v_off, cols, nrows, lo, hi);
+}
+
 __global__ void __launch_bounds__(256) weight_norm_fwd_kernel(const float* __restrict__ params, float* __restrict__ eff,
                                                               const int64_t* __restrict__ v_off,
                                                               const int64_t* __restrict__ g_off,
-                                                              const int32_t* __restrict__ cols, int nrows, int64_t lo, int64_t hi) {
-  __shared__ int64_t s_ga[16], s_gb[16];
-  const int grp = threadIdx.x >> 4;
-  const int row = blockIdx.x * 16 + grp - 1;   // -1: the head of the range
+                                                              const int32_t* __restrict__ cols, int nrows) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
-  if (nrows == 0) { if (blockIdx.x == 0) wn_block_copy(params, eff, lo, hi); return; }
-  const int rc = min(max(row, 0), nrows - 1), rn = min(row + 1, nrows - 1);
-  const int64_t vo = v_off[rc], von = v_off[rn], go = g_off[rc];
-  const int n = cols[rc];
-  // what lies between this row and the next (biases, g, embeddings) passes through unchanged: the workgroup copies its 16 gaps together
-  if (l == 0) {
-    const bool live = row < nrows;
-    s_ga[grp] = live ? (row < 0 ? lo : vo + n) : 0;
-    s_gb[grp] = live ? (row + 1 < nrows ? von : hi) : 0;
-  }
-  __syncthreads();
-  for (int k = 0; k < 16; ++k)
-    if (s_gb[k] > s_ga[k]) wn_block_copy(params, eff, s_ga[k], s_gb[k]);
-  if (row < 0 || row >= nrows) return;
+  if (row >= nrows) return;
+  const int64_t vo = v_off[row], go = g_off[row];
+  const int n = cols[row];
   const float* v = params + vo;
   float* w = eff + vo;
   const float gsc = params[go];
@@ -136,44 +159,19 @@ extern "C" int wae_weight_norm_fwd(const float* params, float* eff, int64_t n_pa
                                    const int64_t* g_off, const int32_t* cols, int32_t nrows, void* stream) {
   WAE_REQUIRE(params && eff && n_params > 0 && nrows >= 0, "weight_norm_fwd: null arena");
   WAE_REQUIRE(nrows == 0 || (v_off && g_off && cols), "weight_norm_fwd: null tables");
-  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((nrows + 1 + 15) / 16), dim3(256), 0, as_stream(stream), params, eff, v_off, g_off, cols,
-                     nrows, (int64_t)0, n_params);
+  hipStream_t st = as_stream(stream);
+  wn_launch_gaps(params, eff, v_off, cols, nrows, 0, n_params, st);
+  if (nrows > 0)
+    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((nrows + 15) / 16), dim3(256), 0, st, params, eff, v_off, g_off, cols, nrows);
   return wae_check_launch("weight_norm_fwd");
 }
 
-// phase WN_GAPS: grads = d_eff on everything between the rows (this also passes over the g slots, which phase WN_ROWS -- a later
-// launch on the same stream -- then overwrites with the gradient of g).  One LANE per row boundary looks its gap up; the wave
-// then copies the (few: ~5 per layer) non-empty ones together.
+// The gap launch also passes over the g slots; the row launch -- later on the same stream -- overwrites them with the gradient of g.
 __global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __restrict__ params,
                                                               const float* __restrict__ d_eff, float* __restrict__ grads,
                                                               const int64_t* __restrict__ v_off,
                                                               const int64_t* __restrict__ g_off,
-                                                              const int32_t* __restrict__ cols, int nrows, int64_t lo, int64_t hi,
-                                                              int phase) {
-  if (phase == WN_GAPS) {
-    const int row = blockIdx.x * 256 + threadIdx.x - 1;
-    int64_t ga = 0, gb = 0;
-    if (row < nrows) {
-      if (nrows == 0) { ga = lo; gb = hi; }
-      else {
-        const int rc = max(row, 0), rn = min(row + 1, nrows - 1);
-        ga = row < 0 ? lo : v_off[rc] + cols[rc];
-        gb = row + 1 < nrows ? v_off[rn] : hi;
-      }
-    }
-    __shared__ int64_t s_a[256], s_b[256];
-    __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    if (gb > ga) {
-      const int k = atomicAdd(&s_n, 1);
-      s_a[k] = ga;
-      s_b[k] = gb;
-    }
-    __syncthreads();
-    for (int k = 0; k < s_n; ++k) wn_block_copy(d_eff, grads, s_a[k], s_b[k]);
-    return;
-  }
+                                                              const int32_t* __restrict__ cols, int nrows) {
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
   if (row >= nrows) return;
@@ -233,11 +231,9 @@ extern "C" int wae_weight_norm_bwd_range(const float* params, const float* d_eff
   const int64_t* vo = nrows ? v_off + row_lo : v_off;
   const int64_t* go = nrows ? g_off + row_lo : g_off;
   const int32_t* co = nrows ? cols + row_lo : cols;
-  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 1 + 255) / 256), dim3(256), 0, st, params, d_eff, grads, vo, go, co, nrows, lo,
-                     hi, WN_GAPS);
+  wn_launch_gaps(d_eff, grads, vo, co, nrows, lo, hi, st);
   if (nrows > 0)
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 15) / 16), dim3(256), 0, st, params, d_eff, grads, vo, go, co, nrows, lo, hi,
-                       WN_ROWS);
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((nrows + 15) / 16), dim3(256), 0, st, params, d_eff, grads, vo, go, co, nrows);
   return wae_check_launch("weight_norm_bwd");
 }
 
