@@ -464,7 +464,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "C2: IN-WAE decoder dims (R256 G368 S256 Cc64 Cg64 k3), 24 layers/2 stacks, "
                                    f"batch {B_PER_GPU}x{T} per GPU, " + ("full train step: weight-norm+pack, forward, fused CE, backward, "
-                                   "clip+Adam+EMA" if args.mode == "train" else "teacher-forced forward incl. weight-norm+pack, upsample, head and fused CE")
+                                   "clip+Adam+EMA" if args.mode == "train" else "teacher-forced forward (weights packed once, before the timed region), upsample, head and fused CE")
                                    + "; closed-form random weights",
                        "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
             "samples_per_sec_per_gpu": value / world,
