@@ -245,7 +245,7 @@ def test_glu_workgroup_shapes_agree(dtype):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("B,T", [(1, 2), (1, 33), (3, 130), (2, 257), (1, 1025)])
+@pytest.mark.parametrize("B,T", [(1, 2), (1, 33), (3, 130), (2, 257), (1, 1025), (40, 48)])   # 40 clips: gproj_bwd stages 32 clips per launch
 def test_odd_shapes_forward_and_backward(B, T):
     """clips shorter than a tile / a wave / the receptive field, odd batch sizes: logits and loss against the oracle (fp32), and a
     backward pass whose gradients match autograd through the oracle"""
