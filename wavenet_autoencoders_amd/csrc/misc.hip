@@ -503,36 +503,39 @@ __global__ void __launch_bounds__(256) enc_conv_fwd_kernel(const float* __restri
 #define EC_NS 8     // reduction slices
 #define EC_CH 256   // input channels staged per chunk
 #define EC_WB 8     // channels whose weights a thread requests together
-template <int K, int S>
+// ET: outputs per block along time (32, or 16 / 8 for the short sequences behind the encoder's strided blocks -- at the reference's
+// 8 x 5120-sample shard the last eight blocks see 8 frames: a 32-frame tile there is 75 % padding and the launch is its dependent trips
+// to memory, so the next batch of weights is requested while the current one is multiplied).
+template <int K, int S, int ET>
 __global__ void __launch_bounds__(256) enc_conv_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, float* __restrict__ y, int Cin,
                                                                  int Tin, int Cout, int Tout, int pad, int relu, int residual) {
   extern __shared__ float sm[];
-  constexpr int WIN = (EC_T - 1) * S + K;
+  constexpr int WIN = (ET - 1) * S + K;
   constexpr int WP = (WIN + 3) & ~3;   // LDS row pitch: whole 16-byte reads
-  const int b = blockIdx.z, co0 = blockIdx.y * EC_T, to0 = blockIdx.x * EC_T;
+  const int b = blockIdx.z, co0 = blockIdx.y * EC_T, to0 = blockIdx.x * ET;
   const int ti0 = to0 * S - pad;
   const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int co = co0 + col;
-  float acc[EC_T];
+  float acc[ET];
 #pragma unroll
-  for (int i = 0; i < EC_T; ++i) acc[i] = 0.f;
+  for (int i = 0; i < ET; ++i) acc[i] = 0.f;
   const float* xb = x + (int64_t)b * Cin * Tin;
   for (int c0 = 0; c0 < Cin; c0 += EC_CH) {
     const int nc = min(EC_CH, Cin - c0);
     __syncthreads();
-    // staged in batches of 8 independent loads per thread (a load -> LDS-store loop with a run-time trip count was one L2 /
+    // staged in batches of 16 independent loads per thread (a load -> LDS-store loop with a run-time trip count was one L2 /
     // HBM round trip per element: 32 dependent round trips, most of the launch)
-    for (int i0 = threadIdx.x; i0 < nc * WP; i0 += 256 * 8) {
-      float v[8];
+    for (int i0 = threadIdx.x; i0 < nc * WP; i0 += 256 * 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int i = i0 + u * 256;
         const int ci = i / WP, wv = i - ci * WP, ti = ti0 + wv;
         v[u] = (i < nc * WP && wv < WIN && ti >= 0 && ti < Tin) ? xb[(int64_t)(c0 + ci) * Tin + ti] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 16; ++u)
         if (i0 + u * 256 < nc * WP) sm[i0 + u * 256] = v[u];
     }
     __syncthreads();
@@ -540,14 +543,18 @@ __global__ void __launch_bounds__(256) enc_conv_fwd_tiled_kernel(const float* __
     const int ca = sl * per, cb = min(nc, ca + per);
     if (co < Cout) {
       // the weights of a thread (row co, channels [ca, cb): one contiguous run) come in batches of EC_WB channels requested
-      // together: one L2 round trip per batch instead of one per channel (32 dependent round trips were most of the launch)
+      // together, the NEXT batch while this one is used: one L2 round trip per thread and chunk is exposed instead of one per batch
       const float* wrow = w + ((int64_t)co * Cin + c0) * K;
-      for (int cc = ca; cc < cb; cc += EC_WB) {
-        float wv[EC_WB][K];
+      float wv[EC_WB][K], wn[EC_WB][K];
+      auto fetch = [&](float (&dst)[EC_WB][K], int cc) {
 #pragma unroll
         for (int u = 0; u < EC_WB; ++u)
 #pragma unroll
-          for (int j = 0; j < K; ++j) wv[u][j] = cc + u < cb ? wrow[(cc + u) * K + j] : 0.f;
+          for (int j = 0; j < K; ++j) dst[u][j] = cc + u < cb ? wrow[(cc + u) * K + j] : 0.f;
+      };
+      if (ca < cb) fetch(wv, ca);
+      for (int cc = ca; cc < cb; cc += EC_WB) {
+        if (cc + EC_WB < cb) fetch(wn, cc + EC_WB);
 #pragma unroll
         for (int u = 0; u < EC_WB; ++u) {
           // the channel's input window moves LDS -> registers once (16-byte broadcast reads) and serves every tap
@@ -561,40 +568,51 @@ __global__ void __launch_bounds__(256) enc_conv_fwd_tiled_kernel(const float* __
 #pragma unroll
           for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int t = 0; t < EC_T; ++t) acc[t] = fmaf(wv[u][j], xw[t * S + j], acc[t]);
+            for (int t = 0; t < ET; ++t) acc[t] = fmaf(wv[u][j], xw[t * S + j], acc[t]);
         }
+#pragma unroll
+        for (int u = 0; u < EC_WB; ++u)
+#pragma unroll
+          for (int j = 0; j < K; ++j) wv[u][j] = wn[u][j];
       }
     }
   }
   __syncthreads();
   float* red = sm;   // [slice][t][33]
 #pragma unroll
-  for (int t = 0; t < EC_T; ++t) red[(sl * EC_T + t) * 33 + col] = acc[t];
+  for (int t = 0; t < ET; ++t) red[(sl * ET + t) * 33 + col] = acc[t];
   __syncthreads();
-  for (int o = threadIdx.x; o < EC_T * EC_T; o += 256) {
-    const int tl = o & 31, cl = o >> 5;
+  for (int o = threadIdx.x; o < ET * EC_T; o += 256) {
+    const int tl = o % ET, cl = o / ET;
     const int oc = co0 + cl, ot = to0 + tl;
     if (oc >= Cout || ot >= Tout) continue;
     float v = bias ? bias[oc] : 0.f;
 #pragma unroll
-    for (int q = 0; q < EC_NS; ++q) v += red[(q * EC_T + tl) * 33 + cl];
+    for (int q = 0; q < EC_NS; ++q) v += red[(q * ET + tl) * 33 + cl];
     if (relu) v = fmaxf(v, 0.f);
     if (residual) v += xb[(int64_t)oc * Tin + ot];
     y[((int64_t)b * Cout + oc) * Tout + ot] = v;
   }
 }
+template <int K, int S, int ET>
+static int launch_enc_fwd_tiled_et(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Tin, int Cout,
+                                   int Tout, int pad, int relu, int residual, hipStream_t st) {
+  constexpr int WIN = (ET - 1) * S + K;
+  constexpr int WP = (WIN + 3) & ~3;
+  const size_t a = (size_t)(Cin < EC_CH ? Cin : EC_CH) * WP, r = (size_t)EC_NS * ET * 33;
+  const size_t lds = (a > r ? a : r) * sizeof(float);
+  static WaeLdsCache cache;
+  if (int rc = wae_ensure_lds((const void*)enc_conv_fwd_tiled_kernel<K, S, ET>, cache, lds, "enc_conv_fwd"); rc != WAE_OK) return rc;   // y untouched: the caller must see the error
+  hipLaunchKernelGGL((enc_conv_fwd_tiled_kernel<K, S, ET>), dim3((Tout + ET - 1) / ET, (Cout + EC_T - 1) / EC_T, B), dim3(256), lds, st,
+                     x, w, bias, y, Cin, Tin, Cout, Tout, pad, relu, residual);
+  return WAE_OK;
+}
 template <int K, int S>
 static int launch_enc_fwd_tiled(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Tin, int Cout,
                                 int Tout, int pad, int relu, int residual, hipStream_t st) {
-  constexpr int WIN = (EC_T - 1) * S + K;
-  constexpr int WP = (WIN + 3) & ~3;
-  const size_t a = (size_t)(Cin < EC_CH ? Cin : EC_CH) * WP, r = (size_t)EC_NS * EC_T * 33;
-  const size_t lds = (a > r ? a : r) * sizeof(float);
-  static WaeLdsCache cache;
-  if (int rc = wae_ensure_lds((const void*)enc_conv_fwd_tiled_kernel<K, S>, cache, lds, "enc_conv_fwd"); rc != WAE_OK) return rc;   // y untouched: the caller must see the error
-  hipLaunchKernelGGL((enc_conv_fwd_tiled_kernel<K, S>), dim3((Tout + EC_T - 1) / EC_T, (Cout + EC_T - 1) / EC_T, B), dim3(256), lds, st,
-                     x, w, bias, y, Cin, Tin, Cout, Tout, pad, relu, residual);
-  return WAE_OK;
+  if (Tout <= 8) return launch_enc_fwd_tiled_et<K, S, 8>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  if (Tout <= 16) return launch_enc_fwd_tiled_et<K, S, 16>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
+  return launch_enc_fwd_tiled_et<K, S, 32>(x, w, bias, y, B, Cin, Tin, Cout, Tout, pad, relu, residual, st);
 }
 
 extern "C" int wae_enc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
