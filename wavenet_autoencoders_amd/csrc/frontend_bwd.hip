@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) conv_bwd_w_kernel(const float* __restrict_
 // dx[b][ci][ti] = sum_{co, j} w[co][ci][j] * dpre[b][co][(ti + PAD - j) / S]: block = 32 input channels x 32 input steps of one
 // clip, thread = (channel, slice of the co reduction); dpre windows of 256 output channels are staged in LDS.  ti0 is a multiple
 // of 32, so which (ti, j) pairs hit a whole output step, and where it sits in the staged window, is known at compile time.
-template <int K, int S, int PAD>
+template <int K, int S, int PAD, int ET>
 __global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ y, const float* __restrict__ dy,
                                                                float* __restrict__ dx, int Cin, int Tin, int Cout, int Tout, int relu,
@@ -198,15 +198,15 @@ __global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __re
   extern __shared__ float sm[];
   constexpr int R0 = (((PAD - K + 1) % S) + S) % S;        // (ti0 + PAD - K + 1) mod S for ti0 = 0 mod S
   constexpr int BASE = K - 1 + R0;                         // ti_l - j + BASE = S * (to - tb) when that is a whole step
-  constexpr int TWIN = (ECB_T - 1 + BASE) / S + 1;
+  constexpr int TWIN = (ET - 1 + BASE) / S + 1;
   constexpr int TP = (TWIN + 3) & ~3;
-  const int b = blockIdx.z, ci0 = blockIdx.y * ECB_T, ti0 = blockIdx.x * ECB_T;
+  const int b = blockIdx.z, ci0 = blockIdx.y * ECB_T, ti0 = blockIdx.x * ET;
   const int tb = (ti0 + PAD - (K - 1) - R0) / S;           // exact: the numerator is a multiple of S (may be negative)
   const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int ci = ci0 + col;
-  float acc[ECB_T];
+  float acc[ET];
 #pragma unroll
-  for (int i = 0; i < ECB_T; ++i) acc[i] = 0.f;
+  for (int i = 0; i < ET; ++i) acc[i] = 0.f;
   const float* xb = x + (int64_t)b * Cin * Tin;
   const float* yb = y ? y + (int64_t)b * Cout * Tout : nullptr;
   const float* dyb = dy + (int64_t)b * Cout * Tout;
@@ -230,13 +230,18 @@ __global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __re
     __syncthreads();
     const int per = (nc + ECB_NS - 1) / ECB_NS;
     const int ca = sl * per, cb = min(nc, ca + per);
-    if (ci < Cin)
-      for (int cc = ca; cc < cb; cc += ECB_WB) {   // weights of ECB_WB output channels requested together (one round trip)
-        float wv[ECB_WB][K];
+    if (ci < Cin) {
+      // weights of ECB_WB output channels requested together, the NEXT batch under this one's FMAs (one exposed round trip per chunk)
+      float wv[ECB_WB][K], wn[ECB_WB][K];
+      auto fetch = [&](float (&dst)[ECB_WB][K], int cc) {
 #pragma unroll
         for (int u = 0; u < ECB_WB; ++u)
 #pragma unroll
-          for (int j = 0; j < K; ++j) wv[u][j] = cc + u < cb ? w[((int64_t)(c0 + cc + u) * Cin + ci) * K + j] : 0.f;
+          for (int j = 0; j < K; ++j) dst[u][j] = cc + u < cb ? w[((int64_t)(c0 + cc + u) * Cin + ci) * K + j] : 0.f;
+      };
+      if (ca < cb) fetch(wv, ca);
+      for (int cc = ca; cc < cb; cc += ECB_WB) {
+        if (cc + ECB_WB < cb) fetch(wn, cc + ECB_WB);
 #pragma unroll
         for (int u = 0; u < ECB_WB; ++u) {
           const f32x4* gr4 = (const f32x4*)(sm + min(cc + u, cb - 1) * TP);
@@ -249,36 +254,41 @@ __global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __re
 #pragma unroll
           for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int t = 0; t < ECB_T; ++t)   // (t, j, BASE, S are compile-time after unrolling: the test folds away)
+            for (int t = 0; t < ET; ++t)   // (t, j, BASE, S are compile-time after unrolling: the test folds away)
               if ((t - j + BASE) >= 0 && (t - j + BASE) % S == 0) acc[t] = fmaf(wv[u][j], gw[(t - j + BASE) / S], acc[t]);
         }
+#pragma unroll
+        for (int u = 0; u < ECB_WB; ++u)
+#pragma unroll
+          for (int j = 0; j < K; ++j) wv[u][j] = wn[u][j];
       }
+    }
   }
   __syncthreads();
   float* red = sm;
 #pragma unroll
-  for (int t = 0; t < ECB_T; ++t) red[(sl * ECB_T + t) * 33 + col] = acc[t];
+  for (int t = 0; t < ET; ++t) red[(sl * ET + t) * 33 + col] = acc[t];
   __syncthreads();
-  for (int o = threadIdx.x; o < ECB_T * ECB_T; o += 256) {
-    const int tl = o & 31, cl = o >> 5;
+  for (int o = threadIdx.x; o < ET * ECB_T; o += 256) {
+    const int tl = o % ET, cl = o / ET;
     const int oc = ci0 + cl, ot = ti0 + tl;
     if (oc >= Cin || ot >= Tin) continue;
     float v = 0.f;
 #pragma unroll
-    for (int q = 0; q < ECB_NS; ++q) v += red[(q * ECB_T + tl) * 33 + cl];
+    for (int q = 0; q < ECB_NS; ++q) v += red[(q * ET + tl) * 33 + cl];
     if (residual) v += dyb[(int64_t)oc * Tout + ot];
     dx[((int64_t)b * Cin + oc) * Tin + ot] = v;
   }
 }
 // dw[co][ci][j] += sum_{b, to} dpre[b][co][to] * x[b][ci][to*S + j - pad] (+ dbias[co] += sum dpre): block = 32 output x 32 input
 // channels over every clip and step (the unique owner of its outputs: plain read-modify-write), thread = (co, 4 input channels).
-template <int K, int S>
+template <int K, int S, int ET>
 __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                const float* __restrict__ dy, float* __restrict__ dw,
                                                                float* __restrict__ dbias, int B, int Cin, int Tin, int Cout, int Tout,
                                                                int pad, int relu, int residual) {
-  constexpr int WIN = (ECB_T - 1) * S + K;
-  constexpr int WP = (WIN + 3) & ~3, GP = 36;      // row pitches: whole 16-byte reads
+  constexpr int WIN = (ET - 1) * S + K;
+  constexpr int WP = (WIN + 3) & ~3, GP = ET + 4;   // row pitches: whole 16-byte reads
   constexpr int GSZ = ECB_T * GP, XSZ = ECB_T * WP;
   extern __shared__ float sm[];     // ECB_RT x (dpre tile [32 co][GP] + x window [32 ci][WP]): one round of (clip, step tile) pairs
   const int co0 = blockIdx.x * ECB_T, ci0 = blockIdx.y * ECB_T;
@@ -289,22 +299,22 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < K; ++j) acc[c][j] = 0.f;
   float accb = 0.f;
-  const int tpc = (Tout + ECB_T - 1) / ECB_T;      // step tiles per clip
+  const int tpc = (Tout + ET - 1) / ET;      // step tiles per clip
   const int ntile = B * tpc;
   for (int r0 = 0; r0 < ntile; r0 += ECB_RT) {
     const int nr = min(ECB_RT, ntile - r0);
     __syncthreads();
     // every global load of the round is issued before the first LDS store of the round is needed: one round trip per round
-    for (int i0 = threadIdx.x; i0 < nr * ECB_T * ECB_T; i0 += 256 * 8) {   // batches of 8 independent loads per thread
+    for (int i0 = threadIdx.x; i0 < nr * ECB_T * ET; i0 += 256 * 8) {   // batches of 8 independent loads per thread
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * 256;
-        const int r = i / (ECB_T * ECB_T), e = i - r * (ECB_T * ECB_T);
-        const int tl = e & 31, cl = e >> 5;
-        const int b = min((r0 + r) / tpc, B - 1), to = ((r0 + r) % tpc) * ECB_T + tl, co = co0 + cl;
+        const int r = i / (ECB_T * ET), e = i - r * (ECB_T * ET);
+        const int tl = e % ET, cl = e / ET;
+        const int b = min((r0 + r) / tpc, B - 1), to = ((r0 + r) % tpc) * ET + tl, co = co0 + cl;
         const float* xb = x + (int64_t)b * Cin * Tin;
-        v[u] = (i < nr * ECB_T * ECB_T && co < Cout && to < Tout)
+        v[u] = (i < nr * ECB_T * ET && co < Cout && to < Tout)
                    ? conv_dpre(dy + (int64_t)b * Cout * Tout, y ? y + (int64_t)b * Cout * Tout : nullptr, xb, (int64_t)co * Tout + to,
                                (int64_t)co * Tin + to, relu, residual)
                    : 0.f;
@@ -312,8 +322,8 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * 256;
-        const int r = i / (ECB_T * ECB_T), e = i - r * (ECB_T * ECB_T);
-        if (i < nr * ECB_T * ECB_T) sm[r * (GSZ + XSZ) + (e >> 5) * GP + (e & 31)] = v[u];
+        const int r = i / (ECB_T * ET), e = i - r * (ECB_T * ET);
+        if (i < nr * ECB_T * ET) sm[r * (GSZ + XSZ) + (e / ET) * GP + (e % ET)] = v[u];
       }
     }
     for (int i0 = threadIdx.x; i0 < nr * XSZ; i0 += 256 * 8) {
@@ -323,7 +333,7 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
         const int i = i0 + u * 256;
         const int r = i / XSZ, e = i - r * XSZ;
         const int cl = e / WP, wv = e - cl * WP;
-        const int b = min((r0 + r) / tpc, B - 1), to0 = ((r0 + r) % tpc) * ECB_T;
+        const int b = min((r0 + r) / tpc, B - 1), to0 = ((r0 + r) % tpc) * ET;
         const int ci = ci0 + cl, ti = to0 * S - pad + wv;
         v[u] = (i < nr * XSZ && wv < WIN && ci < Cin && ti >= 0 && ti < Tin) ? x[((int64_t)b * Cin + ci) * Tin + ti] : 0.f;
       }
@@ -338,9 +348,9 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
     for (int r = 0; r < nr; ++r) {
       const float* gs = sm + r * (GSZ + XSZ);
       const float* xs = gs + GSZ;
-      float g[ECB_T];   // this thread's output channel, the tile's 32 steps
+      float g[ET];   // this thread's output channel, the tile's ET steps
 #pragma unroll
-      for (int q = 0; q < ECB_T / 4; ++q) {
+      for (int q = 0; q < ET / 4; ++q) {
         const f32x4 v = *(const f32x4*)(gs + col * GP + 4 * q);
         g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
         accb += (v.x + v.y) + (v.z + v.w);
@@ -357,7 +367,7 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-          for (int t = 0; t < ECB_T; ++t) acc[c][j] = fmaf(g[t], xw[t * S + j], acc[c][j]);
+          for (int t = 0; t < ET; ++t) acc[c][j] = fmaf(g[t], xw[t * S + j], acc[c][j]);
       }
     }
   }
@@ -373,30 +383,40 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
     if (dbias && cg == 0 && blockIdx.y == 0) dbias[co] += accb;
   }
 }
-template <int K, int S, int PAD>
-static int launch_conv_bwd_tiled(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* dbias,
-                                 int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual, hipStream_t st) {
+// ET: the time tile of both kernels (32, or 16 / 8 for the short sequences behind the encoder's strided blocks: at the reference's
+// 8 x 5120-sample shard eight of the ten blocks see 8 frames, and a 32-step tile there is 75 % padding)
+template <int K, int S, int PAD, int ET>
+static int launch_conv_bwd_tiled_et(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* dbias,
+                                    int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual, hipStream_t st) {
   if (dx) {
     constexpr int R0 = (((PAD - K + 1) % S) + S) % S;
-    constexpr int TWIN = (ECB_T - 1 + K - 1 + R0) / S + 1;
+    constexpr int TWIN = (ET - 1 + K - 1 + R0) / S + 1;
     constexpr int TP = (TWIN + 3) & ~3;
-    const size_t a = (size_t)(Cout < ECB_CH ? Cout : ECB_CH) * TP, r = (size_t)ECB_NS * ECB_T * 33;
+    const size_t a = (size_t)(Cout < ECB_CH ? Cout : ECB_CH) * TP, r = (size_t)ECB_NS * ET * 33;
     const size_t lds = (a > r ? a : r) * sizeof(float);
     static WaeLdsCache cache;
-    if (int rc = wae_ensure_lds((const void*)conv_bwd_x_tiled_kernel<K, S, PAD>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
-    hipLaunchKernelGGL((conv_bwd_x_tiled_kernel<K, S, PAD>), dim3((Tin + ECB_T - 1) / ECB_T, (Cin + ECB_T - 1) / ECB_T, B), dim3(256), lds,
+    if (int rc = wae_ensure_lds((const void*)conv_bwd_x_tiled_kernel<K, S, PAD, ET>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
+    hipLaunchKernelGGL((conv_bwd_x_tiled_kernel<K, S, PAD, ET>), dim3((Tin + ET - 1) / ET, (Cin + ECB_T - 1) / ECB_T, B), dim3(256), lds,
                        st, x, w, y, dy, dx, Cin, Tin, Cout, Tout, relu, residual);
   }
   {
-    constexpr int WIN = (ECB_T - 1) * S + K;
+    constexpr int WIN = (ET - 1) * S + K;
     constexpr int WP = (WIN + 3) & ~3;
-    const size_t lds = (size_t)ECB_RT * (ECB_T * 36 + ECB_T * WP) * sizeof(float);
+    const size_t lds = (size_t)ECB_RT * (ECB_T * (ET + 4) + ECB_T * WP) * sizeof(float);
     static WaeLdsCache cache;
-    if (int rc = wae_ensure_lds((const void*)conv_bwd_w_tiled_kernel<K, S>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
-    hipLaunchKernelGGL((conv_bwd_w_tiled_kernel<K, S>), dim3((Cout + ECB_T - 1) / ECB_T, (Cin + ECB_T - 1) / ECB_T), dim3(256), lds, st, x,
+    if (int rc = wae_ensure_lds((const void*)conv_bwd_w_tiled_kernel<K, S, ET>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
+    hipLaunchKernelGGL((conv_bwd_w_tiled_kernel<K, S, ET>), dim3((Cout + ECB_T - 1) / ECB_T, (Cin + ECB_T - 1) / ECB_T), dim3(256), lds, st, x,
                        y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, PAD, relu, residual);
   }
   return WAE_OK;
+}
+template <int K, int S, int PAD>
+static int launch_conv_bwd_tiled(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* dbias,
+                                 int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual, hipStream_t st) {
+  // one tile size for both kernels, chosen by the longer of the two sequences (Tin >= Tout)
+  if (Tin <= 8) return launch_conv_bwd_tiled_et<K, S, PAD, 8>(x, w, y, dy, dx, dw, dbias, B, Cin, Tin, Cout, Tout, relu, residual, st);
+  if (Tin <= 16) return launch_conv_bwd_tiled_et<K, S, PAD, 16>(x, w, y, dy, dx, dw, dbias, B, Cin, Tin, Cout, Tout, relu, residual, st);
+  return launch_conv_bwd_tiled_et<K, S, PAD, 32>(x, w, y, dy, dx, dw, dbias, B, Cin, Tin, Cout, Tout, relu, residual, st);
 }
 
 extern "C" int wae_enc_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
