@@ -60,16 +60,16 @@ __device__ __forceinline__ float load_e<f16>(const void* p, int64_t i) { return 
 __device__ __forceinline__ bool wn_vec_ok(const float* a, const float* b, const float* c, int n) {
   return n >= 4 && n <= 64 * WN_KMAX && (n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
-// the whole workgroup copies [a, b): four loads in flight per thread (the largest gap of C2 -- the speaker embedding and the upsampling
+// the whole workgroup copies [a, b) (the largest gap of C2 -- the speaker embedding and the upsampling
 // network, 14 000 floats -- copied by ONE 16-lane group, a load and a store per trip, was a 160-us tail on a 30-us launch)
 __device__ __forceinline__ void wn_block_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t a, int64_t b) {
-  for (int64_t i = a + threadIdx.x; i < b; i += 1024) {
-    const int64_t i1 = i + 256, i2 = i + 512, i3 = i + 768;
-    const float x0 = src[i], x1 = i1 < b ? src[i1] : 0.f, x2 = i2 < b ? src[i2] : 0.f, x3 = i3 < b ? src[i3] : 0.f;
-    dst[i] = x0;
-    if (i1 < b) dst[i1] = x1;
-    if (i2 < b) dst[i2] = x2;
-    if (i3 < b) dst[i3] = x3;
+  for (int64_t i0 = a + threadIdx.x; i0 < b; i0 += 256 * 16) {   // a 4096-float piece is ONE trip: sixteen loads in flight per thread
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = i0 + 256 * u < b ? src[i0 + 256 * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + 256 * u < b) dst[i0 + 256 * u] = x[u];
   }
 }
 __device__ __forceinline__ float wn_dot(const f32x4& a, const f32x4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
