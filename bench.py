@@ -386,8 +386,11 @@ def main():
             # weight gradients: 16-bit = ONE launch for all layers (gemm_tn_static_kernel: dW1 taps, dWc + zb sums, dW_out AND dW_skip
             # + the out bias), fp32 = one gemm_tn_kernel per layer.  Algorithmic bytes = the operands each layer must read once: dz
             # (G), x (R), c (Cc), dx-hat (R), u (H); dS (S) is the same array for every layer: once per launch.
-            nl = geom.layers if len(ev_tn) // args.steps == 1 else 1
-            tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn)
+            # launches per step: 1 (the whole stack), 2 (data parallel: the stack in two layer halves, backward.decoder_backward) or one
+            # per layer (fp32 tiles).  The halves are summed: `avg_launch_ms` then is the weight-gradient time of a step.
+            per_step = max(1, len(ev_tn) // args.steps)
+            nl = geom.layers if per_step <= 2 else 1
+            tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn) * (per_step if nl > 1 else 1)
             static = nl > 1 and os.environ.get("WAE_TN_STATIC", "1") != "0"
             tn_bytes = (nl * (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) + (C2["S"] if static else 0)) * es * samples
             tn_flops = nl * 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H + (C2["S"] * H if static else 0)) * samples
