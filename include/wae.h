@@ -282,6 +282,16 @@ int wae_clip_adam_ema(float* params, const float* grads, float* exp_avg, float* 
                       double* scratch, float* grad_norm_out, int32_t step, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double clip_thresh, double ema_decay, void* stream);
 
+/* ---- softmax over the channel dimension of (B, C, T) fp32 logits: WaveNet.forward(softmax=True) / VQVAE.forward(softmax=True)
+ * (wavenet.py:214, vqvae_model.py:79-80: F.softmax(x, dim=1)) and its backward dx = p (dp - sum_c p dp).  p may alias x; dx may alias dp. */
+int wae_softmax_bct_fwd(const float* x, float* p, int32_t B, int32_t C, int32_t T, void* stream);
+int wae_softmax_bct_bwd(const float* p, const float* dp, float* dx, int32_t B, int32_t C, int32_t T, void* stream);
+
+/* C[n] = alpha * A[n] (M x K, row stride lda) B[n] (K x N, ldb), fp32, n < nbatch with the given batch strides: the per-layer products
+ * sqrt(.5) W1_cur[l] W_out[l-1] a caller of wae_ar_generate_coop_fused forms once per weight update (engine.py: _pack_ar_fused). */
+int wae_bmm_f32(const float* a, const float* b, float* c, int32_t nbatch, int32_t M, int32_t K, int32_t N, int64_t lda, int64_t ldb,
+                int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, float alpha, void* stream);
+
 /* ---- a12 incremental (autoregressive) decoding: Conv1d.incremental_forward (conv.py:17-62) and
  * WaveNet.incremental_forward (wavenet.py:218-346) as ONE persistent launch, one workgroup per utterance ------
  * mode 0: teacher-forced (the reference's test_inputs, softmax=False, quantize=False): logits out, inputs consumed

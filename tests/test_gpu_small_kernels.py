@@ -122,3 +122,28 @@ def test_onehot_rows():
             if 0 <= v < 256:
                 want[i, v] = 1.0
         assert torch.equal(out.float(), want)
+
+
+def test_softmax_bct_forward_and_backward_against_torch():
+    from wavenet_autoencoders_amd.losses import softmax_bct
+    torch.manual_seed(3)
+    x = (torch.randn(3, 256, 301, device="cuda") * 4).requires_grad_(True)
+    w = torch.randn(3, 256, 301, device="cuda")
+    p = softmax_bct(x)
+    (p * w).sum().backward()
+    gx = x.grad.clone()
+    x.grad = None
+    pr = torch.softmax(x, dim=1)
+    (pr * w).sum().backward()
+    assert (p - pr).abs().max() < 2e-6 and (gx - x.grad).abs().max() < 2e-6 * max(1.0, float(x.grad.abs().max()))
+
+
+def test_bmm_f32_against_torch():
+    L, lib = _lib()
+    torch.manual_seed(4)
+    a = torch.randn(5, 37, 50, device="cuda")
+    b = torch.randn(5, 50, 21, device="cuda")
+    c = torch.full((5, 37, 21), 9.0, device="cuda")
+    L.check(lib.wae_bmm_f32(L.ptr(a), L.ptr(b), L.ptr(c), 5, 37, 50, 21, 50, 21, 21, 37 * 50, 50 * 21, 37 * 21, 0.5, None))
+    want = 0.5 * torch.bmm(a.double(), b.double())
+    assert (c.double() - want).abs().max() < 1e-5

@@ -104,6 +104,9 @@ SIGNATURES = {
     "wae_vq_slice_bwd": (c_i32, [c_vp] * 6 + [c_i32] * 5 + [c_f32, c_f32, c_vp]),
     "wae_first_conv_fwd": (c_i32, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "wae_onehot_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "wae_softmax_bct_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "wae_softmax_bct_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "wae_bmm_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, ctypes.c_float, c_vp]),
     "wae_glu_layer_fwd": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "wae_glu_layer_fwd_drop": (c_i32, [ctypes.POINTER(GluDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "wae_dropout_fwd": (c_i32, [c_vp, c_vp, c_i64, ctypes.c_uint64, c_f32, c_i32, c_vp]),

@@ -288,3 +288,73 @@ extern "C" int wae_weighted_mean(const float* v, const float* m, int64_t n, floa
   hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(1024), 0, as_stream(stream), v, m, n, out);
   return wae_check_launch("weighted_mean");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// softmax over the channel dimension of (B, C, T) fp32 logits -- WaveNet.forward(softmax=True), wavenet.py:214 / vqvae_model.py:79-80
+// (F.softmax(x, dim=1)) -- and its backward dx = p * (dp - sum_c p dp).  thread = one (b, t); channels are T apart: coalesced along t.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_bct_fwd_kernel(const float* __restrict__ x, float* __restrict__ p, int C, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float* xr = x + (int64_t)b * C * T + t;
+  float* pr = p + (int64_t)b * C * T + t;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, xr[(int64_t)c * T]);
+  float den = 0.f;
+  for (int c = 0; c < C; ++c) den += expf(xr[(int64_t)c * T] - mx);
+  const float inv = 1.0f / den;
+  for (int c = 0; c < C; ++c) pr[(int64_t)c * T] = expf(xr[(int64_t)c * T] - mx) * inv;
+}
+__global__ void __launch_bounds__(256) softmax_bct_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                              float* __restrict__ dx, int C, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int64_t o = (int64_t)b * C * T + t;
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) dot = fmaf(p[o + (int64_t)c * T], dp[o + (int64_t)c * T], dot);
+  for (int c = 0; c < C; ++c) dx[o + (int64_t)c * T] = p[o + (int64_t)c * T] * (dp[o + (int64_t)c * T] - dot);
+}
+extern "C" int wae_softmax_bct_fwd(const float* x, float* p, int32_t B, int32_t C, int32_t T, void* stream) {
+  WAE_REQUIRE(x && p && B > 0 && C > 0 && T > 0, "softmax_bct_fwd: bad arguments");
+  hipLaunchKernelGGL(softmax_bct_fwd_kernel, dim3((T + 255) / 256, B), dim3(256), 0, as_stream(stream), x, p, C, T);
+  return wae_check_launch("softmax_bct_fwd");
+}
+extern "C" int wae_softmax_bct_bwd(const float* p, const float* dp, float* dx, int32_t B, int32_t C, int32_t T, void* stream) {
+  WAE_REQUIRE(p && dp && dx && B > 0 && C > 0 && T > 0, "softmax_bct_bwd: bad arguments");
+  hipLaunchKernelGGL(softmax_bct_bwd_kernel, dim3((T + 255) / 256, B), dim3(256), 0, as_stream(stream), p, dp, dx, C, T);
+  return wae_check_launch("softmax_bct_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C[n] = alpha * A[n] B[n], fp32 row-major, small batched products formed once per weight update (the per-layer matrices
+// sqrt(.5) W1_cur W_out of wae_ar_generate_coop_fused).  16 x 16 output tile per workgroup, K in steps of 16 through LDS.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bmm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c,
+                                                      int M, int K, int N, int64_t lda, int64_t ldb, int64_t ldc, int64_t sa, int64_t sb,
+                                                      int64_t sc, float alpha) {
+  __shared__ float ta[16][17], tb[16][17];
+  const int n = blockIdx.z;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+  const float* an = a + n * sa;
+  const float* bn = b + n * sb;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    ta[ty][tx] = (row < M && k0 + tx < K) ? an[(int64_t)row * lda + k0 + tx] : 0.f;
+    tb[ty][tx] = (k0 + ty < K && col < N) ? bn[(int64_t)(k0 + ty) * ldb + col] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(ta[ty][k], tb[k][tx], acc);
+    __syncthreads();
+  }
+  if (row < M && col < N) c[n * sc + (int64_t)row * ldc + col] = alpha * acc;
+}
+extern "C" int wae_bmm_f32(const float* a, const float* b, float* c, int32_t nbatch, int32_t M, int32_t K, int32_t N, int64_t lda,
+                           int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, float alpha, void* stream) {
+  WAE_REQUIRE(a && b && c && nbatch > 0 && M > 0 && K > 0 && N > 0 && lda >= K && ldb >= N && ldc >= N, "bmm_f32: bad arguments");
+  hipLaunchKernelGGL(bmm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16, nbatch), dim3(256), 0, as_stream(stream), a, b, c, M, K, N, lda, ldb,
+                     ldc, stride_a, stride_b, stride_c, alpha);
+  return wae_check_launch("bmm_f32");
+}

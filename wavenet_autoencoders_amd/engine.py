@@ -487,7 +487,10 @@ class WaeEngine:
         w2 = w[:, self.ar_w2_off:self.ar_w2_off + nkbh * w_pad * epl].view(g.layers, nkbh, w_pad, epl)
         wout = w2[:, :, :g.R].permute(0, 2, 1, 3).reshape(g.layers, g.R, nkbh * epl)[:, :, :g.H]
         wm = torch.zeros(g.layers, g.G, g.H, dtype=torch.float32, device=self.device)
-        wm[1:] = math.sqrt(0.5) * torch.bmm(w1c[1:], wout[:-1])
+        a, b = w1c[1:].contiguous(), wout[:-1].contiguous()        # (L-1, G, R), (L-1, R, H)
+        L.check(self.lib.wae_bmm_f32(L.ptr(a), L.ptr(b), L.ptr(wm[1:]), g.layers - 1, g.G, g.R, g.H, g.R, g.H, g.H, g.G * g.R, g.R * g.H,
+                                     g.G * g.H, math.sqrt(0.5), self.stream()), "bmm_f32")
+        self._fused_keep = (a, b)
         return wm.to(self.tdtype).contiguous()
 
     def incremental_forward(self, c: Optional[torch.Tensor], gid: Optional[torch.Tensor], T: int, mode: str = "sample",

@@ -169,3 +169,33 @@ class ExponentialMovingAverage(object):
     def update(self, name, x):
         assert name in self.shadow
         self.shadow[name] -= (1.0 - self.decay) * (self.shadow[name] - x)
+
+
+class _SoftmaxBCT(torch.autograd.Function):
+    """F.softmax(x, dim=1) on (B, C, T) logits (WaveNet.forward(softmax=True), wavenet.py:214; VQVAE.forward, vqvae_model.py:79-80) through
+    wae_softmax_bct_fwd / _bwd: the drop-in modules form no arithmetic with torch operators."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib as L
+        xf = x.contiguous().float()
+        B, C, T = xf.shape
+        p = torch.empty_like(xf)
+        L.check(L.lib().wae_softmax_bct_fwd(L.ptr(xf), L.ptr(p), B, C, T, _stream(xf)), "softmax_bct_fwd")
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        from . import _lib as L
+        (p,) = ctx.saved_tensors
+        B, C, T = p.shape
+        dpf = dp.contiguous().float()
+        dx = torch.empty_like(p)
+        L.check(L.lib().wae_softmax_bct_bwd(L.ptr(p), L.ptr(dpf), L.ptr(dx), B, C, T, _stream(p)), "softmax_bct_bwd")
+        return dx
+
+
+def softmax_bct(x: torch.Tensor) -> torch.Tensor:
+    """softmax over dim 1 of (B, C, T) logits on the HIP path (differentiable)."""
+    return _SoftmaxBCT.apply(x)

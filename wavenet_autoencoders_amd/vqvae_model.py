@@ -6,7 +6,7 @@ import torch
 
 from . import packing as P
 from .wavenet_vocoder._base import ArenaModel
-from .wavenet_vocoder.wavenet import WaveNet, _ids_from_input
+from .wavenet_vocoder.wavenet import WaveNet, _ids_from_input, softmax_bct
 
 
 class _VQVAEFn(torch.autograd.Function):
@@ -76,7 +76,7 @@ class VQVAE(ArenaModel):
         train = train or (self.training and self.dropout > 0)                       # F.dropout follows module.training
         y, vq_loss, perp = _VQVAEFn.apply(self, ids, c.float(), gid, train, *params)
         if softmax:
-            y = torch.softmax(y, dim=1)
+            y = softmax_bct(y)
         return y, vq_loss, perp
 
     def incremental_forward(self, initial_input, c, g, T, softmax, quantize, tqdm, log_scale_min):

@@ -12,6 +12,12 @@ from .. import packing as P
 from ._base import ArenaModel
 
 
+def softmax_bct(y):
+    """F.softmax(y, dim=1) of (B, C, T) logits on the HIP path (losses.softmax_bct; imported late: losses imports this package)."""
+    from ..losses import softmax_bct as f
+    return f(y)
+
+
 def receptive_field_size(total_layers, num_cycles, kernel_size, dilation=lambda x: 2 ** x):
     """(kernel_size - 1) * sum(dilations) + 1 (wavenet.py:42-60)."""
     assert total_layers % num_cycles == 0
@@ -154,7 +160,7 @@ class WaveNet(ArenaModel):
             # applies the mask) even when nothing requires a gradient
             train = True
         y = _DecoderFn.apply(self, ids, c, g, c_is_up, train, *params)
-        return torch.softmax(y, dim=1) if softmax else y
+        return softmax_bct(y) if softmax else y
 
     def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None, tqdm=lambda x: x,
                             softmax=True, quantize=True, log_scale_min=-50.0):
@@ -210,7 +216,7 @@ class WaveNet(ArenaModel):
                 return torch.nn.functional.one_hot(out["idx"].long(), self.out_channels).float().transpose(1, 2).contiguous()
             if nf >= T:                      # fully teacher-forced: logits (or probabilities) of every step
                 y = eng.incremental_forward(c, gid, T, mode="logits", **kw)["logits"]
-                return torch.softmax(y, dim=1) if softmax else y
+                return softmax_bct(y) if softmax else y
             # quantize=False, free-running: the probability (softmax=True) or logit vector itself is fed back (wavenet.py:303-305)
             return eng.incremental_forward(c, gid, T, mode="probs" if softmax else "raw", **kw)["logits"]
 
