@@ -349,3 +349,47 @@ def test_split_head_agrees_with_the_one_kernel_head(name, dtype, monkeypatch):
         assert rel_err(outs[-1][0], z["y_hat"]) < BF16_TOL
     assert rel_err(outs[0][0], outs[1][0]) < 1e-2
     assert abs(outs[0][1] - outs[1][1]) < 2e-3
+
+
+@pytest.mark.parametrize("k", [1, 2, 4])
+def test_kernel_sizes_against_oracle(k):
+    """kernel_size 1, 2 and 4 (modules.py:71-107 accepts any; every preset uses 3): teacher-forced logits, loss, every parameter
+    gradient (fp32: 1e-3 of each tensor's range) and teacher-forced incremental decoding against the oracle; 16-bit logits at the
+    bf16 / fp16 bounds.  (T = 640: no ReLU pre-activation of this closed-form model sits within rounding of zero there -- at other
+    lengths one flipped mask moves a head-bias gradient by ~1/sqrt(T), in the oracle's favour or ours.)"""
+    from wavenet_autoencoders_amd import Geometry, backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=6, stacks=2, R=128, G=192, S=128, O=256, Cc=64, Cg=32, k=k, n_speakers=7, upsample_scales=None)
+    sd = O.make_state_dict(dict(cfg), 11, with_encoder=False)
+    B, T = 2, 640
+    x = ((O.hash_fill((B, T), 91) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    c = O.hash_fill((B, 64, T), 92, 1.1)
+    g = torch.arange(B) % 7
+    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
+    lengths = torch.tensor([T, T - 50])
+    psd = {kk: v.clone().requires_grad_(True) for kk, v in sd.items() if kk.startswith("wavenet.")}
+    y_ref = O.wavenet_forward(psd, dict(cfg), xin, c, g)
+    loss_ref = O.masked_ce_loss(y_ref, x.unsqueeze(-1), lengths)
+    loss_ref.backward()
+    y_ref = y_ref.detach()
+    for dtype, tol in (("fp32", FP32_TOL), ("bf16", BF16_TOL), ("fp16", 1e-2)):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        out = eng.decoder_forward(x.cuda(), c.cuda(), g.cuda(), targets=x.cuda(), lengths=lengths.cuda(), train=True, c_is_upsampled=True)
+        BW.decoder_backward(eng, x.cuda(), x.cuda(), lengths, g.cuda())
+        grads = BW.finish_grads(eng)
+        ar = eng.incremental_forward(c[:, :, :96].contiguous().cuda(), g.cuda(), 96, mode="logits", test_inputs=x[:, :96].cuda(),
+                                     c_is_upsampled=True, want_logits=True)
+        torch.cuda.synchronize()
+        assert rel_err(out["logits"].cpu(), y_ref) < tol
+        assert rel_err(ar["logits"].cpu(), y_ref[:, :, :96]) < tol
+        assert abs(float(out["loss"]) - float(loss_ref.detach())) < (1e-4 if dtype == "fp32" else 2e-2)
+        if dtype == "fp32":
+            bad = {}
+            for kk, v in psd.items():
+                gref = v.grad if v.grad is not None else torch.zeros_like(v)
+                got = grads[eng.lay.off(kk):eng.lay.off(kk) + eng.lay.numel(kk)].view(eng.lay.shapes[kk]).cpu()
+                err, ref = float((got - gref).abs().max()), float(gref.abs().max())
+                if err > 1e-3 * max(ref, 1e-6) + 1e-7:
+                    bad[kk] = (err, ref)
+            assert not bad, bad

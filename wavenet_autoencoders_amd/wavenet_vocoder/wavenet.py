@@ -127,10 +127,11 @@ class WaveNet(ArenaModel):
             # the network's own cin_pad is the one in upsample_params (the reference ignores the constructor argument for it)
             # -- ConvInUpsampleNetwork(**upsample_params) defaults it to 0 when the key is absent (upsample.py:72)
             cin_pad = int(upsample_params.get("cin_pad", 0))
-        if kernel_size != 3:
-            # kernel_size is a template constant of the layer kernels; 3 is what every preset and every parity fixture uses
-            raise NotImplementedError(f"kernel_size={kernel_size}: only the reference presets' kernel_size=3 is verified against the "
-                                      "reference; other tap counts are refused rather than run unverified")
+        if not 1 <= int(kernel_size) <= 4:
+            # the backward's tap sources are wae_gemm_tm's TM_MAX_SRC = 4; 1..4 taps are checked against the oracle (forward, backward,
+            # incremental decoding: tests/test_gpu_parity.py::test_kernel_sizes_against_oracle); 3 is what every preset uses, and the
+            # only tap count with static-schedule layer-kernel instantiations (the others run the run-time-scheduled kernel)
+            raise NotImplementedError(f"kernel_size={kernel_size}: 1..4 taps are implemented and verified; wider kernels are refused")
         geom = P.Geometry(layers=layers, stacks=stacks, R=residual_channels, G=gate_channels, S=skip_out_channels,
                           O=out_channels, Cc=cin_channels, Cg=gin_channels, k=kernel_size,
                           n_speakers=n_speakers if (gin_channels > 0 and use_speaker_embedding) else None,
