@@ -838,8 +838,7 @@ __global__ void __launch_bounds__(256) upsample_stage_kernel(const float* __rest
 
 // Last stage (time-major output, audio rate): a block = UPT output steps of one clip.  The input frames those steps touch
 // ((UPT + 2s)/s + 2 per channel) are staged in LDS with reads that run along time, then thread (c, t) walks its 2s+1 taps
-// with an incremental (u / s, u % s) -- same fmaf chain, same order as the direct form above (bit-identical), but the
-// direct form's loads were one cache line per lane (64 channel rows apart) and took 0.1 ms per step at C2.
+// (the direct form's loads were one cache line per lane, 64 channel rows apart: 0.1 ms per step at C2).
 #define UPT 64
 template <typename E>
 __global__ void __launch_bounds__(256) upsample_last_kernel(const float* __restrict__ in, const float* __restrict__ w,
@@ -854,16 +853,37 @@ __global__ void __launch_bounds__(256) upsample_last_kernel(const float* __restr
   }
   if (threadIdx.x <= 2 * s) taps[threadIdx.x] = w[threadIdx.x];
   __syncthreads();
+  // An output step whose 2s + 1 taps all fall inside the sequence touches three input frames f - 1, f, f + 1 (f = t / s) with the taps
+  // summed per frame: A[r] = sum_{j < s - r} w[j], B[r] = the next s taps, C[r] = the rest (r = t % s) -- three FMAs instead of a walk
+  // over 2s + 1 taps with an incremental (u / s, u % s): the walk was what this launch spent its 27 us on.  (Round 4; the sums reorder
+  // the reference's FIR additions -- 1e-7 relative, far below a 16-bit output's rounding -- so fp32 launches and the s steps at either end of a
+  // clip keep the tap-by-tap form.)
+  float* co3 = taps + 2 * s + 1;             // [3][s]
+  if (threadIdx.x < 3 * s) {
+    const int which = threadIdx.x / s, rr = threadIdx.x - which * s;
+    const int ja = which == 0 ? 0 : (which == 1 ? s - rr : 2 * s - rr), jb = which == 0 ? s - rr : (which == 1 ? 2 * s - rr : 2 * s + 1);
+    float a = 0.f;
+    for (int j = ja; j < jb; ++j) a += taps[j];
+    co3[threadIdx.x] = a;
+  }
+  __syncthreads();
   const int c = threadIdx.x % Cp, tl = threadIdx.x / Cp, tstep = 256 / Cp;
   const float* r = sm + c * nfp - fl;
   for (int t = t0 + tl; t < min(t0 + UPT, Tout); t += tstep) {
     float acc = 0.f;
     if (c < C) {
-      int j0 = max(0, s - t), u = t + j0 - s;      // first tap with u >= 0
-      int q = u / s, rem = u - q * s;
-      for (int j = j0; j <= 2 * s && u < Tout; ++j, ++u) {
-        acc = fmaf(taps[j], r[q], acc);
-        if (++rem == s) { rem = 0; ++q; }
+      if (sizeof(E) == 2 && t >= s && t + s < Tout) {   // (fp32, the parity mode, keeps the reference's summation order everywhere)
+        const int f = t / s, rr = t - f * s;
+        acc = co3[rr] * r[f - 1];
+        acc = fmaf(co3[s + rr], r[f], acc);
+        acc = fmaf(co3[2 * s + rr], r[f + 1], acc);
+      } else {
+        int j0 = max(0, s - t), u = t + j0 - s;      // first tap with u >= 0
+        int q = u / s, rem = u - q * s;
+        for (int j = j0; j <= 2 * s && u < Tout; ++j, ++u) {
+          acc = fmaf(taps[j], r[q], acc);
+          if (++rem == s) { rem = 0; ++q; }
+        }
       }
     }
     store_e<E>(out, ((int64_t)b * Tout + t) * Cp + c, acc);
@@ -882,7 +902,8 @@ extern "C" int wae_upsample_stage_fwd(const float* in, const float* w, void* out
     WAE_REQUIRE(Cp >= C, "upsample_stage: Cp < C");
     if (Cp <= 256 && 256 % Cp == 0) {
       const int nfp = UPT / s + 5;           // frames per channel row (+1: odd pitch against bank conflicts)
-      const size_t lds = ((size_t)Cp * (nfp | 1) + 2 * s + 1) * sizeof(float);
+      const size_t lds = ((size_t)Cp * (nfp | 1) + 2 * s + 1 + 3 * s) * sizeof(float);
+      WAE_REQUIRE(3 * s <= 256, "upsample_stage: scale %d too large for the last-stage kernel", s);
       dim3 g2((Tout + UPT - 1) / UPT, B);
       if (dtype == WAE_BF16)
         hipLaunchKernelGGL(upsample_last_kernel<__bf16>, g2, dim3(256), lds, st, in, w, out, C, Tin, s, Cp, nfp | 1);
