@@ -154,7 +154,7 @@ def test_stream_weight_gradients_match_per_layer_tiles(name, lengths, monkeypatc
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,T", [(1, 33), (3, 130), (2, 257), (5, 1000), (32, 40), (7, 4099)])
+@pytest.mark.parametrize("B,T", [(1, 2), (1, 15), (2, 16), (32, 17), (1, 33), (3, 130), (2, 257), (5, 1000), (32, 40), (7, 4099)])
 def test_static_weight_gradient_launch_at_odd_shapes(B, T, dtype, monkeypatch):
     """wae_gemm_tn_static (hardware zero fill through per-clip buffer descriptors, teams walking segments that start and end anywhere)
     against the per-layer 128 x 128 tile launches on the same 16-bit operands: clips shorter than a half-slab, T % 16 != 0, the
