@@ -100,6 +100,27 @@ def pack_bwd_weights(eng):
     L.check(lib.wae_pack_gather_multi(jobs, len(jobs), st), "pack backward weights")
 
 
+def prepare_backward_early(eng):
+    """The backward's own preparation -- its weight packs (39 us of divergent gathers) and the zeroing of the two gradient staging
+    arenas (18 us) -- issued on a SIDE stream right after prepare_weights, so that it runs under the forward's launches instead of
+    in front of the head's backward.  decoder_backward waits for the event (WAE_SIDE_PACK=0: everything on the launch stream)."""
+    if os.environ.get("WAE_SIDE_PACK", "1") == "0" or eng.device.type != "cuda":
+        return
+    _prepare_bwd(eng)
+    side = getattr(eng, "_side_stream", None)
+    if side is None:
+        side = eng._side_stream = torch.cuda.Stream(device=eng.device)
+    main = torch.cuda.current_stream(eng.device)
+    side.wait_stream(main)                     # the effective weights (weight norm) are ready on the launch stream's order
+    with torch.cuda.stream(side):
+        pack_bwd_weights(eng)
+        eng.d_eff.zero_()
+        eng.cbuf.zero_()
+        ev = torch.cuda.Event()
+        ev.record(side)
+    eng._bwd_early = ev
+
+
 def _arr(ctype, vals):
     return (ctype * len(vals))(*vals)
 
@@ -584,9 +605,14 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     ws = bwd_workspace(eng, B, T)
     es = eng.w_glu.element_size()
     sm = eng.sm
-    pack_bwd_weights(eng)
-    eng.d_eff.zero_()
-    eng.cbuf.zero_()
+    early = getattr(eng, "_bwd_early", None)
+    if early is not None:                      # packs and zeroed arenas were produced on the side stream under the forward
+        torch.cuda.current_stream(eng.device).wait_event(early)
+        eng._bwd_early = None
+    else:
+        pack_bwd_weights(eng)
+        eng.d_eff.zero_()
+        eng.cbuf.zero_()
     if lengths is None:
         count = B * (T - 1)
     else:

@@ -693,6 +693,8 @@ class WaeEngine:
             x = x.to(self.device, torch.int32).contiguous()
         if gid is not None and gid.dtype != torch.int32:
             gid = gid.to(self.device, torch.int32).contiguous()
+        from . import backward as BW
+        BW.prepare_backward_early(self)
         if self.g.scalar_input:
             fwd = self.forward if self.g.has_encoder else self.decoder_forward
             out = fwd(x, c, gid, targets=None, lengths=None, want_logits=True, train=True)
