@@ -67,7 +67,8 @@ def _prepare_bwd(eng):
                  c3=g.Op * sm["ldh"], c1h=g.Sp * sm["ldh"], ctab=P._ru(g.O, 128) * g.Rp, fb=g.Rp)
     if static_tn_geometry(eng):
         # wae_gemm_tn_static (kind OUTSKIP) writes dW_out / dW_skip of a layer transposed: rows = gated channel, and the out bias
-        # as one more row; the skip bias (column sums of dS, the same for every layer) comes from a small tile job
+        # as one more row; the skip bias (column sums of dS, the same for every layer) is the Cb of the LAST layer's OUTSKIP job, whose
+        # first operand is dS (its conv1x1_out gradient is dead): a plain (Sp,) vector in the first floats of `cbs`
         sizes.update(coT=g.layers * sm["ldoT_rows"] * g.Rp, csT=g.layers * g.Hp * g.Sp, cbs=g.Sp * P.ONES_PAD)
     total = sum(sizes.values())
     eng.cbuf = torch.zeros(total, dtype=torch.float32, device=dev)

@@ -386,8 +386,8 @@ class WaeEngine:
         if self.wide_head:
             self._head_fwd_wide(ws, B, T, logits, tg, train)
         elif self.split_head:
-            # the skip contraction (K = Ku: 72 chunks at C2, its operand 590 MB of u) as a wae_gemm_tm launch -- two workgroups per CU,
-            # 125 us against the ~200 us the same loop takes inside the head kernel's one workgroup per CU -- then the rest from h0
+            # the skip contraction (K = Ku: 72 chunks at C2, its operand 590 MB of u) as a wae_gemm_tm launch -- 197 us against the ~210 us
+            # the same loop takes inside the one-workgroup-per-CU head kernel -- then the rest from h0 (45 us)
             from . import backward as BW
             es = self.w_head.element_size()
             BW._tm(self, B, T, g.Sp, 3, math.sqrt(1.0 / g.layers), [(ws["u"].data_ptr(), g.Ku, g.Ku, 0)], self.w_head.data_ptr(),
