@@ -418,3 +418,26 @@ def test_dropout_train_step_bf16_learns():
         assert bool(torch.isfinite(eng.params).all())
     assert runs[0][0] == runs[1][0]
     assert runs[0][-1] < runs[0][0]
+
+
+def test_side_stream_backward_preparation_gives_the_same_step(monkeypatch):
+    """WAE_SIDE_PACK=1 (the backward's weight packs and arena zeroing on a side stream under the forward) is a scheduling switch: the
+    gradients of a train step are the same up to the arrival order of the weight-gradient atomics."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    got = []
+    for v in ("0", "1"):
+        monkeypatch.setenv("WAE_SIDE_PACK", v)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+        eng.load_state_dict(sd)
+        eng.init_optimizer()
+        seen = {}
+        for _ in range(2):      # the second step starts with the first one's side work behind it
+            eng.train_step(x, c, g, lr=0.0, clip_thresh=-1.0, grad_hook=lambda gr: seen.update(g=gr.clone()))
+        torch.cuda.synchronize()
+        assert (getattr(eng, "_side_stream", None) is not None) == (v == "1")
+        got.append(seen["g"])
+    err, ref = float((got[0] - got[1]).abs().max()), float(got[0].abs().max())
+    assert err < 1e-5 * ref + 1e-9, (err, ref)
