@@ -26,7 +26,9 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     r = eng.train_step(x, lat, g)
+host = (time.perf_counter() - t0) / steps      # the host's issue time per step (it runs ahead of the GPU when this is the smaller)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+print(f"host issue time {host * 1e3:.2f} ms per step")
 print(f"train step {dtype}: {dt * 1e3:.2f} ms -> {B * T / dt / 1e6:.2f} M samples/s; loss {float(r['loss']):.4f} gnorm {float(r['grad_norm']):.4f}")
 print("peak memory GB", torch.cuda.max_memory_allocated() / 2**30)
