@@ -10,7 +10,7 @@ dx}, conditioning/upsample gradients, weight-norm backward), [N > 1: bucketed RC
 and the fused clip_grad_norm_ + Adam + EMA update.  Inputs are resident in HBM before the timed region.
 `--mode forward` times the teacher-forced forward pass alone.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--mode train|forward] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--dtype bf16|fp16|fp32] [--mode train|forward] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, each rank trains on its own shard of the global
@@ -32,18 +32,41 @@ sys.path.insert(0, ROOT)
 C2 = dict(layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153,
           upsample_scales=[4, 4, 4, 5], cin_pad=0)
 B_PER_GPU, T = 8, 8000
+# --config: the three trainable configurations BASELINE.json names.  c2 (the default, configs[1]) is the one the metric is quoted on;
+# c3 = configs[2], hps/vqwae.json in full (encoder + VQ + 20-layer decoder), the per-GPU shard of its global batch 64 on 8 GPUs;
+# c5 = configs[4], 48 layers x 512 channels in fp16, the per-GPU shard of batch 128.
+CONFIGS = {
+    "c2": dict(cfg=C2, B=8, T=8000, dtype="bf16", encoder=False, salt=5,
+               name="C2: IN-WAE decoder dims (R256 G368 S256 Cc64 Cg64 k3), 24 layers/2 stacks"),
+    "c3": dict(cfg=dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5],
+                        encoder_hid=256, c_in=39, K=256, cin_pad=0), B=8, T=5120, dtype="bf16", encoder=True, salt=7,
+               name="C3: hps/vqwae.json in full (encoder 39->256 x10 blocks, VQ K=256, upsample x640, 20-layer decoder R=G=S=256)"),
+    "c5": dict(cfg=dict(layers=48, stacks=4, R=512, G=512, S=512, O=256, Cc=64, Cg=32, k=3, n_speakers=8, upsample_scales=[4, 4, 4, 5],
+                        cin_pad=0), B=16, T=5120, dtype="fp16", encoder=False, salt=3,
+               name="C5: 48 layers/4 stacks, R=G=S=512 decoder (Cc64 Cg32 k3)"),
+}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = 2500.0      # dense bf16
 FP32_MFMA_PEAK_TF = 157.3
 
 
-def synth_inputs(rank, device):
+def synth_inputs(rank, device, conf=None, on_device=True):
+    """(class ids (B,T), conditioning, speaker ids): the conditioning is the latent sequence (B, Cc, T/hop) for a decoder-only
+    configuration and the encoder's input features (B, c_in, T/160: hps/vqwae.json's 100 frames/s at 16 kHz) for c3."""
     import numpy as np
     import torch
+    conf = conf or CONFIGS["c2"]
+    cfg, B, T_ = conf["cfg"], conf["B"], conf["T"]
+    hop = int(np.prod(cfg["upsample_scales"]))
     rng = np.random.default_rng(1234 + rank)
-    x = torch.from_numpy(rng.integers(0, 256, size=(B_PER_GPU, T), dtype=np.int64))
-    lat = torch.from_numpy(rng.standard_normal((B_PER_GPU, C2["Cc"], T // 320)).astype(np.float32))
-    g = torch.from_numpy(rng.integers(0, C2["n_speakers"], size=(B_PER_GPU,), dtype=np.int64))
+    x = torch.from_numpy(rng.integers(0, cfg["O"], size=(B, T_), dtype=np.int64))
+    if conf["encoder"]:
+        lat = torch.from_numpy(rng.standard_normal((B, cfg["c_in"], T_ // (hop // 4))).astype(np.float32))   # the encoder strides by 4 (vqvae_model.py:32-40)
+    else:
+        lat = torch.from_numpy(rng.standard_normal((B, cfg["Cc"], T_ // hop)).astype(np.float32))
+    g = torch.from_numpy(rng.integers(0, cfg["n_speakers"], size=(B,), dtype=np.int64))
+    if not on_device:
+        return x, lat, g
     return x.to(device), lat.to(device), g.to(device)
 
 
@@ -151,30 +174,34 @@ def ar_leg(device, T_ar=4000, cpu=True, full_clip=True):
     return res
 
 
-def cpu_baseline_train(sd, nclips=8):
+def cpu_baseline_train(sd, nclips=8, conf=None):
     """Oracle train step (autograd through the CPU restatement + its Adam/EMA), bounded sample of the same workload."""
-    import numpy as np
     import torch
     from oracle import wae_oracle as O
+    conf = conf or CONFIGS["c2"]
+    cfg, T = conf["cfg"], conf["T"]
+    B_PER_GPU = conf["B"]
     nthreads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(nthreads)
-    rng = np.random.default_rng(1234)
-    x = torch.from_numpy(rng.integers(0, 256, size=(nclips, T), dtype=np.int64))
-    lat = torch.from_numpy(rng.standard_normal((nclips, C2["Cc"], T // 320)).astype(np.float32))
-    g = torch.from_numpy(rng.integers(0, C2["n_speakers"], size=(nclips,), dtype=np.int64))
-    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
-    ocfg = dict(layers=C2["layers"], stacks=C2["stacks"], upsample_scales=C2["upsample_scales"], cin_pad=0)
+    x, lat, g = (a[:nclips] for a in synth_inputs(0, None, conf, on_device=False))
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
     psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     m = {k: torch.zeros_like(v) for k, v in sd.items()}
     v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
     sh = {k: v.clone() for k, v in sd.items()}
+
+    def loss_of(xin_, x_, lat_, g_):
+        if conf["encoder"]:       # VQVAE.forward (vqvae_model.py:66-72): CE + vq_loss
+            y_, vq_, _, _ = O.vqvae_forward(psd, ocfg, xin_, lat_, g_)
+            return O.masked_ce_loss(y_, x_.unsqueeze(-1), torch.full((x_.shape[0],), T)) + vq_
+        return O.masked_ce_loss(O.wavenet_forward(psd, ocfg, xin_, lat_, g_), x_.unsqueeze(-1), torch.full((x_.shape[0],), T))
     # warm-up on one clip (thread pool, oneDNN primitive caches), then ONE timed pass over the sample
-    O.masked_ce_loss(O.wavenet_forward(psd, ocfg, xin[:1], lat[:1], g[:1]), x[:1].unsqueeze(-1), torch.full((1,), T)).backward()
+    loss_of(xin[:1], x[:1], lat[:1], g[:1]).backward()
     for p in psd.values():
         p.grad = None
     t0 = time.perf_counter()
-    y = O.wavenet_forward(psd, ocfg, xin, lat, g)
-    loss = O.masked_ce_loss(y, x.unsqueeze(-1), torch.full((nclips,), T))
+    loss = loss_of(xin, x, lat, g)
     loss.backward()
     with torch.no_grad():
         grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in psd.items()}
@@ -185,28 +212,67 @@ def cpu_baseline_train(sd, nclips=8):
                        f"oracle/wae_oracle.py on torch CPU fp32, {nthreads} threads of {os.cpu_count()} cores ({dt:.1f} s, after a one-clip warm-up)"), float(loss)
 
 
-def cpu_baseline(sd, nclips=8):
+def cpu_baseline(sd, nclips=8, conf=None):
     """Oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload."""
-    import numpy as np
     import torch
     from oracle import wae_oracle as O
+    conf = conf or CONFIGS["c2"]
+    cfg, T = conf["cfg"], conf["T"]
+    B_PER_GPU = conf["B"]
     nthreads = min(os.cpu_count() or 1, 16)       # more threads than this only slows torch's CPU conv1d down
     torch.set_num_threads(nthreads)
-    rng = np.random.default_rng(1234)
-    x = torch.from_numpy(rng.integers(0, 256, size=(nclips, T), dtype=np.int64))
-    lat = torch.from_numpy(rng.standard_normal((nclips, C2["Cc"], T // 320)).astype(np.float32))
-    g = torch.from_numpy(rng.integers(0, C2["n_speakers"], size=(nclips,), dtype=np.int64))
-    xin = torch.nn.functional.one_hot(x, 256).float().transpose(1, 2).contiguous()
-    ocfg = dict(layers=C2["layers"], stacks=C2["stacks"], upsample_scales=C2["upsample_scales"], cin_pad=0)
+    x, lat, g = (a[:nclips] for a in synth_inputs(0, None, conf, on_device=False))
+    xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+    ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0)
+    fwd = (lambda a, b_, c_: O.vqvae_forward(sd, ocfg, a, b_, c_)[0]) if conf["encoder"] else (lambda a, b_, c_: O.wavenet_forward(sd, ocfg, a, b_, c_))
     with torch.no_grad():
-        O.wavenet_forward(sd, ocfg, xin[:1], lat[:1], g[:1])       # warm-up (thread pool, oneDNN primitive caches)
+        fwd(xin[:1], lat[:1], g[:1])       # warm-up (thread pool, oneDNN primitive caches)
         t0 = time.perf_counter()
-        y = O.wavenet_forward(sd, ocfg, xin, lat, g)
+        y = fwd(xin, lat, g)
         loss = O.masked_ce_loss(y, x.unsqueeze(-1), torch.full((nclips,), T))
         dt = time.perf_counter() - t0
     return dict(value=nclips * T / dt, unit="samples/s", cores=nthreads, kind="port",
                 sample=f"{nclips} of the {B_PER_GPU} clips x {T} samples, 1 forward+CE pass, oracle/wae_oracle.py on "
                        f"torch CPU fp32, {nthreads} threads of {os.cpu_count()} cores ({dt:.1f} s)"), float(loss)
+
+
+def fp32_leg(conf, sd, device, steps=4):
+    """The parity-grade mode's throughput: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), libm gate -- the mode in which the
+    north star's 1e-3 tolerance is met at ~1e-6 (tests/test_gpu_parity.py).  Same workload, a few steps, train and forward."""
+    import torch
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    eng = WaeEngine(Geometry.from_cfg(conf["cfg"]), dtype="fp32", device=str(device))
+    eng.load_state_dict(sd)
+    eng.init_optimizer()
+    x, lat, g = synth_inputs(0, device, conf)
+    xi = x.to(torch.int32)
+    fwd = eng.forward if conf["encoder"] else eng.decoder_forward
+    out = {}
+    for name, fn in (("train", lambda: eng.train_step(xi, lat, g, lengths=None)["loss"]),
+                     ("forward", lambda: fwd(xi, lat, g, targets=xi, want_logits=False)["loss"])):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            loss = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        out[name] = {"ms_per_step": ms, "samples_per_s": conf["B"] * conf["T"] / (ms * 1e-3), "loss": float(loss)}
+    fl = conf["cfg"]
+    H = fl["G"] // 2
+    fwd_flops = (fl["layers"] * 2 * (fl["G"] * fl["R"] * fl["k"] + fl["G"] * fl["Cc"] + H * fl["R"] + H * fl["S"])
+                 + 2 * (fl["S"] * fl["S"] + fl["S"] * fl["O"])) * conf["B"] * conf["T"]
+    out["train"]["mfma_frac"] = 3 * fwd_flops / (out["train"]["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF
+    out["forward"]["mfma_frac"] = fwd_flops / (out["forward"]["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF
+    out["note"] = ("dtype fp32: fp32 activations / weights / accumulation (the parity gate: logits and latents <= 1e-3 relative, measured "
+                   "~1e-6); mfma_frac against the dense fp32 matrix peak %.1f TFLOP/s" % FP32_MFMA_PEAK_TF)
+    del eng
+    torch.cuda.empty_cache()
+    return out
 
 
 def csrc_hash():
@@ -264,12 +330,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="c2 (default): the configuration the metric is quoted on; c3: hps/vqwae.json in full, 8 x 5120 per GPU; "
+                         "c5: 48 layers x 512 channels, 16 x 5120 per GPU, fp16")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"], help="default: the configuration's (c2, c3: bf16; c5: fp16)")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--ar-short", action="store_true", help="autoregressive leg: skip the full 160 000-sample C4 clip (about 24 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ar", action="store_true", help="skip the autoregressive leg (BASELINE config C4, rank 0 only)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the short fp32 (parity-grade mode) leg of the default line")
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
+    args.dtype = args.dtype or conf["dtype"]
+    C2, B_PER_GPU, T = conf["cfg"], conf["B"], conf["T"]      # (the names the formulas below were written with)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
@@ -301,10 +374,11 @@ def main():
     from wavenet_autoencoders_amd.engine import WaeEngine
 
     geom = Geometry.from_cfg(C2)
-    sd = O.make_state_dict(dict(C2), salt=5, with_encoder=False)
+    sd = O.make_state_dict(dict(C2), salt=conf["salt"], with_encoder=conf["encoder"])
     eng = WaeEngine(geom, dtype=args.dtype, device=str(device))
     eng.load_state_dict(sd)
-    x, lat, g = synth_inputs(rank, device)
+    x, lat, g = synth_inputs(rank, device, conf)
+    fwd_fn = eng.forward if conf["encoder"] else eng.decoder_forward
     lengths = torch.full((B_PER_GPU,), T, dtype=torch.int32, device=device)
     xi = x.to(torch.int32)
 
@@ -320,8 +394,7 @@ def main():
     def step(record=False):
         if args.mode == "forward":
             # (weight norm + fragment packing run inside decoder_forward only when a parameter changed since the last pack: never here)
-            out = eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False,
-                                      layer_events=ev if record else None)
+            out = fwd_fn(xi, lat, g, targets=xi, lengths=lengths, want_logits=False, layer_events=ev if record else None)
             return out["loss"]
         eng._layer_events = ev if record is True else None
         eng._tn_events = ev_tn if record is True else None
@@ -370,7 +443,7 @@ def main():
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": glu_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "mfma_achieved_tflops": achieved_tf,
                 "mfma_frac": achieved_tf / peak_tf,
-                "note": "SURVEY 8(d) forward bytes per layer (2R+2S+Cc)*e x 64000 samples; HIP events around the 24-layer stack"}
+                "note": "SURVEY 8(d) forward bytes per layer (2R+2S+Cc)*e x %d samples; HIP events around the %d-layer stack" % (samples, geom.layers)}
     roof = fwd_roof
     extra = {}
     if args.mode == "train":
@@ -379,8 +452,8 @@ def main():
         tb = (2 * C2["R"] + 2 * C2["S"] + C2["Cc"] + C2["G"]) * es * samples
         glu_roof = dict(fwd_roof, achieved=tb / (glu_ms * 1e-3) / 1e9, frac=tb / (glu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         algorithmic_bytes_per_launch=tb, ms_per_step=glu_ms * geom.layers,
-                        note="training forward of one layer: SURVEY 8(d) (2R+2S+Cc+G)*e x 64000 samples (z saved for backward); "
-                             "HIP events around the 24-layer stack")
+                        note="training forward of one layer: SURVEY 8(d) (2R+2S+Cc+G)*e x %d samples (z saved for backward); "
+                             "HIP events around the %d-layer stack" % (samples, geom.layers))
         families = {"glu_fwd_z": glu_roof}
         if ev_tn:
             # weight gradients: 16-bit = ONE launch for all layers (gemm_tn_static_kernel: dW1 taps, dWc + zb sums, dW_out AND dW_skip
@@ -391,7 +464,8 @@ def main():
             per_step = max(1, len(ev_tn) // args.steps)
             nl = geom.layers if per_step <= 2 else 1
             tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn) * (per_step if nl > 1 else 1)
-            static = nl > 1 and os.environ.get("WAE_TN_STATIC", "1") != "0"
+            from wavenet_autoencoders_amd import backward as BW
+            static = nl > 1 and isinstance(eng._ws[("bwd", B_PER_GPU, T)]["stream"], BW.StaticStreamTable)
             tn_bytes = (nl * (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) + (C2["S"] if static else 0)) * es * samples
             tn_flops = nl * 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H + (C2["S"] * H if static else 0)) * samples
             tn_gbs = tn_bytes / (tn_ms * 1e-3) / 1e9
@@ -461,14 +535,14 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "teacher-forced audio samples/sec (24-layer decoder), " + ("train step" if args.mode == "train" else "forward + CE"),
+            "metric": "teacher-forced audio samples/sec (%d-layer decoder), " % geom.layers + ("train step" if args.mode == "train" else "forward + CE"),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "C2: IN-WAE decoder dims (R256 G368 S256 Cc64 Cg64 k3), 24 layers/2 stacks, "
-                                   f"batch {B_PER_GPU}x{T} per GPU, " + ("full train step: weight-norm+pack, forward, fused CE, backward, "
-                                   "clip+Adam+EMA" if args.mode == "train" else "teacher-forced forward (weights packed once, before the timed region), upsample, head and fused CE")
-                                   + "; closed-form random weights",
+            "config": {"workload": conf["name"] + f", batch {B_PER_GPU}x{T} per GPU, "
+                                   + ("full train step: weight-norm+pack, " + ("encoder, VQ, " if conf["encoder"] else "") + "forward, fused CE, backward, "
+                                      "clip+Adam+EMA" if args.mode == "train" else "teacher-forced forward (weights packed once, before the timed region), upsample, head and fused CE")
+                                   + "; closed-form random weights", "name": args.config,
                        "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
             "samples_per_sec_per_gpu": value / world,
             "loss": loss_v,
@@ -493,41 +567,58 @@ def main():
             # above recomputes them every step, like the reference's weight-norm hooks.
             eng.prepare_weights()
             for i in range(2 + nf):
-                eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False, layer_events=ev_f if i >= 2 else None)
+                fwd_fn(xi, lat, g, targets=xi, lengths=lengths, want_logits=False, layer_events=ev_f if i >= 2 else None)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(nf):
-                eng.decoder_forward(xi, lat, g, targets=xi, lengths=lengths, want_logits=False)
+                fwd_fn(xi, lat, g, targets=xi, lengths=lengths, want_logits=False)
             e1.record()
+            # ... and the same pass INCLUDING weight norm + fragment packing (what a forward cost in this line up to round 3, and what
+            # the reference's forward pays while its weight-norm hooks are attached: every pass re-derives w from g, v)
+            e2 = torch.cuda.Event(enable_timing=True)
+            for _ in range(nf):
+                eng.prepare_weights()
+                fwd_fn(xi, lat, g, targets=xi, lengths=lengths, want_logits=False)
+            e2.record()
             torch.cuda.synchronize()
             f_ms = sum(a.elapsed_time(b) for a, b in ev_f) / len(ev_f) / geom.layers
             f_step = e0.elapsed_time(e1) / nf
+            f_step_prep = e1.elapsed_time(e2) / nf
             res["forward_inference"] = {
-                "metric": "teacher-forced audio samples/sec (24-layer decoder), forward + CE", "value": samples / (f_step * 1e-3),
+                "metric": "teacher-forced audio samples/sec (%d-layer decoder), forward + CE" % geom.layers, "value": samples / (f_step * 1e-3),
                 "unit": "samples/s", "ms_per_step": f_step, "steps": nf,
+                "ms_per_step_with_weight_prep": f_step_prep,
+                "weight_prep_note": "ms_per_step: weight norm + fragment packing done once before the timed passes (inference over fixed "
+                                    "weights, the reference after make_generation_fast_); ms_per_step_with_weight_prep: redone in every "
+                                    "pass (the definition of this leg up to round 3; BASELINE's 30 % target is stated on the layer stack and "
+                                    "priced here on ms_per_step)",
                 "roofline_whole": {"bound": "hbm", "achieved": fwd_bytes_whole * samples / (f_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": fwd_bytes_whole * samples / (f_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_sample": fwd_bytes_whole,
-                                   "note": "the whole inference forward (upsample, speaker projection, first conv, 24 layers, head, fused CE; "
-                                           "weights prepared once) on SURVEY 8(d)'s forward bytes per sample; BASELINE.md derives the 30 % "
-                                           "target (<= 1.42 ms) from this figure"},
+                                   "note": "the whole inference forward (%supsample, speaker projection, first conv, %d layers, head, fused CE; "
+                                           "weights prepared once) on SURVEY 8(d)'s DECODER forward bytes per sample; BASELINE.md derives the "
+                                           "30 %% target (C2: <= 1.42 ms) from this figure" % ("encoder, VQ, " if conf["encoder"] else "", geom.layers)},
                 "roofline": {"bound": "hbm", "kernel": glu_kernel_name(args.dtype, False), "achieved": bytes_per_launch / (f_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "traffic": None, "avg_launch_ms": f_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                              "mfma_frac": flops_per_launch / (f_ms * 1e-3) / 1e12 / peak_tf,
-                             "note": "inference launch (no z saved): SURVEY 8(d) forward bytes (2R+2S+Cc)*e x 64000 samples; HIP "
-                                     "events around the 24-layer stack"}}
+                             "note": "inference launch (no z saved): SURVEY 8(d) forward bytes (2R+2S+Cc)*e x %d samples; HIP "
+                                     "events around the %d-layer stack" % (samples, geom.layers)}}
             if traffic_doc is not None and args.dtype in ("bf16", "fp16"):
                 # the inference launch is its own kernel symbol: its own PMC entry (the train-mode profile runs this leg too)
                 for k, v in traffic_doc["kernels"].items():
                     if kernel_matches(res["forward_inference"]["roofline"]["kernel"], k):
                         res["forward_inference"]["roofline"]["traffic"] = v["hbm_bytes_per_launch"]
                         res["forward_inference"]["roofline"]["traffic_source"] = traffic_src
-        if not args.no_ar and world == 1:
+        if args.config == "c2" and args.dtype != "fp32" and args.mode == "train" and world == 1 and not args.no_fp32:
+            res["fp32_parity_mode"] = fp32_leg(conf, sd, device)
+        if not args.no_ar and world == 1 and args.config == "c2":
             res["autoregressive"] = ar_leg(device, cpu=not args.no_cpu, full_clip=not args.ar_short)
         if not args.no_cpu and world == 1:
-            cb, cpu_loss = cpu_baseline_train(sd) if args.mode == "train" else cpu_baseline(sd)
+            # a bounded sample (~10-30 s of host work): c2 / c3 the whole shard, c5 (105 MFLOP per sample forward) two clips
+            ncl = 2 if args.config == "c5" else B_PER_GPU
+            cb, cpu_loss = cpu_baseline_train(sd, ncl, conf) if args.mode == "train" else cpu_baseline(sd, ncl, conf)
             res["cpu_baseline"] = cb
         print(json.dumps(res))
     if dist is not None:

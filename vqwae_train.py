@@ -38,7 +38,7 @@ from wavenet_autoencoders_amd import Geometry, lrschedule  # noqa: E402
 from wavenet_autoencoders_amd import distributed as D  # noqa: E402
 from wavenet_autoencoders_amd.checkpoint import load_checkpoint, restore_parts, save_checkpoint  # noqa: E402
 from wavenet_autoencoders_amd.data import CropBatcher, Prefetcher, SyntheticBatcher, read_index  # noqa: E402
-from wavenet_autoencoders_amd.hparams import hparams  # noqa: E402
+from wavenet_autoencoders_amd.hparams import adam_settings, hparams  # noqa: E402
 
 
 def build_geometry(hp) -> Geometry:
@@ -206,13 +206,14 @@ def main(argv=None):
     max_steps = args.max_steps or hp.max_train_steps
     sched = getattr(lrschedule, hp.lr_schedule) if hp.lr_schedule else None
     t0, step0 = time.time(), step
-    lr = hp.optimizer_params["lr"]
+    adam = adam_settings(hp)               # raises for anything the fused update is not (vqwae_train.py:1119-1120)
+    lr = adam["lr"]
     try:
         while epoch < hp.nepochs and step < max_steps:
             run = torch.zeros(3, dtype=torch.float64, device=device)
             nb = 0
             for x, c, g, lengths in Prefetcher(loader, device):
-                lr = hp.optimizer_params["lr"]
+                lr = adam["lr"]
                 if sched is not None:
                     lr = sched(lr, step, **hp.lr_schedule_kwargs)                     # vqwae_train.py:729-735
                 T = x.shape[1]
@@ -220,8 +221,8 @@ def main(argv=None):
                 # ragged shards: the CE is normalised by the mask sum of the GLOBAL batch (vqwae_train.py:374-379 after :705)
                 # (every rank enters the mask-sum all-reduce or none does: decided by the preset, not by this rank's shard)
                 ce_scale, n_glob = D.step_ce_scale(lengths, T, x.shape[0], variable_length=hp.max_time_steps is None)
-                res = eng.train_step(x, c, g, lengths=ln, lr=lr, eps=hp.optimizer_params.get("eps", 1e-8),
-                                     weight_decay=hp.optimizer_params.get("weight_decay", 0.0), clip_thresh=hp.clip_thresh,
+                res = eng.train_step(x, c, g, lengths=ln, lr=lr, betas=adam["betas"], eps=adam["eps"],
+                                     weight_decay=adam["weight_decay"], clip_thresh=hp.clip_thresh,
                                      ema_decay=hp.ema_decay, grad_sync=sync, ce_scale=ce_scale,
                                      quantize_channels=hp.quantize_channels, log_scale_min=hp.log_scale_min)
                 step += 1

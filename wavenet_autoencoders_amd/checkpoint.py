@@ -87,9 +87,9 @@ def save_checkpoint(eng, step: int, epoch: int, checkpoint_dir: str, hp, rank: i
     sd = {k: v.cpu() for k, v in eng.state_dict().items()}
     opt = None
     if hp.save_optimizer_state and hasattr(eng, "exp_avg"):
-        op = hp.optimizer_params
-        opt = adam_state_dict(eng, lr if lr is not None else op["lr"], eps=op.get("eps", 1e-8), weight_decay=op.get("weight_decay", 0.0),
-                              amsgrad=bool(getattr(hp, "amsgrad", False)))
+        from .hparams import adam_settings
+        op = adam_settings(hp)
+        opt = adam_state_dict(eng, lr if lr is not None else op["lr"], betas=op["betas"], eps=op["eps"], weight_decay=op["weight_decay"])
     torch.save({"state_dict": sd, "optimizer": opt, "global_step": step, "global_epoch": epoch, "global_test_step": test_step}, path)
     shutil.copyfile(path, os.path.join(checkpoint_dir, "checkpoint_latest.pth"))
     if getattr(eng, "shadow", None) is not None:

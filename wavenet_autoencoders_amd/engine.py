@@ -618,13 +618,13 @@ class WaeEngine:
 
     # ------------------------------------------------------------------ full autoencoder
     def forward(self, x: torch.Tensor, c: torch.Tensor, gid: Optional[torch.Tensor], targets=None, lengths=None,
-                want_logits=True, train=False, beta: float = 0.25, dropout_on: bool = True):
+                want_logits=True, train=False, beta: float = 0.25, dropout_on: bool = True, layer_events: Optional[list] = None):
         """VQVAE.forward (vqvae_model.py:66-72) -> dict(logits, vq_loss, perp, latents, idx, quant, loss)."""
         if self.weights_dirty:
             self.prepare_weights()
         lat = self.encoder_forward(c)
         quant, idx, stats = self.vq_forward(lat, beta)
-        out = self.decoder_forward(x, quant, gid, targets, lengths, want_logits, train, dropout_on=dropout_on)
+        out = self.decoder_forward(x, quant, gid, targets, lengths, want_logits, train, dropout_on=dropout_on, layer_events=layer_events)
         out.update(latents=lat, quant=quant, idx=idx, vq_loss=stats[0], perp=stats[1])
         self._fe = dict(lat=lat, quant=quant, idx=idx, beta=beta)
         return out
@@ -704,7 +704,8 @@ class WaeEngine:
             out["loss"] = loss
             grads = self.backward(x, gid, None, lengths, ext_dy=dyt, vq_scale=1.0, grad_sync=grad_sync)
         elif self.g.has_encoder:
-            out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True)
+            out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
+                               layer_events=getattr(self, "_layer_events", None))
         else:
             out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
                                        layer_events=getattr(self, "_layer_events", None))

@@ -120,3 +120,39 @@ hparams = HParams(**_DEFAULTS)
 def hparams_debug_string():
     v = hparams.values()
     return "Hyperparameters:\n" + "\n".join("  %s: %s" % (k, v[k]) for k in sorted(v))
+
+
+def adam_settings(hp):
+    """The reference builds ``getattr(torch.optim, hparams.optimizer)(model.parameters(), **hparams.optimizer_params)``
+    (vqwae_train.py:1119-1120).  The engine's update is ONE fused kernel that is torch.optim.Adam's arithmetic (plain L2 weight decay,
+    no amsgrad; csrc/loss.hip: clip_adam_ema_kernel), so: any other optimizer, amsgrad / maximize, and any key torch.optim.Adam would
+    reject RAISE here instead of training silently with something else; lr, betas, eps and weight_decay are forwarded.
+    Returns dict(lr, betas, eps, weight_decay)."""
+    name = hp.optimizer
+    if name != "Adam":
+        raise NotImplementedError(f"hparams.optimizer={name!r}: the engine's fused update implements torch.optim.Adam only "
+                                  "(the reference would build torch.optim.%s)" % name)
+    op = dict(hp.optimizer_params or {})
+    # arguments of torch.optim.Adam that only choose an implementation of the same arithmetic
+    for k in ("foreach", "capturable", "differentiable", "fused"):
+        op.pop(k, None)
+    for k in ("amsgrad", "maximize"):
+        if op.pop(k, False):
+            raise NotImplementedError(f"optimizer_params.{k}=True is not implemented by the fused Adam update")
+    out = dict(lr=float(op.pop("lr", 1e-3)), betas=tuple(float(b) for b in op.pop("betas", (0.9, 0.999))),
+               eps=float(op.pop("eps", 1e-8)), weight_decay=float(op.pop("weight_decay", 0.0)))
+    if op:
+        raise TypeError("Adam.__init__() got an unexpected keyword argument %r" % sorted(op)[0])     # what torch.optim.Adam raises
+    # torch.optim.Adam's own range checks, same messages
+    if not 0.0 <= out["lr"]:
+        raise ValueError(f"Invalid learning rate: {out['lr']}")
+    if not 0.0 <= out["eps"]:
+        raise ValueError(f"Invalid epsilon value: {out['eps']}")
+    if len(out["betas"]) != 2:
+        raise ValueError(f"betas must be a pair, got {out['betas']}")
+    for i, b in enumerate(out["betas"]):
+        if not 0.0 <= b < 1.0:
+            raise ValueError(f"Invalid beta parameter at index {i}: {b}")
+    if not 0.0 <= out["weight_decay"]:
+        raise ValueError(f"Invalid weight_decay value: {out['weight_decay']}")
+    return out
