@@ -166,3 +166,56 @@ def test_wide_incremental_forward_matches_teacher_forced_fp32():
     out = eng.incremental_forward(c.cuda(), g.cuda(), T=x.shape[1], mode="logits", test_inputs=x.cuda(), c_is_upsampled=True)
     torch.cuda.synchronize()
     assert rel_err(out["logits"].cpu(), y_ref) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("geom", ["c5", "hp256", "r512s256"])
+def test_static_weight_gradient_launch_on_cut_layers(geom, dtype, monkeypatch):
+    """Round 5: layers wider than one region of wae_gemm_tn_static (dz > 384 columns, x / Ghat / dS > 256, u > 192) are cut into several
+    jobs per kind, dealt into groups of at most six (backward._build_stream_table: C5's 512-wide layer = 12 tap + 2 conditioning + 4
+    out/skip jobs in three groups).  Same 16-bit operands, three kinds of cut: against the per-layer 128 x 128 tile launches
+    (WAE_TN_STREAM=0) to 2e-4 of each tensor's range; the any-shape stream-K launch (WAE_TN_STATIC=0) agrees to the same bound."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(WIDE)
+    if geom == "hp256":       # only u (Hp = 256) and dz (512 columns) are cut; x, Ghat, dS are one region
+        cfg.update(R=256, S=256, G=512)
+    elif geom == "r512s256":      # x / Ghat cut in two, dS (256), dz (384 columns) and u (192) one region: out/skip jobs with and without a dS half
+        cfg.update(R=512, S=256, G=384)
+    sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+    B, T = 3, 777
+    x = ((O.hash_fill((B, T), 21) * 0.5 + 0.5) * 256).long().clamp(0, 255).cuda()
+    c = O.hash_fill((B, cfg["Cc"], T), 22, 1.3).cuda()
+    g = (torch.arange(B) % cfg["n_speakers"]).cuda()
+    lengths = torch.tensor([T, T - 137, T - 400])
+    got = {}
+    for tag, env in (("tiles", {"WAE_TN_STREAM": "0"}), ("static", {}), ("streamk", {"WAE_TN_STATIC": "0"})):
+        for k in ("WAE_TN_STREAM", "WAE_TN_STATIC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        eng.decoder_forward(x, c, g, targets=x, lengths=lengths.cuda(), train=True, c_is_upsampled=True, want_logits=False)
+        BW.decoder_backward(eng, x, x, lengths, g)
+        st = BW.bwd_workspace(eng, B, T)["stream"]
+        if tag == "tiles":
+            assert st is None
+        elif tag == "static":
+            assert isinstance(st, BW.StaticStreamTable) and BW.static_tn_split(eng) and not BW.static_head(eng, B, T)
+            assert st.team_size <= 6 and len(st.groups) % cfg["layers"] == 0
+        else:
+            assert isinstance(st, BW.StreamTable)
+        got[tag] = BW.finish_grads(eng).clone()
+        torch.cuda.synchronize()
+    lay = eng.lay
+    for tag in ("static", "streamk"):
+        bad = {}
+        for kk in lay.offsets:
+            a = got["tiles"][lay.off(kk):lay.off(kk) + lay.numel(kk)]
+            b = got[tag][lay.off(kk):lay.off(kk) + lay.numel(kk)]
+            err, ref = float((a - b).abs().max()), float(a.abs().max())
+            if err > 2e-4 * max(ref, 1e-6) + 1e-7:
+                bad[kk] = (err, ref)
+        assert not bad, (tag, bad)

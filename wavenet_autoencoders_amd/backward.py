@@ -31,6 +31,15 @@ def _prepare_bwd(eng):
         return
     g, dev, lay = eng.g, eng.device, eng.lay
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    # Which weight-gradient launches this engine uses is decided HERE, once: the arenas sized below, the job tables of every (B, T)
+    # workspace and the scatter lists all follow from it (round-4 advisor: re-reading the environment per call let them disagree).
+    #   WAE_TN_STREAM=0       one 128 x 128 tile launch per layer (what fp32 always uses; the yardstick of the 16-bit launches)
+    #   WAE_TN_STATIC=0       the any-shape stream-K launch (csrc/gemm_tn_stream.hip) instead of the static-schedule one
+    #   WAE_TN_STATIC_HEAD=0  head + first-conv weight gradients on the tile launches instead of a group of the static launch
+    eng.opt_tn_stream = eng.dt in (L.WAE_BF16, L.WAE_F16) and os.environ.get("WAE_TN_STREAM", "1") != "0"
+    eng.opt_tn_static = (os.environ.get("WAE_TN_STATIC", "1") != "0" and int(os.environ.get("WAE_TN_PACE", "0")) == 0
+                         and os.environ.get("WAE_TN_SHARES", "teams") == "teams")     # (the opt-in schedules belong to the any-shape kernel)
+    eng.opt_tn_static_head = os.environ.get("WAE_TN_STATIC_HEAD", "1") != "0"
     # A/B switch: WAE_TM_OCC bit 1 (2) gate-backward, bit 2 (4) residual launches with two workgroups per CU (default: both)
     occ = int(os.environ.get("WAE_TM_OCC", "6"))
     eng.tm_flags_u = 0 if occ & 2 else L.TM_ONE_WG
@@ -309,22 +318,40 @@ class StreamTable:
                 "gemm_tn_stream")
 
 
+def _cuts(n, cap, gran):
+    """[0, n) in the fewest equal parts of at most `cap` columns, each a multiple of `gran` -> [(first column, width)]"""
+    parts = -(-n // cap)
+    w = -(-(-(-n // parts)) // gran) * gran
+    out, c = [], 0
+    while c < n:
+        out.append((c, min(w, n - c)))
+        c += w
+    return out
+
+
 def static_tn_geometry(eng):
-    """The static-schedule weight-gradient launch (csrc/gemm_tn_static.hip) covers geometries whose layer fits one region per job
-    kind: dz (2 Hp <= 384 columns) x x (Rp <= 256), dz x [c (Ccp = 64) | ones], u (Hp <= 192) x [Ghat (Rp) | dS (Sp <= 256)].
-    WAE_TN_STATIC=0 keeps the any-shape kernel (csrc/gemm_tn_stream.hip)."""
+    """The static-schedule weight-gradient launch (csrc/gemm_tn_static.hip): 16-bit operands, Ccp = 64.  A job of the kernel is one
+    output region -- TAPS: dz (<= 384 columns) x x (<= 256), COND: dz (<= 384) x [c (64) | ones], OUTSKIP: u (<= 192) x [Ghat (<= 256) |
+    dS (<= 256)] -- and a layer whose matrices are wider is cut into several jobs per kind (round 5: C5's 512-wide layers are 18 jobs
+    in three groups of six; C2 and hps/vqwae.json stay at the five jobs of one region each).  WAE_TN_STATIC=0 keeps the any-shape
+    stream-K kernel (csrc/gemm_tn_stream.hip)."""
     g = eng.g
-    if int(os.environ.get("WAE_TN_PACE", "0")) > 0 or os.environ.get("WAE_TN_SHARES", "teams") != "teams":
-        return False                  # the opt-in schedules (pacing, equal-time shares) belong to the any-shape kernel
-    return (eng.dt in (L.WAE_BF16, L.WAE_F16) and os.environ.get("WAE_TN_STATIC", "1") != "0" and 2 * g.Hp <= 384 and g.Rp <= 256
-            and g.Sp <= 256 and g.Hp <= 192 and g.Ccp == 64)
+    return (eng.dt in (L.WAE_BF16, L.WAE_F16) and eng.opt_tn_static and g.Ccp == 64 and (2 * g.Hp) % 64 == 0 and g.Rp % 128 == 0
+            and g.Sp % 128 == 0)
+
+
+def static_tn_split(eng):
+    """Does a layer need more than one job per kind (see static_tn_geometry)?"""
+    g = eng.g
+    return 2 * g.Hp > 384 or g.Rp > 256 or g.Sp > 256 or g.Hp > 192
 
 
 def static_tn_shape(eng, B, T):
     """... and shapes it can address: one ones column per clip inside one 32-column tile, every operand clip below 2^30 bytes
     (the per-clip buffer descriptors carry 32-bit offsets; rows before a clip wrap to offsets beyond num_records)."""
     g = eng.g
-    widest = max(g.layers * 2 * g.Hp, g.Ku, g.Rp, g.Sp, g.Ccp) * 2            # bytes per time row of the widest operand array
+    # bytes per time row of the widest operand array (the head's dy and the first conv's one-hot operand ride in the launch too)
+    widest = max(g.layers * 2 * g.Hp, g.Ku, g.Rp, g.Sp, g.Ccp, g.Op, P._ru(g.O, 128)) * 2
     reach = T + (g.k - 1) * max(g.dilations) + 32
     return static_tn_geometry(eng) and use_stream_tn(eng) and B <= 32 and reach * widest < (1 << 30)
 
@@ -332,10 +359,11 @@ def static_tn_shape(eng, B, T):
 def static_head(eng, B, T):
     """The head's weight gradients (dW3 = dy^T h1, dW1 = dh1^T h0, their biases = column sums of dy / dh1) and -- class-id input -- the
     first conv's (onehot^T dx0) ride in the static launch as one more group of jobs when they fit its regions (P <= 384 columns,
-    Q <= 256) and a layer has at least five jobs (k >= 3); otherwise they stay on the 128 x 128 tile launches (csrc/gemm_tn.hip)."""
+    Q <= 256) and a layer is one group of at least five jobs (k >= 3, no cut matrices); otherwise they stay on the 128 x 128 tile
+    launches (csrc/gemm_tn.hip)."""
     g = eng.g
-    return (static_tn_shape(eng, B, T) and not eng.wide_head and g.k >= 3 and g.Op <= 384 and g.Sp <= 256 and P._ru(g.O, 128) <= 384
-            and os.environ.get("WAE_TN_STATIC_HEAD", "1") != "0")
+    return (static_tn_shape(eng, B, T) and not static_tn_split(eng) and not eng.wide_head and g.k >= 3 and g.Op <= 384 and g.Sp <= 256
+            and P._ru(g.O, 128) <= 384 and eng.opt_tn_static_head)
 
 
 class StaticStreamTable:
@@ -402,10 +430,10 @@ class StaticStreamTable:
 
 
 def use_stream_tn(eng):
-    """bf16 runs take every layer's weight gradients in one wae_gemm_tn_stream launch after the backward sweep (needs the
-    residual-stream gradient of every layer kept); fp32 (the parity mode) keeps one wae_gemm_tn_tiles launch per layer."""
-    import os
-    return eng.dt in (L.WAE_BF16, L.WAE_F16) and os.environ.get("WAE_TN_STREAM", "1") != "0"
+    """16-bit runs take every layer's weight gradients in one launch after the backward sweep (needs the residual-stream gradient
+    of every layer kept); fp32 (the parity mode) keeps one wae_gemm_tn_tiles launch per layer."""
+    _prepare_bwd(eng)
+    return eng.opt_tn_stream
 
 
 def bwd_workspace(eng, B, T):
@@ -445,30 +473,67 @@ def _build_stream_table(eng, ws, fw, B, T, l0, l1):
         coT, csT = eng.cview["coT"], eng.cview["csT"]
         rows = sm["ldoT_rows"]
         stt = StaticStreamTable(eng, B, T)
-        for l in range(l0, l1):
+        m_taps, n_taps = _cuts(Z2, 384, 64), _cuts(g.Rp, 256, 128)
+        m_cond = _cuts(Z2, 384, 32)
+        m_os, n_os0, n_os1 = _cuts(g.Hp, 192, 64), _cuts(g.Rp, 256, 128), _cuts(g.Sp, 256, 128)
+
+        def layer_jobs(l):
             d = g.dilations[l]
-            stt.begin_group()
             dz_ptr = ws["dz"].data_ptr() + l * Z2 * es
             c1l = c1.data_ptr() + l * Z2 * sm["ld1"] * 4
             xl = fw["xd"][l] if "xd" in fw else fw["x"][l]      # dW1 contracts dz against the convolution's operand
+            jobs = []
             for tap in range(g.k):
-                stt.add(kind=L.TQ_TAPS, P=dz_ptr, p_stride=dzs, m_valid=Z2, Q0=xl.data_ptr(), q0_stride=g.Rp, n0_valid=g.Rp,
-                        shift=-(g.k - 1 - tap) * d, C0=c1l + tap * g.Rp * 4, ldc0=sm["ld1"], alpha=ia)
-            stt.add(kind=L.TQ_COND, P=dz_ptr, p_stride=dzs, m_valid=Z2, Q0=fw["c_up"].data_ptr(), q0_stride=g.Ccp, n0_valid=g.Ccp,
-                    ones_col=g.Ccp, C0=c1l + g.k * g.Rp * 4, ldc0=sm["ld1"], alpha=ia)
+                for m0, mw in m_taps:
+                    for n0, nw in n_taps:
+                        jobs.append(dict(kind=L.TQ_TAPS, P=dz_ptr + m0 * es, p_stride=dzs, m_valid=mw, Q0=xl.data_ptr() + n0 * es,
+                                         q0_stride=g.Rp, n0_valid=nw, shift=-(g.k - 1 - tap) * d,
+                                         C0=c1l + (m0 * sm["ld1"] + tap * g.Rp + n0) * 4, ldc0=sm["ld1"], alpha=ia))
+            for m0, mw in m_cond:
+                jobs.append(dict(kind=L.TQ_COND, P=dz_ptr + m0 * es, p_stride=dzs, m_valid=mw, Q0=fw["c_up"].data_ptr(), q0_stride=g.Ccp,
+                                 n0_valid=g.Ccp, ones_col=g.Ccp, C0=c1l + (m0 * sm["ld1"] + g.k * g.Rp) * 4, ldc0=sm["ld1"], alpha=ia))
             has_out = l < g.layers - 1       # the last layer's x' is dead (wavenet.py:205-207): no conv1x1_out gradient
             coTl = coT.data_ptr() + l * rows * g.Rp * 4
             csTl = csT.data_ptr() + l * g.Hp * g.Sp * 4
-            if has_out:
-                stt.add(kind=L.TQ_OUTSKIP, P=fw["u"].data_ptr() + l * g.Hp * es, p_stride=g.Ku, m_valid=g.Hp,
-                        Q0=ws["gx"][l + 1].data_ptr(), q0_stride=g.Rp, n0_valid=g.Rp, Q1=ws["dskip"].data_ptr(), q1_stride=g.Sp,
-                        n1_valid=g.Sp, C0=coTl, ldc0=g.Rp, C1=csTl, ldc1=g.Sp, Cb=coTl + g.Hp * g.Rp * 4, alpha=ia)
-            else:
-                # ... which frees the job's first operand: dS takes its place, and the column sums the kernel forms of that operand
-                # are the skip bias gradient (the same for every layer, modules.py:157-160)
-                stt.add(kind=L.TQ_OUTSKIP, P=fw["u"].data_ptr() + l * g.Hp * es, p_stride=g.Ku, m_valid=g.Hp,
-                        Q0=ws["dskip"].data_ptr(), q0_stride=g.Sp, n0_valid=g.Sp, C0=csTl, ldc0=g.Sp,
-                        Cb=eng.cview["cbs"].data_ptr(), alpha=ia)
+            u_ptr = fw["u"].data_ptr() + l * g.Hp * es
+            for m0, mw in m_os:
+                if has_out:
+                    for i in range(max(len(n_os0), len(n_os1))):
+                        j = dict(kind=L.TQ_OUTSKIP, P=u_ptr + m0 * es, p_stride=g.Ku, m_valid=mw, alpha=ia)
+                        if i < len(n_os0):
+                            n0, nw = n_os0[i]
+                            j.update(Q0=ws["gx"][l + 1].data_ptr() + n0 * es, q0_stride=g.Rp, n0_valid=nw,
+                                     C0=coTl + (m0 * g.Rp + n0) * 4, ldc0=g.Rp)
+                            if m0 == 0:          # the out bias: column sums of Ghat, formed by the job that holds rows 0..63 of u
+                                j.update(Cb=coTl + (g.Hp * g.Rp + n0) * 4)
+                        if i < len(n_os1):
+                            n1, nw1 = n_os1[i]
+                            j.update(Q1=ws["dskip"].data_ptr() + n1 * es, q1_stride=g.Sp, n1_valid=nw1,
+                                     C1=csTl + (m0 * g.Sp + n1) * 4, ldc1=g.Sp)
+                        jobs.append(j)
+                else:
+                    # ... which frees the job's first operand: dS takes its place, and the column sums the kernel forms of that operand
+                    # are the skip bias gradient (the same for every layer, modules.py:157-160)
+                    for n1, nw1 in n_os1:
+                        j = dict(kind=L.TQ_OUTSKIP, P=u_ptr + m0 * es, p_stride=g.Ku, m_valid=mw, Q0=ws["dskip"].data_ptr() + n1 * es,
+                                 q0_stride=g.Sp, n0_valid=nw1, C0=csTl + (m0 * g.Sp + n1) * 4, ldc0=g.Sp, alpha=ia)
+                        if m0 == 0:
+                            j.update(Cb=eng.cview["cbs"].data_ptr() + n1 * 4)
+                        jobs.append(j)
+            return jobs
+
+        # a layer's jobs form one group (a team of that many workgroups walks the layer's slabs) up to six jobs; more are dealt into
+        # equal groups of at most six -- jobs that share operands (the cuts of one tap) side by side --, padded with null jobs
+        njobs = max(len(layer_jobs(l)) for l in range(l0, l1))
+        ngrp = -(-njobs // 6) if njobs > 6 else 1
+        gsz = -(-njobs // ngrp)
+        for l in range(l0, l1):
+            jobs = layer_jobs(l)
+            jobs += [{}] * (ngrp * gsz - len(jobs))
+            for gi in range(ngrp):
+                stt.begin_group()
+                for j in jobs[gi * gsz:(gi + 1) * gsz]:
+                    stt.add(**j)
         if static_head(eng, B, T):
             gs = g.k + 2
             first = None
