@@ -443,12 +443,16 @@ int wae_gemm_tn_tiles(int32_t dtype, const wae_tn_tile* tiles_dev, int32_t ntile
  * = wae_gemm_tm mode 1 for layer l followed by mode 2 for layer l-1, without re-reading dx_l-hat.  dz / dz_prev point at
  * the layers' 2Hp columns inside the (B,T,dz_stride) buffer; z_prev is (B,T,2Hp); w_x = the mode-1 weights of layer l,
  * w_uo = W_out_{l-1}^T in accumulator-row k order (packing.py: bwd_uo_map), w_us = the W_skip part of the mode-2 weights.
- * wae_glu_bwd_fused_supported(Rp, Hp) tells whether an instance exists (else use the two wae_gemm_tm launches). */
+ * wae_glu_bwd_fused_supported(Rp, Hp) tells whether an fp32 instance exists (else use the two wae_gemm_tm launches),
+ * wae_glu_bwd_fused_supported16 the same for 16-bit storage.  16-bit storage runs the two-workgroups-per-CU form of round 5
+ * (csrc/glu_bwd.hip: glu_bwd_pair_kernel), which takes w_x in the INTERLEAVED chunk order of wae_gemm_tm mode 1 with
+ * WAE_TM_INTERLEAVE (packing.py: bwd_x_map) -- dx_l-hat is then bitwise what that launch stores; fp32 takes w_x tap by tap. */
 typedef struct wae_glu_bwd_desc {
   int32_t dtype, B, T, Rp, Hp, Sp, ktaps, dilation;
   float alpha;
 } wae_glu_bwd_desc;
 int wae_glu_bwd_fused_supported(int32_t Rp, int32_t Hp);
+int wae_glu_bwd_fused_supported16(int32_t Rp, int32_t Hp);
 int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
                       const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
                       const void* w_us, void* stream);

@@ -441,3 +441,79 @@ def test_side_stream_backward_preparation_gives_the_same_step(monkeypatch):
         got.append(seen["g"])
     err, ref = float((got[0] - got[1]).abs().max()), float(got[0].abs().max())
     assert err < 1e-5 * ref + 1e-9, (err, ref)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["B", "s44", "c2", "c3dec"])
+def test_fused_residual_gate_launch_16bit(case, dtype, monkeypatch):
+    """Round 5: K_X of layer l + K_U of layer l-1 as ONE launch in 16-bit storage (csrc/glu_bwd.hip: glu_bwd_pair_kernel; two workgroups
+    per CU, the residual launch's weight stream and chunk order; opt-in WAE_BWD_FUSED=1) against the two wae_gemm_tm launches on the
+    same operands: the top layer's dx-hat BITWISE equal (same weights, same MFMA order), dz and the dx-hat below to 2e-2 of their range
+    (the W_out^T contraction sums the same products in accumulator-row order; dz is rounded to 16 bits once in both paths, and every
+    layer below inherits that rounding), dc and every parameter gradient to 2e-2 of each tensor's range.  Golden model B (Rp 128, Hp 64: instance <4, 2>), a 128 x 128 geometry (<4, 4>), C2 at full size (<8, 6>), the
+    hps/vqwae.json decoder (<8, 4>); ragged lengths."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    if case == "s44":
+        cfg = dict(layers=4, stacks=2, R=96, G=256, S=96, O=64, Cc=64, Cg=16, k=3, n_speakers=5, upsample_scales=None)
+        sd = O.make_state_dict(dict(cfg), salt=9, with_encoder=False)
+        B, T = 3, 700
+        x = ((O.hash_fill((B, T), 31) * 0.5 + 0.5) * 64).long().clamp(0, 63).cuda()
+        c = O.hash_fill((B, 64, T), 32, 1.2).cuda()
+        g = (torch.arange(B) % 5).cuda()
+        up = True
+    elif case == "B":
+        cfg, sd, ins, z, ocfg = golden_model(case)
+        cfg = {k: v for k, v in cfg.items() if k not in ("encoder_hid", "c_in", "K")}
+        sd = {k: v for k, v in sd.items() if k.startswith("wavenet.")}
+        x, g = ins["x"].cuda(), ins["g"].cuda()
+        c = torch.from_numpy(z["c_up"]).cuda()
+        up = True
+    else:
+        if case == "c2":
+            cfg = dict(layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153, upsample_scales=[4, 4, 4, 5],
+                       cin_pad=0)
+            B, T, hop = 8, 8000, 320
+        else:
+            cfg = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5],
+                       cin_pad=0)
+            B, T, hop = 3, 1920, 640
+        sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+        gen = torch.Generator().manual_seed(77)
+        x = torch.randint(0, 256, (B, T), generator=gen).cuda()
+        c = torch.randn(B, 64, T // hop, generator=gen).cuda()
+        g = torch.randint(0, cfg["n_speakers"], (B,), generator=gen).cuda()
+        up = False
+    B, T = x.shape
+    lengths = torch.tensor([T - 53 * i for i in range(B)])
+    got = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("WAE_BWD_FUSED", fused)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd, strict=False)
+        eng.decoder_forward(x, c, g, targets=x, lengths=lengths.cuda(), train=True, c_is_upsampled=up, want_logits=False)
+        dc = BW.decoder_backward(eng, x, x, lengths, g)
+        assert eng.fused_bwd == (fused == "1")
+        ws = eng._ws[("bwd", B, T)]
+        got[fused] = (ws["dz"].clone(), [t_.clone() for t_ in ws["gx"]], dc.clone(), BW.finish_grads(eng).clone())
+        torch.cuda.synchronize()
+        lay = eng.lay
+        del eng
+        torch.cuda.empty_cache()
+    a, b_ = got["0"][1][-1].float(), got["1"][1][-1].float()          # dx-hat of the top layer: same weights, same chunk order
+    assert float((a - b_).abs().max()) <= 4e-3 * float(a.abs().max()), ("top dx-hat", float((a - b_).abs().max()), float(a.abs().max()))
+    for a, b_ in zip(got["0"][1], got["1"][1]):
+        err, ref = float((a.float() - b_.float()).abs().max()), float(a.float().abs().max())
+        assert err < 2e-2 * ref + 1e-9, ("dx-hat", err, ref)
+    for name, a, b_ in (("dz", got["0"][0], got["1"][0]), ("dc", got["0"][2], got["1"][2])):
+        err, ref = float((a.float() - b_.float()).abs().max()), float(a.float().abs().max())
+        assert err < 2e-2 * ref + 1e-9, (name, err, ref)
+    bad = {}
+    for k in lay.offsets:
+        a = got["0"][3][lay.off(k):lay.off(k) + lay.numel(k)]
+        b_ = got["1"][3][lay.off(k):lay.off(k) + lay.numel(k)]
+        err, ref = float((a - b_).abs().max()), float(a.abs().max())
+        if err > 2e-2 * max(ref, 1e-6) + 1e-7:
+            bad[k] = (err, ref)
+    assert not bad, bad

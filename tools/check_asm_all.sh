@@ -7,7 +7,7 @@ TMP=$(mktemp -d)
 {
 echo "# tools/check_asm_all.sh: no compiler-generated instruction may touch a register between its inline-asm request and the"
 echo "# counted wait that retires it (csrc/wae_common.hpp: gload_async).  hipcc $(/opt/rocm/bin/hipcc --version | grep -o 'HIP version.*')"
-for f in glu_fwd glu_fwd_static head_fwd gemm_tm; do
+for f in glu_fwd glu_fwd_static head_fwd gemm_tm glu_bwd; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only $ROOT/wavenet_autoencoders_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
   # lookahead: glu_fwd requests two chunks ahead; glu_fwd_static mixes two-chunks-ahead fragments with residual rows that are retired
   # by the very next counted wait (text-order scanning cannot tell them apart): the always-valid lookahead 1

@@ -120,6 +120,7 @@ SIGNATURES = {
     "wae_gemm_tm_ce": (c_i32, [ctypes.POINTER(TmDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(TmCe), c_vp]),
     "wae_gemm_tn_tiles": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "wae_glu_bwd_fused_supported": (c_i32, [c_i32, c_i32]),
+    "wae_glu_bwd_fused_supported16": (c_i32, [c_i32, c_i32]),
     "wae_glu_bwd_fused": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wae_gemm_tn_stream": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "wae_gemm_tn_static": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

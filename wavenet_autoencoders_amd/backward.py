@@ -51,15 +51,19 @@ def _prepare_bwd(eng):
     eng.tm_flags_x |= L.TM_BLDS if blds & 2 else 0
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
-    # Fusing K_X(l) with K_U(l-1) (csrc/glu_bwd.hip) measured SLOWER than the two launches at C2 (118 us vs 60 + 50 us:
-    # the chunk loop is bound by weight/operand movement per chunk, which fusion does not reduce), so it is opt-in.
-    eng.fused_bwd = bool(eng.lib.wae_glu_bwd_fused_supported(g.Rp, g.Hp)) and os.environ.get("WAE_BWD_FUSED", "0") == "1"
+    # K_X(l) + K_U(l-1) in one launch (csrc/glu_bwd.hip).  The round-1 kernel measured SLOWER than the two launches (118 us vs 60 + 50);
+    # the 16-bit form of round 5 (two workgroups per CU, the residual launch's own weight stream and chunk order) is opt-in until
+    # measured: WAE_BWD_FUSED=1.  fp32 keeps the round-1 kernel (tap-by-tap weights) behind the same switch.
+    is16 = eng.dt in (L.WAE_BF16, L.WAE_F16)
+    sup = eng.lib.wae_glu_bwd_fused_supported16(g.Rp, g.Hp) if is16 else eng.lib.wae_glu_bwd_fused_supported(g.Rp, g.Hp)
+    eng.fused_bwd = bool(sup) and g.Sp % (64 if is16 else 32) == 0 and os.environ.get("WAE_BWD_FUSED", "0") == "1"
     if eng.fused_bwd:
         eng.m_buo = up(P.bwd_uo_map(g, lay, eng.dt))
         eng.n_buo = eng.m_buo.numel()
         eng.w_buo = torch.zeros(g.layers * eng.n_buo, dtype=eng.tdtype, device=dev)
-        eng.m_bxf = up(P.bwd_x_map(g, lay, eng.dt, interleave=False))     # the fused kernel walks the taps one by one
-        eng.w_bxf = torch.zeros(g.layers * eng.m_bxf.numel(), dtype=eng.tdtype, device=dev)
+        if not is16:
+            eng.m_bxf = up(P.bwd_x_map(g, lay, eng.dt, interleave=False))     # the fp32 kernel walks the taps one by one
+            eng.w_bxf = torch.zeros(g.layers * eng.m_bxf.numel(), dtype=eng.tdtype, device=dev)
     eng.m_bc = up(P.bwd_c_map(g, lay, eng.dt)) if g.Ccp else None
     eng.m_hb_w = up(P.head_bwd_map(g, lay, eng.dt)) if not eng.wide_head else torch.zeros(0, dtype=torch.int32, device=dev)
     eng.n_bu, eng.n_bx = eng.m_bu.numel(), eng.m_bx.numel()
@@ -98,8 +102,9 @@ def pack_bwd_weights(eng):
         lst = [J(eng.m_bu, eng.w_bu, eng.n_bu, g.layers, lay.layer_stride, eng.n_bu),
                J(eng.m_bx, eng.w_bx, eng.n_bx, g.layers, lay.layer_stride, eng.n_bx)]
         if eng.fused_bwd:
-            lst += [J(eng.m_buo, eng.w_buo, eng.n_buo, g.layers, lay.layer_stride, eng.n_buo),
-                    J(eng.m_bxf, eng.w_bxf, eng.n_bx, g.layers, lay.layer_stride, eng.n_bx)]       # tap by tap
+            lst.append(J(eng.m_buo, eng.w_buo, eng.n_buo, g.layers, lay.layer_stride, eng.n_buo))
+            if hasattr(eng, "m_bxf"):
+                lst.append(J(eng.m_bxf, eng.w_bxf, eng.n_bx, g.layers, lay.layer_stride, eng.n_bx))       # tap by tap (fp32)
         if g.Ccp:
             lst.append(J(eng.m_bc, eng.w_bc, eng.m_bc.numel(), 1, 0, 0))
         if eng.wide_head:
@@ -850,7 +855,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             L.check(lib.wae_glu_bwd_fused(ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
                                           L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][l - 1]),
                                           ctypes.c_void_p(ws["dz"].data_ptr() + (l - 1) * Z2 * es),
-                                          ctypes.c_void_p(eng.w_bxf.data_ptr() + l * eng.n_bx * es),
+                                          ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
                                           ctypes.c_void_p(eng.w_buo.data_ptr() + (l - 1) * eng.n_buo * es),
                                           ctypes.c_void_p(eng.w_bu.data_ptr() + (l - 1) * eng.n_bu * es + us_off), st), "glu_bwd_fused")
         else:

@@ -193,6 +193,257 @@ __global__ void __launch_bounds__(256, 1) glu_bwd_fused_kernel(GbArgs p) {
   stage_store_tiles<E, NTU>(stg, zg, orow + (int64_t)NTU * 32 * ES, p.dz_stride * ES, rows_valid, lane);
 }
 
+
+// ---- 16-bit storage: the round-5 form of the same launch ---------------------------------------------------------------------------
+// The per-layer backward launches are bound by what a CU takes in -- a residual workgroup pulls 864 KB through L2 in ~20 us whether it
+// has the CU to itself or shares it (profiles/EXPERIMENT_LOG.md, round 5) -- and the gate launch by HBM bytes (4.5 TB/s).  Fusing K_X of
+// layer l with K_U of layer l-1 removes the re-read of dx_l-hat (32.8 of the gate launch's 164 MB at C2) and one launch boundary per
+// layer.  The round-1 kernel above did that on one workgroup per CU with plain loads and a drain per chunk and lost (118 against 110 us);
+// this one is built like csrc/gemm_tm.hip's two-workgroups-per-CU shape:
+//   * 4 waves x 32 time columns, TWO workgroups per CU (64 KiB of LDS each: a two-slot weight ring that doubles as staging area);
+//   * phase A (K_X): the interleaved tap order and packed weights of wae_gemm_tm mode 1 (same accumulation order: dx-hat is bitwise
+//     what the two-launch path stores), operand fragments two chunks ahead by asm loads under counted waits;
+//   * epilogue A walks the tiles two at a time (residual rows of the next pair fetched under this pair's math), stores dx-hat once and
+//     keeps it, rounded exactly as stored, as the B operand of phase B1 (W_out^T, k in accumulator-row order);
+//   * phase B2 (W_skip^T dS) streams dS like phase A streams dz; the saved pre-activations arrive under B1 / B2;
+//   * epilogue B = the pairwise gate-derivative epilogue of wae_gemm_tm mode 2.
+// One chunk sequence runs through all three GEMMs (the weight ring never drains between them).
+// vmcnt(0) that carries the three operand groups as read-write operands: the redundant requests at the end of a chunk loop are never
+// consumed, so to the compiler their destinations are dead the moment they are issued -- it hoisted the epilogue's address arithmetic
+// into those registers above a bare s_waitcnt, and the loads, landing afterwards, turned the addresses into wild pointers
+// (tools/check_asm_regs.py finds it; three of the four instantiations had it).  With the groups as operands they live until the wait.
+template <typename F>
+__device__ __forceinline__ void drain_groups(F (&a)[4], F (&b)[4], F (&c)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]),
+                 "+v"(c[2]), "+v"(c[3])
+               :
+               : "memory");
+}
+
+template <typename E, int NTX, int NTU>
+__global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
+  static_assert(sizeof(E) == 2 && NTX % 2 == 0 && NTU % 2 == 0, "16-bit storage, pairwise epilogues");
+  using T_ = ET<E>;
+  using frag = typename T_::frag;
+  constexpr int ES = sizeof(E);
+  constexpr int KBU = T_::KBU;                   // 2
+  constexpr int CHX = NTX * 4 * 1024;            // phase-A chunk = ring slot
+  constexpr int NKB = NTX * KBU;                 // 16-byte k-blocks of GEMM B1 (K = Rp)
+  constexpr int MTB = (CHX / (NKB * 1024) >= 2) ? 2 : 1;
+  constexpr int CHB1 = MTB * NKB * 1024;
+  constexpr int CHB2 = NTU * 4 * 1024;
+  static_assert(CHB1 <= CHX && CHB2 <= CHX && NTU % MTB == 0, "ring slots are sized for the first GEMM's chunks");
+  constexpr int Z2 = 2 * NTU * 32;
+  constexpr int STGB = 4096;                     // per-wave staging tile (row pitch 128 B)
+  static_assert(4 * STGB <= CHX, "the staging tiles of the four waves fit one ring slot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int tiles_per_b = (p.T + 127) >> 7;
+  const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int b = tile_id / tiles_per_b;
+  const int t0w = (tile_id % tiles_per_b) * 128 + wave * 32;
+  const int t = t0w + n;
+  const bool tvalid = t < p.T;
+  const int rows_valid = min(max(p.T - t0w, 0), 32);
+  const int64_t row0 = (int64_t)b * p.T + t0w;
+
+  const int cpt = Z2 / T_::CK;                   // column blocks per tap
+  const int nqa = p.ktaps * cpt;
+  constexpr int nqb1 = NTU / MTB;
+  const int nqb2 = p.Sp / T_::CK;
+  const int nq_total = nqa + nqb1 + nqb2;
+  auto dma = [&](int qi) {                       // chunk qi of the whole sequence -> ring slot qi & 1
+    char* dst = smem + (qi & 1) * CHX;
+    qi = min(qi, nq_total - 1);                  // (past the end: the last chunk again, into the slot nobody reads -- constant counts)
+    const char* src;
+    int bytes;
+    if (qi < nqa) { bytes = CHX; src = p.w_x + (int64_t)qi * CHX; }
+    else if (qi < nqa + nqb1) { bytes = CHB1; src = p.w_uo + (int64_t)(qi - nqa) * CHB1; }
+    else { bytes = CHB2; src = p.w_us + (int64_t)(qi - nqa - nqb1) * CHB2; }
+    dma_chunk(src, dst, bytes, wave, lane);
+  };
+
+  // operand fragments by asm loads, two chunks ahead (csrc/gemm_tm.hip: TM_ASM_B); clamped address, zero fill at use
+  auto a_addr = [&](int q, bool& ok) -> const char* {      // phase A, chunk q = column block q / ktaps of tap q % ktaps
+    q = min(q, nqa - 1);
+    const int tap = q % p.ktaps, cb = q / p.ktaps;
+    const int ts = t + (p.ktaps - 1 - tap) * p.dilation;
+    ok = tvalid && ts < p.T;
+    return p.dz + (((int64_t)b * p.T + (ok ? ts : 0)) * p.dz_stride) * ES + cb * 128 + h * 16;
+  };
+  auto s_addr = [&](int q) -> const char* {                // phase B2, chunk q of dS
+    q = min(q, nqb2 - 1);
+    return p.dskip + (((int64_t)b * p.T + (tvalid ? t : 0)) * p.Sp) * ES + q * 128 + h * 16;
+  };
+  auto request = [&](frag (&G)[4], const char* src) {
+    gload_async<0>(G[0], src); gload_async<32>(G[1], src); gload_async<64>(G[2], src); gload_async<96>(G[3], src);
+  };
+  auto zero_unless = [&](frag (&G)[4], bool ok) {
+    const frag z = {};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) G[i] = ok ? G[i] : z;
+  };
+
+  // ---- phase A: acc_x = sum_tap W1_tap^T dz_l ------------------------------------------------------------------------------------
+  f32x16 accx[NTX];
+#pragma unroll
+  for (int m = 0; m < NTX; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[m][r] = 0.f;
+  f32x4 fa[8], fb[8];
+  const char* arow = p.g_next + row0 * NTX * 32 * ES;
+  if (rows_valid > 0) stage_fetch_pass<E, 2>(fa, arow, (int64_t)NTX * 32 * ES, rows_valid, lane);   // residual rows of the first tile pair
+  frag G0[4] = {}, G1[4] = {}, G2[4] = {};
+  bool k0, k1, k2;
+  dma(0);
+  request(G0, a_addr(0, k0));
+  request(G1, a_addr(1, k1));
+  auto step_a = [&](int q, frag (&Gc)[4], bool kc, frag (&Gl)[4], bool& kl) {
+    wait_vmcnt_frags<4>(Gc);
+    __builtin_amdgcn_s_barrier();     // chunk q visible; every wave is past its reads of chunk q-1, whose slot is refilled now
+    zero_unless(Gc, kc);
+    dma(q + 1);                       // (q + 1 == nqa: the first chunk of phase B1)
+    request(Gl, a_addr(q + 2, kl));
+    gemm_chunk<4 * NTX, NTX, 4>(smem + (q & 1) * CHX + lane * 16, Gc, accx);
+  };
+  for (int q = 0; q < nqa; q += 3) {
+    step_a(q, G0, k0, G2, k2);
+    if (q + 1 < nqa) step_a(q + 1, G1, k1, G0, k0);
+    if (q + 2 < nqa) step_a(q + 2, G2, k2, G1, k1);
+  }
+  drain_groups(G0, G1, G2);                          // chunk nqa (B1's first) has landed; the redundant operand requests are retired
+  __builtin_amdgcn_s_barrier();                      // every wave has left slot (nqa - 1) & 1: it is the staging area of epilogue A
+
+  // ---- epilogue A: dx_l-hat = alpha * (acc + residual), stored once, kept as the operand of GEMM B1 ------------------------------
+  frag xf[NKB];
+  {
+    char* stg = smem + ((nqa - 1) & 1) * CHX + wave * STGB;
+    char* orow = p.g_out + row0 * NTX * 32 * ES;
+#pragma unroll
+    for (int pr = 0; pr < NTX / 2; ++pr) {
+      f32x16 res[2];
+      if (rows_valid > 0) {
+        stage_unpack_pass<E, 2, 128>(stg, res, fa, lane);
+        if (pr + 1 < NTX / 2) stage_fetch_pass<E, 2>(fa, arow + (pr + 1) * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[2 * pr + i][r] = p.alpha * (accx[2 * pr + i][r] + (rows_valid > 0 ? res[i][r] : 0.f));
+        frag tmp[KBU];
+        acc_to_frags(accx[2 * pr + i], tmp);
+#pragma unroll
+        for (int s = 0; s < KBU; ++s) xf[(2 * pr + i) * KBU + s] = tmp[s];
+      }
+      if (rows_valid > 0) stage_store_pass<E, 2, 128>(stg, &accx[2 * pr], orow + pr * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, lane);
+    }
+  }
+
+  // ---- GEMM B: du = W_out^T dx_l-hat (operand from registers) + W_skip^T dskip (operand from memory) -------------------------------
+  f32x16 accu[NTU];
+#pragma unroll
+  for (int m = 0; m < NTU; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accu[m][r] = 0.f;
+  const char* zrow = p.z_prev + row0 * Z2 * ES;
+#pragma unroll
+  for (int q1 = 0; q1 < nqb1; ++q1) {
+    const int qi = nqa + q1;
+    if (q1 > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (chunk nqa landed before epilogue A)
+    __builtin_amdgcn_s_barrier();                                   // q1 == 0: every wave is done staging in the slot refilled now
+    dma(qi + 1);
+    if (q1 == 0) {    // dS of the first two B2 chunks: they arrive under B1
+      // (fresh values: an asm request reads its destination ("+v"), which would keep the three groups of phase A alive through
+      //  epilogue A -- 48 registers the tile pairs there do not have)
+      const frag zf = {};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { G0[i] = zf; G1[i] = zf; }
+      request(G0, s_addr(0));
+      request(G1, s_addr(1));
+    }
+    gemm_chunk<MTB * NKB, MTB, NKB, true>(smem + (qi & 1) * CHX + lane * 16, xf, *(f32x16(*)[MTB]) & accu[q1 * MTB]);
+  }
+  // B2: VMEM order per step j: [DMA(next)][dS(j + 2)]; at the top of step j >= 1 only dS(j + 1) may be outstanding
+  // (the first step is peeled at compile time: a run-time branch around an asm request or its counted wait is what lets hipcc park a
+  //  fragment's register elsewhere between the request and its wait -- csrc/wae_common.hpp: gload_async)
+  auto step_s = [&](auto first, int j, frag (&Gc)[4], frag (&Gl)[4]) {
+    constexpr bool FIRST = decltype(first)::value != 0;
+    const int qi = nqa + nqb1 + j;
+    if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(0)" : "+v"(Gc[0]), "+v"(Gc[1]), "+v"(Gc[2]), "+v"(Gc[3]));
+    else wait_vmcnt_frags<4>(Gc);
+    __builtin_amdgcn_s_barrier();
+    zero_unless(Gc, tvalid);
+    if constexpr (FIRST) {
+      // the saved pre-activations of the first tile pair (xf is dead: their registers are free now); they arrive under B2.  Older than
+      // every request of the steps below: the counted waits only get stricter.
+      if (rows_valid > 0) {
+        stage_fetch_pass<E, 2>(fa, zrow, (int64_t)Z2 * ES, rows_valid, lane);
+        stage_fetch_pass<E, 2>(fb, zrow + (int64_t)NTU * 32 * ES, (int64_t)Z2 * ES, rows_valid, lane);
+      }
+    }
+    dma(qi + 1);
+    if constexpr (FIRST) {
+      const frag zf = {};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Gl[i] = zf;
+    }
+    request(Gl, s_addr(j + 2));
+    gemm_chunk<4 * NTU, NTU, 4>(smem + (qi & 1) * CHX + lane * 16, Gc, accu);
+  };
+  step_s(IntC<1>{}, 0, G0, G2);
+  for (int j = 1; j < nqb2; j += 3) {
+    step_s(IntC<0>{}, j, G1, G0);
+    if (j + 1 < nqb2) step_s(IntC<0>{}, j + 1, G2, G1);
+    if (j + 2 < nqb2) step_s(IntC<0>{}, j + 2, G0, G2);
+  }
+  drain_groups(G0, G1, G2);                          // the redundant tail requests must not outlive the ring (or their registers)
+  __syncthreads();                                   // every wave is done with the weight ring: it becomes the staging area
+  if (rows_valid <= 0) return;
+
+  // ---- epilogue B: gate backward (modules.py:154: u = tanh(a) * sigmoid(b)):  da = du s (1 - th^2),  db = du th s (1 - s) ------------
+  {
+    char* stg = smem + wave * STGB;
+    char* orow = p.dz_prev + row0 * p.dz_stride * ES;
+#pragma unroll
+    for (int pr = 0; pr < NTU / 2; ++pr) {
+      f32x16 za[2], zg[2];
+      stage_unpack_pass<E, 2, 128>(stg, za, fa, lane);
+      stage_unpack_pass<E, 2, 128>(stg, zg, fb, lane);
+      if (pr + 1 < NTU / 2) {
+        stage_fetch_pass<E, 2>(fa, zrow + (pr + 1) * 64 * ES, (int64_t)Z2 * ES, rows_valid, lane);
+        stage_fetch_pass<E, 2>(fb, zrow + ((int64_t)NTU * 32 + (pr + 1) * 64) * ES, (int64_t)Z2 * ES, rows_valid, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ea = __builtin_amdgcn_exp2f(fmaxf(za[i][r], -15.0f) * -2.885390081777927f);
+          const float th = (1.0f - ea) * fast_rcp(1.0f + ea);
+          const float sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(zg[i][r] * -1.4426950408889634f));
+          const float du = accu[2 * pr + i][r];
+          za[i][r] = du * sg * (1.0f - th * th);
+          zg[i][r] = du * th * sg * (1.0f - sg);
+        }
+      stage_store_pass<E, 2, 128>(stg, za, orow + pr * 64 * ES, p.dz_stride * ES, rows_valid, lane);
+      stage_store_pass<E, 2, 128>(stg, zg, orow + ((int64_t)NTU * 32 + pr * 64) * ES, p.dz_stride * ES, rows_valid, lane);
+    }
+  }
+}
+
+template <typename E, int NTX, int NTU>
+static int launch_gb_pair(const GbArgs& a, hipStream_t st) {
+  constexpr int CHX = NTX * 4 * 1024;
+  const size_t lds = 2 * CHX;
+  static WaeLdsCache lds_cache;
+  if (int rc = wae_ensure_lds((const void*)glu_bwd_pair_kernel<E, NTX, NTU>, lds_cache, lds, "glu_bwd_pair"); rc != WAE_OK) return rc;
+  const int tiles = (a.T + 127) / 128;
+  hipLaunchKernelGGL((glu_bwd_pair_kernel<E, NTX, NTU>), dim3(a.B * tiles), dim3(256), lds, st, a);
+  return wae_check_launch("glu_bwd_pair");
+}
+
 template <typename E, int NTX, int NTU>
 static int launch_gb(const GbArgs& a, hipStream_t st) {
   constexpr int CHX = NTX * 4 * 1024;
@@ -206,6 +457,15 @@ static int launch_gb(const GbArgs& a, hipStream_t st) {
 
 template <typename E>
 static int dispatch_gb(int ntx, int ntu, const GbArgs& a, hipStream_t st) {
+  // 16-bit storage: the two-workgroups-per-CU form (w_x in the INTERLEAVED chunk order of wae_gemm_tm mode 1)
+  if constexpr (sizeof(E) == 2) {
+    if (ntx == 8 && ntu == 6) return launch_gb_pair<E, 8, 6>(a, st);
+    if (ntx == 8 && ntu == 4) return launch_gb_pair<E, 8, 4>(a, st);
+    if (ntx == 4 && ntu == 2) return launch_gb_pair<E, 4, 2>(a, st);
+    if (ntx == 4 && ntu == 4) return launch_gb_pair<E, 4, 4>(a, st);
+    wae_set_error("glu_bwd_fused: no 16-bit instance for Rp=%d, Hp=%d (use the two wae_gemm_tm launches)", ntx * 32, ntu * 32);
+    return WAE_EUNSUPPORTED;
+  }
   // (Rp/32, Hp/32) pairs of the shipped presets and the test configurations
   if (ntx == 8 && ntu == 6) return launch_gb<E, 8, 6>(a, st);
   if (ntx == 8 && ntu == 4) return launch_gb<E, 8, 4>(a, st);
@@ -220,6 +480,11 @@ static int dispatch_gb(int ntx, int ntu, const GbArgs& a, hipStream_t st) {
 extern "C" int wae_glu_bwd_fused_supported(int32_t Rp, int32_t Hp) {
   const int x = Rp / 32, u = Hp / 32;
   return (x == 8 && (u == 6 || u == 4)) || (x == 4 && u >= 1 && u <= 4);
+}
+// ... and for 16-bit storage (the pairwise epilogues need even tile counts)
+extern "C" int wae_glu_bwd_fused_supported16(int32_t Rp, int32_t Hp) {
+  const int x = Rp / 32, u = Hp / 32;
+  return (x == 8 && (u == 6 || u == 4)) || (x == 4 && (u == 2 || u == 4));
 }
 
 extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
