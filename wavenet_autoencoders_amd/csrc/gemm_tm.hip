@@ -358,7 +358,14 @@ __global__ void __launch_bounds__(NW * 64, OCC) gemm_tm_kernel(TmArgs p) {
       if (q + 1 < nq) step(q + 1, G1, k1, G0, k0);
       if (q + 2 < nq) step(q + 2, G2, k2, G1, k1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail requests must not outlive the ring
+    // the redundant tail requests must not outlive the ring -- nor their registers: the groups are operands of the wait, or hipcc,
+    // to which a request that is never consumed is a dead definition, may move epilogue arithmetic into them above it (round 5:
+    // csrc/glu_bwd.hip faulted that way; tools/check_asm_regs.py)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(G0[0]), "+v"(G0[1]), "+v"(G0[2]), "+v"(G0[3]), "+v"(G1[0]), "+v"(G1[1]), "+v"(G1[2]), "+v"(G1[3]), "+v"(G2[0]),
+                   "+v"(G2[1]), "+v"(G2[2]), "+v"(G2[3])
+                 :
+                 : "memory");
     __syncthreads();
   } else {
   if (!TM_ABL(2)) dma_chunk(wbase, smem, CHB, wave, lane);

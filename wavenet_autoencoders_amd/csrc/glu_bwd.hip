@@ -465,16 +465,17 @@ static int dispatch_gb(int ntx, int ntu, const GbArgs& a, hipStream_t st) {
     if (ntx == 4 && ntu == 4) return launch_gb_pair<E, 4, 4>(a, st);
     wae_set_error("glu_bwd_fused: no 16-bit instance for Rp=%d, Hp=%d (use the two wae_gemm_tm launches)", ntx * 32, ntu * 32);
     return WAE_EUNSUPPORTED;
+  } else {
+    // fp32 (the round-1 kernel): (Rp/32, Hp/32) pairs of the shipped presets and the test configurations
+    if (ntx == 8 && ntu == 6) return launch_gb<E, 8, 6>(a, st);
+    if (ntx == 8 && ntu == 4) return launch_gb<E, 8, 4>(a, st);
+    if (ntx == 4 && ntu == 1) return launch_gb<E, 4, 1>(a, st);
+    if (ntx == 4 && ntu == 2) return launch_gb<E, 4, 2>(a, st);
+    if (ntx == 4 && ntu == 3) return launch_gb<E, 4, 3>(a, st);
+    if (ntx == 4 && ntu == 4) return launch_gb<E, 4, 4>(a, st);
+    wae_set_error("glu_bwd_fused: no instance for Rp=%d, Hp=%d (use the two wae_gemm_tm launches)", ntx * 32, ntu * 32);
+    return WAE_EUNSUPPORTED;
   }
-  // (Rp/32, Hp/32) pairs of the shipped presets and the test configurations
-  if (ntx == 8 && ntu == 6) return launch_gb<E, 8, 6>(a, st);
-  if (ntx == 8 && ntu == 4) return launch_gb<E, 8, 4>(a, st);
-  if (ntx == 4 && ntu == 1) return launch_gb<E, 4, 1>(a, st);
-  if (ntx == 4 && ntu == 2) return launch_gb<E, 4, 2>(a, st);
-  if (ntx == 4 && ntu == 3) return launch_gb<E, 4, 3>(a, st);
-  if (ntx == 4 && ntu == 4) return launch_gb<E, 4, 4>(a, st);
-  wae_set_error("glu_bwd_fused: no instance for Rp=%d, Hp=%d (use the two wae_gemm_tm launches)", ntx * 32, ntu * 32);
-  return WAE_EUNSUPPORTED;
 }
 
 extern "C" int wae_glu_bwd_fused_supported(int32_t Rp, int32_t Hp) {
