@@ -163,9 +163,7 @@ def test_standalone_residual_conv1d_glu_against_golden(name, d):
         with pytest.raises(RuntimeError):
             layer.incremental_forward(xs[:, :, :1].transpose(1, 2))
         layer.eval()
-        # a gradient with respect to the global features is the one thing the stand-alone layer refuses (never a detached answer)
-        with pytest.raises(NotImplementedError):
-            layer(xs, cs, gv.cuda().expand(-1, -1, n).clone().requires_grad_(True))
+        # (a gradient with respect to the global features: test_standalone_layer_with_time_varying_global_features)
         with torch.no_grad():
             layer.train()
             layer(xs, cs, gv.cuda().expand(-1, -1, n))          # train mode without autograd is an ordinary forward (dropout 0)
@@ -386,3 +384,106 @@ def test_out_of_range_ids_raise_index_error():
         eng.check_errors()
     eng.train_step(ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda())
     eng.check_errors()
+
+
+@pytest.mark.parametrize("name,d,with_c", [("A", 2, True), ("B", 4, True), ("A", 1, False)])
+def test_standalone_layer_with_time_varying_global_features(name, d, with_c):
+    """modules.py:148-152 convolves whatever (B, gin_channels, T) tensor it is given; the reference's WaveNet hands it one speaker vector
+    expanded over time, a caller of the stand-alone layer may hand it a time series and ask for its gradient.  Round 5: such a call
+    switches the layer to Geometry.g_local (conv1x1g's columns behind conv1x1c's in the kernel's conditioning operand).  Outputs and the
+    gradients of x, c, g and every parameter against autograd through the oracle's layer; a constant-over-time g through the same
+    geometry afterwards gives the hoisted path's result."""
+    from helpers import golden_model, rel_err
+    from oracle import wae_oracle as O
+    from wavenet_autoencoders_amd.wavenet_vocoder.modules import ResidualConv1dGLU
+    cfg, sd, ins, zm, ocfg = golden_model(name)
+    pre = "wavenet.conv_layers.1."
+    lsd = {k[len(pre):]: v.clone() for k, v in sd.items() if k.startswith(pre) and (with_c or "conv1x1c" not in k)}
+    layer = ResidualConv1dGLU(cfg["R"], cfg["G"], cfg["k"], skip_out_channels=cfg["S"], cin_channels=cfg["Cc"] if with_c else -1,
+                              gin_channels=cfg["Cg"], dropout=0.0, dilation=d)
+    layer.load_state_dict(lsd)
+    layer = layer.cuda().train()
+    B, T = 2, 300
+    x = O.hash_fill((B, cfg["R"], T), 41, 0.8)
+    c = O.hash_fill((B, cfg["Cc"], T), 42, 0.8) if with_c else None
+    g = O.hash_fill((B, cfg["Cg"], T), 43, 0.8)                    # varies over time
+    wx, wsk = O.hash_fill((B, cfg["R"], T), 44), O.hash_fill((B, cfg["S"], T), 45)
+    psd = {pre + k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+    xr, gr = x.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    cr = c.clone().requires_grad_(True) if with_c else None
+    xo_r, so_r = O.glu_layer_forward(psd, pre, xr, cr, gr, d)
+    ((xo_r * wx).sum() + (so_r * wsk).sum()).backward()
+    xg, gg = x.cuda().requires_grad_(True), g.cuda().requires_grad_(True)
+    cg = c.cuda().requires_grad_(True) if with_c else None
+    assert not layer.geom.g_local
+    xo, so = layer(xg, cg, gg)
+    assert layer.geom.g_local and layer.geom.Cx == (cfg["Cc"] if with_c else 0) + cfg["Cg"]
+    assert rel_err(xo.detach().cpu(), xo_r.detach()) < 1e-4 and rel_err(so.detach().cpu(), so_r.detach()) < 1e-4
+    ((xo * wx.cuda()).sum() + (so * wsk.cuda()).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-4
+    assert rel_err(gg.grad.cpu(), gr.grad) < 1e-4
+    if with_c:
+        assert rel_err(cg.grad.cpu(), cr.grad) < 1e-4
+    params = dict(layer.named_parameters())
+    assert set(params) == set(lsd)
+    for k, p_ in params.items():
+        assert p_.grad is not None, k
+        assert rel_err(p_.grad.cpu(), psd[pre + k].grad) < 2e-4, k
+    # a constant-over-time g (B, Cg, 1) through the same geometry = the reference's expanded speaker vector
+    layer.eval()
+    gv = O.hash_fill((B, cfg["Cg"], 1), 46, 0.8)
+    with torch.no_grad():
+        xo2, so2 = layer(x.cuda(), c.cuda() if with_c else None, gv.cuda())
+        xo2_r, so2_r = O.glu_layer_forward({k: v.detach() for k, v in psd.items()}, pre, x, c, gv.expand(-1, -1, T), d)
+    assert rel_err(xo2.cpu(), xo2_r) < 1e-4 and rel_err(so2.cpu(), so2_r) < 1e-4
+
+
+@pytest.mark.parametrize("p_drop", [0.05, 0.4])
+def test_standalone_layer_trains_with_dropout(p_drop):
+    """modules.py:127-128: the reference's constructor default is dropout = 0.05 and F.dropout is active in training mode.  The stand-alone
+    layer now applies the engine's counter-based mask (one seed per forward call); torch's Philox stream cannot be reproduced, so parity is
+    against the oracle under the SAME mask (oracle.wae_oracle.dropout_keep restates the hash): outputs, gradients of x, c and every
+    parameter; two forwards draw different masks; eval mode is the identity."""
+    from helpers import golden_model, rel_err
+    from oracle import wae_oracle as O
+    from wavenet_autoencoders_amd.wavenet_vocoder.modules import ResidualConv1dGLU
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    pre = "wavenet.conv_layers.1."
+    lsd = {k[len(pre):]: v.clone() for k, v in sd.items() if k.startswith(pre)}
+    d = 2
+    layer = ResidualConv1dGLU(cfg["R"], cfg["G"], cfg["k"], skip_out_channels=cfg["S"], cin_channels=cfg["Cc"],
+                              gin_channels=cfg["Cg"], dropout=p_drop, dilation=d)
+    layer.load_state_dict(lsd)
+    layer = layer.cuda().train()
+    B, T = 2, 300
+    x = O.hash_fill((B, cfg["R"], T), 51, 0.8)
+    c = O.hash_fill((B, cfg["Cc"], T), 52, 0.8)
+    gv = O.hash_fill((B, cfg["Cg"], 1), 53, 0.8)
+    wx, wsk = O.hash_fill((B, cfg["R"], T), 54), O.hash_fill((B, cfg["S"], T), 55)
+    outs = []
+    for call in (1, 2):
+        xg, cg = x.cuda().requires_grad_(True), c.cuda().requires_grad_(True)
+        for p_ in layer.parameters():
+            p_.grad = None
+        xo, so = layer(xg, cg, gv.cuda().expand(-1, -1, T))
+        eng = layer._engine
+        assert eng.drop_calls == call
+        keep = O.dropout_keep(eng.layer_drop_seed(call, 0), B, cfg["R"], T, p_drop)
+        assert abs(float(keep.float().mean()) - (1 - p_drop)) < 0.03
+        psd = {pre + k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+        xr, cr = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        xo_r, so_r = O.glu_layer_forward(psd, pre, xr, cr, gv.expand(-1, -1, T), d, keep=keep, p=p_drop)
+        ((xo_r * wx).sum() + (so_r * wsk).sum()).backward()
+        assert rel_err(xo.detach().cpu(), xo_r.detach()) < 1e-4 and rel_err(so.detach().cpu(), so_r.detach()) < 1e-4
+        ((xo * wx.cuda()).sum() + (so * wsk.cuda()).sum()).backward()
+        assert rel_err(xg.grad.cpu(), xr.grad) < 1e-4
+        assert rel_err(cg.grad.cpu(), cr.grad) < 1e-4
+        for k, p_ in layer.named_parameters():
+            assert rel_err(p_.grad.cpu(), psd[pre + k].grad) < 2e-4, k
+        outs.append(xo.detach().clone())
+    assert not torch.equal(outs[0], outs[1])               # another call, another mask
+    layer.eval()
+    with torch.no_grad():
+        xe, _ = layer(x.cuda(), c.cuda(), gv.cuda().expand(-1, -1, T))
+        xe_r, _ = O.glu_layer_forward({pre + k: v for k, v in lsd.items()}, pre, x, c, gv.expand(-1, -1, T), d)
+    assert rel_err(xe.cpu(), xe_r) < 1e-4

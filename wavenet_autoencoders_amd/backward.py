@@ -918,7 +918,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
 
 
 
-def layer_backward(eng, B, T, gx_hat, ds, gvec):
+def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None):
     """Backward of ONE ResidualConv1dGLU layer (an engine of geometry layers == 1, wavenet_vocoder.modules.ResidualConv1dGLU) -- the
     autograd of modules.py:115-163 from the same kernels the stack uses, last train-mode forward of that (B, T):
         dz  = gate'(z) * (W_out^T gx_hat + W_skip^T ds)                   (wae_gemm_tm GATE_BWD)
@@ -926,7 +926,8 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec):
         dc  = Wc^T dz                                                     (wae_gemm_tm PLAIN)
         dW1, dWc, per-clip sums of dz, dW_out + bias, dW_skip + bias      (wae_gemm_tn_tiles), gproj / weight-norm backward
     gx_hat (B,T,Rp) = sqrt(.5) * d loss / d x' (x' = (conv1x1_out(u) + x) sqrt(.5)), ds (B,T,Sp) = d loss / d s, both in the engine's
-    storage dtype (times eng.grad_scale for fp16).  Fills eng.grads (finish_grads) and returns (dx (B,T,Rp), dc (B,T,Ccp) | None)."""
+    storage dtype (times eng.grad_scale for fp16).  drop_seed: the seed of the dropout mask the forward applied to the convolution's
+    operand (modules.py:127-128), or None.  Fills eng.grads (finish_grads) and returns (dx (B,T,Rp), dc (B,T,Ccp) | None)."""
     _prepare_bwd(eng)
     g, lib, lay, st, sm = eng.g, eng.lib, eng.lay, eng.stream(), eng.sm
     assert g.layers == 1
@@ -946,7 +947,8 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec):
         tt = TileTable(eng)
         for tap in range(g.k):
             last = tap == g.k - 1 and not g.Ccp
-            tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, ws["dz"].data_ptr(), Z2, fw["x"][0].data_ptr(), g.Rp,
+            xop = fw["xd"][0] if "xd" in fw else fw["x"][0]          # dW1 contracts dz against the convolution's (masked) operand
+            tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, ws["dz"].data_ptr(), Z2, xop.data_ptr(), g.Rp,
                    c1.data_ptr() + tap * g.Rp * 4, sm["ld1"])
         if g.Ccp:
             tt.add(Z2, g.Ccp, 0, g.Ccp, ia, ws["dz"].data_ptr(), Z2, fw["c_up"].data_ptr(), g.Ccp, c1.data_ptr() + g.k * g.Rp * 4, sm["ld1"])
@@ -963,8 +965,16 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec):
         ws["dz"].data_ptr(), Z2, fw["z"][0].data_ptr(), Z2, flags=eng.tm_flags_u)
     ws["tt"].launch(B, T)
     srcs = [(ws["dz"].data_ptr(), Z2, Z2, (g.k - 1 - tap) * g.dilations[0]) for tap in range(g.k)]
-    _tm(eng, B, T, g.Rp, 1, 1.0, srcs, eng.w_bx.data_ptr(), ws["gx"].data_ptr(), g.Rp, ws["gn"].data_ptr(), g.Rp,
-        flags=P.TM_INTERLEAVE | eng.tm_flags_x)
+    if drop_seed is None:
+        _tm(eng, B, T, g.Rp, 1, 1.0, srcs, eng.w_bx.data_ptr(), ws["gx"].data_ptr(), g.Rp, ws["gn"].data_ptr(), g.Rp,
+            flags=P.TM_INTERLEAVE | eng.tm_flags_x)
+    else:
+        # dropout: the tap contraction alone, then dx = gx_hat + keep * acc / (1 - p) with the forward's mask
+        if "gtmp" not in ws:
+            ws["gtmp"] = torch.zeros(B, T, g.Rp, dtype=eng.tdtype, device=eng.device)
+        _tm(eng, B, T, g.Rp, 0, 1.0, srcs, eng.w_bx.data_ptr(), ws["gtmp"].data_ptr(), g.Rp, flags=P.TM_INTERLEAVE)
+        L.check(lib.wae_dropout_bwd(L.ptr(ws["gtmp"]), L.ptr(ws["gn"]), L.ptr(ws["gx"]), B * T * g.Rp, drop_seed, eng.dropout, 1.0, eng.dt, st),
+                "dropout_bwd")
     if g.Ccp:
         _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), Z2, Z2, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
     OP = P.ONES_PAD

@@ -58,6 +58,11 @@ class Geometry:
     encoder_hid: Optional[int] = None
     K: int = 256
     dilations_override: Optional[List[int]] = None   # standalone layers (wavenet_vocoder.modules.ResidualConv1dGLU)
+    # Global features that VARY over time (modules.py:148-152 convolves any (B, Cg, T) tensor): conv1x1g then is one more 1x1 over a
+    # time series, exactly what conv1x1c is -- its Cg columns ride behind the Cc columns of the local conditioning in the layer
+    # kernel's operand ([c ; g] in c_up, [Wc | Wg] in the packed GEMM-1 stream), forward and backward; the hoisted per-clip projection
+    # (gproj) is not used.  Set by the stand-alone layer module when it is handed such a tensor.
+    g_local: bool = False
 
     def __post_init__(self):
         assert self.layers % self.stacks == 0                       # wavenet.py:117
@@ -67,6 +72,11 @@ class Geometry:
         self.Sp = _ru(self.S, 128)
         self.Op = _ru(self.O, 128)
         self.Ccp = _ru(self.Cc, 64) if self.Cc > 0 else 0
+        self.Cx = max(self.Cc, 0)                     # conditioning columns of the layer kernel's operand
+        if self.g_local:
+            assert self.Cg > 0
+            self.Cx += self.Cg
+            self.Ccp = _ru(self.Cx, 64)
         self.Hp = _ru(self.H, 32)
         self.NP = self.Hp // 32
         self.Ku = _ru(self.layers * self.Hp, 64)       # columns of the (B,T,Ku) buffer of all layers' gated activations
@@ -193,6 +203,25 @@ def glu_pass_tiles(NP: int) -> int:
     return {1: 1, 2: 1, 3: 3, 4: 4, 6: 3, 8: 4}[NP]
 
 
+def cond_weight_src(g: Geometry, lay: ParamLayout, row, cc):
+    """arena offset (layer 0) of the 1x1 conditioning weight [gate row `row`][operand column `cc`], and its validity: columns
+    [0, Cc) = conv1x1c; with g_local, [Cc, Cc + Cg) = conv1x1g (Geometry.g_local)."""
+    Cc = max(g.Cc, 0)
+    src = np.zeros(np.broadcast(row, cc).shape, dtype=np.int64)
+    ok = np.zeros(src.shape, dtype=bool)
+    if Cc > 0:
+        c_off = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
+        isc = (cc >= 0) & (cc < Cc)
+        src = np.where(isc, c_off + row * Cc + cc, src)
+        ok |= isc
+    if g.g_local:
+        g_off = lay.off("wavenet.conv_layers.0.conv1x1g.weight_v")
+        isg = (cc >= Cc) & (cc < Cc + g.Cg)
+        src = np.where(isg, g_off + row * g.Cg + (cc - Cc), src)
+        ok |= isg
+    return src, ok
+
+
 def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     """int32 map (relative to arena start, layer 0) for the GEMM-1 stream of one GLU layer."""
     t = _traits(dtype)
@@ -215,13 +244,8 @@ def glu_w1_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
     conv_off = lay.off("wavenet.conv_layers.0.conv.weight_v")
     src_conv = conv_off + (row * g.R + ch) * g.k + tap
     valid_conv = (ig < g.H) & (ch < g.R)
-    if g.Cc > 0:
-        c_off = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
-        src_c = c_off + row * g.Cc + ch
-        valid_c = (ig < g.H) & (ch < g.Cc)
-    else:
-        src_c = np.zeros_like(src_conv)
-        valid_c = np.zeros_like(valid_conv)
+    src_c, valid_c = cond_weight_src(g, lay, row, ch)
+    valid_c = valid_c & (ig < g.H)
     out = np.where(is_conv, np.where(valid_conv, src_conv, -1), np.where(valid_c, src_c, -1))
     return out.astype(np.int32).reshape(-1)
 
@@ -465,13 +489,12 @@ def bwd_x_map(g: Geometry, lay: ParamLayout, dtype: int, interleave: bool = True
 
 
 def bwd_c_map(g: Geometry, lay: ParamLayout, dtype: int) -> np.ndarray:
-    """dc = sum_l Wc_l^T dz_l: rows cc (Ccp), K = L * 2Hp (absolute offsets)."""
-    cw = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
-
+    """dc = sum_l Wc_l^T dz_l: rows cc (Ccp), K = L * 2Hp (absolute offsets).  (g_local: rows [Cc, Cc + Cg) are conv1x1g's.)"""
     def src(cc, kk):
         l, c2 = kk // (2 * g.Hp), kk % (2 * g.Hp)
         row, ok = _gate_row(g, c2)
-        return np.where(ok & (cc < g.Cc), cw + l * lay.layer_stride + row * g.Cc + cc, -1)
+        off, okc = cond_weight_src(g, lay, row, cc)
+        return np.where(ok & okc, off + l * lay.layer_stride, -1)
     return first_gemm_map(g.Ccp, g.layers * 2 * g.Hp, dtype, src)
 
 
@@ -528,10 +551,10 @@ def grad_scatter_maps(g: Geometry, lay: ParamLayout) -> dict:
     conv = lay.off("wavenet.conv_layers.0.conv.weight_v")
     tap, r = col // g.Rp, col % g.Rp
     m = np.where(ok & (col < g.k * g.Rp) & (r < g.R), conv + (grow * g.R + r) * g.k + np.minimum(tap, g.k - 1), -1)
-    if g.Cc > 0:
-        cw = lay.off("wavenet.conv_layers.0.conv1x1c.weight_v")
+    if g.Ccp:
         cc = col - g.k * g.Rp
-        m = np.where(ok & (cc >= 0) & (cc < g.Cc), cw + grow * g.Cc + cc, m)
+        off, okc = cond_weight_src(g, lay, grow, cc)
+        m = np.where(ok & okc, off, m)
     out["w1"], out["ld1"], out["ncol1"] = m.astype(np.int32).reshape(-1), ld1, ncol1
     # dW_out: rows r (Rp), cols h (Hp) ; ones -> bias
     ldo = g.Hp + ONES_PAD

@@ -13,7 +13,8 @@ from ._base import ArenaModel
 
 
 class _LayerFn(torch.autograd.Function):
-    """(x', s) = layer(x, c, g) with gradients for x, c and every parameter (g: a constant-over-time feature vector, no gradient)."""
+    """(x', s) = layer(x, c, g) with gradients for x, c, every parameter and -- when the layer runs with the global features as a time
+    series (Geometry.g_local) -- for g."""
 
     @staticmethod
     def forward(ctx, mod, x, c, g, *params):
@@ -22,6 +23,8 @@ class _LayerFn(torch.autograd.Function):
         eng.fwd_gen = getattr(eng, "fwd_gen", 0) + 1           # the saved activations now belong to THIS forward
         ctx.mod, ctx.gen, ctx.shape, ctx.has_c = mod, eng.fwd_gen, tuple(x.shape), c is not None
         ctx.gvec = mod._keep[1]
+        ctx.has_g = g is not None and eng.g.g_local
+        ctx.seed = mod._keep[2]                 # dropout seed of THIS forward (None: no mask)
         return xo, so
 
     @staticmethod
@@ -41,15 +44,21 @@ class _LayerFn(torch.autograd.Function):
             L.check(lib.wae_to_btc(L.ptr((dxo.float() * (math.sqrt(0.5) * eng.grad_scale)).contiguous()), L.ptr(gx), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc dx'")
         if dso is not None:
             L.check(lib.wae_to_btc(L.ptr((dso.float() * eng.grad_scale).contiguous()), L.ptr(ds), B, gm.S, T, gm.Sp, eng.dt, st), "to_btc ds")
-        dx_btc, dc_btc = BW.layer_backward(eng, B, T, gx, ds, ctx.gvec)
+        dx_btc, dc_btc = BW.layer_backward(eng, B, T, gx, ds, ctx.gvec, drop_seed=ctx.seed)
         dx = torch.empty(B, gm.R, T, dtype=torch.float32, device=dev)
         L.check(lib.wae_from_btc_scaled(L.ptr(dx_btc), L.ptr(dx), B, gm.R, T, gm.Rp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc dx")
-        dc = None
-        if ctx.has_c and dc_btc is not None:
-            dc = torch.empty(B, gm.Cc, T, dtype=torch.float32, device=dev)
-            L.check(lib.wae_from_btc_scaled(L.ptr(dc_btc), L.ptr(dc), B, gm.Cc, T, gm.Ccp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc dc")
+        dc = dg = None
+        if (ctx.has_c or ctx.has_g) and dc_btc is not None:
+            # the conditioning operand's gradient: columns [0, Cc) are c's, with g as a time series [Cc, Cc + Cg) are g's
+            dcg = torch.empty(B, gm.Cx, T, dtype=torch.float32, device=dev)
+            L.check(lib.wae_from_btc_scaled(L.ptr(dc_btc), L.ptr(dcg), B, gm.Cx, T, gm.Ccp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc dc")
+            nc = max(gm.Cc, 0)
+            if ctx.has_c:
+                dc = dcg[:, :nc].contiguous()
+            if ctx.has_g:
+                dg = dcg[:, nc:nc + gm.Cg].contiguous()
         _, views = mod._grad_views(eng)
-        return (None, dx, dc, None) + tuple(v.clone() for v in views)
+        return (None, dx, dc, dg) + tuple(v.clone() for v in views)
 
 
 class ResidualConv1dGLU(ArenaModel):
@@ -57,14 +66,18 @@ class ResidualConv1dGLU(ArenaModel):
     s = conv1x1_skip(u); x' = (conv1x1_out(u) + x) * sqrt(.5)   (modules.py:115-163).
 
     Same constructor as the reference (modules.py:71-75).  Supported: causal=True, bias=True (what the reference's WaveNet builds,
-    wavenet.py:127-134), any dropout in eval mode and dropout 0 in train mode, global features constant over time (the reference expands one
-    speaker vector, wavenet.py:185-194).  Trainable: gradients for x, c and every parameter (weight_g / weight_v / bias of conv,
-    conv1x1c, conv1x1g, conv1x1_out, conv1x1_skip) through ``_LayerFn``."""
+    wavenet.py:127-134); dropout (modules.py:127-128): the identity in eval mode, in training mode the engine's counter-based mask (one
+    seed per forward call; parity against the oracle under the same mask, oracle.wae_oracle.dropout_keep); global features as ONE vector per
+    clip (what the reference's WaveNet expands, wavenet.py:185-194: hoisted into a per-clip bias) or -- round 5 -- as any (B, Cg, T) time
+    series, with a gradient for g (modules.py:148-152 convolves whatever it is given): the first call that sees a g that varies over
+    time or requires a gradient switches the layer to Geometry.g_local, where conv1x1g's columns ride behind conv1x1c's in the kernel's
+    conditioning operand.  Trainable: gradients for x, c, g and every parameter (weight_g / weight_v / bias of conv, conv1x1c, conv1x1g,
+    conv1x1_out, conv1x1_skip) through ``_LayerFn``."""
 
     def __init__(self, residual_channels, gate_channels, kernel_size, skip_out_channels=None, cin_channels=-1, gin_channels=-1,
                  dropout=1 - 0.95, padding=None, dilation=1, causal=True, bias=True, *args, **kwargs):
         super().__init__()
-        self.dropout = float(dropout)          # identity in eval mode (modules.py:127-128); a train-mode call with p > 0 raises
+        self.dropout = float(dropout)          # identity in eval mode (modules.py:127-128); the engine's hashed mask in train mode
         if not causal or not bias:
             raise NotImplementedError("only the causal, biased layer the reference's WaveNet builds is implemented")
         if padding is not None and padding != (kernel_size - 1) * dilation:
@@ -80,10 +93,23 @@ class ResidualConv1dGLU(ArenaModel):
         self._skip_w = None
 
     # ------------------------------------------------------------------ kernels
+    def _g_as_time_series(self):
+        """Switch the layer to Geometry.g_local (a new engine over the same parameters; one-way)."""
+        import dataclasses
+        if self.geom.g_local:
+            return
+        sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
+        self._engine = None
+        for k, p_ in self.named_parameters():
+            p_.data = sd[k]
+        self.geom = dataclasses.replace(self.geom, g_local=True)
+        self._skip_w = None
+
     def _run(self, x, c, g, train=False):
-        if self.training and self.dropout > 0:
-            raise NotImplementedError(f"training-mode forward with dropout={self.dropout} is not implemented (every preset uses 0.0; "
-                                      "eval mode is exact for any value): pass dropout=0.0 or call .eval()")
+        gm0 = self.geom
+        if gm0.Cg > 0 and g is not None and not gm0.g_local:
+            if g.requires_grad or (g.shape[-1] > 1 and not bool((g == g[:, :, :1]).all())):
+                self._g_as_time_series()
         eng = self.engine()
         gm, lib, st = eng.g, eng.lib, eng.stream()
         B, R, T = x.shape
@@ -91,15 +117,26 @@ class ResidualConv1dGLU(ArenaModel):
         eng.prepare_weights()
         ws = eng.workspace(B, T, train)
         L.check(lib.wae_to_btc(L.ptr(x.contiguous().float()), L.ptr(ws["x"][0]), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc x")
-        if gm.Ccp:
-            if c is None or c.shape[-1] != T:
-                raise ValueError("local conditioning c must be (B, cin_channels, T)")
-            L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(ws["c_up"]), B, gm.Cc, T, gm.Ccp, eng.dt, st), "to_btc c")
         gvec = None
-        if gm.Cg > 0 and g is not None:
-            if g.shape[-1] > 1 and not bool((g == g[:, :, :1]).all()):
-                raise NotImplementedError("global features that vary over time are not supported (the reference expands one vector)")
-            gvec = g[:, :, 0].contiguous().float()
+        if gm.g_local:
+            if g is None:
+                raise ValueError("this layer has been run with global features as a time series: g (B, gin_channels, T) is required")
+            gt = g.detach().float()
+            if gt.shape[-1] == 1:
+                gt = gt.expand(-1, -1, T)
+            if gt.shape[-1] != T:
+                raise ValueError("global features g must be (B, gin_channels, T) or (B, gin_channels, 1)")
+            if gm.Cc > 0 and (c is None or c.shape[-1] != T):
+                raise ValueError("local conditioning c must be (B, cin_channels, T)")
+            cg = torch.cat([c.detach().float(), gt], dim=1) if gm.Cc > 0 else gt       # the kernel's conditioning operand [c ; g]
+            L.check(lib.wae_to_btc(L.ptr(cg.contiguous()), L.ptr(ws["c_up"]), B, gm.Cx, T, gm.Ccp, eng.dt, st), "to_btc [c ; g]")
+        else:
+            if gm.Ccp:
+                if c is None or c.shape[-1] != T:
+                    raise ValueError("local conditioning c must be (B, cin_channels, T)")
+                L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(ws["c_up"]), B, gm.Cc, T, gm.Ccp, eng.dt, st), "to_btc c")
+            if gm.Cg > 0 and g is not None:
+                gvec = g[:, :, 0].contiguous().float()
         wg_off = eng.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if gm.Cg > 0 else -1
         L.check(lib.wae_gproj_fwd(L.ptr(eng.eff), wg_off if gvec is not None else -1, eng.lay.off("wavenet.conv_layers.0.conv.bias"),
                                   eng.lay.layer_stride, None, 0, L.ptr(gvec), L.ptr(ws["zb"]), B, 1, gm.G, gm.Hp, max(gm.Cg, 0), 0, None,
@@ -107,9 +144,22 @@ class ResidualConv1dGLU(ArenaModel):
                 "gproj")
         ws["u"].zero_()
         d = L.GluDesc(eng.dt, B, T, gm.Rp, gm.Ccp, gm.Hp, gm.k, self.dilation, L.GLU_SAVE_Z if train else 0)
-        L.check(lib.wae_glu_layer_fwd(ctypes.byref(d), L.ptr(ws["x"][0]), L.ptr(ws["x"][1]), L.ptr(ws["c_up"]), L.ptr(ws["u"]), gm.Ku,
-                                      L.ptr(ws["zb"]), 2 * gm.Hp, L.ptr(ws["z"][0]) if train else None, L.ptr(eng.w_glu), L.ptr(eng.b_glu),
-                                      st), "glu layer")
+        # dropout (modules.py:127-128): F.dropout on the convolution's operand in training mode, the residual path keeps x.  One seed per
+        # forward call from the engine's call counter (engine.layer_drop_seed); backward regenerates the mask from the seed kept in ctx.
+        seed = None
+        xconv = ws["x"][0]
+        if self.training and self.dropout > 0:
+            eng.drop_calls += 1
+            seed = eng.layer_drop_seed(eng.drop_calls, 0)
+        if seed is not None or (train and "xd" in ws):
+            if "xd" not in ws:          # (an inference-shaped workspace: the masked operand lives for this call only)
+                ws["xd_tmp"] = ws.get("xd_tmp") if ws.get("xd_tmp") is not None else torch.empty_like(ws["x"][0])
+            xconv = ws["xd"][0] if "xd" in ws else ws["xd_tmp"]
+            L.check(lib.wae_dropout_fwd(L.ptr(ws["x"][0]), L.ptr(xconv), B * T * gm.Rp, seed or 0, self.dropout if seed is not None else 0.0,
+                                        eng.dt, st), "dropout")
+        L.check(lib.wae_glu_layer_fwd_drop(ctypes.byref(d), L.ptr(ws["x"][0]), L.ptr(xconv), L.ptr(ws["x"][1]), L.ptr(ws["c_up"]),
+                                           L.ptr(ws["u"]), gm.Ku, L.ptr(ws["zb"]), 2 * gm.Hp, L.ptr(ws["z"][0]) if train else None,
+                                           L.ptr(eng.w_glu), L.ptr(eng.b_glu), st), "glu layer")
         # skip output: s = W_skip u + b as one time-major GEMM over the layer's gated activations
         if self._skip_w is None or self._skip_w[0] is not eng:
             lay = eng.lay
@@ -131,7 +181,7 @@ class ResidualConv1dGLU(ArenaModel):
         L.check(lib.wae_from_btc(L.ptr(ws["x"][1]), L.ptr(xo), B, gm.R, T, gm.Rp, eng.dt, st), "from_btc x")
         L.check(lib.wae_from_btc(L.ptr(sbt), L.ptr(so_), B, gm.S, T, gm.Sp, eng.dt, st), "from_btc s")
         bias = dict(self.named_parameters())["conv1x1_skip.bias"].detach().float()
-        self._keep = (sbt, gvec)
+        self._keep = (sbt, gvec, seed)
         return xo, so_ + bias.view(1, -1, 1)
 
     # ------------------------------------------------------------------ reference API
@@ -139,10 +189,7 @@ class ResidualConv1dGLU(ArenaModel):
         """x (B, R, T), c (B, Cc, T), g (B, Cg, T) -> (x' (B, R, T), s (B, S, T))   (modules.py:109-110)."""
         if torch.is_grad_enabled():
             params = [p for _, p in sorted(((n, p) for n, p in self.named_parameters()), key=lambda kv: self._pnames.index(kv[0]))]
-            wants = any(t is not None and t.requires_grad for t in (x, c)) or any(p.requires_grad for p in params)
-            if g is not None and g.requires_grad:
-                raise NotImplementedError("no gradient with respect to the global features g (a constant-over-time vector here); "
-                                          "detach it, or train through wavenet_vocoder.WaveNet (speaker embedding)")
+            wants = any(t is not None and t.requires_grad for t in (x, c, g)) or any(p.requires_grad for p in params)
             if wants:
                 return _LayerFn.apply(self, x, c, g, *params)
         with torch.no_grad():
