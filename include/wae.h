@@ -385,9 +385,7 @@ typedef struct wae_tm_desc {
 #define WAE_TM_INTERLEAVE 1
 #define WAE_TM_ONE_WG 2   /* bf16 gate-backward / residual / ReLU-backward launches: one 4-wave workgroup per CU with the 8 KiB
                              staging tiles instead of two per CU (same results; an A/B switch per launch) */
-#define WAE_TM_BLDS 4     /* 16-bit gate-backward / residual launches: the 8-wave shape (one 256-column workgroup per CU) whose activation
-                             operand is staged through LDS by coalesced LDS-DMA pieces and whose requests are issued between the MFMAs;
-                             same results bit for bit; measured not faster than the default (an A/B switch per launch) */
+/* (flag value 4 was WAE_TM_BLDS, the 8-wave LDS-staged-operand shape of rounds 3-4: measured not faster, removed in round 5) */
 int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
                 const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,
                 int64_t out_stride, const void* aux, int64_t aux_stride, void* stream);

@@ -193,39 +193,6 @@ def test_static_weight_gradient_launch_at_odd_shapes(B, T, dtype, monkeypatch):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("env", [{"WAE_TN_PACE": "2"}, {"WAE_TN_PACE": "8", "WAE_TN_PACE_FROM": "1"}, {"WAE_TN_SHARES": "weighted"},
-                                 {"WAE_TQ_PACE": "2"}, {"WAE_TQ_PACE": "6", "WAE_TQ_PACE_COND": "-2"}])
-def test_stream_schedules_do_not_change_the_gradients(env, monkeypatch):
-    """The opt-in schedules of the one weight-gradient launch (narrow jobs paced against the taps; equal-time shares instead of
-    teams) are timing devices: same operands, same fp32 sums, only the arrival order of the atomics differs (1e-6 of the range)."""
-    from wavenet_autoencoders_amd import Geometry
-    from wavenet_autoencoders_amd import backward as BW
-    from wavenet_autoencoders_amd.engine import WaeEngine
-    cfg, sd, ins, z, ocfg = golden_model("A")
-    x, g = ins["x"].cuda(), ins["g"].cuda()
-    c_up = torch.from_numpy(z["c_up"]).cuda()
-    ln = torch.tensor([1280, 1280 - 137])
-    got = []
-    for e in ({}, env):
-        for k in ("WAE_TN_PACE", "WAE_TN_PACE_FROM", "WAE_TN_SHARES", "WAE_TQ_PACE", "WAE_TQ_PACE_COND"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in e.items():
-            monkeypatch.setenv(k, v)
-        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
-        eng.load_state_dict(sd)
-        eng.decoder_forward(x, c_up, g, targets=x, lengths=ln.cuda(), train=True, c_is_upsampled=True, want_logits=False)
-        BW.decoder_backward(eng, x, x, ln, g)
-        st = BW.bwd_workspace(eng, *x.shape)["stream"]
-        if not e or "WAE_TQ_PACE" in e:   # the default: the static-schedule launch (csrc/gemm_tn_static.hip); WAE_TQ_PACE = its team pacing
-            assert isinstance(st, BW.StaticStreamTable) and (st.window > 0) == ("WAE_TQ_PACE" in e)
-        else:          # the other opt-in schedules belong to the any-shape kernel (csrc/gemm_tn_stream.hip)
-            assert isinstance(st, BW.StreamTable) and (st.window > 0) == ("WAE_TN_PACE" in e) and (st.team_size == 1) == ("WAE_TN_SHARES" in e)
-        got.append(BW.finish_grads(eng).clone())
-        torch.cuda.synchronize()
-    err, ref = float((got[0] - got[1]).abs().max()), float(got[0].abs().max())
-    assert err < 1e-6 * ref + 1e-9, (err, ref)
-
-
 def test_full_train_step_against_golden():
     """(7) of SURVEY 8c: parameter gradients of one step, post-Adam weights and EMA shadow of the reference."""
     from helpers import load_npz
@@ -418,29 +385,6 @@ def test_dropout_train_step_bf16_learns():
         assert bool(torch.isfinite(eng.params).all())
     assert runs[0][0] == runs[1][0]
     assert runs[0][-1] < runs[0][0]
-
-
-def test_side_stream_backward_preparation_gives_the_same_step(monkeypatch):
-    """WAE_SIDE_PACK=1 (the backward's weight packs and arena zeroing on a side stream under the forward) is a scheduling switch: the
-    gradients of a train step are the same up to the arrival order of the weight-gradient atomics."""
-    from wavenet_autoencoders_amd import Geometry
-    from wavenet_autoencoders_amd.engine import WaeEngine
-    cfg, sd, ins, z, ocfg = golden_model("A")
-    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
-    got = []
-    for v in ("0", "1"):
-        monkeypatch.setenv("WAE_SIDE_PACK", v)
-        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
-        eng.load_state_dict(sd)
-        eng.init_optimizer()
-        seen = {}
-        for _ in range(2):      # the second step starts with the first one's side work behind it
-            eng.train_step(x, c, g, lr=0.0, clip_thresh=-1.0, grad_hook=lambda gr: seen.update(g=gr.clone()))
-        torch.cuda.synchronize()
-        assert (getattr(eng, "_side_stream", None) is not None) == (v == "1")
-        got.append(seen["g"])
-    err, ref = float((got[0] - got[1]).abs().max()), float(got[0].abs().max())
-    assert err < 1e-5 * ref + 1e-9, (err, ref)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

@@ -172,29 +172,6 @@ def test_feature_export_output_path_follows_reference_layout():
         I.output_path("/abs/db/x/english/test/utt9/", "out/")
 
 
-def test_weighted_shares_cover_the_work_list_once():
-    """backward.weighted_shares (the equal-time split of the weight-gradient launch, WAE_TN_SHARES=weighted): every (job, slab)
-    lands in exactly one share, shares are contiguous runs in list order, and their weights differ by less than one slab."""
-    from wavenet_autoencoders_amd.backward import weighted_shares
-    rng = np.random.default_rng(0)
-    for nsl, nshares in ((2000, 256), (160, 256), (37, 8), (5, 16)):
-        items = [(j, float(w)) for j, w in enumerate(rng.choice([1.0, 0.62, 0.7, 0.51], size=int(rng.integers(3, 120))))]
-        shares = weighted_shares(items, nsl, nshares)
-        assert len(shares) == nshares
-        pos = {}
-        for sh in shares:
-            for job, lo, hi in sh:
-                assert 0 <= lo < hi <= nsl and pos.get(job, 0) == lo       # contiguous, in order, no gap, no overlap
-                pos[job] = hi
-        assert pos == {j: nsl for j, _ in items}
-        flat = [job for sh in shares for job, _, _ in sh]
-        assert flat == sorted(flat)                                         # list order is kept across shares
-        w = dict(items)
-        tot = [sum((hi - lo) * w[job] for job, lo, hi in sh) for sh in shares]
-        if nsl * len(items) > 4 * nshares:
-            assert max(tot[:-1]) - min(tot[:-1]) <= 2.0 * max(w.values()) + 1e-9
-
-
 def test_wavenet_constructor_refuses_options_it_does_not_implement():
     """wavenet.py:151 builds ConvInUpsampleNetwork(**upsample_params) (upsample.py:69-85).  Every option of that signature is
     either implemented or refused: a silently ignored key would give silently different numbers."""

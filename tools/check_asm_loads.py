@@ -29,9 +29,9 @@ def child(libpath, out):
     res = {}
     for name, cfg in CONFIGS.items():
         for nw in (8, 4):
-            os.environ["WAE_GLU_WAVES"] = str(nw)
             sd = O.make_state_dict(dict(cfg), salt=9, with_encoder=False)
             eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+            eng.glu_flags |= L.GLU_WAVES4 if nw == 4 else 0          # wae_glu_desc.flags of every layer launch
             eng.load_state_dict(sd)
             B, T = 3, 2000
             x = ((O.hash_fill((B, T), 41) * 0.5 + 0.5) * 256).long().clamp(0, 255).cuda()

@@ -23,7 +23,7 @@ g = eng.g
 nwg = B * ((T + 127) // 128)
 buf = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
 eng.lib.wae_debug_set_tm_stamps.argtypes = [ctypes.c_void_p]
-for name, flags in (("two workgroups per CU", 0), ("one workgroup per CU", L.TM_ONE_WG), ("8-wave, LDS-staged operand", L.TM_BLDS)):
+for name, flags in (("two workgroups per CU", 0), ("one workgroup per CU", L.TM_ONE_WG)):
     k = lambda: BW._tm(eng, B, T, g.Sp, 3, math.sqrt(1.0 / g.layers), [(ws["u"].data_ptr(), g.Ku, g.Ku, 0)], eng.w_head.data_ptr(),
                        ws["h0"].data_ptr(), g.Sp, eng.b_head.data_ptr(), 0, flags=flags)
     for _ in range(5):

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("WAE_LIB_PATH") or os.path.join(_HERE, "libwae_hip.so"
 
 WAE_F32, WAE_BF16, WAE_F16 = 0, 1, 2
 GLU_SAVE_Z, GLU_NO_OUT, GLU_WAVES4, GLU_CG2, GLU_PAIR, GLU_GENERIC = 2, 4, 8, 16, 32, 64
-TM_INTERLEAVE, TM_ONE_WG, TM_BLDS = 1, 2, 4
+TM_INTERLEAVE, TM_ONE_WG = 1, 2
 ERR_CLASS_ID, ERR_SPEAKER_ID, ERR_TARGET_ID = 1, 2, 4
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p

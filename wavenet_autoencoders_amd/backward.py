@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
+
 from typing import Optional
 
 import numpy as np
@@ -31,32 +31,19 @@ def _prepare_bwd(eng):
         return
     g, dev, lay = eng.g, eng.device, eng.lay
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    # Which weight-gradient launches this engine uses is decided HERE, once: the arenas sized below, the job tables of every (B, T)
-    # workspace and the scatter lists all follow from it (round-4 advisor: re-reading the environment per call let them disagree).
-    #   WAE_TN_STREAM=0       one 128 x 128 tile launch per layer (what fp32 always uses; the yardstick of the 16-bit launches)
-    #   WAE_TN_STATIC=0       the any-shape stream-K launch (csrc/gemm_tn_stream.hip) instead of the static-schedule one
-    #   WAE_TN_STATIC_HEAD=0  head + first-conv weight gradients on the tile launches instead of a group of the static launch
-    eng.opt_tn_stream = eng.dt in (L.WAE_BF16, L.WAE_F16) and os.environ.get("WAE_TN_STREAM", "1") != "0"
-    eng.opt_tn_static = (os.environ.get("WAE_TN_STATIC", "1") != "0" and int(os.environ.get("WAE_TN_PACE", "0")) == 0
-                         and os.environ.get("WAE_TN_SHARES", "teams") == "teams")     # (the opt-in schedules belong to the any-shape kernel)
-    eng.opt_tn_static_head = os.environ.get("WAE_TN_STATIC_HEAD", "1") != "0"
-    # A/B switch: WAE_TM_OCC bit 1 (2) gate-backward, bit 2 (4) residual launches with two workgroups per CU (default: both)
-    occ = int(os.environ.get("WAE_TM_OCC", "6"))
-    eng.tm_flags_u = 0 if occ & 2 else L.TM_ONE_WG
-    eng.tm_flags_x = 0 if occ & 4 else L.TM_ONE_WG
-    # A/B switch: WAE_TM_BLDS bit 0 gate-backward, bit 1 residual launches on the 8-wave shape whose operand is staged through LDS
-    # (default 0: bit-identical and measured not faster)
-    blds = int(os.environ.get("WAE_TM_BLDS", "0"))
-    eng.tm_flags_u |= L.TM_BLDS if blds & 1 else 0
-    eng.tm_flags_x |= L.TM_BLDS if blds & 2 else 0
+    # Which weight-gradient launches this engine uses follows from eng.opt (options.py: read once per engine): the arenas sized below, the
+    # job tables of every (B, T) workspace and the scatter lists all follow from it.
+    eng.opt_tn_stream = eng.dt in (L.WAE_BF16, L.WAE_F16) and eng.opt.tn_stream
+    eng.opt_tn_static = eng.opt.tn_static
+    eng.opt_tn_static_head = eng.opt.tn_static_head
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
     # K_X(l) + K_U(l-1) in one launch (csrc/glu_bwd.hip).  The round-1 kernel measured SLOWER than the two launches (118 us vs 60 + 50);
-    # the 16-bit form of round 5 (two workgroups per CU, the residual launch's own weight stream and chunk order) is opt-in until
-    # measured: WAE_BWD_FUSED=1.  fp32 keeps the round-1 kernel (tap-by-tap weights) behind the same switch.
+    # the 16-bit form of round 5 (two workgroups per CU, the residual launch's own weight stream and chunk order) measures EQUAL
+    # (profiles/EXPERIMENT_LOG.md): opt-in (EngineOptions.bwd_fused).  fp32 keeps the round-1 kernel (tap-by-tap weights) behind the same switch.
     is16 = eng.dt in (L.WAE_BF16, L.WAE_F16)
     sup = eng.lib.wae_glu_bwd_fused_supported16(g.Rp, g.Hp) if is16 else eng.lib.wae_glu_bwd_fused_supported(g.Rp, g.Hp)
-    eng.fused_bwd = bool(sup) and g.Sp % (64 if is16 else 32) == 0 and os.environ.get("WAE_BWD_FUSED", "0") == "1"
+    eng.fused_bwd = bool(sup) and g.Sp % (64 if is16 else 32) == 0 and eng.opt.bwd_fused
     if eng.fused_bwd:
         eng.m_buo = up(P.bwd_uo_map(g, lay, eng.dt))
         eng.n_buo = eng.m_buo.numel()
@@ -113,28 +100,6 @@ def pack_bwd_weights(eng):
             lst.append(J(eng.m_hb_w, eng.w_hb, eng.m_hb_w.numel(), 1, 0, 0))
         jobs = eng._pack_bwd_jobs = (L.GatherJob * len(lst))(*lst)
     L.check(lib.wae_pack_gather_multi(jobs, len(jobs), st), "pack backward weights")
-
-
-def prepare_backward_early(eng):
-    """The backward's own preparation -- its weight packs (39 us of divergent gathers) and the zeroing of the two gradient staging
-    arenas (18 us) -- issued on a SIDE stream right after prepare_weights, so that it runs under the forward's launches instead of
-    in front of the head's backward.  decoder_backward waits for the event.  Opt-in (WAE_SIDE_PACK=1): A/B over three interleaved rounds
-    each measured -15 us per step on one box and nothing (5.874 against 5.891 ms, inside that box's 0.1-ms run-to-run spread) on another."""
-    if os.environ.get("WAE_SIDE_PACK", "0") != "1" or eng.device.type != "cuda":
-        return
-    _prepare_bwd(eng)
-    side = getattr(eng, "_side_stream", None)
-    if side is None:
-        side = eng._side_stream = torch.cuda.Stream(device=eng.device)
-    main = torch.cuda.current_stream(eng.device)
-    side.wait_stream(main)                     # the effective weights (weight norm) are ready on the launch stream's order
-    with torch.cuda.stream(side):
-        pack_bwd_weights(eng)
-        eng.d_eff.zero_()
-        eng.cbuf.zero_()
-        ev = torch.cuda.Event()
-        ev.record(side)
-    eng._bwd_early = ev
 
 
 def _arr(ctype, vals):
@@ -197,32 +162,6 @@ class TileTable:
         L.check(eng.lib.wae_gemm_tn_tiles(eng.dt, L.ptr(self.dev), self.n, B, T, self.splits, eng.stream()), "gemm_tn_tiles")
 
 
-def weighted_shares(items, nsl, nshares):
-    """Cuts the work list [(job, weight per slab)] x nsl slabs, in order, into nshares contiguous shares of (nearly) equal total
-    weight; a share is a list of (job, slab_begin, slab_end).  Every (job, slab) lands in exactly one share."""
-    total = sum(w for _, w in items) * nsl
-    shares, it, pos, cum = [], 0, 0, 0.0
-    for k in range(nshares):
-        target = total * (k + 1) / nshares
-        cur = []
-        while it < len(items):
-            job, w = items[it]
-            if k + 1 == nshares:
-                take = nsl - pos
-            else:
-                if target - cum < 0.5 * w:
-                    break
-                take = min(nsl - pos, max(1, int((target - cum) / w + 0.5)))
-            cur.append((job, pos, pos + take))
-            pos += take
-            cum += take * w
-            if pos == nsl:
-                it, pos = it + 1, 0
-        shares.append(cur)
-    assert it == len(items) and pos == 0
-    return shares
-
-
 class StreamTable:
     """Host builder for wae_gemm_tn_stream (csrc/gemm_tn_stream.hip): the weight-gradient contractions of every layer as
     ONE launch.  A *group* is the list of jobs of one layer (every dilated-conv tap, the conditioning 1x1 with the per-clip
@@ -264,60 +203,33 @@ class StreamTable:
         ncu = torch.cuda.get_device_properties(eng.device).multi_processor_count
         spc = (T + self.KT - 1) // self.KT
         segs, team_seg = [], [0]
-        mode = os.environ.get("WAE_TN_SHARES", "teams")
-        if mode == "weighted":
-            # One workgroup per share of the (layer, job, slab) list, shares of equal estimated TIME: a slab of a narrow job (the
-            # conditioning 1x1: 36 of 96 tiles; conv1x1_out: 56) costs less than a slab of a full 384 x 256 tap job, and a team
-            # that gives every job of a layer its own workgroup over the same slab range leaves the narrow jobs' CUs idle for
-            # the difference (tools/ab_tn_shares.py).  Cost per slab = a fixed part (DMA wait, barrier, issue: the same for
-            # every job) + the share of active 64 x 128 wave blocks.
-            fixed = float(os.environ.get("WAE_TN_SHARE_FIXED", "0.45"))
-            self.team_size = 1
-            self.nteams = self.nwg = ncu
-            items = []                   # (job index, weight per slab)
-            for gi, grp in enumerate(self.groups):
-                for ji, jb in enumerate(grp):
-                    if jb.m_valid <= 0:
-                        continue
-                    n_end = jb.ones_col + B if jb.ones_col >= 0 else jb.n_valid
-                    blocks = ((jb.m_valid + 63) // 64) * ((n_end + 127) // 128)            # of 6 x 2 wave blocks
-                    useful = max(0.02, 1.0 - abs(jb.shift) / T)      # slabs that pair only with rows outside the clip are skipped
-                    items.append((gi * gs + ji, (fixed + (1.0 - fixed) * blocks / 12.0) * useful))
-            for share in weighted_shares(items, B * spc, self.nwg):
-                segs += [L.TsSeg(job, lo, hi) for job, lo, hi in share]
-                team_seg.append(len(segs))
-        else:
-            self.team_size = gs
-            self.nteams = max(1, ncu // gs)
-            self.nwg = ncu if ncu % 8 == 0 and ncu >= self.nteams * gs else self.nteams * gs
-            # Every member of a team sweeps the same slab range; a slab is skipped by a member when all of its rows pair with
-            # rows before the clip (kernel: useful()).  Shares are cut on the raw slab count: the skipped slabs differ by tap.
-            total = len(self.groups) * B * spc
-            for t in range(self.nteams):
-                lo, hi = total * t // self.nteams, total * (t + 1) // self.nteams
-                while lo < hi:
-                    grp = lo // (B * spc)
-                    end = min(hi, (grp + 1) * B * spc)
-                    segs.append(L.TsSeg(grp * gs, lo - grp * B * spc, end - grp * B * spc))
-                    lo = end
-                team_seg.append(len(segs))
+        self.team_size = gs
+        self.nteams = max(1, ncu // gs)
+        self.nwg = ncu if ncu % 8 == 0 and ncu >= self.nteams * gs else self.nteams * gs
+        # Every member of a team sweeps the same slab range; a slab is skipped by a member when all of its rows pair with
+        # rows before the clip (kernel: useful()).  Shares are cut on the raw slab count: the skipped slabs differ by tap.
+        total = len(self.groups) * B * spc
+        for t in range(self.nteams):
+            lo, hi = total * t // self.nteams, total * (t + 1) // self.nteams
+            while lo < hi:
+                grp = lo // (B * spc)
+                end = min(hi, (grp + 1) * B * spc)
+                segs.append(L.TsSeg(grp * gs, lo - grp * B * spc, end - grp * B * spc))
+                lo = end
+            team_seg.append(len(segs))
         jobs = [j for g in self.groups for j in g]
         dev = eng.device
         self.jobs_dev = torch.frombuffer(bytearray(bytes((L.TsJob * len(jobs))(*jobs))), dtype=torch.uint8).to(dev)
         self.segs_dev = torch.frombuffer(bytearray(bytes((L.TsSeg * len(segs))(*segs))), dtype=torch.uint8).to(dev)
         self.team_seg_dev = torch.tensor(team_seg, dtype=torch.int32, device=dev)
-        # team pacing (csrc/gemm_tn_stream.hip): one row of consumed-slab positions per team, zeroed before every launch
+        # (the kernel's team pacing and equal-time shares -- rounds 2-3, measured slower: profiles/EXPERIMENT_LOG.md -- stay reachable
+        #  through wae_gemm_tn_stream's own arguments; the product launches unpaced teams)
         self.pace = torch.zeros(self.nteams * 8, dtype=torch.int32, device=dev)
-        # A/B only: measured SLOWER at C2 (unpaced 1.46-1.70 ms; window 2 / 4 / 8 / 16 / 32 slabs: 1.96 / 1.87 / 1.83 / 1.81 /
-        # 1.82 ms, tools/ab_tn_pace.py) -- the launch is bound by the per-slab issue / barrier pipeline, not by HBM bytes
-        self.window = int(os.environ.get("WAE_TN_PACE", "0"))      # slabs; 0 = no pacing (default)
-        self.pace_from = int(os.environ.get("WAE_TN_PACE_FROM", str(self.lead_jobs)))
+        self.window, self.pace_from = 0, self.lead_jobs
         return self
 
     def launch(self):
         eng = self.eng
-        if self.window > 0:
-            self.pace.zero_()
         L.check(eng.lib.wae_gemm_tn_stream(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
                                            self.team_size, self.nwg, self.B, self.T, L.ptr(self.pace), self.window, self.pace_from, eng.stream()),
                 "gemm_tn_stream")
@@ -415,20 +327,15 @@ class StaticStreamTable:
         self.segs_dev = torch.frombuffer(bytearray(bytes((L.TsSeg * len(segs))(*segs))), dtype=torch.uint8).to(dev)
         self.team_seg_dev = torch.tensor(team_seg, dtype=torch.int32, device=dev)
         self.stamps = None          # diagnostic builds (-DWAE_TQ_STAMPS): an int64 [nwg][16][4] tensor, zeroed before the launch
-        # team pacing (csrc/gemm_tn_static.hip): one 32-bit word of request positions per team (three 10-bit fields, in slabs), zeroed
-        # before every launch; a team's share must stay below 1000 slabs.  WAE_TQ_PACE=<slabs>, 0 = off
+        # (team pacing of the tap members -- round 4: 6.7 -> 4.7 GB of HBM traffic at identical time, profiles/r04_tq_experiments.txt --
+        #  stays reachable through wae_gemm_tn_static's own arguments; the product launches unpaced: window 0)
         self.ntaps = gs - 2
-        self.window = int(os.environ.get("WAE_TQ_PACE", "0"))
-        self.window_cond = int(os.environ.get("WAE_TQ_PACE_COND", str(self.window)))
-        if self.ntaps > 3 or total // self.nteams + 2 >= 1000:
-            self.window = 0
+        self.window = self.window_cond = 0
         self.pace = torch.zeros(self.nteams, dtype=torch.int32, device=dev)
         return self
 
     def launch(self):
         eng = self.eng
-        if self.window > 0:
-            self.pace.zero_()
         L.check(eng.lib.wae_gemm_tn_static(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
                                            self.team_size, self.nwg, self.B, self.T, L.ptr(self.stamps), L.ptr(self.pace), self.window,
                                            self.window_cond, self.ntaps, eng.stream()), "gemm_tn_static")
@@ -677,14 +584,9 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     ws = bwd_workspace(eng, B, T)
     es = eng.w_glu.element_size()
     sm = eng.sm
-    early = getattr(eng, "_bwd_early", None)
-    if early is not None:                      # packs and zeroed arenas were produced on the side stream under the forward
-        torch.cuda.current_stream(eng.device).wait_event(early)
-        eng._bwd_early = None
-    else:
-        pack_bwd_weights(eng)
-        eng.d_eff.zero_()
-        eng.cbuf.zero_()
+    pack_bwd_weights(eng)
+    eng.d_eff.zero_()
+    eng.cbuf.zero_()
     if lengths is None:
         count = B * (T - 1)
     else:
@@ -745,7 +647,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     def k_u(l, gn):                            # du -> dz of layer l
         timed("gate", lambda: _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
                                   eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2,
-                                  flags=eng.tm_flags_u))
+                                  flags=0))
 
     seeds = getattr(eng, "_drop_seeds", None)   # set by the train-mode forward when dropout is active
 
@@ -753,7 +655,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
         if seeds is None:
             timed("res", lambda: _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp,
-                                     gn.data_ptr(), g.Rp, flags=P.TM_INTERLEAVE | eng.tm_flags_x))
+                                     gn.data_ptr(), g.Rp, flags=P.TM_INTERLEAVE))
         else:
             # dropout: the tap contraction alone (mode 0), then out = sqrt(.5) * (g_next + keep * acc / (1 - p)) with the mask
             # the forward applied to this layer's convolution operand
@@ -837,7 +739,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     eng._grads_done = None
     seg_lo, seg_hi = layer_segment(eng)
     split = None
-    if grad_sync is not None and ws["stream"] is not None and g.layers >= 4 and os.environ.get("WAE_DP_SPLIT", "1") != "0":
+    if grad_sync is not None and ws["stream"] is not None and g.layers >= 4 and eng.opt.dp_split:
         split = g.layers // 2
         seg_mid = layer_segment_mid(eng)
         if "stream_hi" not in ws:
@@ -962,12 +864,12 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None):
     eng.d_eff.zero_()
     eng.cbuf.zero_()
     _tm(eng, B, T, g.Hp, 2, 1.0, [(ws["gn"].data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)], eng.w_bu.data_ptr(),
-        ws["dz"].data_ptr(), Z2, fw["z"][0].data_ptr(), Z2, flags=eng.tm_flags_u)
+        ws["dz"].data_ptr(), Z2, fw["z"][0].data_ptr(), Z2)
     ws["tt"].launch(B, T)
     srcs = [(ws["dz"].data_ptr(), Z2, Z2, (g.k - 1 - tap) * g.dilations[0]) for tap in range(g.k)]
     if drop_seed is None:
         _tm(eng, B, T, g.Rp, 1, 1.0, srcs, eng.w_bx.data_ptr(), ws["gx"].data_ptr(), g.Rp, ws["gn"].data_ptr(), g.Rp,
-            flags=P.TM_INTERLEAVE | eng.tm_flags_x)
+            flags=P.TM_INTERLEAVE)
     else:
         # dropout: the tap contraction alone, then dx = gx_hat + keep * acc / (1 - p) with the forward's mask
         if "gtmp" not in ws:

@@ -73,16 +73,11 @@ extern "C" void wae_debug_set_tm_stamps(unsigned long long* dev_buf) { g_tm_stam
 #else
 #define TM_STAMP(v) do { } while (0)
 #endif
-// NW = waves per workgroup (each owns 32 time columns).  BLDS (16-bit, NW = 8, one 256-column workgroup per CU): half the weight bytes per
-// column of the two-workgroup shape, and the activation operand takes the coalesced road -- LDS-DMA pieces of 8 full 128-byte rows into
-// a wave-private XOR-swizzled 4-KiB tile, then four ds_read_b128 per chunk -- instead of fragment-shaped loads straight from L2 (32
-// rows x 32 bytes per request: the L1 fetches whole 128-byte lines for them).  Round 3, tools/stamps_tm.py: the chunk loops of both
-// per-layer launches run at ~3000 clocks per chunk whatever their MFMA count (1536 / 2048): what a CU can pull out of L2 (~27-30 bytes
-// per clock with every CU streaming) divided into the 80-96 KiB per chunk the two resident workgroups request.  All requests of a chunk
-// are issued BETWEEN its MFMAs (a burst at the chunk top queues at the CU's one texture-address unit while the matrix pipe idles).
-template <typename E, int NT, int MODE, int OCC, int NW = 4, bool BLDS = false>
+// NW = waves per workgroup (each owns 32 time columns).  (Round 3 also built an 8-wave, one-workgroup-per-CU shape whose operand went
+// through LDS -- half the weight bytes per column, coalesced operand requests; bit-identical, measured not faster, removed in round 5:
+// profiles/EXPERIMENT_LOG.md.)
+template <typename E, int NT, int MODE, int OCC, int NW = 4>
 __global__ void __launch_bounds__(NW * 64, OCC) gemm_tm_kernel(TmArgs p) {
-  static_assert(!BLDS || (NW == 8 && OCC == 1 && sizeof(E) == 2), "the LDS-staged operand path is the 8-wave 16-bit shape");
   using T_ = ET<E>;
   using frag = typename T_::frag;
   constexpr int CHB = NT * 4 * 1024;
@@ -110,13 +105,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) gemm_tm_kernel(TmArgs p) {
   constexpr bool BIASED = MODE == TM_BIAS_RELU || MODE == TM_CE || MODE == TM_CE_BWD;
   // PAIRED: two workgroups per CU; the gate-backward epilogue then walks the tiles two at a time (fetch of the next
   // pair under the math of this one) so that it fits 256 registers, and stages through 4 KiB per wave
-  constexpr bool PAIRED = (OCC == 2 || BLDS) && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD || MODE == TM_BIAS_RELU) && NT % 2 == 0 && sizeof(E) == 2;
-  static_assert(!BLDS || PAIRED, "the 8-wave shape has 256 registers per wave: only the pairwise epilogues fit");
+  constexpr bool PAIRED = OCC == 2 && (MODE == TM_GATE_BWD || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD || MODE == TM_BIAS_RELU) && NT % 2 == 0 && sizeof(E) == 2;
   constexpr int STGB = PAIRED ? 4096 : STG_BYTES;
-  constexpr int NSW = BLDS ? 3 : 2;   // weight-ring slots
-  // PAIRED stages through the (then idle) weight ring after the chunk loop: 2 x (2 CHB) <= 128 KiB of LDS per CU;
-  // BLDS: through the wave's own (then idle) operand tiles behind the ring
-  char* stg = BLDS ? smem + NSW * CHB + wave * 8192 : (PAIRED ? smem + wave * STGB : smem + 2 * CHB + wave * STGB);
+  // PAIRED stages through the (then idle) weight ring after the chunk loop: 2 x (2 CHB) <= 128 KiB of LDS per CU
+  char* stg = PAIRED ? smem + wave * STGB : smem + 2 * CHB + wave * STGB;
 
   // chunk -> (source, column block)
   int qend[TM_MAX_SRC];
@@ -189,115 +181,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) gemm_tm_kernel(TmArgs p) {
     }
   }
 
-  if constexpr (BLDS) {
-    // Operand tile of chunk q: 32 rows (this wave's time columns, shifted by the source's tap) x 128 bytes in slot q & 1 of the wave's
-    // own 8 KiB behind the ring.  Piece pc = rows 8 pc .. 8 pc + 7: lane l fetches 16 bytes of row 8 pc + (l >> 3) -- eight lanes cover
-    // one full 128-byte line -- and LDS-DMA lands them at (lane * 16), i.e. row-major with a 128-byte pitch.  Read back as MFMA fragments
-    // (lane (n, h), k-step blk: segment 2 blk + h of row n) that would be a 16-way bank conflict, so segment g of row r is STORED at
-    // position g ^ (r & 7): the swizzle goes on the per-lane SOURCE address (the LDS side of a DMA is always lane-linear).  Rows outside
-    // the clip are fetched from a clamped row and zeroed at use, like the register path.
-    // Weights: three-slot ring, two chunks ahead.  VMEM order of a wave:  W(0) B(0) W(1) B(1) | step q: W(q+2) B(q+2) | ...  -- at the top
-    // of step q `vmcnt(PPW + 4)` leaves exactly step q-1's requests in flight: W(q) and B(q) have landed (past the end the last chunk is
-    // requested again, into a slot nobody reads: the count never changes).  W(q+2) refills the slot of chunk q-1, which every wave left
-    // before the barrier of step q; B(q+2) reuses the tile B(q) was just read from, after `lgkmcnt(0)` retired those reads (issued in
-    // FRONT of the barrier -- the tile is wave-private -- so their latency passes while the waves meet).
-    constexpr int PPW = CHB / NW / 1024, NOPS = PPW + 4, NSTEP = 4 * NT, SP = NSTEP / NOPS;
-    static_assert(PPW * NW * 1024 == CHB && SP >= 1 && NOPS * SP <= NSTEP, "whole pieces per wave; enough MFMA steps to carry a chunk's requests");
-    char* bst = smem + NSW * CHB + wave * 8192;
-    const unsigned bst_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)bst;
-    const int lr = lane >> 3;
-    const int sw16 = ((lane & 7) ^ lr) * 16;
-    auto chunk_src = [&](int q, int& s_, int& q0) {
-      s_ = 0; q0 = 0;
-      if (p.interleave) {
-        s_ = q % p.nsrc;
-        q0 = q - q / p.nsrc;
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM_MAX_SRC - 1; ++i)
-          if (q >= qend[i] && i + 1 < p.nsrc) { s_ = i + 1; q0 = qend[i]; }
-      }
-    };
-    const char* bsrc[4];   // the four pieces of the operand chunk to request (per-lane addresses)
-    auto b_addr4 = [&](int q) {
-      int s_, q0;
-      chunk_src(q, s_, q0);
-      const int64_t rstride = p.src_stride[s_] * ES;
-      const char* sbase = p.src[s_] + (int64_t)b * p.T * rstride + (q - q0) * 128 + sw16;
-      const int r0 = t0w + lr + p.src_shift[s_];
-#pragma unroll
-      for (int pc = 0; pc < 4; ++pc) bsrc[pc] = sbase + min(max(r0 + 8 * pc, 0), p.T - 1) * rstride;
-    };
-    const int per_wave = CHB / NW;
-    const char* w_lane = wbase + wave * per_wave + lane * 16;
-    auto issue_all = [&](int qw, int wslot, int bslot) {   // prologue: a whole chunk's requests at once
-      if (!TM_ABL(2))
-        for (int k = 0; k < PPW; ++k) dma_piece(w_lane + (int64_t)qw * CHB + k * 1024, smem + wslot * CHB + wave * per_wave + k * 1024);
-      b_addr4(qw);
-      if (!TM_ABL(1))
-        for (int pc = 0; pc < 4; ++pc) dma_piece(bsrc[pc], bst + bslot * 4096 + pc * 1024);
-    };
-    issue_all(0, 0, 0);
-    issue_all(min(1, nq - 1), 1, 1);
-    const unsigned rd_base = bst_lds + n * 128;
-    const int nk = n & 7;
-    int slot_c = 0, slot_n = 2;   // ring slot of chunk q / of chunk q + 2
-#ifdef WAE_TM_STAMPS
-    k_loop0 = TM_TICK();
-#endif
-    for (int q = 0; q < nq; ++q) {
-      TM_STAMP(s0);
-      if (TM_ABL(1) || TM_ABL(2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 4) : "memory");
-      frag Gc[4];
-      const unsigned ra = rd_base + (q & 1) * 4096;
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const unsigned a_ = ra + (((2 * blk + h) ^ nk) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(Gc[blk]) : "v"(a_));
-      }
-      TM_STAMP(s1);
-      __builtin_amdgcn_s_barrier();     // chunk q visible; every wave is past its reads of chunk q-1, whose slot is refilled now
-      TM_STAMP(s2);
-#ifdef WAE_TM_STAMPS
-      k_wait += s1 - s0; k_bar += s2 - s1; ++k_n;
-#endif
-      const int qd = min(q + 2, nq - 1);
-      const char* wsrc = w_lane + (int64_t)qd * CHB;
-      char* wdst = smem + slot_n * CHB + wave * per_wave;
-      char* bdst = bst + (q & 1) * 4096;
-      b_addr4(qd);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Gc[0]), "+v"(Gc[1]), "+v"(Gc[2]), "+v"(Gc[3]));
-      {
-        int s_, q0;
-        chunk_src(q, s_, q0);
-        const int ts = t + p.src_shift[s_];
-        const bool ok = tvalid && ts >= 0 && ts < p.T && !TM_ABL(1);
-        const frag z = {};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Gc[i] = ok ? Gc[i] : z;
-      }
-      // this chunk's requests, spread over its MFMAs: weight pieces first, then the operand pieces
-      auto filler = [&](auto ic) {
-        constexpr int I = decltype(ic)::value;
-        if constexpr (I % SP == 0 && I / SP < NOPS) {
-          constexpr int k = I / SP;
-          if constexpr (k < PPW) {
-            if (!TM_ABL(2)) dma_piece(wsrc + k * 1024, wdst + k * 1024);
-          } else {
-            if (!TM_ABL(1)) dma_piece(bsrc[k - PPW], bdst + (k - PPW) * 1024);
-          }
-        }
-      };
-      const char* buf = smem + slot_c * CHB + lane * 16;
-      if (!TM_ABL(4)) gemm_chunk_fill<4 * NT, NT, 4, false, 8>(buf, Gc, acc, filler);
-      else asm volatile("" : "+v"(Gc[0]), "+v"(Gc[1]), "+v"(Gc[2]), "+v"(Gc[3]));
-      slot_c = slot_c == 2 ? 0 : slot_c + 1;
-      slot_n = slot_n == 2 ? 0 : slot_n + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail requests must not outlive the ring
-    __syncthreads();
-  } else if constexpr (sizeof(E) == 2 && TM_ASM_B) {
+  if constexpr (sizeof(E) == 2 && TM_ASM_B) {
     // bf16: operand fragments of chunk q live in group q % 3, requested TWO chunks ahead by inline-asm loads (clamped address,
     // zero fill at use) and retired by a counted wait that leaves the youngest request in flight.  With plain loads hipcc
     // guards the first use of a loop-carried fragment with s_waitcnt vmcnt(0), i.e. every chunk waited for everything it had
@@ -569,24 +453,8 @@ static int launch_tm_occ(const TmArgs& a, int nslices, hipStream_t st) {
   hipLaunchKernelGGL((gemm_tm_kernel<E, NT, MODE, OCC>), dim3(a.B * tiles, nslices), dim3(256), lds, st, a);
   return wae_check_launch("gemm_tm");
 }
-// the 8-wave shape with the LDS-staged operand: weight ring (3 chunks) + 8 KiB of operand tiles per wave, one workgroup per CU
-template <typename E, int NT, int MODE>
-static int launch_tm_blds(const TmArgs& a, int nslices, hipStream_t st) {
-  constexpr int CHB = NT * 4 * 1024;
-  const size_t lds = 3 * CHB + 8 * 8192;
-  static_assert(3 * CHB + 8 * 8192 <= 160 * 1024, "LDS budget");
-  static WaeLdsCache lds_cache;
-  if (int rc = wae_ensure_lds((const void*)gemm_tm_kernel<E, NT, MODE, 1, 8, true>, lds_cache, lds, "gemm_tm"); rc != WAE_OK) return rc;
-  const int tiles = (a.T + 255) / 256;
-  hipLaunchKernelGGL((gemm_tm_kernel<E, NT, MODE, 1, 8, true>), dim3(a.B * tiles, nslices), dim3(512), lds, st, a);
-  return wae_check_launch("gemm_tm");
-}
 template <typename E, int NT, int MODE>
 static int launch_tm(const TmArgs& a, int nslices, hipStream_t st) {
-  // opt-in (WAE_TM_BLDS): bit-identical, measured NOT faster than the two-workgroup register-operand shape
-  if constexpr (sizeof(E) == 2 && NT % 2 == 0 && NT >= 4 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_BIAS_RELU)) {
-    if ((a.flags & WAE_TM_BLDS) && !(a.flags & WAE_TM_ONE_WG)) return launch_tm_blds<E, NT, MODE>(a, nslices, st);
-  }
   if constexpr (sizeof(E) == 2 && NT % 2 == 0 && ((MODE == TM_GATE_BWD && NT <= 6) || MODE == TM_RESIDUAL || MODE == TM_RELU_BWD || MODE == TM_BIAS_RELU)) {
     if (!(a.flags & WAE_TM_ONE_WG)) return launch_tm_occ<E, NT, MODE, 2>(a, nslices, st);
   }

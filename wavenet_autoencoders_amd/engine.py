@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
+
 from typing import Dict, Optional
 
 import numpy as np
@@ -42,15 +42,12 @@ class WaeEngine:
         if not torch.cuda.is_available():
             raise L.WaeError("WaeEngine needs a ROCm GPU: the hot path has no CPU implementation")
         self.lib = L.lib()
-        # A/B switch of the fused layer kernel's workgroup shape (4 or 8 waves): a descriptor flag of every launch
-        self.glu_flags = L.GLU_WAVES4 if os.environ.get("WAE_GLU_WAVES") == "4" else 0
-        # WAE_GLU_PAIR (barrier on every second weight chunk of the fused layer kernel; bit-identical): measured -2.3 % per launch
-        # without the z save, nothing with it -- so inference launches take it by default; =0: never, =1: always
-        self.glu_pair = os.environ.get("WAE_GLU_PAIR", "inference")
-        if self.glu_pair == "1":
-            self.glu_flags |= L.GLU_PAIR
-        if os.environ.get("WAE_GLU_CG", "1") == "2":
-            self.glu_flags |= L.GLU_CG2
+        from .options import EngineOptions
+        self.opt = EngineOptions.from_env()       # every launch-path switch, read once (options.py)
+        # GLU_PAIR (barrier on every second weight chunk of the fused layer kernel; bit-identical): measured -2.3 % per launch without
+        # the z save, nothing with it -- so inference launches take it by default
+        self.glu_flags = L.GLU_PAIR if self.opt.glu_pair == "1" else 0
+        self.glu_pair = self.opt.glu_pair
         self.g = geom
         self.dt = _dt(dtype)
         self.tdtype = {L.WAE_BF16: torch.bfloat16, L.WAE_F16: torch.float16, L.WAE_F32: torch.float32}[self.dt]
@@ -74,10 +71,9 @@ class WaeEngine:
         tab, fb = P.first_conv_maps(g, self.lay)
         self.m_tab, self.m_fb = up(tab), up(fb)
         # head: register-chained kernels up to 256 skip channels; wider heads as separate GEMM launches (csrc/gemm_tm.hip)
-        self.wide_head = P.head_is_wide(g)
+        self.wide_head = P.head_is_wide(g) or self.opt.head_wide
         # 16-bit dtypes: GEMM 0 of the head as its own wae_gemm_tm launch (decoder_forward); WAE_HEAD_SPLIT=0 keeps the one-kernel head
-        self.split_head = (not self.wide_head and self.dt in (L.WAE_BF16, L.WAE_F16) and g.Sp in (128, 256)
-                           and os.environ.get("WAE_HEAD_SPLIT", "1") != "0")
+        self.split_head = not self.wide_head and self.dt in (L.WAE_BF16, L.WAE_F16) and g.Sp in (128, 256) and self.opt.head_split
         if self.wide_head:
             hm = P.head_wide_maps(g, self.lay, self.dt)
             self.m_hwide = {k: up(v) for k, v in hm.items()}
@@ -391,7 +387,7 @@ class WaeEngine:
             from . import backward as BW
             es = self.w_head.element_size()
             BW._tm(self, B, T, g.Sp, 3, math.sqrt(1.0 / g.layers), [(ws["u"].data_ptr(), g.Ku, g.Ku, 0)], self.w_head.data_ptr(),
-                   ws["h0"].data_ptr(), g.Sp, self.b_head.data_ptr(), 0, flags=int(os.environ.get("WAE_HEAD_TM_FLAGS", "0")))
+                   ws["h0"].data_ptr(), g.Sp, self.b_head.data_ptr(), 0)
             ck = 64 if es == 2 else 32
             tail = self.w_head.data_ptr() + (g.Ku // ck) * (g.Sp // 32) * 4096
             L.check(lib.wae_head_fwd_from_h0(ctypes.byref(hd), L.ptr(ws["h0"]), ctypes.c_void_p(tail), L.ptr(self.b_head), L.ptr(logits),
@@ -475,7 +471,7 @@ class WaeEngine:
         longer window (its requests miss L2: 11.7 MB of weights cycle through a 4-MB L2 every sample) measures 19 kHz against 22.7."""
         g = self.g
         if not (g.R == 256 and g.S == 256 and g.O == 256 and g.G == 256 and g.k == 3 and g.layers >= 2 and not g.scalar_input
-                and os.environ.get("WAE_AR_FUSED", "0") == "1"):
+                and self.opt.ar_fused):
             return None
         epl = 4 if self.dt == L.WAE_F32 else 8
         K1 = 3 * g.R + max(g.Cc, 0)
@@ -552,8 +548,8 @@ class WaeEngine:
         # one utterance per XCD, its gate rows split over up to 32 CUs (csrc/ar_coop.hip); bigger batches run one
         # utterance per CU (csrc/ar_fwd.hip): better aggregate throughput, 3-4x lower speed per utterance
         coop = (B <= 8 and g.R <= 256 and g.S <= 256 and g.O <= 256 and not g.scalar_input and m <= 2
-                and os.environ.get("WAE_AR_COOP", "1") != "0")
-        C = max(1, min(int(os.environ.get("WAE_AR_COOP_C", "32")), 32, g.H, g.S)) if coop else 1
+                and self.opt.ar_coop)
+        C = max(1, min(self.opt.ar_coop_c, 32, g.H, g.S)) if coop else 1
         ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
         if g.scalar_input:
             es = self.ar_w.element_size()
@@ -694,7 +690,6 @@ class WaeEngine:
         if gid is not None and gid.dtype != torch.int32:
             gid = gid.to(self.device, torch.int32).contiguous()
         from . import backward as BW
-        BW.prepare_backward_early(self)
         if self.g.scalar_input:
             fwd = self.forward if self.g.has_encoder else self.decoder_forward
             out = fwd(x, c, gid, targets=None, lengths=None, want_logits=True, train=True)

@@ -1,0 +1,50 @@
+"""The engine's launch-path switches: ONE place, read ONCE per engine (WaeEngine.__init__ -> eng.opt).
+
+Every entry selects between two implementations that are both kept correct and both tested -- the alternative is the yardstick of
+the default (or, for the last group, an opt-in that has not earned the default).  Nothing else in the host code reads the
+environment: the experiment switches of rounds 1-4 (request schedules, pacing, launch shapes that measured equal or slower;
+profiles/EXPERIMENT_LOG.md) are gone from the product; what remains of them in the kernels is reachable through the C ABI's own
+arguments (include/wae.h) from tools/.
+
+    variable               default   alternative
+    WAE_TN_STREAM          1         0: weight gradients as one 128 x 128 tile launch per layer (what fp32 always runs)
+    WAE_TN_STATIC          1         0: the any-shape stream-K launch (csrc/gemm_tn_stream.hip) instead of the static-schedule one
+    WAE_TN_STATIC_HEAD     1         0: head + first-conv weight gradients on the tile launches, not as a group of the static launch
+    WAE_HEAD_SPLIT         1         0: the one-kernel head (16-bit engines run GEMM 0 as its own wae_gemm_tm launch by default)
+    WAE_HEAD_WIDE          0         1: the separate-launch head of skip widths > 256, forced onto narrow models (tests)
+    WAE_GLU_PAIR           inference 0 / 1: workgroup barrier on every second weight chunk of the layer kernel never / always
+    WAE_DP_SPLIT           1         0: data parallel: the gradient arena handed to the all-reduce once, at the end of the sweep
+    WAE_AR_COOP            1         0: autoregressive decoding on the one-CU kernel even for <= 8 utterances
+    WAE_AR_COOP_C          32        cooperating workgroups per utterance (1..32)
+    WAE_BWD_FUSED          0         1: K_X(l) + K_U(l-1) of the backward sweep as one launch (csrc/glu_bwd.hip; measured equal)
+    WAE_AR_FUSED           0         1: one hand-over per layer in the cooperative decode kernel (measured slower)
+"""
+import os
+from dataclasses import dataclass
+
+
+@dataclass
+class EngineOptions:
+    tn_stream: bool = True
+    tn_static: bool = True
+    tn_static_head: bool = True
+    head_split: bool = True
+    head_wide: bool = False
+    glu_pair: str = "inference"
+    dp_split: bool = True
+    ar_coop: bool = True
+    ar_coop_c: int = 32
+    bwd_fused: bool = False
+    ar_fused: bool = False
+
+    @staticmethod
+    def from_env() -> "EngineOptions":
+        e = os.environ.get
+        pair = e("WAE_GLU_PAIR", "inference")
+        if pair not in ("inference", "0", "1"):
+            raise ValueError(f"WAE_GLU_PAIR={pair!r}: 'inference', '0' or '1'")
+        return EngineOptions(tn_stream=e("WAE_TN_STREAM", "1") != "0", tn_static=e("WAE_TN_STATIC", "1") != "0",
+                             tn_static_head=e("WAE_TN_STATIC_HEAD", "1") != "0", head_split=e("WAE_HEAD_SPLIT", "1") != "0",
+                             head_wide=e("WAE_HEAD_WIDE", "0") == "1", glu_pair=pair, dp_split=e("WAE_DP_SPLIT", "1") != "0",
+                             ar_coop=e("WAE_AR_COOP", "1") != "0", ar_coop_c=int(e("WAE_AR_COOP_C", "32")),
+                             bwd_fused=e("WAE_BWD_FUSED", "0") == "1", ar_fused=e("WAE_AR_FUSED", "0") == "1")

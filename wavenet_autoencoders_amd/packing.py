@@ -528,10 +528,9 @@ def head_wide_maps(g: Geometry, lay: ParamLayout, dtype: int) -> Dict[str, np.nd
 
 
 def head_is_wide(g: Geometry) -> bool:
-    """The register-chained head kernels hold Sp/32 <= 8 accumulator tiles per wave; wider heads (or WAE_HEAD_WIDE=1, for
+    """The register-chained head kernels hold Sp/32 <= 8 accumulator tiles per wave; wider heads (or EngineOptions.head_wide, for
     tests) run as separate wae_gemm_tm launches."""
-    import os
-    return g.Sp > 256 or os.environ.get("WAE_HEAD_WIDE", "0") == "1"
+    return g.Sp > 256
 
 
 ONES_PAD = 128   # spare C columns that receive the per-clip "ones column" sums (B <= 128)
