@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 tag, old = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else None)
 FILES = ("bench_train.json", "bench_forward.json", "bench_fp16.json", "kernel_stats.csv", "forward_kernel_stats.csv", "profiled_line.json",
          "profiled_forward_line.json", "pmc_FETCH_SIZE_per_kernel_mean_kb.csv", "pmc_WRITE_SIZE_per_kernel_mean_kb.csv", "pmc_traffic.json",
-         "glu_layer_durations.csv", "c3_probe.json", "c5_probe.json", "pytest_gpu.log")
+         "glu_layer_durations.csv", "bench_c3.json", "bench_c5.json", "pytest_gpu.log")
 NAMES = {"glu_fwd_static_kernel<": "glu_fwd_static_kernel (inference launch of the fused layer)",
          "glu_fwd_static_z_kernel<": "glu_fwd_static_z_kernel (training launch, z saved)",
          "gemm_tm_kernelIDF16bLi8ELi1E": "gemm_tm_kernel<bf16, NT=8, MODE=1> (residual backward, per layer)",
@@ -59,6 +59,7 @@ print("train %.3f ms %.2f M/s | forward %.3f ms, layer %.1f us frac %.3f, whole 
     d["roofline_residual_bwd"]["avg_launch_ms"] * 1e3, d["autoregressive"]["value"], d["cpu_baseline"]["value"]))
 for fn in ("bench_forward.json", "bench_fp16.json"):
     print(fn, json.loads(open(f"gpurun_out/{tag}/{fn}").read().strip().splitlines()[-1])["ms_per_step"])
-for fn in ("c3_probe.json", "c5_probe.json"):
-    r = json.loads(open(f"gpurun_out/{tag}/{fn}").read().strip().splitlines()[-1])["bf16"]; print(fn, r["forward_ms"], r["train_ms"])
+for fn in ("bench_c3.json", "bench_c5.json"):
+    r = json.loads(open(f"gpurun_out/{tag}/{fn}").read().strip().splitlines()[-1])
+    print(fn, r["dtype"], "train", r["ms_per_step"], "forward", r["forward_inference"]["ms_per_step"], "step roofline", r["roofline_step"]["hbm_frac"], r["roofline_step"]["mfma_frac"])
 print("\n".join(l for l in out if "derived:" in l))

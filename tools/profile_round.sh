@@ -6,6 +6,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 python3 bench.py > $OUT/bench_train.json 2> $OUT/bench_train.err
 python3 bench.py --mode forward --no-cpu --no-ar > $OUT/bench_forward.json 2> $OUT/bench_forward.err
+python3 bench.py --dtype fp16 --no-cpu --no-ar --no-fp32 > $OUT/bench_fp16.json 2> $OUT/bench_fp16.err
+# BASELINE configs 3 and 5 (the two 8-GPU configurations), the per-GPU shard of each: the full line (roofline family, roofline_step, cpu_baseline)
+python3 bench.py --config c3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
+python3 bench.py --config c5 --steps 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-ar > $OUT/profiled_line.json 2> $OUT/stats.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fwd -- python3 $ROOT/bench.py --mode forward --steps 10 --warmup 3 --no-cpu --no-ar > $OUT/profiled_forward_line.json 2> $OUT/stats_fwd.err
