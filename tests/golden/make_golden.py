@@ -668,6 +668,50 @@ def gen_cin_pad():
          perp=perp, c_up=c_up, y_hat=y_hat, feats=feats.detach(), y_dec_probe=y_dec.detach()[:, :, ::7], dfeats=feats.grad, w_salt=44)
 
 
+CFG_U = dict(name="U", layers=4, stacks=2, R=32, G=48, S=32, O=64, Cc=16, Cg=8, k=3, n_speakers=5,
+             upsample_scales=[4, 4, 8, 5], cin_pad=1, conv_in=False)
+
+
+def gen_plain_upsample():
+    """upsample_net = "UpsampleNetwork" (upsample.py:29-66: the stages without conv_in, the output trimmed by cin_pad * prod(scales)
+    samples at either end; state_dict keys `upsample_net.up_layers.N`): the reference's WaveNet on (B, Cc, Tc) features with
+    cin_pad = 1 and cin_pad = 0 -- c_up, logits, and the gradient of a weighted logit sum with respect to the features."""
+    out = {}
+    for pad in (1, 0):
+        cfg = dict(CFG_U, cin_pad=pad)
+        sd = O.make_state_dict(cfg, 6, with_encoder=False)
+        assert "wavenet.upsample_net.conv_in.weight" not in sd and "wavenet.upsample_net.up_layers.1.weight_v" in sd
+        wn = RefWaveNet(out_channels=cfg["O"], layers=cfg["layers"], stacks=cfg["stacks"], residual_channels=cfg["R"],
+                        gate_channels=cfg["G"], skip_out_channels=cfg["S"], kernel_size=cfg["k"], dropout=0.0,
+                        cin_channels=cfg["Cc"], gin_channels=cfg["Cg"], n_speakers=cfg["n_speakers"],
+                        upsample_conditional_features=True, upsample_net="UpsampleNetwork",
+                        upsample_params=dict(upsample_scales=cfg["upsample_scales"], cin_channels=cfg["Cc"], cin_pad=pad),
+                        scalar_input=False, use_speaker_embedding=True, output_distribution="Logistic", cin_pad=pad)
+        missing = wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        wn.eval()
+        B, Tc = 2, 4
+        hop = int(np.prod(cfg["upsample_scales"]))
+        T = (Tc - 2 * pad) * hop
+        feats = O.hash_fill((B, cfg["Cc"], Tc), 61 + pad, 1.1).requires_grad_(True)
+        x = ((O.hash_fill((B, T), 63 + pad) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+        xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+        g = torch.tensor([1, 3])
+        with torch.no_grad():
+            c_up = wn.upsample_net(feats)
+        assert c_up.shape[-1] == T, (c_up.shape, T)
+        y = wn(xin, feats, g, False)
+        wsum = O.hash_fill(tuple(y.shape), 65 + pad, 1.0)
+        (y * wsum).sum().backward()
+        ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=pad, conv_in=False)
+        close(O.upsample_forward(sd, feats.detach(), cfg["upsample_scales"], cin_pad=pad, conv_in=False), c_up, what="plain upsample c_up")
+        e = close(O.wavenet_forward(sd, ocfg, xin, feats.detach(), g), y.detach(), what="plain upsample logits")
+        print(f"  UpsampleNetwork cin_pad={pad}: T={T} from {Tc} frames, logits max|oracle-ref| = {e:.2e}")
+        out.update({f"feats{pad}": feats.detach(), f"x{pad}": x.numpy(), f"c_up_probe{pad}": c_up[:, :, ::3], f"y_probe{pad}": y.detach()[:, :, ::5],
+                    f"dfeats{pad}": feats.grad, f"w_salt{pad}": 65 + pad})
+    save("model_U", cfg=json.dumps(CFG_U), salt=6, g=torch.tensor([1, 3]), **out)
+
+
 def _ref_sampler_class():
     """The reference's PartialyRandomizedSimilarTimeLengthSampler, cut out of vqwae_train.py by its syntax tree (the file itself
     cannot be imported: docopt / nnmnkwii / librosa / tensorboardX are absent) and executed as is."""
@@ -928,6 +972,8 @@ def main():
         return gen_c2()
     if sys.argv[1:] == ["cin_pad"]:
         return gen_cin_pad()
+    if sys.argv[1:] == ["plain_upsample"]:
+        return gen_plain_upsample()
     if sys.argv[1:] == ["sampler"]:
         return gen_sampler()
     gen_quantizers()
@@ -951,6 +997,7 @@ def main():
     gen_c5_probe()
     gen_c2()
     gen_cin_pad()
+    gen_plain_upsample()
     gen_sampler()
 
 

@@ -193,8 +193,13 @@ def test_wavenet_constructor_refuses_options_it_does_not_implement():
             WaveNet(**base, upsample_params=dict(up, **bad))
     with pytest.raises(TypeError):
         WaveNet(**base, upsample_params=dict(cin_channels=16))
-    with pytest.raises(NotImplementedError):
-        WaveNet(**base, upsample_params=up, upsample_net="UpsampleNetwork")
+    # the plain UpsampleNetwork (round 5): no conv_in, the stages under `upsample_net.up_layers.N`; any other name is what the reference's
+    # getattr(upsample, upsample_net) raises for (wavenet.py:150)
+    wu = WaveNet(**base, upsample_params=dict(up, cin_pad=1), upsample_net="UpsampleNetwork")
+    assert not wu.geom.conv_in and wu.geom.cin_pad == 1 and "upsample_net.conv_in.weight" not in wu.state_dict()
+    assert tuple(wu.state_dict()["upsample_net.up_layers.3.weight_v"].shape) == (1, 1, 1, 9)
+    with pytest.raises(AttributeError):
+        WaveNet(**base, upsample_params=up, upsample_net="FancyUpsampleNetwork")
     with pytest.raises(NotImplementedError):
         WaveNet(**base, upsample_params=up, kernel_size=5)     # 1..4 taps are implemented (tests/test_gpu_parity.py), wider ones refused
     from wavenet_autoencoders_amd.wavenet_vocoder.wavenet import receptive_field_size

@@ -360,3 +360,27 @@ def test_cin_pad_model():
     assert rel_err(yd[:, :, ::7].detach(), z["y_dec_probe"]) < TOL
     (yd * O.hash_fill(tuple(yd.shape), int(z["w_salt"]), 1.0)).sum().backward()
     assert rel_err(feats.grad, z["dfeats"]) < 1e-4
+
+
+def test_plain_upsample_network_model():
+    """upsample_net = "UpsampleNetwork" (upsample.py:29-66): no conv_in, keys `upsample_net.up_layers.N`, the output trimmed by
+    cin_pad * prod(scales) samples at either end -- c_up, logits and the feature gradient of the REFERENCE's WaveNet (model_U.npz) for
+    cin_pad = 1 and 0."""
+    z = load_npz("model_U")
+    cfg0 = json.loads(str(z["cfg"]))
+    g = torch.from_numpy(z["g"])
+    for pad in (1, 0):
+        cfg = dict(cfg0, cin_pad=pad)
+        sd = O.make_state_dict(cfg, int(z["salt"]), with_encoder=False)
+        assert "wavenet.upsample_net.conv_in.weight" not in sd
+        x = torch.from_numpy(z[f"x{pad}"]).long()
+        xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+        feats = torch.from_numpy(z[f"feats{pad}"]).clone().requires_grad_(True)
+        ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=pad, conv_in=False)
+        c_up = O.upsample_forward(sd, feats.detach(), cfg["upsample_scales"], cin_pad=pad, conv_in=False)
+        assert c_up.shape[-1] == x.shape[1]
+        assert rel_err(c_up[:, :, ::3], z[f"c_up_probe{pad}"]) < TOL
+        y = O.wavenet_forward(sd, ocfg, xin, feats, g)
+        assert rel_err(y[:, :, ::5].detach(), z[f"y_probe{pad}"]) < TOL
+        (y * O.hash_fill(tuple(y.shape), int(z[f"w_salt{pad}"]), 1.0)).sum().backward()
+        assert rel_err(feats.grad, z[f"dfeats{pad}"]) < 1e-4

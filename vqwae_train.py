@@ -47,11 +47,13 @@ def build_geometry(hp) -> Geometry:
     from wavenet_autoencoders_amd.wavenet_vocoder.util import is_mulaw_quantize, is_scalar_input
     if is_mulaw_quantize(hp.input_type) and hp.out_channels != hp.quantize_channels:
         raise RuntimeError("out_channels must equal to quantize_chennels if input_type is 'mulaw-quantize'")
+    if hp.upsample_conditional_features and hp.upsample_net not in ("ConvInUpsampleNetwork", "UpsampleNetwork"):
+        raise AttributeError(f"module 'wavenet_vocoder.upsample' has no attribute {hp.upsample_net!r}")       # wavenet.py:150
     return Geometry(layers=hp.layers, stacks=hp.stacks, R=hp.residual_channels, G=hp.gate_channels, S=hp.skip_out_channels,
                     O=hp.out_channels, Cc=hp.cin_channels, Cg=hp.gin_channels, k=hp.kernel_size, n_speakers=hp.n_speakers,
                     upsample_scales=list(hp.upsample_params["upsample_scales"]) if hp.upsample_conditional_features else None,
                     cin_pad=hp.cin_pad, scalar_input=is_scalar_input(hp.input_type), use_speaker_embedding=True,
-                    c_in=hp.dim_in, encoder_hid=hp.encoder_hid, K=256)
+                    c_in=hp.dim_in, encoder_hid=hp.encoder_hid, K=256, conv_in=hp.upsample_net != "UpsampleNetwork")
 
 
 def evaluate(eng, loader, device, hp):

@@ -942,23 +942,30 @@ def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0, stop_at_qu
     dev = eng.device
     d = torch.empty(B, g.Cc, T, dtype=torch.float32, device=dev)
     L.check(lib.wae_from_btc_scaled(L.ptr(dc), L.ptr(d), B, g.Cc, T, g.Ccp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc")
-    acts = eng._up_acts                      # [conv_in input, stage-0 input, stage-1 input, ...]
+    acts = eng._up_acts                      # [conv_in input | None, stage-0 input, stage-1 input, ...]
     keep = [d]
+    if not g.conv_in and g.cin_pad > 0:      # plain UpsampleNetwork: the forward trimmed `indent` samples at either end (upsample.py:64-65)
+        trim = g.cin_pad * int(np.prod(g.upsample_scales))
+        d = torch.nn.functional.pad(d, (trim, trim))
+        keep.append(d)
     for i in range(len(g.upsample_scales) - 1, -1, -1):
         s = g.upsample_scales[i]
         xin = acts[1 + i]
-        name = f"wavenet.upsample_net.upsample.up_layers.{2 * i + 1}.weight_v"
+        name = P.up_stage_name(g, i) + ".weight_v"
         din = torch.empty_like(xin)
         L.check(lib.wae_upsample_stage_bwd(L.ptr(d), L.ptr(xin), L.ptr(eng.eff[lay.off(name):]), L.ptr(din),
                                            L.ptr(eng.d_eff[lay.off(name):]), B, g.Cc, xin.shape[-1], s, st), "upsample_stage_bwd")
         d = din
         keep.append(d)
-    cin = acts[0]
-    kin = 2 * g.cin_pad + 1
-    name = "wavenet.upsample_net.conv_in.weight"
-    dq = torch.empty_like(cin)
-    L.check(lib.wae_enc_conv_bwd(L.ptr(cin), L.ptr(eng.eff[lay.off(name):]), None, L.ptr(d), L.ptr(dq),
-                                 L.ptr(eng.d_eff[lay.off(name):]), None, B, g.Cc, cin.shape[-1], g.Cc, kin, 1, 0, 0, 0, st), "conv_in bwd")
+    if g.conv_in:
+        cin = acts[0]
+        kin = 2 * g.cin_pad + 1
+        name = "wavenet.upsample_net.conv_in.weight"
+        dq = torch.empty_like(cin)
+        L.check(lib.wae_enc_conv_bwd(L.ptr(cin), L.ptr(eng.eff[lay.off(name):]), None, L.ptr(d), L.ptr(dq),
+                                     L.ptr(eng.d_eff[lay.off(name):]), None, B, g.Cc, cin.shape[-1], g.Cc, kin, 1, 0, 0, 0, st), "conv_in bwd")
+    else:
+        dq = d                               # no conv_in: the stages' input gradient IS the gradient of the features
     keep.append(dq)
     eng._fe_keep = keep
     fe = getattr(eng, "_fe", None)

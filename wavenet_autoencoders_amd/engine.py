@@ -252,19 +252,28 @@ class WaeEngine:
         return quant, idx, stats
 
     def upsample_forward(self, c: torch.Tensor, out: torch.Tensor):
-        """a3: c (B,Cc,Tc) fp32 -> out (B, Tc*prod(scales), Ccp) time-major compute dtype (upsample.py:83-85)."""
+        """a3: c (B,Cc,Tc) fp32 -> out (B, (Tc - 2 cin_pad) * prod(scales), Ccp) time-major compute dtype.  ConvInUpsampleNetwork
+        (upsample.py:69-85): conv_in eats cin_pad frames at either end, then the stages; plain UpsampleNetwork (Geometry.conv_in False,
+        upsample.py:29-66): the stages on all Tc frames, then cin_pad * prod(scales) samples trimmed at either end."""
         g, lib, st = self.g, self.lib, self.stream()
         B, Cc, Tc = c.shape
-        kin = 2 * g.cin_pad + 1
-        Tin = Tc - 2 * g.cin_pad
-        x = torch.empty(B, Cc, Tin, dtype=torch.float32, device=self.device)
-        L.check(lib.wae_enc_conv_fwd(L.ptr(c.contiguous()), L.ptr(self.eff[self.lay.off("wavenet.upsample_net.conv_in.weight"):]),
-                                     None, L.ptr(x), B, Cc, Tc, Cc, kin, 1, 0, 0, 0, st), "conv_in")
+        c = c.contiguous()
         n = len(g.upsample_scales)
-        self._up_acts = [c.contiguous(), x]     # conv_in input, then every stage's input
+        trim = 0
+        if g.conv_in:
+            kin = 2 * g.cin_pad + 1
+            Tin = Tc - 2 * g.cin_pad
+            x = torch.empty(B, Cc, Tin, dtype=torch.float32, device=self.device)
+            L.check(lib.wae_enc_conv_fwd(L.ptr(c), L.ptr(self.eff[self.lay.off("wavenet.upsample_net.conv_in.weight"):]),
+                                         None, L.ptr(x), B, Cc, Tc, Cc, kin, 1, 0, 0, 0, st), "conv_in")
+            self._up_acts = [c, x]          # conv_in input, then every stage's input
+        else:
+            x, Tin = c, Tc
+            trim = g.cin_pad * int(np.prod(g.upsample_scales))
+            self._up_acts = [None, x]
         for i, s in enumerate(g.upsample_scales):
-            w = self.eff[self.lay.off(f"wavenet.upsample_net.upsample.up_layers.{2 * i + 1}.weight_v"):]
-            last = i == n - 1
+            w = self.eff[self.lay.off(P.up_stage_name(g, i) + ".weight_v"):]
+            last = i == n - 1 and trim == 0          # the last stage writes the time-major operand itself, unless a trim follows
             if last:
                 assert out.shape[1] == Tin * s, (out.shape, Tin * s)
                 y = out
@@ -273,8 +282,13 @@ class WaeEngine:
             L.check(lib.wae_upsample_stage_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, Cc, Tin, s, int(last), g.Ccp, self.dt, st),
                     "upsample_stage")
             x, Tin = y, Tin * s
-            if not last:
+            if i < n - 1:
                 self._up_acts.append(x)
+        if trim:       # upsample.py:64-65: c[:, :, indent:-indent]
+            assert out.shape[1] == Tin - 2 * trim, (out.shape, Tin, trim)
+            xt = x[:, :, trim:Tin - trim].contiguous()
+            L.check(lib.wae_to_btc(L.ptr(xt), L.ptr(out), B, Cc, Tin - 2 * trim, g.Ccp, self.dt, st), "to_btc (trimmed c_up)")
+            self._up_keep = xt
         return out
 
     def layer_drop_seed(self, call: int, layer: int) -> int:

@@ -58,6 +58,10 @@ class Geometry:
     encoder_hid: Optional[int] = None
     K: int = 256
     dilations_override: Optional[List[int]] = None   # standalone layers (wavenet_vocoder.modules.ResidualConv1dGLU)
+    # upsample_net "ConvInUpsampleNetwork" (upsample.py:69-85: a Conv1d of 2 cin_pad + 1 taps without padding in front of the stages;
+    # every preset) or, conv_in = False, the plain "UpsampleNetwork" (upsample.py:29-66: the stages alone, the output trimmed by
+    # cin_pad * prod(scales) samples at either end) -- the same output length, other state_dict keys
+    conv_in: bool = True
     # Global features that VARY over time (modules.py:148-152 convolves any (B, Cg, T) tensor): conv1x1g then is one more 1x1 over a
     # time series, exactly what conv1x1c is -- its Cg columns ride behind the Cc columns of the local conditioning in the layer
     # kernel's operand ([c ; g] in c_up, [Wc | Wg] in the packed GEMM-1 stream), forward and backward; the hoisted per-clip projection
@@ -94,10 +98,16 @@ class Geometry:
                         Cc=cfg.get("Cc", -1), Cg=cfg.get("Cg", -1), k=cfg.get("k", 3), n_speakers=cfg.get("n_speakers"),
                         upsample_scales=cfg.get("upsample_scales"), cin_pad=cfg.get("cin_pad", 0),
                         scalar_input=bool(cfg.get("scalar_input")), c_in=cfg.get("c_in"),
-                        encoder_hid=cfg.get("encoder_hid"), K=cfg.get("K", 256))
+                        encoder_hid=cfg.get("encoder_hid"), K=cfg.get("K", 256), conv_in=bool(cfg.get("conv_in", True)))
 
 
 ENCODER_BLOCKS = [(3, 1), (3, 1), (5, 2), (5, 2), (3, 1), (3, 1), (1, 1), (1, 1), (1, 1), (1, 1)]  # vqvae_model.py:32-40
+
+
+def up_stage_name(g: Geometry, i: int) -> str:
+    """state_dict prefix of upsampling stage i's smoothing FIR: the ModuleList holds [Stretch2d, Conv2d] per stage (upsample.py:38-44),
+    under `.upsample` when ConvInUpsampleNetwork wraps it (upsample.py:80-82)"""
+    return f"wavenet.upsample_net.{'upsample.' if g.conv_in else ''}up_layers.{2 * i + 1}"
 
 
 def param_specs(g: Geometry) -> List[Tuple[str, Tuple[int, ...], bool]]:
@@ -127,9 +137,10 @@ def param_specs(g: Geometry) -> List[Tuple[str, Tuple[int, ...], bool]]:
     if g.Cg > 0 and g.use_speaker_embedding and g.n_speakers:
         out.append(("wavenet.embed_speakers.weight", (g.n_speakers, g.Cg), False))
     if g.upsample_scales:
-        out.append(("wavenet.upsample_net.conv_in.weight", (g.Cc, g.Cc, 2 * g.cin_pad + 1), False))
+        if g.conv_in:
+            out.append(("wavenet.upsample_net.conv_in.weight", (g.Cc, g.Cc, 2 * g.cin_pad + 1), False))
         for i, s in enumerate(g.upsample_scales):
-            wn(f"wavenet.upsample_net.upsample.up_layers.{2 * i + 1}", 1, 1, 2 * s + 1, bias=False, conv2d=True)
+            wn(up_stage_name(g, i), 1, 1, 2 * s + 1, bias=False, conv2d=True)
     if g.has_encoder:
         dims = [(g.c_in, g.encoder_hid)] + [(g.encoder_hid, g.encoder_hid)] * 9
         for i, ((ci, co), (kk, _)) in enumerate(zip(dims, ENCODER_BLOCKS)):

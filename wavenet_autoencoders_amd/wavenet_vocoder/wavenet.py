@@ -95,8 +95,9 @@ class WaveNet(ArenaModel):
         # 0.0 (hps/*.json).  In training mode the engine applies a counter-based mask (wae_dropout_fwd / wae_dropout_bwd): same
         # distribution as torch's, not the same random stream.
         self.dropout = float(dropout)
-        if upsample_conditional_features and upsample_net != "ConvInUpsampleNetwork":
-            raise NotImplementedError("only ConvInUpsampleNetwork (the reference default) is implemented")
+        # wavenet.py:150-151: getattr(upsample, upsample_net)(**upsample_params) -- the two classes of upsample.py
+        if upsample_conditional_features and upsample_net not in ("ConvInUpsampleNetwork", "UpsampleNetwork"):
+            raise AttributeError(f"module 'wavenet_vocoder.upsample' has no attribute {upsample_net!r}")
         self.scalar_input = scalar_input
         self.out_channels = out_channels
         self.cin_channels = cin_channels
@@ -136,7 +137,7 @@ class WaveNet(ArenaModel):
                           O=out_channels, Cc=cin_channels, Cg=gin_channels, k=kernel_size,
                           n_speakers=n_speakers if (gin_channels > 0 and use_speaker_embedding) else None,
                           upsample_scales=scales, cin_pad=cin_pad, scalar_input=scalar_input,
-                          use_speaker_embedding=bool(use_speaker_embedding))
+                          use_speaker_embedding=bool(use_speaker_embedding), conv_in=upsample_net != "UpsampleNetwork")
         self._init_arena(geom, "wavenet.")
         self.receptive_field = receptive_field_size(layers, stacks, kernel_size)
 
