@@ -11,10 +11,10 @@ python3 bench.py --dtype fp16 --no-cpu --no-ar --no-fp32 > $OUT/bench_fp16.json 
 python3 bench.py --config c3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 python3 bench.py --config c5 --steps 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-ar > $OUT/profiled_line.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-ar --no-fp32 > $OUT/profiled_line.json 2> $OUT/stats.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fwd -- python3 $ROOT/bench.py --mode forward --steps 10 --warmup 3 --no-cpu --no-ar > $OUT/profiled_forward_line.json 2> $OUT/stats_fwd.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-ar > $OUT/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-ar --no-fp32 > $OUT/pmc_$c.log 2>&1
 done
 cd $ROOT
 python3 - <<PY
