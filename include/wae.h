@@ -552,6 +552,11 @@ int wae_from_btc(const void* in, float* out, int32_t B, int32_t C, int32_t T, in
  * leaves the 16-bit stack for the fp32 front end) */
 int wae_from_btc_scaled(const void* in, float* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype, float scale,
                         void* stream);
+/* upsample_activation (upsample.py:44-46): the element-wise module the reference puts behind every stage's smoothing FIR --
+ * kind 1 nn.ReLU, 2 nn.LeakyReLU(negative_slope = slope), 3 nn.Tanh, 4 nn.Sigmoid.  wae_act_fwd: x <- act(x) in place (fp32);
+ * wae_act_bwd: d <- d * act'(.) formed from the activation's OUTPUT y. */
+int wae_act_fwd(float* x, int64_t n, int32_t kind, float slope, void* stream);
+int wae_act_bwd(const float* y, float* d, int64_t n, int32_t kind, float slope, void* stream);
 
 #ifdef __cplusplus
 }

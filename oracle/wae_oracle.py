@@ -190,17 +190,30 @@ def vq_distances(emb: torch.Tensor, lat: torch.Tensor) -> torch.Tensor:
 # a3: conditioning upsample net (upsample.py:12-21, :29-66, :69-85)
 # --------------------------------------------------------------------------
 def upsample_forward(sd: SD, c: torch.Tensor, scales: Sequence[int], prefix: str = "wavenet.upsample_net.",
-                     cin_pad: int = 0, conv_in: bool = True) -> torch.Tensor:
+                     cin_pad: int = 0, conv_in: bool = True, act: str = "none", act_slope: float = 0.01) -> torch.Tensor:
     """ConvInUpsampleNetwork (upsample.py:69-85): conv_in (plain Conv1d, k = 2*cin_pad+1, no bias, no weight-norm; :77-78) then per
     scale s: nearest stretch x s (:19-21) + one shared 1-channel FIR of 2s+1 taps, zero padded (:39-46).
     conv_in=False: the plain UpsampleNetwork (upsample.py:29-66): the stages alone (keys `up_layers.N`, no `.upsample`), then
-    `indent = cin_pad * prod(scales)` samples trimmed at either end (:64-65)."""
+    `indent = cin_pad * prod(scales)` samples trimmed at either end (:64-65).
+    act != "none": upsample_activation (:44-46), an element-wise module behind every stage's FIR (ReLU, LeakyReLU(act_slope), Tanh,
+    Sigmoid here); the ModuleList then holds three modules per stage, the FIRs at up_layers.{3 i + 1}."""
     x = F.conv1d(c, sd[prefix + "conv_in.weight"]) if conv_in else c
     x = x.unsqueeze(1)
+    per = 2 if act == "none" else 3
     for i, s in enumerate(scales):
         x = F.interpolate(x, scale_factor=(1, s), mode="nearest")
-        w = eff_weight(sd, f"{prefix}{'upsample.' if conv_in else ''}up_layers.{2 * i + 1}")
+        w = eff_weight(sd, f"{prefix}{'upsample.' if conv_in else ''}up_layers.{per * i + 1}")
         x = F.conv2d(x, w, padding=(0, s))
+        if act == "ReLU":
+            x = torch.relu(x)
+        elif act == "LeakyReLU":
+            x = F.leaky_relu(x, act_slope)
+        elif act == "Tanh":
+            x = torch.tanh(x)
+        elif act == "Sigmoid":
+            x = torch.sigmoid(x)
+        else:
+            assert act == "none", act
     x = x.squeeze(1)
     indent = 0 if conv_in else cin_pad * int(np.prod(list(scales)))
     return x[:, :, indent:x.shape[-1] - indent] if indent > 0 else x
@@ -301,7 +314,8 @@ def wavenet_forward(sd: SD, cfg: dict, x: torch.Tensor, c: Optional[torch.Tensor
             gb = g if g.dim() == 3 else g.unsqueeze(-1)
         gb = gb.expand(B, -1, T)  # :194
     if c is not None and cfg.get("upsample_scales"):
-        c = upsample_forward(sd, c, cfg["upsample_scales"], prefix + "upsample_net.", cfg.get("cin_pad", 0), cfg.get("conv_in", True))
+        c = upsample_forward(sd, c, cfg["upsample_scales"], prefix + "upsample_net.", cfg.get("cin_pad", 0), cfg.get("conv_in", True),
+                             cfg.get("up_act", "none"), cfg.get("up_act_slope", 0.01))
         if c.shape[-1] != T:
             raise Exception("upsampled c length != T")  # :198-200
     h = F.conv1d(x, eff_weight(sd, prefix + "first_conv"), sd[prefix + "first_conv.bias"])  # :203
@@ -642,7 +656,7 @@ def make_state_dict(cfg: dict, salt: int = 1, with_encoder: bool = True) -> SD:
         if conv_in:
             sd["wavenet.upsample_net.conv_in.weight"] = fill((Cc, Cc, 2 * cfg.get("cin_pad", 0) + 1), Cc, 1.5)
         for i, s in enumerate(cfg["upsample_scales"]):
-            p = f"wavenet.upsample_net.{'upsample.' if conv_in else ''}up_layers.{2 * i + 1}"
+            p = f"wavenet.upsample_net.{'upsample.' if conv_in else ''}up_layers.{(2 if cfg.get('up_act', 'none') == 'none' else 3) * i + 1}"
             n[0] += 1
             v = 1.0 / (2 * s + 1) + 0.02 * hash_fill((1, 1, 1, 2 * s + 1), n[0])
             sd[p + ".weight_v"] = v

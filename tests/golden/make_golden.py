@@ -712,6 +712,48 @@ def gen_plain_upsample():
     save("model_U", cfg=json.dumps(CFG_U), salt=6, g=torch.tensor([1, 3]), **out)
 
 
+def gen_upsample_activation():
+    """upsample_activation (upsample.py:44-46: an element-wise torch.nn module behind every stage's FIR; the conv keys move to
+    up_layers.{3 i + 1}): the reference's WaveNet with ConvInUpsampleNetwork + LeakyReLU(0.2) and with the plain UpsampleNetwork + Tanh --
+    c_up, logits and the gradient of a weighted logit sum with respect to the features."""
+    out = {}
+    for tag, net, act, params, slope in (("leaky", "ConvInUpsampleNetwork", "LeakyReLU", {"negative_slope": 0.2}, 0.2),
+                                         ("tanh", "UpsampleNetwork", "Tanh", {}, 0.01), ("relu", "ConvInUpsampleNetwork", "ReLU", {}, 0.01),
+                                         ("sigm", "ConvInUpsampleNetwork", "Sigmoid", {}, 0.01)):
+        cfg = dict(CFG_U, cin_pad=0, conv_in=net == "ConvInUpsampleNetwork", up_act=act, up_act_slope=slope)
+        sd = O.make_state_dict(cfg, 8, with_encoder=False)
+        wn = RefWaveNet(out_channels=cfg["O"], layers=cfg["layers"], stacks=cfg["stacks"], residual_channels=cfg["R"],
+                        gate_channels=cfg["G"], skip_out_channels=cfg["S"], kernel_size=cfg["k"], dropout=0.0,
+                        cin_channels=cfg["Cc"], gin_channels=cfg["Cg"], n_speakers=cfg["n_speakers"],
+                        upsample_conditional_features=True, upsample_net=net,
+                        upsample_params=dict(upsample_scales=cfg["upsample_scales"], cin_channels=cfg["Cc"], cin_pad=0,
+                                             upsample_activation=act, upsample_activation_params=params),
+                        scalar_input=False, use_speaker_embedding=True, output_distribution="Logistic", cin_pad=0)
+        missing = wn.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        wn.eval()
+        B, Tc = 2, 2
+        T = Tc * int(np.prod(cfg["upsample_scales"]))
+        feats = O.hash_fill((B, cfg["Cc"], Tc), 71, 1.1).requires_grad_(True)
+        x = ((O.hash_fill((B, T), 72) * 0.5 + 0.5) * cfg["O"]).long().clamp(0, cfg["O"] - 1)
+        xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+        g = torch.tensor([1, 3])
+        with torch.no_grad():
+            c_up = wn.upsample_net(feats)
+        y = wn(xin, feats, g, False)
+        wsum = O.hash_fill(tuple(y.shape), 73, 1.0)
+        (y * wsum).sum().backward()
+        ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0, conv_in=cfg["conv_in"],
+                    up_act=act, up_act_slope=slope)
+        close(O.upsample_forward(sd, feats.detach(), cfg["upsample_scales"], conv_in=cfg["conv_in"], act=act, act_slope=slope), c_up,
+              what="upsample_activation c_up")
+        e = close(O.wavenet_forward(sd, ocfg, xin, feats.detach(), g), y.detach(), what="upsample_activation logits")
+        print(f"  upsample_activation {act} on {net}: logits max|oracle-ref| = {e:.2e}")
+        out.update({f"cfg_{tag}": json.dumps(cfg), f"c_up_probe_{tag}": c_up[:, :, ::3], f"y_probe_{tag}": y.detach()[:, :, ::5],
+                    f"dfeats_{tag}": feats.grad})
+    save("model_V", salt=8, g=torch.tensor([1, 3]), feats=O.hash_fill((2, CFG_U["Cc"], 2), 71, 1.1), x=x.numpy(), w_salt=73, **out)
+
+
 def _ref_sampler_class():
     """The reference's PartialyRandomizedSimilarTimeLengthSampler, cut out of vqwae_train.py by its syntax tree (the file itself
     cannot be imported: docopt / nnmnkwii / librosa / tensorboardX are absent) and executed as is."""
@@ -974,6 +1016,8 @@ def main():
         return gen_cin_pad()
     if sys.argv[1:] == ["plain_upsample"]:
         return gen_plain_upsample()
+    if sys.argv[1:] == ["upsample_activation"]:
+        return gen_upsample_activation()
     if sys.argv[1:] == ["sampler"]:
         return gen_sampler()
     gen_quantizers()
@@ -998,6 +1042,7 @@ def main():
     gen_c2()
     gen_cin_pad()
     gen_plain_upsample()
+    gen_upsample_activation()
     gen_sampler()
 
 

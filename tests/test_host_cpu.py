@@ -186,7 +186,12 @@ def test_wavenet_constructor_refuses_options_it_does_not_implement():
     # cin_pad argument to the network (wavenet.py:151)
     w0 = WaveNet(**base, upsample_params=up, cin_pad=2)
     assert w0.geom.cin_pad == 0 and tuple(w0.state_dict()["upsample_net.conv_in.weight"].shape) == (16, 16, 1)
-    for bad, exc in ((dict(upsample_activation="ReLU"), NotImplementedError), (dict(mode="linear"), NotImplementedError),
+    # upsample_activation: ReLU / LeakyReLU / Tanh / Sigmoid are implemented since round 5 (three modules per stage: FIRs at 3 i + 1)
+    wa = WaveNet(**base, upsample_params=dict(up, upsample_activation="LeakyReLU", upsample_activation_params={"negative_slope": 0.3}))
+    assert wa.geom.up_act == "LeakyReLU" and wa.geom.up_act_slope == 0.3 and "upsample_net.upsample.up_layers.4.weight_v" in wa.state_dict()
+    for bad, exc in ((dict(upsample_activation="PReLU"), NotImplementedError),
+                     (dict(upsample_activation="ReLU", upsample_activation_params={"foo": 1}), NotImplementedError),
+                     (dict(mode="linear"), NotImplementedError),
                      (dict(freq_axis_kernel_size=3), NotImplementedError), (dict(cin_channels=80), ValueError),
                      (dict(typo_scales=[4]), TypeError)):
         with pytest.raises(exc):

@@ -384,3 +384,28 @@ def test_plain_upsample_network_model():
         assert rel_err(y[:, :, ::5].detach(), z[f"y_probe{pad}"]) < TOL
         (y * O.hash_fill(tuple(y.shape), int(z[f"w_salt{pad}"]), 1.0)).sum().backward()
         assert rel_err(feats.grad, z[f"dfeats{pad}"]) < 1e-4
+
+
+def test_upsample_activation_models():
+    """upsample_activation (upsample.py:44-46): LeakyReLU(0.2) and ReLU / Sigmoid behind the stages of ConvInUpsampleNetwork, Tanh behind
+    those of the plain UpsampleNetwork (FIR keys at up_layers.{3 i + 1}) -- c_up, logits and the feature gradient of the REFERENCE's
+    WaveNet (model_V.npz)."""
+    z = load_npz("model_V")
+    g = torch.from_numpy(z["g"])
+    x = torch.from_numpy(z["x"]).long()
+    for tag in ("leaky", "tanh", "relu", "sigm"):
+        cfg = json.loads(str(z[f"cfg_{tag}"]))
+        sd = O.make_state_dict(cfg, int(z["salt"]), with_encoder=False)
+        key = "wavenet.upsample_net." + ("upsample." if cfg["conv_in"] else "") + "up_layers.4.weight_v"
+        assert key in sd                                  # three modules per stage: the second stage's FIR is module 4
+        xin = torch.nn.functional.one_hot(x, cfg["O"]).float().transpose(1, 2).contiguous()
+        feats = torch.from_numpy(z["feats"]).clone().requires_grad_(True)
+        ocfg = dict(layers=cfg["layers"], stacks=cfg["stacks"], upsample_scales=cfg["upsample_scales"], cin_pad=0, conv_in=cfg["conv_in"],
+                    up_act=cfg["up_act"], up_act_slope=cfg["up_act_slope"])
+        c_up = O.upsample_forward(sd, feats.detach(), cfg["upsample_scales"], conv_in=cfg["conv_in"], act=cfg["up_act"],
+                                  act_slope=cfg["up_act_slope"])
+        assert rel_err(c_up[:, :, ::3], z[f"c_up_probe_{tag}"]) < TOL
+        y = O.wavenet_forward(sd, ocfg, xin, feats, g)
+        assert rel_err(y[:, :, ::5].detach(), z[f"y_probe_{tag}"]) < TOL
+        (y * O.hash_fill(tuple(y.shape), int(z["w_salt"]), 1.0)).sum().backward()
+        assert rel_err(feats.grad, z[f"dfeats_{tag}"]) < 1e-4

@@ -147,6 +147,8 @@ SIGNATURES = {
     "wae_to_btc_masked": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp, c_f32, c_vp]),
     "wae_from_btc": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_vp]),
     "wae_from_btc_scaled": (c_i32, [c_vp, c_vp] + [c_i32] * 5 + [c_f32, c_vp]),
+    "wae_act_fwd": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_vp]),
+    "wae_act_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
 }
 
 _lib = None

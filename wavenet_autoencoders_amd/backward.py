@@ -948,10 +948,15 @@ def frontend_backward(eng, dc: torch.Tensor, loss_scale: float = 1.0, stop_at_qu
         trim = g.cin_pad * int(np.prod(g.upsample_scales))
         d = torch.nn.functional.pad(d, (trim, trim))
         keep.append(d)
+    act = P.UP_ACT_KINDS.get(g.up_act, 0)
     for i in range(len(g.upsample_scales) - 1, -1, -1):
         s = g.upsample_scales[i]
         xin = acts[1 + i]
         name = P.up_stage_name(g, i) + ".weight_v"
+        if act:        # through the stage's activation, whose output is the next stage's input (the last stage's: kept by the forward)
+            yout = acts[2 + i] if i + 1 < len(g.upsample_scales) else eng._up_last
+            d = d.contiguous()
+            L.check(lib.wae_act_bwd(L.ptr(yout), L.ptr(d), d.numel(), act, float(g.up_act_slope), st), "upsample activation bwd")
         din = torch.empty_like(xin)
         L.check(lib.wae_upsample_stage_bwd(L.ptr(d), L.ptr(xin), L.ptr(eng.eff[lay.off(name):]), L.ptr(din),
                                            L.ptr(eng.d_eff[lay.off(name):]), B, g.Cc, xin.shape[-1], s, st), "upsample_stage_bwd")

@@ -1258,6 +1258,44 @@ extern "C" int wae_to_btc(const float* in, void* out, int32_t B, int32_t C, int3
     hipLaunchKernelGGL(to_btc_kernel<float>, grid, dim3(256), 0, as_stream(stream), in, out, C, T, Cp, nullptr, 1.f, 0);
   return wae_check_launch("to_btc");
 }
+// ---- upsample_activation (upsample.py:44-46: getattr(nn, upsample_activation)(**params) behind every stage's smoothing FIR) ----------
+// kind 1 ReLU, 2 LeakyReLU(slope), 3 Tanh, 4 Sigmoid.  Forward in place on the stage's fp32 output; backward from the activation's
+// OUTPUT (all four derivatives are functions of it: sign, 1 - y^2, y (1 - y)), which is the next stage's saved input anyway.
+__global__ void __launch_bounds__(256) act_fwd_kernel(float* __restrict__ x, int64_t n, int kind, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    float y;
+    if (kind == 1) y = fmaxf(v, 0.f);
+    else if (kind == 2) y = v > 0.f ? v : v * slope;
+    else if (kind == 3) y = tanhf(v);
+    else y = 1.0f / (1.0f + expf(-v));
+    x[i] = y;
+  }
+}
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ y, float* __restrict__ d, int64_t n, int kind, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = y[i];
+    float g;
+    if (kind == 1) g = v > 0.f ? 1.f : 0.f;
+    else if (kind == 2) g = v > 0.f ? 1.f : slope;
+    else if (kind == 3) g = 1.f - v * v;
+    else g = v * (1.f - v);
+    d[i] *= g;
+  }
+}
+extern "C" int wae_act_fwd(float* x, int64_t n, int32_t kind, float slope, void* stream) {
+  WAE_REQUIRE(x && n > 0 && kind >= 1 && kind <= 4, "act_fwd: bad arguments (kind 1 ReLU, 2 LeakyReLU, 3 Tanh, 4 Sigmoid)");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, kind, slope);
+  return wae_check_launch("act_fwd");
+}
+extern "C" int wae_act_bwd(const float* y, float* d, int64_t n, int32_t kind, float slope, void* stream) {
+  WAE_REQUIRE(y && d && n > 0 && kind >= 1 && kind <= 4, "act_bwd: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, d, n, kind, slope);
+  return wae_check_launch("act_bwd");
+}
+
 extern "C" int wae_to_btc_masked(const float* in, void* out, int32_t B, int32_t C, int32_t T, int32_t Cp, int32_t dtype,
                                  const int32_t* lengths, float scale, void* stream) {
   WAE_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && Cp >= C, "to_btc_masked: bad arguments");

@@ -260,6 +260,7 @@ class WaeEngine:
         c = c.contiguous()
         n = len(g.upsample_scales)
         trim = 0
+        act = P.UP_ACT_KINDS.get(g.up_act, 0)          # upsample_activation behind every stage (upsample.py:44-46), 0 = none
         if g.conv_in:
             kin = 2 * g.cin_pad + 1
             Tin = Tc - 2 * g.cin_pad
@@ -273,7 +274,7 @@ class WaeEngine:
             self._up_acts = [None, x]
         for i, s in enumerate(g.upsample_scales):
             w = self.eff[self.lay.off(P.up_stage_name(g, i) + ".weight_v"):]
-            last = i == n - 1 and trim == 0          # the last stage writes the time-major operand itself, unless a trim follows
+            last = i == n - 1 and trim == 0 and not act    # the last stage writes the time-major operand itself, unless something follows
             if last:
                 assert out.shape[1] == Tin * s, (out.shape, Tin * s)
                 y = out
@@ -282,12 +283,15 @@ class WaeEngine:
             L.check(lib.wae_upsample_stage_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, Cc, Tin, s, int(last), g.Ccp, self.dt, st),
                     "upsample_stage")
             x, Tin = y, Tin * s
+            if act:
+                L.check(lib.wae_act_fwd(L.ptr(x), x.numel(), act, float(g.up_act_slope), st), "upsample activation")
             if i < n - 1:
                 self._up_acts.append(x)
-        if trim:       # upsample.py:64-65: c[:, :, indent:-indent]
+        self._up_last = x if act else None      # the last stage's activated output: backward forms act' from it
+        if trim or act:       # upsample.py:64-65: c[:, :, indent:-indent]
             assert out.shape[1] == Tin - 2 * trim, (out.shape, Tin, trim)
-            xt = x[:, :, trim:Tin - trim].contiguous()
-            L.check(lib.wae_to_btc(L.ptr(xt), L.ptr(out), B, Cc, Tin - 2 * trim, g.Ccp, self.dt, st), "to_btc (trimmed c_up)")
+            xt = x[:, :, trim:Tin - trim].contiguous() if trim else x
+            L.check(lib.wae_to_btc(L.ptr(xt), L.ptr(out), B, Cc, Tin - 2 * trim, g.Ccp, self.dt, st), "to_btc (c_up)")
             self._up_keep = xt
         return out
 

@@ -62,6 +62,11 @@ class Geometry:
     # every preset) or, conv_in = False, the plain "UpsampleNetwork" (upsample.py:29-66: the stages alone, the output trimmed by
     # cin_pad * prod(scales) samples at either end) -- the same output length, other state_dict keys
     conv_in: bool = True
+    # upsample_activation (upsample.py:44-46): "none" (every preset) or an element-wise torch.nn module behind every stage's FIR --
+    # ReLU, LeakyReLU (up_act_slope = negative_slope), Tanh, Sigmoid are implemented (csrc/misc.hip: wae_act_fwd / _bwd).  With an
+    # activation the ModuleList holds three modules per stage, so the FIRs sit at up_layers.{3 i + 1}.
+    up_act: str = "none"
+    up_act_slope: float = 0.01
     # Global features that VARY over time (modules.py:148-152 convolves any (B, Cg, T) tensor): conv1x1g then is one more 1x1 over a
     # time series, exactly what conv1x1c is -- its Cg columns ride behind the Cc columns of the local conditioning in the layer
     # kernel's operand ([c ; g] in c_up, [Wc | Wg] in the packed GEMM-1 stream), forward and backward; the hoisted per-clip projection
@@ -98,16 +103,21 @@ class Geometry:
                         Cc=cfg.get("Cc", -1), Cg=cfg.get("Cg", -1), k=cfg.get("k", 3), n_speakers=cfg.get("n_speakers"),
                         upsample_scales=cfg.get("upsample_scales"), cin_pad=cfg.get("cin_pad", 0),
                         scalar_input=bool(cfg.get("scalar_input")), c_in=cfg.get("c_in"),
-                        encoder_hid=cfg.get("encoder_hid"), K=cfg.get("K", 256), conv_in=bool(cfg.get("conv_in", True)))
+                        encoder_hid=cfg.get("encoder_hid"), K=cfg.get("K", 256), conv_in=bool(cfg.get("conv_in", True)),
+                        up_act=cfg.get("up_act", "none"), up_act_slope=float(cfg.get("up_act_slope", 0.01)))
 
 
 ENCODER_BLOCKS = [(3, 1), (3, 1), (5, 2), (5, 2), (3, 1), (3, 1), (1, 1), (1, 1), (1, 1), (1, 1)]  # vqvae_model.py:32-40
 
 
+UP_ACT_KINDS = {"ReLU": 1, "LeakyReLU": 2, "Tanh": 3, "Sigmoid": 4}      # include/wae.h: wae_act_fwd
+
+
 def up_stage_name(g: Geometry, i: int) -> str:
     """state_dict prefix of upsampling stage i's smoothing FIR: the ModuleList holds [Stretch2d, Conv2d] per stage (upsample.py:38-44),
     under `.upsample` when ConvInUpsampleNetwork wraps it (upsample.py:80-82)"""
-    return f"wavenet.upsample_net.{'upsample.' if g.conv_in else ''}up_layers.{2 * i + 1}"
+    per = 2 if g.up_act == "none" else 3
+    return f"wavenet.upsample_net.{'upsample.' if g.conv_in else ''}up_layers.{per * i + 1}"
 
 
 def param_specs(g: Geometry) -> List[Tuple[str, Tuple[int, ...], bool]]:

@@ -55,7 +55,7 @@ class VQVAE(ArenaModel):
         geom = P.Geometry(layers=wg.layers, stacks=wg.stacks, R=wg.R, G=wg.G, S=wg.S, O=wg.O, Cc=wg.Cc, Cg=wg.Cg, k=wg.k,
                           n_speakers=wg.n_speakers, upsample_scales=wg.upsample_scales, cin_pad=wg.cin_pad,
                           scalar_input=wg.scalar_input, use_speaker_embedding=wg.use_speaker_embedding, c_in=c_in,
-                          encoder_hid=encoder_hid, K=K, conv_in=wg.conv_in)
+                          encoder_hid=encoder_hid, K=K, conv_in=wg.conv_in, up_act=wg.up_act, up_act_slope=wg.up_act_slope)
         self.out_channels, self.scalar_input = wavenet.out_channels, wavenet.scalar_input
         self.dropout = float(getattr(wavenet, "dropout", 0.0))          # the decoder layers' dropout (modules.py:127-128)
         self._init_arena(geom, "")

@@ -103,6 +103,7 @@ class WaveNet(ArenaModel):
         self.cin_channels = cin_channels
         self.output_distribution = output_distribution
         scales = None
+        up_act, up_slope = "none", 0.01
         if upsample_conditional_features:
             # the reference builds ConvInUpsampleNetwork(**upsample_params) (wavenet.py:151, upsample.py:69-85): its signature is
             # (upsample_scales, upsample_activation="none", upsample_activation_params={}, mode="nearest",
@@ -115,8 +116,15 @@ class WaveNet(ArenaModel):
                 raise TypeError(f"__init__() got an unexpected keyword argument {unknown[0]!r} (upsample_params)")
             if "upsample_scales" not in upsample_params:
                 raise TypeError("__init__() missing 1 required positional argument: 'upsample_scales' (upsample_params)")
-            if upsample_params.get("upsample_activation", "none") != "none":
-                raise NotImplementedError("upsample_activation other than 'none' is not implemented (upsample.py:44-46; no preset sets it)")
+            up_act = upsample_params.get("upsample_activation", "none")
+            act_params = dict(upsample_params.get("upsample_activation_params", {}) or {})
+            act_params.pop("inplace", None)
+            up_slope = 0.01
+            if up_act == "LeakyReLU":
+                up_slope = float(act_params.pop("negative_slope", 0.01))
+            if up_act != "none" and (up_act not in P.UP_ACT_KINDS or act_params):
+                raise NotImplementedError(f"upsample_activation={up_act!r} with parameters {act_params}: ReLU, LeakyReLU(negative_slope), Tanh "
+                                          "and Sigmoid are implemented (upsample.py:44-46 takes any torch.nn module; no preset sets one)")
             if upsample_params.get("mode", "nearest") != "nearest":
                 raise NotImplementedError("only nearest-neighbour stretching (Stretch2d mode='nearest', upsample.py:19-21) is implemented")
             if int(upsample_params.get("freq_axis_kernel_size", 1)) != 1:
@@ -137,7 +145,8 @@ class WaveNet(ArenaModel):
                           O=out_channels, Cc=cin_channels, Cg=gin_channels, k=kernel_size,
                           n_speakers=n_speakers if (gin_channels > 0 and use_speaker_embedding) else None,
                           upsample_scales=scales, cin_pad=cin_pad, scalar_input=scalar_input,
-                          use_speaker_embedding=bool(use_speaker_embedding), conv_in=upsample_net != "UpsampleNetwork")
+                          use_speaker_embedding=bool(use_speaker_embedding), conv_in=upsample_net != "UpsampleNetwork",
+                          up_act=up_act, up_act_slope=up_slope)
         self._init_arena(geom, "wavenet.")
         self.receptive_field = receptive_field_size(layers, stacks, kernel_size)
 
