@@ -487,3 +487,35 @@ def test_standalone_layer_trains_with_dropout(p_drop):
         xe, _ = layer(x.cuda(), c.cuda(), gv.cuda().expand(-1, -1, T))
         xe_r, _ = O.glu_layer_forward({pre + k: v for k, v in lsd.items()}, pre, x, c, gv.expand(-1, -1, T), d)
     assert rel_err(xe.cpu(), xe_r) < 1e-4
+
+
+def test_standalone_layer_without_biases():
+    """modules.py:88-107 with bias=False: conv, conv1x1_out and conv1x1_skip have no bias (state_dict without the three keys); outputs and
+    the gradients of x, c and every parameter against autograd through the oracle's layer on a state_dict without them."""
+    from helpers import golden_model, rel_err
+    from oracle import wae_oracle as O
+    from wavenet_autoencoders_amd.wavenet_vocoder.modules import ResidualConv1dGLU
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    pre = "wavenet.conv_layers.1."
+    lsd = {k[len(pre):]: v.clone() for k, v in sd.items() if k.startswith(pre) and not k.endswith(".bias")}
+    layer = ResidualConv1dGLU(cfg["R"], cfg["G"], cfg["k"], skip_out_channels=cfg["S"], cin_channels=cfg["Cc"],
+                              gin_channels=cfg["Cg"], dropout=0.0, dilation=2, bias=False)
+    assert set(layer.state_dict()) == set(lsd) and not any(k.endswith(".bias") for k in layer.state_dict())
+    layer.load_state_dict(lsd)
+    layer = layer.cuda().train()
+    B, T = 2, 300
+    x = O.hash_fill((B, cfg["R"], T), 81, 0.8)
+    c = O.hash_fill((B, cfg["Cc"], T), 82, 0.8)
+    gv = O.hash_fill((B, cfg["Cg"], 1), 83, 0.8)
+    wx, wsk = O.hash_fill((B, cfg["R"], T), 84), O.hash_fill((B, cfg["S"], T), 85)
+    psd = {pre + k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+    xr, cr = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    xo_r, so_r = O.glu_layer_forward(psd, pre, xr, cr, gv.expand(-1, -1, T), 2)
+    ((xo_r * wx).sum() + (so_r * wsk).sum()).backward()
+    xg, cg = x.cuda().requires_grad_(True), c.cuda().requires_grad_(True)
+    xo, so = layer(xg, cg, gv.cuda().expand(-1, -1, T))
+    assert rel_err(xo.detach().cpu(), xo_r.detach()) < 1e-4 and rel_err(so.detach().cpu(), so_r.detach()) < 1e-4
+    ((xo * wx.cuda()).sum() + (so * wsk.cuda()).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-4 and rel_err(cg.grad.cpu(), cr.grad) < 1e-4
+    for k, p_ in layer.named_parameters():
+        assert p_.grad is not None and rel_err(p_.grad.cpu(), psd[pre + k].grad) < 2e-4, k

@@ -26,7 +26,7 @@ def _leaf(root, dotted):
     return m, parts[-1]
 
 
-def register_params(root: nn.Module, geom: P.Geometry, strip: str = ""):
+def register_params(root: nn.Module, geom: P.Geometry, strip: str = "", skip=None):
     """Create nn.Parameters for every entry of packing.param_specs (names relative to ``strip``) with the reference's
     initialisation: kaiming-normal conv weights under weight norm (g = ||v||), zero biases (modules.py:13-19),
     N(0, 0.1) speaker embedding (wavenet.py:143-147, modules.py:21-24), 1/(2s+1) smoothing FIRs (upsample.py:42-44),
@@ -36,6 +36,8 @@ def register_params(root: nn.Module, geom: P.Geometry, strip: str = ""):
         if not name.startswith(strip):
             continue
         rel = name[len(strip):]
+        if skip is not None and skip(rel):
+            continue                # no such parameter in this module: its arena slot stays at zero and is never trained
         t = torch.zeros(shape)
         if rel.endswith("weight_v"):
             if "upsample" in rel:
@@ -69,12 +71,12 @@ def register_params(root: nn.Module, geom: P.Geometry, strip: str = ""):
 class ArenaModel(nn.Module):
     """Base of WaveNet / VQVAE: owns a WaeEngine once the parameters sit on a GPU."""
 
-    def _init_arena(self, geom: P.Geometry, strip: str, dtype="fp32"):
+    def _init_arena(self, geom: P.Geometry, strip: str, dtype="fp32", skip=None):
         self.geom = geom
         self._strip = strip
         self._compute_dtype = dtype
         self._engine = None
-        self._pnames = register_params(self, geom, strip)
+        self._pnames = register_params(self, geom, strip, skip)
 
     def set_compute_dtype(self, dtype: str):
         """'fp32' (exact, default), 'bf16' or 'fp16' (16-bit storage of activations and packed weights, fp32 accumulate)."""

@@ -65,8 +65,8 @@ class ResidualConv1dGLU(ArenaModel):
     """x' , s = layer(x, c, g):  z = conv_dilated(x) + conv1x1c(c) + conv1x1g(g); u = tanh(z_a) * sigmoid(z_b);
     s = conv1x1_skip(u); x' = (conv1x1_out(u) + x) * sqrt(.5)   (modules.py:115-163).
 
-    Same constructor as the reference (modules.py:71-75).  Supported: causal=True, bias=True (what the reference's WaveNet builds,
-    wavenet.py:127-134); dropout (modules.py:127-128): the identity in eval mode, in training mode the engine's counter-based mask (one
+    Same constructor as the reference (modules.py:71-75).  Supported: causal=True (what the reference's WaveNet builds,
+    wavenet.py:127-134), bias=True or False; dropout (modules.py:127-128): the identity in eval mode, in training mode the engine's counter-based mask (one
     seed per forward call; parity against the oracle under the same mask, oracle.wae_oracle.dropout_keep); global features as ONE vector per
     clip (what the reference's WaveNet expands, wavenet.py:185-194: hoisted into a per-clip bias) or -- round 5 -- as any (B, Cg, T) time
     series, with a gradient for g (modules.py:148-152 convolves whatever it is given): the first call that sees a g that varies over
@@ -78,8 +78,10 @@ class ResidualConv1dGLU(ArenaModel):
                  dropout=1 - 0.95, padding=None, dilation=1, causal=True, bias=True, *args, **kwargs):
         super().__init__()
         self.dropout = float(dropout)          # identity in eval mode (modules.py:127-128); the engine's hashed mask in train mode
-        if not causal or not bias:
-            raise NotImplementedError("only the causal, biased layer the reference's WaveNet builds is implemented")
+        if not causal:
+            raise NotImplementedError("only the causal layer the reference's WaveNet builds is implemented (modules.py:82-88: causal=False "
+                                      "pads (kernel_size - 1) // 2 * dilation on both sides)")
+        self.bias = bool(bias)       # modules.py:88-107: bias=False builds conv, conv1x1_out and conv1x1_skip without one
         if padding is not None and padding != (kernel_size - 1) * dilation:
             raise NotImplementedError("padding must be the causal (kernel_size - 1) * dilation")
         if skip_out_channels is None:
@@ -88,7 +90,8 @@ class ResidualConv1dGLU(ArenaModel):
         geom = P.Geometry(layers=1, stacks=1, R=residual_channels, G=gate_channels, S=skip_out_channels, O=2,
                           Cc=cin_channels, Cg=gin_channels, k=kernel_size, n_speakers=None, use_speaker_embedding=False,
                           dilations_override=[dilation])
-        self._init_arena(geom, "wavenet.conv_layers.0.")
+        # (bias=False: the three bias slots of the engine's arena exist, stay at zero and are not parameters of this module)
+        self._init_arena(geom, "wavenet.conv_layers.0.", skip=None if self.bias else (lambda rel: rel.endswith(".bias")))
         self._buf = None
         self._skip_w = None
 
@@ -180,8 +183,10 @@ class ResidualConv1dGLU(ArenaModel):
         so_ = torch.empty(B, gm.S, T, dtype=torch.float32, device=eng.device)
         L.check(lib.wae_from_btc(L.ptr(ws["x"][1]), L.ptr(xo), B, gm.R, T, gm.Rp, eng.dt, st), "from_btc x")
         L.check(lib.wae_from_btc(L.ptr(sbt), L.ptr(so_), B, gm.S, T, gm.Sp, eng.dt, st), "from_btc s")
-        bias = dict(self.named_parameters())["conv1x1_skip.bias"].detach().float()
         self._keep = (sbt, gvec, seed)
+        if not self.bias:
+            return xo, so_
+        bias = dict(self.named_parameters())["conv1x1_skip.bias"].detach().float()
         return xo, so_ + bias.view(1, -1, 1)
 
     # ------------------------------------------------------------------ reference API
