@@ -239,3 +239,39 @@ def test_long_decode_40960_steps_against_the_oracle(monkeypatch):
     a = decode("bf16", "1", mode="sample", uniforms=uni)["idx"].cpu()
     b = decode("bf16", "1", mode="sample", uniforms=uni)["idx"].cpu()
     assert torch.equal(a, b) and int(torch.unique(a).numel()) > 200
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch):
+    """Round 5: the 16-bit fast cooperative kernel keeps the packets of 6 layers in LDS and of 11 more in the accumulation registers,
+    and its 32 members share one history ring (csrc/ar_coop.hip: LDSW).  Where a layer's packets live is not arithmetic: a sampled
+    decode at the C4 geometry (20 layers, dilations to 512, T = 1500: the rings of the wide layers wrap) must be BITWISE the decode of the
+    streaming form (WAE_AR_LDS_LAYERS=0: no resident layer, private rings), for every split of the layers between LDS, registers and
+    memory; teacher-forced logits likewise."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5], cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=7, with_encoder=False)
+    T = 1280 + 640
+    gen = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 64, T // 640, generator=gen).cuda()
+    gid = torch.tensor([3, 77]).cuda()
+    uni = torch.rand(2, T, generator=gen).cuda()
+    forced = torch.randint(0, 256, (2, T), generator=gen).cuda()
+    got = {}
+    for tag, env in (("stream", {"WAE_AR_LDS_LAYERS": "0"}), ("default", {}), ("lds3", {"WAE_AR_LDS_LAYERS": "3", "WAE_AR_BANK_LAYERS": "0"}),
+                     ("lds2+bank5", {"WAE_AR_LDS_LAYERS": "2", "WAE_AR_BANK_LAYERS": "5"})):
+        for k in ("WAE_AR_LDS_LAYERS", "WAE_AR_BANK_LAYERS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        a = eng.incremental_forward(lat, gid, T, mode="sample", uniforms=uni)["idx"].clone()
+        b_ = eng.incremental_forward(lat, gid, T, mode="logits", test_inputs=forced, want_logits=True)["logits"].clone()
+        torch.cuda.synchronize()
+        got[tag] = (a, b_)
+    assert len(torch.unique(got["stream"][0])) > 50
+    for tag in ("default", "lds3", "lds2+bank5"):
+        assert torch.equal(got["stream"][0], got[tag][0]), tag
+        assert torch.equal(got["stream"][1], got[tag][1]), tag

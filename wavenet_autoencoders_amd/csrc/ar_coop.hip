@@ -27,6 +27,8 @@
 #define ARC_ACC_FLOATS(R, S, O) (4 * ((S) + (O)) + 4 * ARC_CMAX * ((R) + (S)) + 4 * ((R) + (S)) + 4 * ARC_CMAX * (R) + 32)
 
 struct ArcArgs {
+  int nlds;               // layers whose packets the fast 16-bit kernel keeps in LDS (0: none)
+  int nbank;              // ... and in the accumulation registers (the layers behind those; at most ARC_NBANK)
   int dtype, B, T, L, R, G, S, O, Cc, Ccp, Hp, ktaps, mode, Rp, C;
   float scale;
   const int32_t* dil;
@@ -942,8 +944,55 @@ __device__ __forceinline__ void arc_packet_fma(const f32x4& raw, const float* v,
   }
 }
 
-template <typename E, int NU, bool FUSED>
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+// ---- a layer's per-thread packets in the accumulation registers (round 5) -----------------------------------------------------------
+// The fast kernel runs one wave per SIMD and needs ~150 of the SIMD's 512 registers per lane; hipcc uses no AGPR in it.  a[0:252] hold
+// the packets of up to ARC_NBANK layers for the whole clip: 23 registers per layer and thread (16 of W1, 2 + 2 of the W_out / W_skip
+// shares, zb_a, zb_g, b_out), written once and read back by v_accvgpr_read -- the register index is part of the instruction text, so a
+// layer is a case of a switch (23 instructions each) and the layer loop stays rolled.  (Round 3 let the compiler keep every layer's
+// packets: 20 unrolled layers, 512 registers + 138 spilled to scratch, 18 against 23 kHz.)  Only "a255" is named as a clobber: it sizes
+// the kernel's AGPR file; nothing the compiler generates touches an AGPR (checked in the ISA: tools/check_asm_all.sh).
+#define ARC_NBANK 11
+#define ARC_NB 23
+#define ARC_BANK_WR(K)                                                                                                                 \
+  asm volatile("v_accvgpr_write_b32 a[23*" #K "+0], %0\n\tv_accvgpr_write_b32 a[23*" #K "+1], %1\n\tv_accvgpr_write_b32 a[23*" #K "+2], %2\n\t" \
+               "v_accvgpr_write_b32 a[23*" #K "+3], %3\n\tv_accvgpr_write_b32 a[23*" #K "+4], %4\n\tv_accvgpr_write_b32 a[23*" #K "+5], %5\n\t" \
+               "v_accvgpr_write_b32 a[23*" #K "+6], %6\n\tv_accvgpr_write_b32 a[23*" #K "+7], %7\n\tv_accvgpr_write_b32 a[23*" #K "+8], %8\n\t" \
+               "v_accvgpr_write_b32 a[23*" #K "+9], %9\n\tv_accvgpr_write_b32 a[23*" #K "+10], %10\n\tv_accvgpr_write_b32 a[23*" #K "+11], %11\n\t" \
+               "v_accvgpr_write_b32 a[23*" #K "+12], %12\n\tv_accvgpr_write_b32 a[23*" #K "+13], %13\n\tv_accvgpr_write_b32 a[23*" #K "+14], %14\n\t" \
+               "v_accvgpr_write_b32 a[23*" #K "+15], %15\n\tv_accvgpr_write_b32 a[23*" #K "+16], %16\n\tv_accvgpr_write_b32 a[23*" #K "+17], %17\n\t" \
+               "v_accvgpr_write_b32 a[23*" #K "+18], %18\n\tv_accvgpr_write_b32 a[23*" #K "+19], %19\n\tv_accvgpr_write_b32 a[23*" #K "+20], %20\n\t" \
+               "v_accvgpr_write_b32 a[23*" #K "+21], %21\n\tv_accvgpr_write_b32 a[23*" #K "+22], %22"                                \
+               :                                                                                                                      \
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]),    \
+                 "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]),    \
+                 "v"(v[21]), "v"(v[22])                                                                                               \
+               : "a255")
+#define ARC_BANK_RD(K)                                                                                                                 \
+  asm volatile("v_accvgpr_read_b32 %0, a[23*" #K "+0]\n\tv_accvgpr_read_b32 %1, a[23*" #K "+1]\n\tv_accvgpr_read_b32 %2, a[23*" #K "+2]\n\t"   \
+               "v_accvgpr_read_b32 %3, a[23*" #K "+3]\n\tv_accvgpr_read_b32 %4, a[23*" #K "+4]\n\tv_accvgpr_read_b32 %5, a[23*" #K "+5]\n\t"   \
+               "v_accvgpr_read_b32 %6, a[23*" #K "+6]\n\tv_accvgpr_read_b32 %7, a[23*" #K "+7]\n\tv_accvgpr_read_b32 %8, a[23*" #K "+8]\n\t"   \
+               "v_accvgpr_read_b32 %9, a[23*" #K "+9]\n\tv_accvgpr_read_b32 %10, a[23*" #K "+10]\n\tv_accvgpr_read_b32 %11, a[23*" #K "+11]\n\t" \
+               "v_accvgpr_read_b32 %12, a[23*" #K "+12]\n\tv_accvgpr_read_b32 %13, a[23*" #K "+13]\n\tv_accvgpr_read_b32 %14, a[23*" #K "+14]\n\t" \
+               "v_accvgpr_read_b32 %15, a[23*" #K "+15]\n\tv_accvgpr_read_b32 %16, a[23*" #K "+16]\n\tv_accvgpr_read_b32 %17, a[23*" #K "+17]\n\t" \
+               "v_accvgpr_read_b32 %18, a[23*" #K "+18]\n\tv_accvgpr_read_b32 %19, a[23*" #K "+19]\n\tv_accvgpr_read_b32 %20, a[23*" #K "+20]\n\t" \
+               "v_accvgpr_read_b32 %21, a[23*" #K "+21]\n\tv_accvgpr_read_b32 %22, a[23*" #K "+22]"                                  \
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]), "=v"(v[8]), "=v"(v[9]),     \
+                 "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15]), "=v"(v[16]), "=v"(v[17]), "=v"(v[18]),    \
+                 "=v"(v[19]), "=v"(v[20]), "=v"(v[21]), "=v"(v[22])                                                                   \
+               :                                                                                                                      \
+               : "a255")
+#define ARC_BANK_CASES(OP) \
+  case 0: OP(0); break; case 1: OP(1); break; case 2: OP(2); break; case 3: OP(3); break; case 4: OP(4); break; case 5: OP(5); break; \
+  case 6: OP(6); break; case 7: OP(7); break; case 8: OP(8); break; case 9: OP(9); break; default: OP(10); break;
+__device__ __forceinline__ void arc_bank_write(int k, const float (&v)[ARC_NB]) { switch (k) { ARC_BANK_CASES(ARC_BANK_WR) } }
+__device__ __forceinline__ void arc_bank_read(int k, float (&v)[ARC_NB]) { switch (k) { ARC_BANK_CASES(ARC_BANK_RD) } }
+// LDSW (16-bit, two hand-overs per layer; round 5): the packets of the first p.nlds layers -- per thread NU W1 packets, its W_out / W_skip
+// shares and three scalars, (NU + 2) x 16 bytes -- live in LDS for the whole clip.  A layer whose weights are there issues no request
+// that can miss L2, so nothing sits in front of its exchange polls in the wave's in-order queue.
+template <typename E, int NU, bool FUSED, bool LDSW = false>
 __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
+  static_assert(!LDSW || (!FUSED && ET<E>::EPL == 8), "LDS-resident layers: the 16-bit two-hand-over kernel");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int EPL = ET<E>::EPL, R = 256, S = 256, O = 256, H = 128, C = 32, NCH = 4;
   constexpr int G_PAD = 256, W_PAD = 512, S_PAD = 256, O_PAD = 256;
@@ -968,16 +1017,28 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   int* ldil = (int*)(ltab + L + 1);
   int* lroff = ldil + L;
   int* lpos = lroff + L;                  // current row of every ring = t mod (2d + 1)
+  // LDSW: [layer][slot][thread][16 B]; slots 0 .. NU-1 = W1 packets, NU = {W_out share | W_skip share}, NU + 1 = {zb_a, zb_g, b_out, -}
+  [[maybe_unused]] char* wl0 = (char*)(((uintptr_t)(lpos + L) + 15) & ~(uintptr_t)15);
+  constexpr int PWL = (NU + 2) * 16 * ARC_THREADS;    // bytes per resident layer
+  const int nlds = LDSW ? p.nlds : 0;
+  const int nbank = (LDSW && NU == 4) ? min(max(L - nlds, 0), p.nbank) : 0;     // layers [nlds, nlds + nbank): packets in a[0:252]
 
-  float* ring = p.ring + ((int64_t)b * C + m) * p.ring_total;
+  // Round 5: ONE ring per utterance (member 0's region), shared by its 32 members, instead of 32 private copies.  Every member still
+  // writes every row -- the same bits (the exchange is bitwise reproducible), to the same addresses -- so a member's own cache can
+  // never hold a line older than its own write, and any copy it reads is some member's write of the same sample: no ordering
+  // between members is needed.  What changes is the footprint: 4.2 MB per utterance instead of 135 MB, i.e. the history rows of a
+  // sample are L2 hits (an XCD's L2 holds 4 MB) once the weights no longer stream through it.
+  float* ring = p.ring + ((int64_t)b * C + (LDSW ? 0 : m)) * p.ring_total;
   unsigned long long* msg_b = p.msg + (int64_t)b * 2 * C * p.NV;
   for (int i = tid; i < 32 + K1p + 2 * S; i += ARC_THREADS) sm[i] = 0.f;
   if (tid == 0) { ibuf[0] = p.n_forced > 0 ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
   for (int i = tid; i < L; i += ARC_THREADS) { ldil[i] = p.dil[i]; lroff[i] = (int)p.ring_off[i]; lpos[i] = 0; }
   {
+    // (shared ring: member m zeroes its 32nd; the members meet in the XCC-id gather below before anyone reads a row)
+    const int64_t n4 = p.ring_total / 4, lo4 = LDSW ? n4 * m / C : 0, hi4 = LDSW ? n4 * (m + 1) / C : n4;
     f32x4* r4 = (f32x4*)ring;
-    for (int64_t i = tid; i < p.ring_total / 4; i += ARC_THREADS) r4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t i = p.ring_total / 4 * 4 + tid; i < p.ring_total; i += ARC_THREADS) ring[i] = 0.f;
+    for (int64_t i = lo4 + tid; i < hi4; i += ARC_THREADS) r4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = n4 * 4 + tid; i < p.ring_total; i += ARC_THREADS) ring[i] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   arc_barrier();
@@ -1036,6 +1097,36 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   float zb_a, zb_g, b2_x, h0 = 0.f, h1 = 0.f;
   int4 te;                                                                // ltab entry of the layer whose taps are being fetched
   auto prefetch = [&](int l, int tab) {                                   // layer l's weights and scalars; ring rows of ltab[tab]
+    if constexpr (LDSW) {
+      if (l < nlds) {                                                     // resident: LDS reads, no request that could miss L2
+        const char* q = wl0 + (size_t)l * PWL + tid * 16;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) w1n[u] = *(const f32x4*)(q + u * 16 * ARC_THREADS);
+        const f32x4 w2 = *(const f32x4*)(q + NU * 16 * ARC_THREADS), sc = *(const f32x4*)(q + (NU + 1) * 16 * ARC_THREADS);
+        wxr = __builtin_bit_cast(typename W2::raw, f32x2_{w2.x, w2.y});
+        wsr = __builtin_bit_cast(typename W2::raw, f32x2_{w2.z, w2.w});
+        zb_a = sc.x; zb_g = sc.y; b2_x = sc.z;
+        te = ltab[tab];
+        h0 = ring[(unsigned)(te.x + tid)];
+        h1 = ring[(unsigned)(te.y + tid)];
+        return;
+      }
+      if constexpr (NU == 4) {
+        if (l - nlds < nbank) {                                           // resident in the accumulation registers
+          float v[ARC_NB];
+          arc_bank_read(l - nlds, v);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) w1n[u] = f32x4{v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]};
+          wxr = __builtin_bit_cast(typename W2::raw, f32x2_{v[16], v[17]});
+          wsr = __builtin_bit_cast(typename W2::raw, f32x2_{v[18], v[19]});
+          zb_a = v[20]; zb_g = v[21]; b2_x = v[22];
+          te = ltab[tab];
+          h0 = ring[(unsigned)(te.x + tid)];
+          h1 = ring[(unsigned)(te.y + tid)];
+          return;
+        }
+      }
+    }
     const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
 #pragma unroll
     for (int u = 0; u < NU; ++u) w1n[u] = *(const f32x4*)(wl + w1off[u]);
@@ -1067,6 +1158,36 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   };
   float creg = tid < Cc ? c_load(0) : 0.f;
   const float fbias = p.first_bias[tid];
+  if constexpr (LDSW) {
+    for (int l = 0; l < nlds; ++l) {       // once per clip: what prefetch() fetches per layer and sample
+      const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
+      char* q = wl0 + (size_t)l * PWL + tid * 16;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) *(f32x4*)(q + u * 16 * ARC_THREADS) = *(const f32x4*)(wl + w1off[u]);
+      const f32x2_ wx2 = *(const f32x2_*)(wl + p.w2_off + w2xoff), ws2 = *(const f32x2_*)(wl + p.w2_off + w2soff);
+      *(f32x4*)(q + NU * 16 * ARC_THREADS) = f32x4{wx2.x, wx2.y, ws2.x, ws2.y};
+      const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
+      *(f32x4*)(q + (NU + 1) * 16 * ARC_THREADS) = f32x4{zbl[gch], zbl[p.Hp + gch], p.bias2[(int64_t)l * (R + S) + tid], 0.f};
+    }
+    if constexpr (NU == 4) {
+      for (int k = 0; k < nbank; ++k) {
+        const int l = nlds + k;
+        const char* wl = p.w_layers + (int64_t)l * p.layer_stride;
+        float v[ARC_NB];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const f32x4 w = *(const f32x4*)(wl + w1off[u]);
+          v[4 * u] = w.x; v[4 * u + 1] = w.y; v[4 * u + 2] = w.z; v[4 * u + 3] = w.w;
+        }
+        const f32x2_ wx2 = *(const f32x2_*)(wl + p.w2_off + w2xoff), ws2 = *(const f32x2_*)(wl + p.w2_off + w2soff);
+        v[16] = wx2.x; v[17] = wx2.y; v[18] = ws2.x; v[19] = ws2.y;
+        const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
+        v[20] = zbl[gch]; v[21] = zbl[p.Hp + gch]; v[22] = p.bias2[(int64_t)l * (R + S) + tid];
+        arc_bank_write(k, v);
+      }
+    }
+    arc_barrier();
+  }
   prefetch(0, 0);
   arc_barrier();      // ltab
   // Only the current tap of a layer's operand depends on the sample being computed: the packets of the two history taps and of the
@@ -1373,16 +1494,31 @@ static void launch_arc_fast(const ArcArgs& a, size_t lds, hipStream_t st) {
   if (a.w_fused) {
     (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, true>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, false>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+    return;
   }
+  if constexpr (sizeof(E) == 2) {
+    if (a.nlds > 0) {
+      (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, false, true>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+      return;
+    }
+  }
+  (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, false>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
 }
 
-// WAE_AR_COOP_GENERIC=1 in the environment: the any-shape kernel also on the reference's geometry (A/B, tests)
 static int flags_env() {
   const char* e = getenv("WAE_AR_COOP_GENERIC");
   return e && e[0] == '1' ? 1 : 0;
+}
+static int nlds_env(int dflt) {     // debugging aid: WAE_AR_LDS_LAYERS=n overrides the number of LDS-resident layers (0: none)
+  const char* e = getenv("WAE_AR_LDS_LAYERS");
+  return e ? atoi(e) : dflt;
+}
+static int nbank_env(int dflt) {    // ... WAE_AR_BANK_LAYERS=n the number of layers kept in the accumulation registers (0 .. ARC_NBANK)
+  const char* e = getenv("WAE_AR_BANK_LAYERS");
+  const int v = e ? atoi(e) : dflt;
+  return v < 0 ? 0 : (v > ARC_NBANK ? ARC_NBANK : v);
 }
 
 extern "C" int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d) {
@@ -1428,6 +1564,8 @@ static int ar_generate_coop_impl(const wae_ar_desc* d, int32_t C, const int32_t*
   a.layer_stride = layer_stride_bytes; a.w2_off = w2_off_bytes; a.bias2 = bias2; a.zb = zb; a.first_tab = first_tab;
   a.first_bias = first_bias; a.w_head = (const char*)w_head; a.head_bias = head_bias; a.c_up = (const char*)c_up;
   a.w_fused = nullptr;
+  a.nlds = 0;
+  a.nbank = 0;
   a.c_dtype = c_dtype; a.inputs = inputs; a.init_idx = d->init_idx; a.uniforms = uniforms; a.out_idx = out_idx;
   a.n_forced = inputs ? (d->n_forced > 0 && d->n_forced < d->T ? d->n_forced : d->T) : 0;
   a.out_logits = out_logits; a.msg = (unsigned long long*)msg; a.NV = hc > sc ? hc : sc; a.acc = acc; a.error = error;
@@ -1444,7 +1582,19 @@ static int ar_generate_coop_impl(const wae_ar_desc* d, int32_t C, const int32_t*
                           ring_total % 4 == 0 && !(flags_env() & 1);
   if (fast_shape) {
     a.w_fused = d->L >= 2 ? (const char*)w_fused : nullptr;     // the one-hand-over-per-layer kernel (else: ar_coop_fast_kernel's two)
-    const size_t lds_f = sizeof(float) * (size_t)(32 + 4 * nu * 32 * epl / 4 + 4 * 256 + 8 + 4 * (d->L + 1) + 3 * d->L + epl);
+    size_t lds_f = sizeof(float) * (size_t)(32 + 4 * nu * 32 * epl / 4 + 4 * 256 + 8 + 4 * (d->L + 1) + 3 * d->L + epl);
+    // LDS-resident layers (16-bit, two hand-overs per layer): (nu + 2) x 16 B x 256 threads per layer behind the kernel's own arrays
+    a.nlds = 0;
+    if (wae_is16(d->dtype) && a.w_fused == nullptr) {
+      const size_t per = (size_t)(nu + 2) * 16 * ARC_THREADS;
+      int fit = (int)((160 * 1024 - lds_f - 64) / per);
+      a.nlds = nlds_env(fit);
+      if (a.nlds > fit) a.nlds = fit;
+      if (a.nlds > d->L) a.nlds = d->L;
+      if (a.nlds < 0) a.nlds = 0;
+      lds_f += 64 + per * a.nlds;
+      a.nbank = a.nlds > 0 ? nbank_env(ARC_NBANK) : 0;      // (the register bank belongs to the LDS-resident instantiation)
+    }
     bool done = true;
     if (d->dtype == WAE_BF16 && nu == 3) launch_arc_fast<__bf16, 3>(a, lds_f, st);
     else if (d->dtype == WAE_BF16 && nu == 4) launch_arc_fast<__bf16, 4>(a, lds_f, st);
