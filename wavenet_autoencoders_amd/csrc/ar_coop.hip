@@ -1027,15 +1027,16 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   // writes every row -- the same bits (the exchange is bitwise reproducible), to the same addresses -- so a member's own cache can
   // never hold a line older than its own write, and any copy it reads is some member's write of the same sample: no ordering
   // between members is needed.  What changes is the footprint: 4.2 MB per utterance instead of 135 MB, i.e. the history rows of a
-  // sample are L2 hits (an XCD's L2 holds 4 MB) once the weights no longer stream through it.
-  float* ring = p.ring + ((int64_t)b * C + (LDSW ? 0 : m)) * p.ring_total;
+  // sample are L2 hits (an XCD's L2 holds 4 MB) once the weights no longer stream through it.  (Every instantiation of this kernel:
+  // fp32 and the one-hand-over form too.)
+  float* ring = p.ring + (int64_t)b * C * p.ring_total;
   unsigned long long* msg_b = p.msg + (int64_t)b * 2 * C * p.NV;
   for (int i = tid; i < 32 + K1p + 2 * S; i += ARC_THREADS) sm[i] = 0.f;
   if (tid == 0) { ibuf[0] = p.n_forced > 0 ? p.inputs[(int64_t)b * p.T] : p.init_idx; ibuf[1] = 0; }
   for (int i = tid; i < L; i += ARC_THREADS) { ldil[i] = p.dil[i]; lroff[i] = (int)p.ring_off[i]; lpos[i] = 0; }
   {
     // (shared ring: member m zeroes its 32nd; the members meet in the XCC-id gather below before anyone reads a row)
-    const int64_t n4 = p.ring_total / 4, lo4 = LDSW ? n4 * m / C : 0, hi4 = LDSW ? n4 * (m + 1) / C : n4;
+    const int64_t n4 = p.ring_total / 4, lo4 = n4 * m / C, hi4 = n4 * (m + 1) / C;
     f32x4* r4 = (f32x4*)ring;
     for (int64_t i = lo4 + tid; i < hi4; i += ARC_THREADS) r4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int64_t i = n4 * 4 + tid; i < p.ring_total; i += ARC_THREADS) ring[i] = 0.f;
