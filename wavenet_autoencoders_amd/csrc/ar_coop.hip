@@ -992,7 +992,7 @@ __device__ __forceinline__ void arc_bank_read(int k, float (&v)[ARC_NB]) { switc
 // that can miss L2, so nothing sits in front of its exchange polls in the wave's in-order queue.
 template <typename E, int NU, bool FUSED, bool LDSW = false>
 __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
-  static_assert(!LDSW || (!FUSED && ET<E>::EPL == 8), "LDS-resident layers: the 16-bit two-hand-over kernel");
+  static_assert(!LDSW || ET<E>::EPL == 8, "LDS-resident layers: the 16-bit kernels");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int EPL = ET<E>::EPL, R = 256, S = 256, O = 256, H = 128, C = 32, NCH = 4;
   constexpr int G_PAD = 256, W_PAD = 512, S_PAD = 256, O_PAD = 256;
@@ -1493,6 +1493,13 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
 template <typename E, int NU>
 static void launch_arc_fast(const ArcArgs& a, size_t lds, hipStream_t st) {
   if (a.w_fused) {
+    if constexpr (sizeof(E) == 2) {
+      if (a.nlds > 0) {
+        (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, true, true>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+        return;
+      }
+    }
     (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, true>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
     return;
@@ -1586,7 +1593,7 @@ static int ar_generate_coop_impl(const wae_ar_desc* d, int32_t C, const int32_t*
     size_t lds_f = sizeof(float) * (size_t)(32 + 4 * nu * 32 * epl / 4 + 4 * 256 + 8 + 4 * (d->L + 1) + 3 * d->L + epl);
     // LDS-resident layers (16-bit, two hand-overs per layer): (nu + 2) x 16 B x 256 threads per layer behind the kernel's own arrays
     a.nlds = 0;
-    if (wae_is16(d->dtype) && a.w_fused == nullptr) {
+    if (wae_is16(d->dtype)) {
       const size_t per = (size_t)(nu + 2) * 16 * ARC_THREADS;
       int fit = (int)((160 * 1024 - lds_f - 64) / per);
       a.nlds = nlds_env(fit);
