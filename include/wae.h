@@ -523,10 +523,14 @@ typedef struct wae_tq_job {
  * requests no more than `window` slabs beyond the slowest other tap member, so that the dz half-slabs four jobs of a layer share
  * are fetched from HBM once and found in the XCD's L2 by the others (window_cond: the bound of the COND member; negative = it stays
  * that many slabs behind the slowest tap).  Timing only: results do not depend on it, and a wait that
- * does not end switches it off. */
+ * does not end switches it off.
+ * max_clip_bytes: the caller's statement of the largest operand clip of the job table, (T + the largest |shift| + 32) rows x the
+ * widest p / q row in bytes; refused (WAE_EINVAL) at 2^30 or more, because rows outside a clip are zero-filled by the range check
+ * of a per-clip buffer descriptor with 32-bit offsets. */
 int wae_gemm_tn_static(int32_t dtype /* WAE_BF16 or WAE_F16 */, const wae_tq_job* jobs_dev, const wae_ts_seg* segs_dev,
                        const int32_t* team_seg_dev, int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T,
-                       int64_t* stamps, uint32_t* pace, int32_t window, int32_t window_cond, int32_t ntaps, void* stream);
+                       int64_t* stamps, uint32_t* pace, int32_t window, int32_t window_cond, int32_t ntaps, int64_t max_clip_bytes,
+                       void* stream);
 
 /* ---- backward of the front end (csrc/frontend_bwd.hip) -----------------------------------------------------
  * upsample stage: dout (B,C,Tin*s), in (B,C,Tin) -> din (B,C,Tin), dw[2s+1] += (atomics).

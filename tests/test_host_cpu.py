@@ -29,6 +29,17 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().wae_version()
 
 
+def test_static_weight_gradient_launch_refuses_clips_its_descriptors_cannot_zero_fill():
+    """Round-4 advisor finding: the C entry itself checks the 2^30-byte bound of the per-clip buffer descriptors (argument check only:
+    it returns before any HIP call, so it runs without a GPU)."""
+    from wavenet_autoencoders_amd import _lib
+    lib = _lib.lib()
+    dummy = ctypes.c_void_p(0x1000)
+    for bad in (0, 1 << 30, 1 << 40):
+        rc = lib.wae_gemm_tn_static(1, dummy, dummy, dummy, 1, 5, 5, 1, 64, None, None, 0, 0, 3, bad, None)
+        assert rc == -1 and b"max_clip_bytes" in lib.wae_last_error()
+
+
 def test_param_layout_matches_reference_state_dict():
     g = P.Geometry.from_cfg(CFG)
     lay = P.ParamLayout(g)

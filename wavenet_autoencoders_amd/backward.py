@@ -268,9 +268,13 @@ def static_tn_shape(eng, B, T):
     (the per-clip buffer descriptors carry 32-bit offsets; rows before a clip wrap to offsets beyond num_records)."""
     g = eng.g
     # bytes per time row of the widest operand array (the head's dy and the first conv's one-hot operand ride in the launch too)
+    return static_tn_geometry(eng) and use_stream_tn(eng) and B <= 32 and static_tn_clip_bytes(g, T) < (1 << 30)
+
+
+def static_tn_clip_bytes(g, T):
+    """The largest operand clip the static launch addresses, in bytes (what wae_gemm_tn_static takes as max_clip_bytes)."""
     widest = max(g.layers * 2 * g.Hp, g.Ku, g.Rp, g.Sp, g.Ccp, g.Op, P._ru(g.O, 128)) * 2
-    reach = T + (g.k - 1) * max(g.dilations) + 32
-    return static_tn_geometry(eng) and use_stream_tn(eng) and B <= 32 and reach * widest < (1 << 30)
+    return (T + (g.k - 1) * max(g.dilations) + 32) * widest
 
 
 def static_head(eng, B, T):
@@ -338,7 +342,8 @@ class StaticStreamTable:
         eng = self.eng
         L.check(eng.lib.wae_gemm_tn_static(eng.dt, L.ptr(self.jobs_dev), L.ptr(self.segs_dev), L.ptr(self.team_seg_dev), self.nteams,
                                            self.team_size, self.nwg, self.B, self.T, L.ptr(self.stamps), L.ptr(self.pace), self.window,
-                                           self.window_cond, self.ntaps, eng.stream()), "gemm_tn_static")
+                                           self.window_cond, self.ntaps, static_tn_clip_bytes(eng.g, self.T), eng.stream()),
+                "gemm_tn_static")
 
 
 def use_stream_tn(eng):

@@ -859,8 +859,12 @@ gemm_tn_static_kernel(TqArgs p) {
 
 extern "C" int wae_gemm_tn_static(int32_t dtype, const wae_tq_job* jobs_dev, const wae_ts_seg* segs_dev, const int32_t* team_seg_dev,
                                   int32_t nteams, int32_t team_size, int32_t nwg, int32_t B, int32_t T, int64_t* stamps, uint32_t* pace,
-                                  int32_t window, int32_t window_cond, int32_t ntaps, void* stream) {
+                                  int32_t window, int32_t window_cond, int32_t ntaps, int64_t max_clip_bytes, void* stream) {
   WAE_REQUIRE(dtype == WAE_BF16 || dtype == WAE_F16, "gemm_tn_static: 16-bit operands only");
+  // the zero fill outside a clip is the buffer descriptor's range check: offsets of rows before / behind a clip must land beyond
+  // num_records and below the TQ_OOB / TQ_DEAD markers, which holds while every operand clip (reach x row bytes) stays below 2^30
+  WAE_REQUIRE(max_clip_bytes > 0 && max_clip_bytes < (1ll << 30),
+              "gemm_tn_static: an operand clip of 2^30 bytes or more (or max_clip_bytes not stated): use wae_gemm_tn_stream");
   WAE_REQUIRE(jobs_dev && segs_dev && team_seg_dev && nteams > 0 && team_size > 0 && nwg >= nteams * team_size && B > 0 && T > 0,
               "gemm_tn_static: bad arguments");
   WAE_REQUIRE(B <= 32, "gemm_tn_static: at most 32 clips per launch (one ones column per clip in one tile)");
