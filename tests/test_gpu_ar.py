@@ -243,8 +243,9 @@ def test_long_decode_40960_steps_against_the_oracle(monkeypatch):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch):
-    """Round 5: the 16-bit fast cooperative kernel keeps the packets of 6 layers in LDS and of 11 more in the accumulation registers,
-    and its 32 members share one history ring (csrc/ar_coop.hip: LDSW).  Where a layer's packets live is not arithmetic: a sampled
+    """Round 5: the 16-bit fast cooperative kernel keeps the packets of 6 layers in LDS, of 11 more in the accumulation registers and
+    of the last 3 in hand-allocated arch VGPRs (ar_coop_fast_vb_kernel: bank slots 11-13), and its 32 members share one history ring
+    (csrc/ar_coop.hip: LDSW).  Where a layer's packets live is not arithmetic: a sampled
     decode at the C4 geometry (20 layers, dilations to 512, T = 1500: the rings of the wide layers wrap) must be BITWISE the decode of the
     streaming form (WAE_AR_LDS_LAYERS=0: no resident layer, private rings), for every split of the layers between LDS, registers and
     memory; teacher-forced logits likewise."""
@@ -260,7 +261,9 @@ def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch
     forced = torch.randint(0, 256, (2, T), generator=gen).cuda()
     got = {}
     for tag, env in (("stream", {"WAE_AR_LDS_LAYERS": "0"}), ("default", {}), ("lds3", {"WAE_AR_LDS_LAYERS": "3", "WAE_AR_BANK_LAYERS": "0"}),
-                     ("lds2+bank5", {"WAE_AR_LDS_LAYERS": "2", "WAE_AR_BANK_LAYERS": "5"})):
+                     ("lds2+bank5", {"WAE_AR_LDS_LAYERS": "2", "WAE_AR_BANK_LAYERS": "5"}),
+                     ("lds6+bank11", {"WAE_AR_BANK_LAYERS": "11"}),            # the instantiation without the arch-VGPR bank
+                     ("lds1+bank13", {"WAE_AR_LDS_LAYERS": "1", "WAE_AR_BANK_LAYERS": "13"})):
         for k in ("WAE_AR_LDS_LAYERS", "WAE_AR_BANK_LAYERS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -272,6 +275,6 @@ def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch
         torch.cuda.synchronize()
         got[tag] = (a, b_)
     assert len(torch.unique(got["stream"][0])) > 50
-    for tag in ("default", "lds3", "lds2+bank5"):
+    for tag in ("default", "lds3", "lds2+bank5", "lds6+bank11", "lds1+bank13"):
         assert torch.equal(got["stream"][0], got[tag][0]), tag
         assert torch.equal(got["stream"][1], got[tag][1]), tag

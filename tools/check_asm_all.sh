@@ -31,6 +31,8 @@ for f in gemm_tn_stream glu_fwd head_fwd gemm_tm head_bwd gemm_tn glu_bwd; do
 done
 } > $DR
 rm -rf $TMP
+# third check: the hand-allocated register banks of the autoregressive kernels (tools/check_ar_banks.py)
+python3 $ROOT/tools/check_ar_banks.py > ${OUT%_load_check.txt}_ar_banks.txt || echo "AR register bank check FAILED"
 grep -c " 0 violation" $OUT | sed 's/$/ kernels clean/'
 grep -c ", 0 scratch" $DR | sed 's/$/ kernels without drains in their asynchronous loops/'
 grep "^_Z" $DR | grep -v ", 0 scratch" | sed 's/: .*loop(s) with asynchronous requests,/:/' | head -20

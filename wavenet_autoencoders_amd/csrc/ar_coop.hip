@@ -985,14 +985,61 @@ typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #define ARC_BANK_CASES(OP) \
   case 0: OP(0); break; case 1: OP(1); break; case 2: OP(2); break; case 3: OP(3); break; case 4: OP(4); break; case 5: OP(5); break; \
   case 6: OP(6); break; case 7: OP(7); break; case 8: OP(8); break; case 9: OP(9); break; default: OP(10); break;
-__device__ __forceinline__ void arc_bank_write(int k, const float (&v)[ARC_NB]) { switch (k) { ARC_BANK_CASES(ARC_BANK_WR) } }
-__device__ __forceinline__ void arc_bank_read(int k, float (&v)[ARC_NB]) { switch (k) { ARC_BANK_CASES(ARC_BANK_RD) } }
+// ... and of ARC_NVB more layers in the arch VGPRs v[187:255] of the instantiation whose compiler-visible registers end at v185
+// (ar_coop_fast_vb_kernel: amdgpu_num_vgpr, the technique of csrc/gemm_tn_static.hip -- hipcc needs ~150 there): bank slots
+// ARC_NBANK .. ARC_NBANK + ARC_NVB - 1.  6 layers in LDS + 11 + 3 = all 20 layers of the reference's decoder.
+#define ARC_NVB 3
+#define ARC_VB0 187
+#define ARC_VREG(K, I) "v[187+23*" #K "+" #I "]"
+#define ARC_VBANK_WR(K)                                                                                                                \
+  asm volatile("v_mov_b32 " ARC_VREG(K, 0) ", %0\n\tv_mov_b32 " ARC_VREG(K, 1) ", %1\n\tv_mov_b32 " ARC_VREG(K, 2) ", %2\n\t"               \
+               "v_mov_b32 " ARC_VREG(K, 3) ", %3\n\tv_mov_b32 " ARC_VREG(K, 4) ", %4\n\tv_mov_b32 " ARC_VREG(K, 5) ", %5\n\t"               \
+               "v_mov_b32 " ARC_VREG(K, 6) ", %6\n\tv_mov_b32 " ARC_VREG(K, 7) ", %7\n\tv_mov_b32 " ARC_VREG(K, 8) ", %8\n\t"               \
+               "v_mov_b32 " ARC_VREG(K, 9) ", %9\n\tv_mov_b32 " ARC_VREG(K, 10) ", %10\n\tv_mov_b32 " ARC_VREG(K, 11) ", %11\n\t"           \
+               "v_mov_b32 " ARC_VREG(K, 12) ", %12\n\tv_mov_b32 " ARC_VREG(K, 13) ", %13\n\tv_mov_b32 " ARC_VREG(K, 14) ", %14\n\t"         \
+               "v_mov_b32 " ARC_VREG(K, 15) ", %15\n\tv_mov_b32 " ARC_VREG(K, 16) ", %16\n\tv_mov_b32 " ARC_VREG(K, 17) ", %17\n\t"         \
+               "v_mov_b32 " ARC_VREG(K, 18) ", %18\n\tv_mov_b32 " ARC_VREG(K, 19) ", %19\n\tv_mov_b32 " ARC_VREG(K, 20) ", %20\n\t"         \
+               "v_mov_b32 " ARC_VREG(K, 21) ", %21\n\tv_mov_b32 " ARC_VREG(K, 22) ", %22"                                              \
+               :                                                                                                                      \
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]),    \
+                 "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]),    \
+                 "v"(v[21]), "v"(v[22])                                                                                               \
+               : "v255")
+#define ARC_VBANK_RD(K)                                                                                                                \
+  asm volatile("v_mov_b32 %0, " ARC_VREG(K, 0) "\n\tv_mov_b32 %1, " ARC_VREG(K, 1) "\n\tv_mov_b32 %2, " ARC_VREG(K, 2) "\n\t"               \
+               "v_mov_b32 %3, " ARC_VREG(K, 3) "\n\tv_mov_b32 %4, " ARC_VREG(K, 4) "\n\tv_mov_b32 %5, " ARC_VREG(K, 5) "\n\t"               \
+               "v_mov_b32 %6, " ARC_VREG(K, 6) "\n\tv_mov_b32 %7, " ARC_VREG(K, 7) "\n\tv_mov_b32 %8, " ARC_VREG(K, 8) "\n\t"               \
+               "v_mov_b32 %9, " ARC_VREG(K, 9) "\n\tv_mov_b32 %10, " ARC_VREG(K, 10) "\n\tv_mov_b32 %11, " ARC_VREG(K, 11) "\n\t"           \
+               "v_mov_b32 %12, " ARC_VREG(K, 12) "\n\tv_mov_b32 %13, " ARC_VREG(K, 13) "\n\tv_mov_b32 %14, " ARC_VREG(K, 14) "\n\t"         \
+               "v_mov_b32 %15, " ARC_VREG(K, 15) "\n\tv_mov_b32 %16, " ARC_VREG(K, 16) "\n\tv_mov_b32 %17, " ARC_VREG(K, 17) "\n\t"         \
+               "v_mov_b32 %18, " ARC_VREG(K, 18) "\n\tv_mov_b32 %19, " ARC_VREG(K, 19) "\n\tv_mov_b32 %20, " ARC_VREG(K, 20) "\n\t"         \
+               "v_mov_b32 %21, " ARC_VREG(K, 21) "\n\tv_mov_b32 %22, " ARC_VREG(K, 22)                                                 \
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]), "=v"(v[8]), "=v"(v[9]),     \
+                 "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15]), "=v"(v[16]), "=v"(v[17]), "=v"(v[18]),    \
+                 "=v"(v[19]), "=v"(v[20]), "=v"(v[21]), "=v"(v[22])                                                                   \
+               :                                                                                                                      \
+               : "v255")
+#define ARC_BANK_CASES_A(OP) \
+  case 0: OP(0); break; case 1: OP(1); break; case 2: OP(2); break; case 3: OP(3); break; case 4: OP(4); break; case 5: OP(5); break; \
+  case 6: OP(6); break; case 7: OP(7); break; case 8: OP(8); break; case 9: OP(9); break; case 10: OP(10); break;
+#define ARC_BANK_CASES_V(OP) case 11: OP(0); break; case 12: OP(1); break; default: OP(2); break;
+template <bool VB>
+__device__ __forceinline__ void arc_bank_write(int k, const float (&v)[ARC_NB]) {
+  if constexpr (VB) { switch (k) { ARC_BANK_CASES_A(ARC_BANK_WR) ARC_BANK_CASES_V(ARC_VBANK_WR) } }
+  else { switch (k) { ARC_BANK_CASES(ARC_BANK_WR) } }
+}
+template <bool VB>
+__device__ __forceinline__ void arc_bank_read(int k, float (&v)[ARC_NB]) {
+  if constexpr (VB) { switch (k) { ARC_BANK_CASES_A(ARC_BANK_RD) ARC_BANK_CASES_V(ARC_VBANK_RD) } }
+  else { switch (k) { ARC_BANK_CASES(ARC_BANK_RD) } }
+}
 // LDSW (16-bit, two hand-overs per layer; round 5): the packets of the first p.nlds layers -- per thread NU W1 packets, its W_out / W_skip
 // shares and three scalars, (NU + 2) x 16 bytes -- live in LDS for the whole clip.  A layer whose weights are there issues no request
 // that can miss L2, so nothing sits in front of its exchange polls in the wave's in-order queue.
-template <typename E, int NU, bool FUSED, bool LDSW = false>
-__global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
+template <typename E, int NU, bool FUSED, bool LDSW, bool VB>
+__device__ __forceinline__ void ar_coop_fast_body(const ArcArgs& p) {
   static_assert(!LDSW || ET<E>::EPL == 8, "LDS-resident layers: the 16-bit kernels");
+  static_assert(!VB || (LDSW && NU == 4 && !FUSED), "the arch-VGPR bank belongs to ar_coop_fast_vb_kernel");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int EPL = ET<E>::EPL, R = 256, S = 256, O = 256, H = 128, C = 32, NCH = 4;
   constexpr int G_PAD = 256, W_PAD = 512, S_PAD = 256, O_PAD = 256;
@@ -1021,7 +1068,8 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
   [[maybe_unused]] char* wl0 = (char*)(((uintptr_t)(lpos + L) + 15) & ~(uintptr_t)15);
   constexpr int PWL = (NU + 2) * 16 * ARC_THREADS;    // bytes per resident layer
   const int nlds = LDSW ? p.nlds : 0;
-  const int nbank = (LDSW && NU == 4) ? min(max(L - nlds, 0), p.nbank) : 0;     // layers [nlds, nlds + nbank): packets in a[0:252]
+  // layers [nlds, nlds + nbank): packets in a[0:252] (and, VB, v[187:255])
+  const int nbank = (LDSW && NU == 4) ? min(max(L - nlds, 0), min(p.nbank, ARC_NBANK + (VB ? ARC_NVB : 0))) : 0;
 
   // Round 5: ONE ring per utterance (member 0's region), shared by its 32 members, instead of 32 private copies.  Every member still
   // writes every row -- the same bits (the exchange is bitwise reproducible), to the same addresses -- so a member's own cache can
@@ -1115,7 +1163,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
       if constexpr (NU == 4) {
         if (l - nlds < nbank) {                                           // resident in the accumulation registers
           float v[ARC_NB];
-          arc_bank_read(l - nlds, v);
+          arc_bank_read<VB>(l - nlds, v);
 #pragma unroll
           for (int u = 0; u < NU; ++u) w1n[u] = f32x4{v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]};
           wxr = __builtin_bit_cast(typename W2::raw, f32x2_{v[16], v[17]});
@@ -1184,7 +1232,7 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
         v[16] = wx2.x; v[17] = wx2.y; v[18] = ws2.x; v[19] = ws2.y;
         const float* zbl = zb_b + (int64_t)l * 2 * p.Hp;
         v[20] = zbl[gch]; v[21] = zbl[p.Hp + gch]; v[22] = p.bias2[(int64_t)l * (R + S) + tid];
-        arc_bank_write(k, v);
+        arc_bank_write<VB>(k, v);
       }
     }
     arc_barrier();
@@ -1490,6 +1538,17 @@ __global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
 #endif
 }
 
+template <typename E, int NU, bool FUSED, bool LDSW = false>
+__global__ void __launch_bounds__(ARC_THREADS) ar_coop_fast_kernel(ArcArgs p) {
+  ar_coop_fast_body<E, NU, FUSED, LDSW, false>(p);
+}
+// the resident form of the reference's geometry in 16-bit storage (NU = 4, two hand-overs): hipcc's registers end at v185
+// (amdgpu_num_vgpr counts in units of two on gfx950), v[187:255] are the hand-allocated bank of ARC_NVB more layers
+template <typename E>
+__global__ void __launch_bounds__(ARC_THREADS) __attribute__((amdgpu_num_vgpr(186))) ar_coop_fast_vb_kernel(ArcArgs p) {
+  ar_coop_fast_body<E, 4, false, true, true>(p);
+}
+
 template <typename E, int NU>
 static void launch_arc_fast(const ArcArgs& a, size_t lds, hipStream_t st) {
   if (a.w_fused) {
@@ -1503,6 +1562,13 @@ static void launch_arc_fast(const ArcArgs& a, size_t lds, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)ar_coop_fast_kernel<E, NU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, true>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
     return;
+  }
+  if constexpr (sizeof(E) == 2 && NU == 4) {
+    if (a.nlds > 0 && a.nbank > ARC_NBANK) {
+      (void)hipFuncSetAttribute((const void*)ar_coop_fast_vb_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((ar_coop_fast_vb_kernel<E>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
+      return;
+    }
   }
   if constexpr (sizeof(E) == 2) {
     if (a.nlds > 0) {
@@ -1523,10 +1589,10 @@ static int nlds_env(int dflt) {     // debugging aid: WAE_AR_LDS_LAYERS=n overri
   const char* e = getenv("WAE_AR_LDS_LAYERS");
   return e ? atoi(e) : dflt;
 }
-static int nbank_env(int dflt) {    // ... WAE_AR_BANK_LAYERS=n the number of layers kept in the accumulation registers (0 .. ARC_NBANK)
-  const char* e = getenv("WAE_AR_BANK_LAYERS");
+static int nbank_env(int dflt) {    // ... WAE_AR_BANK_LAYERS=n the number of layers kept in registers (0 .. ARC_NBANK in the accumulation
+  const char* e = getenv("WAE_AR_BANK_LAYERS");   // registers; up to ARC_NVB more select the instantiation with the arch-VGPR bank)
   const int v = e ? atoi(e) : dflt;
-  return v < 0 ? 0 : (v > ARC_NBANK ? ARC_NBANK : v);
+  return v < 0 ? 0 : (v > ARC_NBANK + ARC_NVB ? ARC_NBANK + ARC_NVB : v);
 }
 
 extern "C" int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d) {
@@ -1601,7 +1667,9 @@ static int ar_generate_coop_impl(const wae_ar_desc* d, int32_t C, const int32_t*
       if (a.nlds > d->L) a.nlds = d->L;
       if (a.nlds < 0) a.nlds = 0;
       lds_f += 64 + per * a.nlds;
-      a.nbank = a.nlds > 0 ? nbank_env(ARC_NBANK) : 0;      // (the register bank belongs to the LDS-resident instantiation)
+      a.nbank = a.nlds > 0 ? nbank_env(ARC_NBANK + ARC_NVB) : 0;      // (the register banks belong to the LDS-resident instantiations)
+      if (a.w_fused && a.nbank > ARC_NBANK) a.nbank = ARC_NBANK;      // (the one-hand-over form has the accumulation registers only)
+      if (a.nbank > d->L - a.nlds) a.nbank = d->L - a.nlds > 0 ? d->L - a.nlds : 0;
     }
     bool done = true;
     if (d->dtype == WAE_BF16 && nu == 3) launch_arc_fast<__bf16, 3>(a, lds_f, st);
