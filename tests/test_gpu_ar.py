@@ -241,6 +241,43 @@ def test_long_decode_40960_steps_against_the_oracle(monkeypatch):
     assert torch.equal(a, b) and int(torch.unique(a).numel()) > 200
 
 
+def test_full_clip_160000_steps_windows_against_the_oracle():
+    """The benchmarked clip in full: 160 000 teacher-forced steps (250 latent frames x 640) of the C4 geometry on the default kernels
+    (fp32; bf16 = every layer's weights resident on chip), logits compared with the oracle inside three windows of 4 096 steps at
+    60 000, 120 000 and the clip's end.  A logit depends on the 4 093 inputs before it only (receptive field of 2 stacks of dilations
+    1 .. 512 at 3 taps), so the oracle's batch forward on [a - 4093, a + 4096) is exact for [a, a + 4096): the windows cost seconds
+    where the whole clip would cost minutes, and an error that grows with the step count -- ring wrap-around, exchange sequence
+    numbers (3.2 million hand-overs per member), the one-hot feedback path -- would show in the late ones."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5], cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=13, with_encoder=False)
+    T, RF, N = 250 * 640, 4093, 4096
+    x = ((O.hash_fill((1, T), 911) * 0.5 + 0.5) * 256).long().clamp(0, 255)
+    lat = O.hash_fill((1, 64, 250), 912)
+    gid = torch.tensor([9])
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    wcfg = dict(layers=20, stacks=2, upsample_scales=None, cin_pad=0)
+    want = {}
+    with torch.no_grad():
+        c_up = O.upsample_forward(sd, lat, cfg["upsample_scales"])                   # (1, 64, T)
+        for a in (60000, 120000, T - N):
+            xin = torch.nn.functional.one_hot(x[:, a - RF:a + N], 256).float().transpose(1, 2).contiguous()
+            want[a] = O.wavenet_forward(sd, wcfg, xin, c_up[:, :, a - RF:a + N].contiguous(), gid)[0][:, RF:]
+    for dtype, tol in (("fp32", 1e-3), ("bf16", 5e-2)):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.load_state_dict(sd)
+        got = eng.incremental_forward(lat.cuda(), gid.cuda(), T, mode="logits", init_idx=127, test_inputs=x.cuda())["logits"]
+        torch.cuda.synchronize()
+        for a, w in want.items():
+            g_ = got[0][:, a:a + N].float().cpu()
+            scale = float(w.abs().max())
+            assert float((g_ - w).abs().max()) < tol * scale, (dtype, a)
+            assert float((torch.logsumexp(g_, 0) - torch.logsumexp(w, 0)).abs().max()) < tol * scale, (dtype, a)
+        del got, eng
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch):
     """Round 5: the 16-bit fast cooperative kernel keeps the packets of 6 layers in LDS, of 11 more in the accumulation registers and
