@@ -340,7 +340,12 @@ int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilations, const
  * the launch; error[0] != 0 afterwards means a wait timed out (the output is then invalid).  No atomics: every share is one
  * stored {sequence number, fp32} granule and the members add them in a fixed order -- results are bitwise reproducible.  The
  * reference's geometry (R = G = S = O = 256, 3 taps, Cc <= 256) on C = 32 runs a kernel with those sizes as constants
- * (WAE_AR_COOP_GENERIC=1 in the environment keeps the any-shape kernel); both zero-fill / overwrite `ring` themselves. */
+ * (WAE_AR_COOP_GENERIC=1 in the environment keeps the any-shape kernel); both zero-fill / overwrite `ring` themselves.  That kernel's
+ * 32 members share ONE history ring per utterance (member 0's region of the (B, C, ring_total) allocation: every member writes every
+ * row, the same bits) and, in 16-bit storage, keep every layer's weight packets on chip for the whole clip -- 6 layers in LDS, 11 in
+ * the accumulation registers, 3 in hand-allocated arch VGPRs at the reference's 20 layers; deeper stacks stream the rest from L2.
+ * Debugging aids read by the library itself: WAE_AR_LDS_LAYERS=n / WAE_AR_BANK_LAYERS=n override the number of layers kept in LDS /
+ * in registers (0 0: the streaming form; results are bitwise the same for every split, tests/test_gpu_ar.py). */
 int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d);
 int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C);
 int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,
