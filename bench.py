@@ -137,7 +137,7 @@ def ar_leg(device, T_ar=4000, cpu=True, full_clip=True):
     # "Replicas only" (the layer chain of one sample is strictly sequential, utterances are independent): aggregate kHz of a
     # batch of utterances on ONE GPU -- 8 utterances on the cooperative kernel (one XCD each), 256 on the one-CU kernel (one CU each)
     batched = {}
-    for nb, Tb in ((8, 1280), (256, 640)):
+    for nb, Tb in ((8, 2560), (256, 640)):      # (8 x 1280 was a 40-ms window: host-side set-up of the call showed in it)
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=best, device=str(device))
         eng.load_state_dict(sd)
         gen = torch.Generator(device="cpu").manual_seed(99 + nb)
