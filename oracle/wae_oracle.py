@@ -244,8 +244,10 @@ def dropout_keep(seed: int, B: int, R: int, T: int, p: float) -> torch.Tensor:
 
 
 def glu_layer_forward(sd: SD, prefix: str, x: torch.Tensor, c: Optional[torch.Tensor],
-                      g: Optional[torch.Tensor], dilation: int, keep: Optional[torch.Tensor] = None, p: float = 0.0):
+                      g: Optional[torch.Tensor], dilation: int, keep: Optional[torch.Tensor] = None, p: float = 0.0,
+                      causal: bool = True):
     """x (B,R,T), c (B,Cc,T) | None, g (B,Cg,T) or (B,Cg,1) | None -> (x' (B,R,T), s (B,S,T)).
+    causal=False (modules.py:82-88,134-136): the convolution pads (k-1)//2 * d on BOTH sides and nothing is trimmed (odd k).
 
     residual = x; x = F.dropout(x, p, training) (:126-128: `keep` (B,R,T) bool is the mask in training, None = eval);
     causal dilated conv with pad (k-1)*d, tail trimmed (:134-136); split a|b (:138); add 1x1(c),
@@ -256,7 +258,10 @@ def glu_layer_forward(sd: SD, prefix: str, x: torch.Tensor, c: Optional[torch.Te
     w = eff_weight(sd, prefix + "conv")
     k = w.shape[-1]
     xc = x if keep is None else x * keep.to(x.dtype) / (1.0 - p)
-    z = F.conv1d(xc, w, sd.get(prefix + "conv.bias"), padding=(k - 1) * dilation, dilation=dilation)[:, :, :T]
+    if causal:
+        z = F.conv1d(xc, w, sd.get(prefix + "conv.bias"), padding=(k - 1) * dilation, dilation=dilation)[:, :, :T]
+    else:
+        z = F.conv1d(xc, w, sd.get(prefix + "conv.bias"), padding=(k - 1) // 2 * dilation, dilation=dilation)
     if c is not None:
         z = z + F.conv1d(c, eff_weight(sd, prefix + "conv1x1c"))
     if g is not None:

@@ -172,6 +172,42 @@ def gen_layers(cfg, sd, model, ins):
     save(f"glu_{cfg['name']}", **out)
 
 
+def gen_noncausal_layer():
+    """ResidualConv1dGLU(causal=False) (modules.py:82-88: symmetric padding (k-1)//2 * d, nothing trimmed): forward and the reference's
+    own autograd gradients of a fixed scalar function of (x', s) at two dilations -> glu_noncausal.npz."""
+    cfg = CFG_A
+    sd = O.make_state_dict(dict(cfg), 1)
+    R, Cc, Cg, G, S = cfg["R"], cfg["Cc"], cfg["Cg"], cfg["G"], cfg["S"]
+    B, T = 2, 200
+    p = "wavenet.conv_layers.1."
+    lsd = {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    out = dict(T=T, B=B, x_salt=921, c_salt=922, g_salt=923, wx_salt=924, ws_salt=925, scale=0.8)
+    x0, c0 = O.hash_fill((B, R, T), 921, 0.8), O.hash_fill((B, Cc, T), 922, 0.8)
+    gv = O.hash_fill((B, Cg, 1), 923, 0.8)
+    wx, wsk = O.hash_fill((B, R, T), 924), O.hash_fill((B, S, T), 925)
+    for d in (1, 8):
+        lay = RefGLU(R, G, kernel_size=3, skip_out_channels=S, cin_channels=Cc, gin_channels=Cg, dropout=0.0, dilation=d,
+                     causal=False, bias=True).eval()
+        lay.load_state_dict({k: v.clone() for k, v in lsd.items()}, strict=True)
+        xr, cr = x0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        xo, so = lay(xr, cr, gv.expand(B, Cg, T).contiguous())
+        assert xo.shape == (B, R, T) and so.shape == (B, S, T)
+        ((xo * wx).sum() + (so * wsk).sum()).backward()
+        psd = {p + k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+        xq, cq = x0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        oxo, oso = O.glu_layer_forward(psd, p, xq, cq, gv.expand(B, Cg, T), d, causal=False)
+        ((oxo * wx).sum() + (oso * wsk).sum()).backward()
+        close(oxo, xo, what=f"non-causal glu x d={d}")
+        close(oso, so, what=f"non-causal glu s d={d}")
+        close(xq.grad, xr.grad, tol=1e-4, what=f"non-causal dx d={d}")
+        close(cq.grad, cr.grad, tol=1e-4, what=f"non-causal dc d={d}")
+        out[f"xo_d{d}"], out[f"so_d{d}"], out[f"dx_d{d}"], out[f"dc_d{d}"] = xo, so, xr.grad, cr.grad
+        for k, v in lay.named_parameters():
+            close(psd[p + k].grad, v.grad, tol=1e-4, what=f"non-causal grad {k} d={d}")
+            out[f"grad_d{d}:{k}"] = v.grad
+    save("glu_noncausal", **out)
+
+
 def gen_losses(cfg, sd, model, ins, ocfg):
     """(6) CE (masked, shifted) value + logits-gradient."""
     c, x, xin, g, T = ins
@@ -1020,6 +1056,8 @@ def main():
         return gen_upsample_activation()
     if sys.argv[1:] == ["sampler"]:
         return gen_sampler()
+    if sys.argv[1:] == ["noncausal"]:
+        return gen_noncausal_layer()
     gen_quantizers()
     gen_misc()
     gen_dmol()
@@ -1044,6 +1082,7 @@ def main():
     gen_plain_upsample()
     gen_upsample_activation()
     gen_sampler()
+    gen_noncausal_layer()
 
 
 if __name__ == "__main__":

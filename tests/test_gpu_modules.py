@@ -519,3 +519,72 @@ def test_standalone_layer_without_biases():
     assert rel_err(xg.grad.cpu(), xr.grad) < 1e-4 and rel_err(cg.grad.cpu(), cr.grad) < 1e-4
     for k, p_ in layer.named_parameters():
         assert p_.grad is not None and rel_err(p_.grad.cpu(), psd[pre + k].grad) < 2e-4, k
+
+
+@pytest.mark.parametrize("d", [1, 8])
+def test_standalone_layer_non_causal_against_reference_vectors(d):
+    """modules.py:82-88 with causal=False (symmetric padding (k-1)//2 * d, nothing trimmed): outputs and the gradients of x, c and every
+    parameter against the REFERENCE module's own forward and autograd (tests/golden/glu_noncausal.npz; the causal kernels on a frame
+    shifted by d).  Then: a time-varying g with a gradient, training-mode dropout and bf16 against autograd through the oracle's layer;
+    even kernel sizes and incremental_forward are refused."""
+    from helpers import golden_model, load_npz, rel_err
+    from oracle import wae_oracle as O
+    from wavenet_autoencoders_amd.wavenet_vocoder.modules import ResidualConv1dGLU
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    z = load_npz("glu_noncausal")
+    pre = "wavenet.conv_layers.1."
+    lsd = {k[len(pre):]: v.clone() for k, v in sd.items() if k.startswith(pre)}
+    B, T, sc = int(z["B"]), int(z["T"]), float(z["scale"])
+    x, c = O.hash_fill((B, cfg["R"], T), int(z["x_salt"]), sc), O.hash_fill((B, cfg["Cc"], T), int(z["c_salt"]), sc)
+    gv = O.hash_fill((B, cfg["Cg"], 1), int(z["g_salt"]), sc)
+    wx, wsk = O.hash_fill((B, cfg["R"], T), int(z["wx_salt"])), O.hash_fill((B, cfg["S"], T), int(z["ws_salt"]))
+
+    def make(**kw):
+        lay = ResidualConv1dGLU(cfg["R"], cfg["G"], 3, skip_out_channels=cfg["S"], cin_channels=cfg["Cc"], gin_channels=cfg["Cg"],
+                                dilation=d, causal=False, **kw)
+        lay.load_state_dict(lsd)
+        return lay.cuda()
+    layer = make(dropout=0.0).train()
+    xg, cg = x.cuda().requires_grad_(True), c.cuda().requires_grad_(True)
+    xo, so = layer(xg, cg, gv.cuda().expand(-1, -1, T))
+    assert xo.shape == (B, cfg["R"], T) and so.shape == (B, cfg["S"], T)
+    assert rel_err(xo.detach().cpu(), z[f"xo_d{d}"]) < 1e-4 and rel_err(so.detach().cpu(), z[f"so_d{d}"]) < 1e-4
+    ((xo * wx.cuda()).sum() + (so * wsk.cuda()).sum()).backward()
+    assert rel_err(xg.grad.cpu(), z[f"dx_d{d}"]) < 1e-4 and rel_err(cg.grad.cpu(), z[f"dc_d{d}"]) < 1e-4
+    for k, p_ in layer.named_parameters():
+        assert p_.grad is not None and rel_err(p_.grad.cpu(), z[f"grad_d{d}:{k}"]) < 2e-4, k
+    with torch.no_grad():            # eval mode, no autograd: the same outputs
+        xe, se = layer.eval()(x.cuda(), c.cuda(), gv.cuda().expand(-1, -1, T))
+    assert rel_err(xe.cpu(), z[f"xo_d{d}"]) < 1e-4 and rel_err(se.cpu(), z[f"so_d{d}"]) < 1e-4
+    # g as a time series with a gradient; training-mode dropout (the mask lives in the kernels' frame of T + d steps); bf16
+    psd = {pre + k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+    gt = O.hash_fill((B, cfg["Cg"], T), 931, 0.7)
+    xr, cr, gr = x.clone().requires_grad_(True), c.clone().requires_grad_(True), gt.clone().requires_grad_(True)
+    xo_r, so_r = O.glu_layer_forward(psd, pre, xr, cr, gr, d, causal=False)
+    ((xo_r * wx).sum() + (so_r * wsk).sum()).backward()
+    for dtype, tol in (("fp32", 1e-4), ("bf16", 4e-2)):
+        lay = make(dropout=0.0).set_compute_dtype(dtype).train()
+        xg, cg, gg = x.cuda().requires_grad_(True), c.cuda().requires_grad_(True), gt.cuda().requires_grad_(True)
+        xo, so = lay(xg, cg, gg)
+        assert rel_err(xo.detach().cpu(), xo_r.detach()) < tol and rel_err(so.detach().cpu(), so_r.detach()) < tol
+        ((xo * wx.cuda()).sum() + (so * wsk.cuda()).sum()).backward()
+        assert rel_err(xg.grad.cpu(), xr.grad) < tol and rel_err(cg.grad.cpu(), cr.grad) < tol and rel_err(gg.grad.cpu(), gr.grad) < tol
+        for k, p_ in lay.named_parameters():
+            assert rel_err(p_.grad.cpu(), psd[pre + k].grad) < 2 * tol, (dtype, k)
+    pd = 0.3
+    lay = make(dropout=pd).train()
+    xg = x.cuda().requires_grad_(True)
+    xo, so = lay(xg, c.cuda(), gv.cuda().expand(-1, -1, T))
+    eng = lay.engine()
+    keep = O.dropout_keep(eng.layer_drop_seed(eng.drop_calls, 0), B, cfg["R"], T + d, pd)[:, :, :T]     # the convolution operand's rows [0, T)
+    xq = x.clone().requires_grad_(True)
+    xo_q, so_q = O.glu_layer_forward({k: v.detach() for k, v in psd.items()}, pre, xq, c, gv.expand(-1, -1, T), d, keep=keep, p=pd, causal=False)
+    assert rel_err(xo.detach().cpu(), xo_q.detach()) < 1e-4 and rel_err(so.detach().cpu(), so_q.detach()) < 1e-4
+    ((xo * wx.cuda()).sum() + (so * wsk.cuda()).sum()).backward()
+    ((xo_q * wx).sum() + (so_q * wsk).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xq.grad) < 1e-4
+    with pytest.raises(NotImplementedError):
+        ResidualConv1dGLU(cfg["R"], cfg["G"], 2, causal=False)
+    with pytest.raises(NotImplementedError):
+        layer.eval().incremental_forward(x[:, :, :1].transpose(1, 2).cuda())
+

@@ -53,6 +53,27 @@ def test_glu_layer(name):
             assert rel_err(so[:, :, pt], z[f"so_d{d}_{tag}"]) < TOL
 
 
+def test_glu_layer_non_causal():
+    """ResidualConv1dGLU(causal=False) of the reference (modules.py:82-88): the oracle's forward and its autograd gradients against the
+    reference's (tests/golden/glu_noncausal.npz)."""
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    z = load_npz("glu_noncausal")
+    pre = "wavenet.conv_layers.1."
+    B, T, sc = int(z["B"]), int(z["T"]), float(z["scale"])
+    x, c = O.hash_fill((B, cfg["R"], T), int(z["x_salt"]), sc), O.hash_fill((B, cfg["Cc"], T), int(z["c_salt"]), sc)
+    g = O.hash_fill((B, cfg["Cg"], 1), int(z["g_salt"]), sc)
+    wx, wsk = O.hash_fill((B, cfg["R"], T), int(z["wx_salt"])), O.hash_fill((B, cfg["S"], T), int(z["ws_salt"]))
+    for d in (1, 8):
+        psd = {k: (v.clone().requires_grad_(True) if k.startswith(pre) else v) for k, v in sd.items()}
+        xr, cr = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        xo, so = O.glu_layer_forward(psd, pre, xr, cr, g.expand(-1, -1, T), d, causal=False)
+        assert rel_err(xo.detach(), z[f"xo_d{d}"]) < TOL and rel_err(so.detach(), z[f"so_d{d}"]) < TOL
+        ((xo * wx).sum() + (so * wsk).sum()).backward()
+        assert rel_err(xr.grad, z[f"dx_d{d}"]) < 1e-4 and rel_err(cr.grad, z[f"dc_d{d}"]) < 1e-4
+        for k in [k for k in z if k.startswith(f"grad_d{d}:")]:
+            assert rel_err(psd[pre + k.split(":", 1)[1]].grad, z[k]) < 1e-4, k
+
+
 @pytest.mark.parametrize("name", ["A", "B"])
 def test_masked_ce(name):
     cfg, sd, ins, zm, ocfg = golden_model(name)

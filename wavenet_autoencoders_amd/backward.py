@@ -825,7 +825,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
 
 
 
-def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None):
+def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None, lead=0):
     """Backward of ONE ResidualConv1dGLU layer (an engine of geometry layers == 1, wavenet_vocoder.modules.ResidualConv1dGLU) -- the
     autograd of modules.py:115-163 from the same kernels the stack uses, last train-mode forward of that (B, T):
         dz  = gate'(z) * (W_out^T gx_hat + W_skip^T ds)                   (wae_gemm_tm GATE_BWD)
@@ -834,7 +834,10 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None):
         dW1, dWc, per-clip sums of dz, dW_out + bias, dW_skip + bias      (wae_gemm_tn_tiles), gproj / weight-norm backward
     gx_hat (B,T,Rp) = sqrt(.5) * d loss / d x' (x' = (conv1x1_out(u) + x) sqrt(.5)), ds (B,T,Sp) = d loss / d s, both in the engine's
     storage dtype (times eng.grad_scale for fp16).  drop_seed: the seed of the dropout mask the forward applied to the convolution's
-    operand (modules.py:127-128), or None.  Fills eng.grads (finish_grads) and returns (dx (B,T,Rp), dc (B,T,Ccp) | None)."""
+    operand (modules.py:127-128), or None.  lead > 0: a causal=False layer run on a frame `lead` steps longer (modules.ResidualConv1dGLU):
+    the convolution operand's rows [0, T - lead) are x, the residual operand's rows [lead, T) are x, so the residual path's gradient of
+    x[t] is gx_hat[t + lead] (gx_hat must own `lead` readable rows behind its end) and dx is returned in the convolution operand's frame.
+    Fills eng.grads (finish_grads) and returns (dx (B,T,Rp), dc (B,T,Ccp) | None)."""
     _prepare_bwd(eng)
     g, lib, lay, st, sm = eng.g, eng.lib, eng.lay, eng.stream(), eng.sm
     assert g.layers == 1
@@ -848,13 +851,15 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None):
     if ws is None:
         dev, td = eng.device, eng.tdtype
         ws = dict(dz=torch.zeros(B, T, Z2, dtype=td, device=dev), gx=torch.zeros(B, T, g.Rp, dtype=td, device=dev),
-                  gn=torch.zeros(B, T, g.Rp, dtype=td, device=dev), dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
+                  gn=torch.zeros(B * T + lead, g.Rp, dtype=td, device=dev)[:B * T].view(B, T, g.Rp),
+                  dskip=torch.zeros(B, T, g.Sp, dtype=td, device=dev),
                   dc=torch.zeros(B, T, max(g.Ccp, 64), dtype=td, device=dev))
         d = g.dilations[0]
         tt = TileTable(eng)
         for tap in range(g.k):
             last = tap == g.k - 1 and not g.Ccp
-            xop = fw["xd"][0] if "xd" in fw else fw["x"][0]          # dW1 contracts dz against the convolution's (masked) operand
+            # dW1 contracts dz against the convolution's operand: the masked one, the non-causal layer's [x ; 0], or x itself
+            xop = fw["xd"][0] if "xd" in fw else (fw["xnc"] if lead else fw["x"][0])
             tt.add(Z2, g.Rp, -(g.k - 1 - tap) * d, (g.Rp if last else -1), ia, ws["dz"].data_ptr(), Z2, xop.data_ptr(), g.Rp,
                    c1.data_ptr() + tap * g.Rp * 4, sm["ld1"])
         if g.Ccp:
@@ -872,16 +877,18 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None):
         ws["dz"].data_ptr(), Z2, fw["z"][0].data_ptr(), Z2)
     ws["tt"].launch(B, T)
     srcs = [(ws["dz"].data_ptr(), Z2, Z2, (g.k - 1 - tap) * g.dilations[0]) for tap in range(g.k)]
-    if drop_seed is None:
+    if drop_seed is None and not lead:
         _tm(eng, B, T, g.Rp, 1, 1.0, srcs, eng.w_bx.data_ptr(), ws["gx"].data_ptr(), g.Rp, ws["gn"].data_ptr(), g.Rp,
             flags=P.TM_INTERLEAVE)
     else:
-        # dropout: the tap contraction alone, then dx = gx_hat + keep * acc / (1 - p) with the forward's mask
+        # dropout and / or the non-causal frame: the tap contraction alone, then dx[t] = gx_hat[t + lead] + keep * acc[t] / (1 - p) with
+        # the forward's mask (no dropout: p = 0 keeps everything)
         if "gtmp" not in ws:
             ws["gtmp"] = torch.zeros(B, T, g.Rp, dtype=eng.tdtype, device=eng.device)
         _tm(eng, B, T, g.Rp, 0, 1.0, srcs, eng.w_bx.data_ptr(), ws["gtmp"].data_ptr(), g.Rp, flags=P.TM_INTERLEAVE)
-        L.check(lib.wae_dropout_bwd(L.ptr(ws["gtmp"]), L.ptr(ws["gn"]), L.ptr(ws["gx"]), B * T * g.Rp, drop_seed, eng.dropout, 1.0, eng.dt, st),
-                "dropout_bwd")
+        gn_late = ctypes.c_void_p(ws["gn"].data_ptr() + lead * g.Rp * ws["gn"].element_size())
+        L.check(lib.wae_dropout_bwd(L.ptr(ws["gtmp"]), gn_late, L.ptr(ws["gx"]), B * T * g.Rp, drop_seed or 0,
+                                    eng.dropout if drop_seed is not None else 0.0, 1.0, eng.dt, st), "dropout_bwd")
     if g.Ccp:
         _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), Z2, Z2, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
     OP = P.ONES_PAD

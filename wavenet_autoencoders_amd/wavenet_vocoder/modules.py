@@ -36,17 +36,24 @@ class _LayerFn(torch.autograd.Function):
             raise RuntimeError("backward through a forward whose saved activations were overwritten by a later training-mode forward "
                                "of the same layer: call backward before the next forward")
         gm, lib, st = eng.g, eng.lib, eng.stream()
-        B, R, T = ctx.shape
+        B, R, T0 = ctx.shape
+        lead = mod.lead                 # non-causal: the kernels' frame is `lead` steps longer, outputs sit at [lead, T0 + lead)
+        T = T0 + lead
         dev = dxo.device if dxo is not None else dso.device
-        gx = torch.zeros(B, T, gm.Rp, dtype=eng.tdtype, device=dev)
+
+        def late(a):
+            return a if not lead else torch.cat([a.new_zeros(a.shape[0], a.shape[1], lead), a], dim=2)
+        gx = torch.zeros(B * T + lead, gm.Rp, dtype=eng.tdtype, device=dev)[:B * T].view(B, T, gm.Rp)   # (+ lead rows: read, never used)
         ds = torch.zeros(B, T, gm.Sp, dtype=eng.tdtype, device=dev)
         if dxo is not None:   # x' = (conv1x1_out(u) + x) sqrt(.5): the kernels take sqrt(.5) * d loss / d x' (backward.py: "hat")
-            L.check(lib.wae_to_btc(L.ptr((dxo.float() * (math.sqrt(0.5) * eng.grad_scale)).contiguous()), L.ptr(gx), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc dx'")
+            L.check(lib.wae_to_btc(L.ptr(late(dxo.float() * (math.sqrt(0.5) * eng.grad_scale)).contiguous()), L.ptr(gx), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc dx'")
         if dso is not None:
-            L.check(lib.wae_to_btc(L.ptr((dso.float() * eng.grad_scale).contiguous()), L.ptr(ds), B, gm.S, T, gm.Sp, eng.dt, st), "to_btc ds")
-        dx_btc, dc_btc = BW.layer_backward(eng, B, T, gx, ds, ctx.gvec, drop_seed=ctx.seed)
+            L.check(lib.wae_to_btc(L.ptr(late(dso.float() * eng.grad_scale).contiguous()), L.ptr(ds), B, gm.S, T, gm.Sp, eng.dt, st), "to_btc ds")
+        dx_btc, dc_btc = BW.layer_backward(eng, B, T, gx, ds, ctx.gvec, drop_seed=ctx.seed, lead=lead)
         dx = torch.empty(B, gm.R, T, dtype=torch.float32, device=dev)
         L.check(lib.wae_from_btc_scaled(L.ptr(dx_btc), L.ptr(dx), B, gm.R, T, gm.Rp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc dx")
+        if lead:
+            dx = dx[:, :, :T0].contiguous()        # (the convolution operand's frame: x sits at [0, T0))
         dc = dg = None
         if (ctx.has_c or ctx.has_g) and dc_btc is not None:
             # the conditioning operand's gradient: columns [0, Cc) are c's, with g as a time series [Cc, Cc + Cg) are g's
@@ -54,9 +61,9 @@ class _LayerFn(torch.autograd.Function):
             L.check(lib.wae_from_btc_scaled(L.ptr(dc_btc), L.ptr(dcg), B, gm.Cx, T, gm.Ccp, eng.dt, 1.0 / eng.grad_scale, st), "from_btc dc")
             nc = max(gm.Cc, 0)
             if ctx.has_c:
-                dc = dcg[:, :nc].contiguous()
+                dc = dcg[:, :nc, lead:].contiguous()
             if ctx.has_g:
-                dg = dcg[:, nc:nc + gm.Cg].contiguous()
+                dg = dcg[:, nc:nc + gm.Cg, lead:].contiguous()
         _, views = mod._grad_views(eng)
         return (None, dx, dc, dg) + tuple(v.clone() for v in views)
 
@@ -66,7 +73,8 @@ class ResidualConv1dGLU(ArenaModel):
     s = conv1x1_skip(u); x' = (conv1x1_out(u) + x) * sqrt(.5)   (modules.py:115-163).
 
     Same constructor as the reference (modules.py:71-75).  Supported: causal=True (what the reference's WaveNet builds,
-    wavenet.py:127-134), bias=True or False; dropout (modules.py:127-128): the identity in eval mode, in training mode the engine's counter-based mask (one
+    wavenet.py:127-134) and causal=False with an odd kernel size (symmetric padding: the causal kernels on a frame shifted by
+    (k-1)/2 * d, forward and backward; no incremental_forward), bias=True or False; dropout (modules.py:127-128): the identity in eval mode, in training mode the engine's counter-based mask (one
     seed per forward call; parity against the oracle under the same mask, oracle.wae_oracle.dropout_keep); global features as ONE vector per
     clip (what the reference's WaveNet expands, wavenet.py:185-194: hoisted into a per-clip bias) or -- round 5 -- as any (B, Cg, T) time
     series, with a gradient for g (modules.py:148-152 convolves whatever it is given): the first call that sees a g that varies over
@@ -78,12 +86,19 @@ class ResidualConv1dGLU(ArenaModel):
                  dropout=1 - 0.95, padding=None, dilation=1, causal=True, bias=True, *args, **kwargs):
         super().__init__()
         self.dropout = float(dropout)          # identity in eval mode (modules.py:127-128); the engine's hashed mask in train mode
-        if not causal:
-            raise NotImplementedError("only the causal layer the reference's WaveNet builds is implemented (modules.py:82-88: causal=False "
-                                      "pads (kernel_size - 1) // 2 * dilation on both sides)")
+        # causal=False (modules.py:82-88,134-136): the convolution pads (k - 1) // 2 * d on both sides and nothing is trimmed, i.e.
+        # z[t] reads x[t + (j - (k-1)/2) d].  The kernels are causal; the non-causal layer runs them on a frame that is `lead` steps
+        # longer: convolution operand [x ; 0], residual operand / conditioning / outputs [0 ; .] (see _run), so no kernel changes.
+        self.causal = bool(causal)
+        if not self.causal and kernel_size % 2 == 0:
+            raise NotImplementedError("causal=False needs an odd kernel_size (the reference's own residual addition fails for even ones: "
+                                      "the symmetric padding (k - 1) // 2 * d shortens the output)")
+        self.lead = 0 if self.causal else (kernel_size - 1) // 2 * dilation
         self.bias = bool(bias)       # modules.py:88-107: bias=False builds conv, conv1x1_out and conv1x1_skip without one
-        if padding is not None and padding != (kernel_size - 1) * dilation:
-            raise NotImplementedError("padding must be the causal (kernel_size - 1) * dilation")
+        want_pad = (kernel_size - 1) * dilation if self.causal else (kernel_size - 1) // 2 * dilation
+        if padding is not None and padding != want_pad:
+            raise NotImplementedError("padding must be the layer's own default: (kernel_size - 1) * dilation (causal) or "
+                                      "(kernel_size - 1) // 2 * dilation (causal=False)")
         if skip_out_channels is None:
             skip_out_channels = residual_channels                     # modules.py:80-81
         self.kernel_size, self.dilation = kernel_size, dilation
@@ -115,11 +130,31 @@ class ResidualConv1dGLU(ArenaModel):
                 self._g_as_time_series()
         eng = self.engine()
         gm, lib, st = eng.g, eng.lib, eng.stream()
-        B, R, T = x.shape
+        B, R, T0 = x.shape
         assert R == gm.R, f"x has {R} channels, the layer {gm.R}"
+        lead = self.lead
+        xnc = None
+        if lead:
+            # non-causal: frame t' = t + lead.  The convolution operand keeps x at [0, T) (its causal taps t' - (k-1-j) d are then
+            # x[t + (j - (k-1)/2) d], zeros beyond either end); everything that is point-wise in time moves to [lead, T + lead)
+            def late(a):
+                return None if a is None else torch.cat([a.new_zeros(a.shape[0], a.shape[1], lead), a.detach().float()], dim=2)
+            if c is not None and c.shape[-1] != T0:
+                raise ValueError("local conditioning c must be (B, cin_channels, T)")
+            if g is not None and g.shape[-1] not in (1, T0):
+                raise ValueError("global features g must be (B, gin_channels, T) or (B, gin_channels, 1)")
+            xnc = torch.cat([x.detach().float(), x.new_zeros(B, R, lead, dtype=torch.float32)], dim=2)
+            x, c = late(x), late(c)
+            if g is not None and g.shape[-1] > 1:
+                g = late(g) if gm0.g_local or self.geom.g_local else torch.cat([g[:, :, :1].expand(-1, -1, lead), g], dim=2)
+        T = T0 + lead
         eng.prepare_weights()
         ws = eng.workspace(B, T, train)
         L.check(lib.wae_to_btc(L.ptr(x.contiguous().float()), L.ptr(ws["x"][0]), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc x")
+        if lead:
+            if "xnc" not in ws:
+                ws["xnc"] = torch.empty_like(ws["x"][0])
+            L.check(lib.wae_to_btc(L.ptr(xnc.contiguous()), L.ptr(ws["xnc"]), B, gm.R, T, gm.Rp, eng.dt, st), "to_btc conv operand")
         gvec = None
         if gm.g_local:
             if g is None:
@@ -150,7 +185,7 @@ class ResidualConv1dGLU(ArenaModel):
         # dropout (modules.py:127-128): F.dropout on the convolution's operand in training mode, the residual path keeps x.  One seed per
         # forward call from the engine's call counter (engine.layer_drop_seed); backward regenerates the mask from the seed kept in ctx.
         seed = None
-        xconv = ws["x"][0]
+        xconv = xsrc = ws["xnc"] if lead else ws["x"][0]
         if self.training and self.dropout > 0:
             eng.drop_calls += 1
             seed = eng.layer_drop_seed(eng.drop_calls, 0)
@@ -158,7 +193,7 @@ class ResidualConv1dGLU(ArenaModel):
             if "xd" not in ws:          # (an inference-shaped workspace: the masked operand lives for this call only)
                 ws["xd_tmp"] = ws.get("xd_tmp") if ws.get("xd_tmp") is not None else torch.empty_like(ws["x"][0])
             xconv = ws["xd"][0] if "xd" in ws else ws["xd_tmp"]
-            L.check(lib.wae_dropout_fwd(L.ptr(ws["x"][0]), L.ptr(xconv), B * T * gm.Rp, seed or 0, self.dropout if seed is not None else 0.0,
+            L.check(lib.wae_dropout_fwd(L.ptr(xsrc), L.ptr(xconv), B * T * gm.Rp, seed or 0, self.dropout if seed is not None else 0.0,
                                         eng.dt, st), "dropout")
         L.check(lib.wae_glu_layer_fwd_drop(ctypes.byref(d), L.ptr(ws["x"][0]), L.ptr(xconv), L.ptr(ws["x"][1]), L.ptr(ws["c_up"]),
                                            L.ptr(ws["u"]), gm.Ku, L.ptr(ws["zb"]), 2 * gm.Hp, L.ptr(ws["z"][0]) if train else None,
@@ -184,6 +219,8 @@ class ResidualConv1dGLU(ArenaModel):
         L.check(lib.wae_from_btc(L.ptr(ws["x"][1]), L.ptr(xo), B, gm.R, T, gm.Rp, eng.dt, st), "from_btc x")
         L.check(lib.wae_from_btc(L.ptr(sbt), L.ptr(so_), B, gm.S, T, gm.Sp, eng.dt, st), "from_btc s")
         self._keep = (sbt, gvec, seed)
+        if lead:
+            xo, so_ = xo[:, :, lead:].contiguous(), so_[:, :, lead:].contiguous()
         if not self.bias:
             return xo, so_
         bias = dict(self.named_parameters())["conv1x1_skip.bias"].detach().float()
@@ -205,6 +242,8 @@ class ResidualConv1dGLU(ArenaModel):
         are kept between calls (conv.py:17-46 keeps the same window)."""
         if self.training:
             raise RuntimeError("incremental_forward only supports eval mode")          # conv.py:19-20
+        if not self.causal:
+            raise NotImplementedError("incremental_forward of a causal=False layer (it would need future inputs)")
         win = (self.kernel_size - 1) * self.dilation + 1
         xt = x.transpose(1, 2).contiguous().float()                                     # (B, R, 1)
         if self._buf is None:
