@@ -555,7 +555,8 @@ def main():
         if gsync is not None:
             comm_ms, wait_ms = gsync.collect_timing()
             res["allreduce"] = {"ms": comm_ms, "exposed_ms": wait_ms, "collectives_per_step": gsync.n_collectives / (args.steps + args.warmup),
-                                "bytes": int(eng.grads.numel()) * 4, "note": "RCCL all-reduce of the fp32 gradient arena, last timed step: "
+                                "bytes": int(eng.grads.numel()) * (2 if gsync.wire_bf16 else 4), "wire_dtype": "bf16" if gsync.wire_bf16 else "fp32",
+                                "note": "RCCL all-reduce of the fp32 gradient arena (WAE_DP_WIRE=bf16: of bf16 copies), last timed step: "
                                 "ms = first launch to last collective done on the side stream (starts inside backward, after the "
                                 "layers' gradients); exposed_ms = how long the compute stream waited for it"}
         if args.mode == "train" and world == 1:

@@ -40,6 +40,17 @@ def _worker(rank, world, port, q):
     g.copy_(torch.full((n,), float(rank)))
     b.finish()
     ok_grad2 = torch.allclose(g, torch.full((n,), (world - 1) / 2.0))
+    # the opt-in bf16 wire: the same mean to bf16 rounding, the arena stays fp32
+    torch.manual_seed(5 + rank)
+    g16 = torch.randn(300_001)
+    ref16 = g16.clone()
+    dist.all_reduce(ref16)
+    ref16 /= world
+    b16 = D.GradBucketer(g16, bucket_bytes=1 << 19, wire_dtype="bf16")
+    b16.ready(150_000)
+    b16.finish()
+    err16 = float((g16 - ref16).abs().max() / ref16.abs().max())
+    ok_grad2 = ok_grad2 and g16.dtype == torch.float32 and 0 < err16 < 8e-3 and not b16._wires
     lo, hi = D.shard_range(8, rank, world)
     sc = D.all_reduce_scalars(torch.tensor([float(rank), 2.0 * rank]))
     gl = D.masked_loss_global(torch.tensor(3.0 * (rank + 1)), torch.tensor(float(rank + 1)))

@@ -62,8 +62,16 @@ class GradBucketer:
     the side stream.  (Round 3 waited on the compute stream and recorded the end event on a side stream the collectives never
     ran on: it measured the gap between hand-overs.)  CPU tensors (gloo, the tests): host wall clock around the same points."""
 
-    def __init__(self, grads: torch.Tensor, bucket_bytes: int = 16 << 20, group=None, cuts=(), timing: bool = False):
+    def __init__(self, grads: torch.Tensor, bucket_bytes: int = 16 << 20, group=None, cuts=(), timing: bool = False,
+                 wire_dtype: str = "fp32"):
         assert grads.dim() == 1 and grads.dtype == torch.float32
+        if wire_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"wire_dtype={wire_dtype!r}: 'fp32' (exact: the rank mean of fp32 gradients) or 'bf16'")
+        # wire_dtype "bf16": every collective carries a bf16 copy of its slice (half the bytes per xGMI link; the ranks' gradients
+        # are rounded to 8 bits of mantissa and summed in bf16) and the sum is widened back into the fp32 arena -- opt-in, for
+        # 16-bit engines whose gradients carry bf16 rounding already; the default keeps the all-reduce in fp32
+        self.wire_bf16 = wire_dtype == "bf16"
+        self._wires = []
         self.grads = grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -100,12 +108,20 @@ class GradBucketer:
                     e = torch.cuda.Event(enable_timing=True)
                     e.record(self.comm_stream)
                     self._ev.append(e)
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.handles.append(dist.all_reduce(self._wire(view), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             if self.timing_host and self._t0 is None:
                 import time
                 self._t0 = time.perf_counter()
-            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.handles.append(dist.all_reduce(self._wire(view), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _wire(self, view: torch.Tensor) -> torch.Tensor:
+        """what the collective carries for this slice of the arena (called under the stream the collective is issued on)"""
+        if not self.wire_bf16:
+            return view
+        w = view.to(torch.bfloat16)
+        self._wires.append((w, view))
+        return w
 
     def _launch_runs(self, idx):
         """launch the not-yet-launched buckets among idx (ascending), every run of adjacent ones as one collective"""
@@ -140,6 +156,8 @@ class GradBucketer:
             with torch.cuda.stream(self.comm_stream):
                 for h in self.handles:      # the SIDE stream waits for the collectives' own streams ...
                     h.wait()
+                for w, view in self._wires:  # ... widens the bf16 sums back into the arena ...
+                    view.copy_(w)
                 if self.timing and self._ev:
                     e = torch.cuda.Event(enable_timing=True)
                     e.record(self.comm_stream)   # ... so this event fires when the last collective is done
@@ -150,6 +168,8 @@ class GradBucketer:
             tw0 = time.perf_counter()
             for h in self.handles:
                 h.wait()
+            for w, view in self._wires:
+                view.copy_(w)
             if self.timing_host and self._t0 is not None:
                 t1 = time.perf_counter()
                 self.last_comm_ms, self.last_wait_ms = (t1 - self._t0) * 1e3, (t1 - tw0) * 1e3
@@ -161,6 +181,7 @@ class GradBucketer:
                 self._pending = (self._ev, (w0, w1))
         self._ev = []
         self.handles = []
+        self._wires = []
         self.launched = [False] * len(self.bounds)
 
     def collect_timing(self):
@@ -180,12 +201,13 @@ class GradSync(GradBucketer):
     of the gated layers + the head in the middle of the sweep, the lower half at its end, first conv / embedding / upsampling /
     encoder / codebook in finish() (pass as train_step(grad_sync=...))."""
 
-    def __init__(self, eng, bucket_bytes: int = 16 << 20, group=None, timing: bool = False):
+    def __init__(self, eng, bucket_bytes: int = 16 << 20, group=None, timing: bool = False, wire_dtype: Optional[str] = None):
         from . import backward as BW
         BW._prepare_bwd(eng)
         # cut at the slice boundaries backward hands over: [lo, mid) lower half of the gated layers, [mid, hi) upper half + head
         lo, hi = BW.layer_segment(eng)
-        super().__init__(eng.grads, bucket_bytes, group, cuts=(lo, BW.layer_segment_mid(eng), hi), timing=timing)
+        super().__init__(eng.grads, bucket_bytes, group, cuts=(lo, BW.layer_segment_mid(eng), hi), timing=timing,
+                         wire_dtype=wire_dtype or eng.opt.dp_wire)       # (WAE_DP_WIRE: options.py)
 
 
 def ragged_ce_scale(lengths: Optional[torch.Tensor], T: int, batch: int, group=None) -> Tuple[float, float]:

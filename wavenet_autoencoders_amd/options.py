@@ -14,6 +14,7 @@ arguments (include/wae.h) from tools/.
     WAE_HEAD_WIDE          0         1: the separate-launch head of skip widths > 256, forced onto narrow models (tests)
     WAE_GLU_PAIR           inference 0 / 1: workgroup barrier on every second weight chunk of the layer kernel never / always
     WAE_DP_SPLIT           1         0: data parallel: the gradient arena handed to the all-reduce once, at the end of the sweep
+    WAE_DP_WIRE            fp32      bf16: data parallel: the gradient all-reduce carries bf16 copies (half the bytes per link)
     WAE_AR_COOP            1         0: autoregressive decoding on the one-CU kernel even for <= 8 utterances
     WAE_AR_COOP_C          32        cooperating workgroups per utterance (1..32)
     WAE_BWD_FUSED          0         1: K_X(l) + K_U(l-1) of the backward sweep as one launch (csrc/glu_bwd.hip; measured equal)
@@ -32,6 +33,7 @@ class EngineOptions:
     head_wide: bool = False
     glu_pair: str = "inference"
     dp_split: bool = True
+    dp_wire: str = "fp32"
     ar_coop: bool = True
     ar_coop_c: int = 32
     bwd_fused: bool = False
@@ -43,7 +45,10 @@ class EngineOptions:
         pair = e("WAE_GLU_PAIR", "inference")
         if pair not in ("inference", "0", "1"):
             raise ValueError(f"WAE_GLU_PAIR={pair!r}: 'inference', '0' or '1'")
-        return EngineOptions(tn_stream=e("WAE_TN_STREAM", "1") != "0", tn_static=e("WAE_TN_STATIC", "1") != "0",
+        wire = e("WAE_DP_WIRE", "fp32")
+        if wire not in ("fp32", "bf16"):
+            raise ValueError(f"WAE_DP_WIRE={wire!r}: 'fp32' or 'bf16'")
+        return EngineOptions(dp_wire=wire, tn_stream=e("WAE_TN_STREAM", "1") != "0", tn_static=e("WAE_TN_STATIC", "1") != "0",
                              tn_static_head=e("WAE_TN_STATIC_HEAD", "1") != "0", head_split=e("WAE_HEAD_SPLIT", "1") != "0",
                              head_wide=e("WAE_HEAD_WIDE", "0") == "1", glu_pair=pair, dp_split=e("WAE_DP_SPLIT", "1") != "0",
                              ar_coop=e("WAE_AR_COOP", "1") != "0", ar_coop_c=int(e("WAE_AR_COOP_C", "32")),
