@@ -539,6 +539,10 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            "dtype_parity": {"fp32": "logits / latents / gradients within 1e-3 of the reference (measured ~1e-6): the north star's tolerance",
+                             "bf16": "16-bit storage, fp32 accumulate: checked at max|a-b| / max|b| <= 5e-2 per tensor against the fp32 oracle, "
+                                     "VQ indices bit-exact (tests/helpers.py, DESIGN.md section 4)",
+                             "fp16": "as bf16 at 1e-2 (logits) / 4e-2 (gradients), loss scale 4096"}[args.dtype],
             "config": {"workload": conf["name"] + f", batch {B_PER_GPU}x{T} per GPU, "
                                    + ("full train step: weight-norm+pack, " + ("encoder, VQ, " if conf["encoder"] else "") + "forward, fused CE, backward, "
                                       "clip+Adam+EMA" if args.mode == "train" else "teacher-forced forward (weights packed once, before the timed region), upsample, head and fused CE")
