@@ -38,12 +38,14 @@ def _prepare_bwd(eng):
     eng.opt_tn_static_head = eng.opt.tn_static_head
     eng.m_bu = up(P.bwd_u_map(g, lay, eng.dt))
     eng.m_bx = up(P.bwd_x_map(g, lay, eng.dt))
-    # K_X(l) + K_U(l-1) in one launch (csrc/glu_bwd.hip).  The round-1 kernel measured SLOWER than the two launches (118 us vs 60 + 50);
-    # the 16-bit form of round 5 (two workgroups per CU, the residual launch's own weight stream and chunk order) measures EQUAL
-    # (profiles/EXPERIMENT_LOG.md): opt-in (EngineOptions.bwd_fused).  fp32 keeps the round-1 kernel (tap-by-tap weights) behind the same switch.
+    # K_X(l) + K_U(l-1) in one launch (csrc/glu_bwd.hip).  16-bit storage: the round-5 kernel (two workgroups per CU, the residual
+    # launch's own weight stream and chunk order) is the DEFAULT where it has an instantiation -- 5.72 -> 5.52 ms per C2 train step once
+    # its epilogues stopped reloading spilled addresses (profiles/EXPERIMENT_LOG.md); EngineOptions.bwd_fused "0" keeps the two launches.
+    # fp32 keeps the two launches unless asked ("1"): its fused form is the round-1 kernel (118 us against 60 + 50).
     is16 = eng.dt in (L.WAE_BF16, L.WAE_F16)
     sup = eng.lib.wae_glu_bwd_fused_supported16(g.Rp, g.Hp) if is16 else eng.lib.wae_glu_bwd_fused_supported(g.Rp, g.Hp)
-    eng.fused_bwd = bool(sup) and g.Sp % (64 if is16 else 32) == 0 and eng.opt.bwd_fused
+    want = eng.opt.bwd_fused == "1" or (eng.opt.bwd_fused == "auto" and is16)
+    eng.fused_bwd = bool(sup) and g.Sp % (64 if is16 else 32) == 0 and want
     if eng.fused_bwd:
         eng.m_buo = up(P.bwd_uo_map(g, lay, eng.dt))
         eng.n_buo = eng.m_buo.numel()

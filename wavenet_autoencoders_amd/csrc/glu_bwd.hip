@@ -26,6 +26,7 @@ struct GbArgs {
   int64_t dz_stride;
   float alpha;
   int B, T, Sp, ktaps, dilation;
+  unsigned long long* stamps;   // diagnostic builds (-DWAE_GBP_STAMPS) only, else null
 };
 
 template <typename E, int NTX, int NTU>
@@ -221,9 +222,23 @@ __device__ __forceinline__ void drain_groups(F (&a)[4], F (&b)[4], F (&c)[4]) {
                : "memory");
 }
 
+#ifdef WAE_GBP_STAMPS
+// diagnostic build (tools/stamps_gbp.py): per workgroup 8 x u64 of wave 0: [0] prologue, [1] phase A, [2] epilogue A, [3] B1, [4] B2,
+// [5] epilogue B (clocks, s_memtime), [6] life in 10-ns ticks (s_memrealtime), [7] 1
+static unsigned long long* g_gbp_stamps = nullptr;
+extern "C" void wae_debug_set_gbp_stamps(unsigned long long* dev_buf) { g_gbp_stamps = dev_buf; }
+#define GBP_TICK(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define GBP_TICK(v) do { } while (0)
+#endif
+
 template <typename E, int NTX, int NTU>
 __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   static_assert(sizeof(E) == 2 && NTX % 2 == 0 && NTU % 2 == 0, "16-bit storage, pairwise epilogues");
+#ifdef WAE_GBP_STAMPS
+  const unsigned long long gw0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  GBP_TICK(g0);
   using T_ = ET<E>;
   using frag = typename T_::frag;
   constexpr int ES = sizeof(E);
@@ -309,6 +324,7 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
     request(Gl, a_addr(q + 2, kl));
     gemm_chunk<4 * NTX, NTX, 4>(smem + (q & 1) * CHX + lane * 16, Gc, accx);
   };
+  GBP_TICK(g1);
   for (int q = 0; q < nqa; q += 3) {
     step_a(q, G0, k0, G2, k2);
     if (q + 1 < nqa) step_a(q + 1, G1, k1, G0, k0);
@@ -316,18 +332,25 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   }
   drain_groups(G0, G1, G2);                          // chunk nqa (B1's first) has landed; the redundant operand requests are retired
   __builtin_amdgcn_s_barrier();                      // every wave has left slot (nqa - 1) & 1: it is the staging area of epilogue A
+  GBP_TICK(g2);
 
   // ---- epilogue A: dx_l-hat = alpha * (acc + residual), stored once, kept as the operand of GEMM B1 ------------------------------
   frag xf[NKB];
   {
+    // the lane id, laundered: hipcc otherwise forms the staging passes' per-lane addresses at the top of the kernel, carries them
+    // through phase A in registers it does not have, and reloads them from scratch once per tile pair -- a scratch reload waits for
+    // EVERY outstanding request, the previous pair's stores included (stamps: 27.6 k clocks for this epilogue against 9.7 k in the
+    // two-launch kernel)
+    int le = lane;
+    asm volatile("" : "+v"(le));
     char* stg = smem + ((nqa - 1) & 1) * CHX + wave * STGB;
     char* orow = p.g_out + row0 * NTX * 32 * ES;
 #pragma unroll
     for (int pr = 0; pr < NTX / 2; ++pr) {
       f32x16 res[2];
       if (rows_valid > 0) {
-        stage_unpack_pass<E, 2, 128>(stg, res, fa, lane);
-        if (pr + 1 < NTX / 2) stage_fetch_pass<E, 2>(fa, arow + (pr + 1) * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, lane);
+        stage_unpack_pass<E, 2, 128>(stg, res, fa, le);
+        if (pr + 1 < NTX / 2) stage_fetch_pass<E, 2>(fa, arow + (pr + 1) * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, le);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -338,10 +361,11 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
 #pragma unroll
         for (int s = 0; s < KBU; ++s) xf[(2 * pr + i) * KBU + s] = tmp[s];
       }
-      if (rows_valid > 0) stage_store_pass<E, 2, 128>(stg, &accx[2 * pr], orow + pr * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, lane);
+      if (rows_valid > 0) stage_store_pass<E, 2, 128>(stg, &accx[2 * pr], orow + pr * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, le);
     }
   }
 
+  GBP_TICK(g3);
   // ---- GEMM B: du = W_out^T dx_l-hat (operand from registers) + W_skip^T dskip (operand from memory) -------------------------------
   f32x16 accu[NTU];
 #pragma unroll
@@ -393,6 +417,7 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
     request(Gl, s_addr(j + 2));
     gemm_chunk<4 * NTU, NTU, 4>(smem + (qi & 1) * CHX + lane * 16, Gc, accu);
   };
+  GBP_TICK(g4);
   step_s(IntC<1>{}, 0, G0, G2);
   for (int j = 1; j < nqb2; j += 3) {
     step_s(IntC<0>{}, j, G1, G0);
@@ -401,20 +426,23 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   }
   drain_groups(G0, G1, G2);                          // the redundant tail requests must not outlive the ring (or their registers)
   __syncthreads();                                   // every wave is done with the weight ring: it becomes the staging area
+  GBP_TICK(g5);
   if (rows_valid <= 0) return;
 
   // ---- epilogue B: gate backward (modules.py:154: u = tanh(a) * sigmoid(b)):  da = du s (1 - th^2),  db = du th s (1 - s) ------------
   {
+    int le = lane;                                   // (laundered like epilogue A's)
+    asm volatile("" : "+v"(le));
     char* stg = smem + wave * STGB;
     char* orow = p.dz_prev + row0 * p.dz_stride * ES;
 #pragma unroll
     for (int pr = 0; pr < NTU / 2; ++pr) {
       f32x16 za[2], zg[2];
-      stage_unpack_pass<E, 2, 128>(stg, za, fa, lane);
-      stage_unpack_pass<E, 2, 128>(stg, zg, fb, lane);
+      stage_unpack_pass<E, 2, 128>(stg, za, fa, le);
+      stage_unpack_pass<E, 2, 128>(stg, zg, fb, le);
       if (pr + 1 < NTU / 2) {
-        stage_fetch_pass<E, 2>(fa, zrow + (pr + 1) * 64 * ES, (int64_t)Z2 * ES, rows_valid, lane);
-        stage_fetch_pass<E, 2>(fb, zrow + ((int64_t)NTU * 32 + (pr + 1) * 64) * ES, (int64_t)Z2 * ES, rows_valid, lane);
+        stage_fetch_pass<E, 2>(fa, zrow + (pr + 1) * 64 * ES, (int64_t)Z2 * ES, rows_valid, le);
+        stage_fetch_pass<E, 2>(fb, zrow + ((int64_t)NTU * 32 + (pr + 1) * 64) * ES, (int64_t)Z2 * ES, rows_valid, le);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -427,10 +455,18 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
           za[i][r] = du * sg * (1.0f - th * th);
           zg[i][r] = du * th * sg * (1.0f - sg);
         }
-      stage_store_pass<E, 2, 128>(stg, za, orow + pr * 64 * ES, p.dz_stride * ES, rows_valid, lane);
-      stage_store_pass<E, 2, 128>(stg, zg, orow + ((int64_t)NTU * 32 + pr * 64) * ES, p.dz_stride * ES, rows_valid, lane);
+      stage_store_pass<E, 2, 128>(stg, za, orow + pr * 64 * ES, p.dz_stride * ES, rows_valid, le);
+      stage_store_pass<E, 2, 128>(stg, zg, orow + ((int64_t)NTU * 32 + pr * 64) * ES, p.dz_stride * ES, rows_valid, le);
     }
   }
+#ifdef WAE_GBP_STAMPS
+  GBP_TICK(g6);
+  if (p.stamps && threadIdx.x == 0) {
+    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+    o[0] = g1 - g0; o[1] = g2 - g1; o[2] = g3 - g2; o[3] = g4 - g3; o[4] = g5 - g4; o[5] = g6 - g5;
+    o[6] = __builtin_amdgcn_s_memrealtime() - gw0; o[7] = 1;
+  }
+#endif
 }
 
 template <typename E, int NTX, int NTU>
@@ -502,6 +538,10 @@ extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int6
   a.z_prev = (const char*)z_prev; a.dz_prev = (char*)dz_prev; a.w_x = (const char*)w_x; a.w_uo = (const char*)w_uo;
   a.w_us = (const char*)w_us; a.dz_stride = dz_stride; a.alpha = d->alpha; a.B = d->B; a.T = d->T; a.Sp = d->Sp;
   a.ktaps = d->ktaps; a.dilation = d->dilation;
+  a.stamps = nullptr;
+#ifdef WAE_GBP_STAMPS
+  a.stamps = g_gbp_stamps;
+#endif
   hipStream_t st = as_stream(stream);
   if (d->dtype == WAE_BF16) return dispatch_gb<__bf16>(d->Rp / 32, d->Hp / 32, a, st);
   if (d->dtype == WAE_F16) return dispatch_gb<f16>(d->Rp / 32, d->Hp / 32, a, st);

@@ -17,7 +17,8 @@ arguments (include/wae.h) from tools/.
     WAE_DP_WIRE            fp32      bf16: data parallel: the gradient all-reduce carries bf16 copies (half the bytes per link)
     WAE_AR_COOP            1         0: autoregressive decoding on the one-CU kernel even for <= 8 utterances
     WAE_AR_COOP_C          32        cooperating workgroups per utterance (1..32)
-    WAE_BWD_FUSED          0         1: K_X(l) + K_U(l-1) of the backward sweep as one launch (csrc/glu_bwd.hip; measured equal)
+    WAE_BWD_FUSED          auto      residual(l) + gate(l-1) of the backward sweep as one launch (csrc/glu_bwd.hip): auto = 16-bit engines
+                                     where the kernel has an instantiation; 0: always the two wae_gemm_tm launches; 1: fp32 too
     WAE_AR_FUSED           0         1: one hand-over per layer in the cooperative decode kernel (measured slower)
 """
 import os
@@ -36,7 +37,7 @@ class EngineOptions:
     dp_wire: str = "fp32"
     ar_coop: bool = True
     ar_coop_c: int = 32
-    bwd_fused: bool = False
+    bwd_fused: str = "auto"
     ar_fused: bool = False
 
     @staticmethod
@@ -45,6 +46,9 @@ class EngineOptions:
         pair = e("WAE_GLU_PAIR", "inference")
         if pair not in ("inference", "0", "1"):
             raise ValueError(f"WAE_GLU_PAIR={pair!r}: 'inference', '0' or '1'")
+        fused = e("WAE_BWD_FUSED", "auto")
+        if fused not in ("auto", "0", "1"):
+            raise ValueError(f"WAE_BWD_FUSED={fused!r}: 'auto', '0' or '1'")
         wire = e("WAE_DP_WIRE", "fp32")
         if wire not in ("fp32", "bf16"):
             raise ValueError(f"WAE_DP_WIRE={wire!r}: 'fp32' or 'bf16'")
@@ -52,4 +56,4 @@ class EngineOptions:
                              tn_static_head=e("WAE_TN_STATIC_HEAD", "1") != "0", head_split=e("WAE_HEAD_SPLIT", "1") != "0",
                              head_wide=e("WAE_HEAD_WIDE", "0") == "1", glu_pair=pair, dp_split=e("WAE_DP_SPLIT", "1") != "0",
                              ar_coop=e("WAE_AR_COOP", "1") != "0", ar_coop_c=int(e("WAE_AR_COOP_C", "32")),
-                             bwd_fused=e("WAE_BWD_FUSED", "0") == "1", ar_fused=e("WAE_AR_FUSED", "0") == "1")
+                             bwd_fused=fused, ar_fused=e("WAE_AR_FUSED", "0") == "1")
