@@ -309,8 +309,6 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accx[m][r] = 0.f;
   f32x4 fa[8], fb[8];
-  const char* arow = p.g_next + row0 * NTX * 32 * ES;
-  if (rows_valid > 0) stage_fetch_pass<E, 2>(fa, arow, (int64_t)NTX * 32 * ES, rows_valid, lane);   // residual rows of the first tile pair
   frag G0[4] = {}, G1[4] = {}, G2[4] = {};
   bool k0, k1, k2;
   dma(0);
@@ -335,27 +333,41 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   GBP_TICK(g2);
 
   // ---- epilogue A: dx_l-hat = alpha * (acc + residual), stored once, kept as the operand of GEMM B1 ------------------------------
+  // The residual rows (dx_{l+1}-hat of this tile) arrive as operand-shaped 16-byte fragments -- lane (n, h): row n, bytes
+  // [32 f + 16 h, +16) -- ALL 2 NTX of them requested at once (the three operand groups of phase A are dead: their registers), and
+  // one half-swap puts them into the accumulator layout (csrc/wae_common.hpp: residual_to_acc_layout, what the layer kernel does with
+  // its residual): ONE exposed round trip for the whole tile and no LDS staging on the way in.  The pairwise form fetched pair
+  // i + 1 under the math of pair i, i.e. paid a round trip per pair (stamps: 16.5 k clocks for this epilogue).
   frag xf[NKB];
   {
     // the lane id, laundered: hipcc otherwise forms the staging passes' per-lane addresses at the top of the kernel, carries them
     // through phase A in registers it does not have, and reloads them from scratch once per tile pair -- a scratch reload waits for
-    // EVERY outstanding request, the previous pair's stores included (stamps: 27.6 k clocks for this epilogue against 9.7 k in the
-    // two-launch kernel)
+    // EVERY outstanding request, the previous pair's stores included (stamps: 27.6 k clocks against 9.7 k in the two-launch kernel)
     int le = lane;
     asm volatile("" : "+v"(le));
+    const int ne = le & 31, he = le >> 5;
+    frag rs[2 * NTX];
+    {
+      // (rows at or behind the clip's end read its last row: never stored)
+      const char* rp = p.g_next + ((int64_t)b * p.T + min(t0w + ne, p.T - 1)) * (int64_t)(NTX * 32 * ES) + he * 16;
+#pragma unroll
+      for (int f = 0; f < 2 * NTX; ++f) rs[f] = *(const frag*)(rp + f * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    residual_to_acc_layout(rs);
     char* stg = smem + ((nqa - 1) & 1) * CHX + wave * STGB;
     char* orow = p.g_out + row0 * NTX * 32 * ES;
 #pragma unroll
     for (int pr = 0; pr < NTX / 2; ++pr) {
-      f32x16 res[2];
-      if (rows_valid > 0) {
-        stage_unpack_pass<E, 2, 128>(stg, res, fa, le);
-        if (pr + 1 < NTX / 2) stage_fetch_pass<E, 2>(fa, arow + (pr + 1) * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, le);
-      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accx[2 * pr + i][r] = p.alpha * (accx[2 * pr + i][r] + (rows_valid > 0 ? res[i][r] : 0.f));
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 r4 = residual_piece<E>(rs, 2 * pr + i, g);
+          f32x16& a = accx[2 * pr + i];
+          a[4 * g] = p.alpha * (a[4 * g] + r4.x); a[4 * g + 1] = p.alpha * (a[4 * g + 1] + r4.y);
+          a[4 * g + 2] = p.alpha * (a[4 * g + 2] + r4.z); a[4 * g + 3] = p.alpha * (a[4 * g + 3] + r4.w);
+        }
         frag tmp[KBU];
         acc_to_frags(accx[2 * pr + i], tmp);
 #pragma unroll
