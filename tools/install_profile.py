@@ -17,6 +17,7 @@ NAMES = {"glu_fwd_static_kernel<": "glu_fwd_static_kernel (inference launch of t
          "gemm_tm_kernelIDF16bLi8ELi3E": "gemm_tm_kernel<bf16, NT=8, MODE=3> (the head's skip contraction, K = 4608)",
          "gemm_tm_kernelIDF16bLi2ELi0E": "gemm_tm_kernel<bf16, NT=2, MODE=0> (dc, K = 9216)",
          "gemm_tn_static_kernel": "gemm_tn_static_kernel (every weight gradient of the step)",
+         "glu_bwd_pair_kernel": "glu_bwd_pair_kernel (residual(l) + gate(l-1) in one launch: the 16-bit backward sweep)",
          "head_fwd_kernel": "head_fwd_kernel<..., FROM_H0> (GEMM 1, GEMM 2, fused CE)", "head_bwd_kernel": "head_bwd_kernel"}
 if old:
     for fn in glob.glob(f"profiles/{old}_*"):

@@ -640,7 +640,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     ck = 64 if eng.dt in (L.WAE_BF16, L.WAE_F16) else 32
     us_off = (g.Rp // ck) * g.NP * 4 * 1024   # bytes: the W_skip chunks follow the W_out chunks in the mode-2 stream
 
-    tm_ev = getattr(eng, "_tm_events", None)   # bench.py: {"gate": [(e0, e1), ...], "res": [...]} -- HIP events around every launch
+    tm_ev = getattr(eng, "_tm_events", None)   # bench.py: {"gate": [(e0, e1), ...], "res": [...], "pair": [...]} -- HIP events around every launch
 
     def timed(kind, fn):
         if tm_ev is None:
@@ -649,7 +649,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         e0.record(torch.cuda.current_stream(eng.device))
         fn()
         e1.record(torch.cuda.current_stream(eng.device))
-        tm_ev[kind].append((e0, e1))
+        tm_ev.setdefault(kind, []).append((e0, e1))
 
     def k_u(l, gn):                            # du -> dz of layer l
         timed("gate", lambda: _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
@@ -761,12 +761,13 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         if l > 0 and eng.fused_bwd and seeds is None:
             # K_X of layer l and K_U of layer l-1 in one launch (csrc/glu_bwd.hip)
             d = L.GluBwdDesc(eng.dt, B, T, g.Rp, g.Hp, g.Sp, g.k, g.dilations[l], RS)
-            L.check(lib.wae_glu_bwd_fused(ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
-                                          L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][l - 1]),
-                                          ctypes.c_void_p(ws["dz"].data_ptr() + (l - 1) * Z2 * es),
-                                          ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
-                                          ctypes.c_void_p(eng.w_buo.data_ptr() + (l - 1) * eng.n_buo * es),
-                                          ctypes.c_void_p(eng.w_bu.data_ptr() + (l - 1) * eng.n_bu * es + us_off), st), "glu_bwd_fused")
+            timed("pair", lambda: L.check(lib.wae_glu_bwd_fused(
+                ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
+                L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][l - 1]),
+                ctypes.c_void_p(ws["dz"].data_ptr() + (l - 1) * Z2 * es),
+                ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
+                ctypes.c_void_p(eng.w_buo.data_ptr() + (l - 1) * eng.n_buo * es),
+                ctypes.c_void_p(eng.w_bu.data_ptr() + (l - 1) * eng.n_bu * es + us_off), st), "glu_bwd_fused"))
         else:
             k_x(l, g_next, g_cur)
             if l > 0:
