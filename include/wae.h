@@ -459,6 +459,16 @@ int wae_glu_bwd_fused_supported16(int32_t Rp, int32_t Hp);
 int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
                       const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
                       const void* w_us, void* stream);
+/* 16-bit storage, three taps, Ccp = 64: the same launch with the conditioning gradient folded in (round 5).  dc = sum_l Wc_l^T dz_l
+ * (the ONE K = L * 2Hp launch of wae_gemm_tm mode 0 that re-reads every layer's dz) rides on phase A's shift-0 tap, whose operand
+ * fragments are dz_l[t]: w_c = layer l's 2Hp / 64 chunks (8 KiB each) of that launch's weight stream (packing.py: bwd_c_map), dc_acc =
+ * the fp32 (B,T,64) running sum over the layers, dc_mode bit 0: add dc_acc's previous content (clear: the first launch of a sweep),
+ * bit 1: write the sum in the storage dtype to dc_out (B,T,64) instead (the last launch of the sweep).  last = 1: layer 0 -- phase A +
+ * its epilogue only (z_prev / dz_prev / w_uo / w_us are not used but must be valid pointers). */
+int wae_glu_bwd_fused_dc(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
+                         const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
+                         const void* w_us, const void* w_c, float* dc_acc, void* dc_out, int32_t dc_mode, int32_t last,
+                         void* stream);
 
 /* ---- all weight-gradient contractions of a step in one launch (csrc/gemm_tn_stream.hip; bf16 operands only) ------
  * Same contraction as wae_gemm_tn_tiles, C[m][n] += alpha * sum_{b,t} P[b,t][m] * Q[b,t+shift][n], cut differently:

@@ -753,21 +753,35 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             ws["stream_hi"] = _build_stream_table(eng, ws, fw, B, T, split, g.layers)
             ws["stream_lo"] = _build_stream_table(eng, ws, fw, B, T, 0, split)
 
+    # 16-bit fused sweep, three taps, 64 conditioning columns: dc = sum_l Wc_l^T dz_l is folded into the pair launches (phase A's
+    # shift-0 tap already holds dz_l[t] as MFMA operand): an fp32 running sum over the layers, written in the storage dtype by the
+    # launch of layer 0 (which runs the pair kernel's first half only) -- the K = L * 2Hp launch that re-read every dz is gone
+    fold_dc = bool(eng.fused_bwd and seeds is None and eng.dt in (L.WAE_BF16, L.WAE_F16) and g.k == 3 and g.Ccp == 64
+                   and eng.opt.bwd_fold_dc)
+    if fold_dc and "dc32" not in ws:
+        ws["dc32"] = torch.empty(B, T, 64, dtype=torch.float32, device=eng.device)
+    cbytes = (Z2 // 64) * 8192                # bytes of one layer's chunks in the dc weight stream (packing.bwd_c_map)
     k_u(g.layers - 1, g_next)
     for l in range(g.layers - 1, -1, -1):
         assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % ngx].data_ptr()
         tn_layer(l)                            # needs dz_l and dx_{l+1}-hat
         g_cur = ws["gx"][l % ngx]
-        if l > 0 and eng.fused_bwd and seeds is None:
-            # K_X of layer l and K_U of layer l-1 in one launch (csrc/glu_bwd.hip)
+        if (l > 0 or fold_dc) and eng.fused_bwd and seeds is None:
+            # K_X of layer l and K_U of layer l-1 in one launch (csrc/glu_bwd.hip); layer 0 (fold_dc): K_X + the last dc term only
             d = L.GluBwdDesc(eng.dt, B, T, g.Rp, g.Hp, g.Sp, g.k, g.dilations[l], RS)
-            timed("pair", lambda: L.check(lib.wae_glu_bwd_fused(
-                ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
-                L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][l - 1]),
-                ctypes.c_void_p(ws["dz"].data_ptr() + (l - 1) * Z2 * es),
-                ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
-                ctypes.c_void_p(eng.w_buo.data_ptr() + (l - 1) * eng.n_buo * es),
-                ctypes.c_void_p(eng.w_bu.data_ptr() + (l - 1) * eng.n_bu * es + us_off), st), "glu_bwd_fused"))
+            lp = max(l - 1, 0)
+            args = [ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
+                    L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][lp]),
+                    ctypes.c_void_p(ws["dz"].data_ptr() + lp * Z2 * es),
+                    ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
+                    ctypes.c_void_p(eng.w_buo.data_ptr() + lp * eng.n_buo * es),
+                    ctypes.c_void_p(eng.w_bu.data_ptr() + lp * eng.n_bu * es + us_off)]
+            if fold_dc:
+                mode = (0 if l == g.layers - 1 else 1) | (2 if l == 0 else 0)
+                args += [ctypes.c_void_p(eng.w_bc.data_ptr() + l * cbytes), L.ptr(ws["dc32"]), L.ptr(ws["dc"]), mode, int(l == 0)]
+                timed("pair", lambda: L.check(lib.wae_glu_bwd_fused_dc(*args, st), "glu_bwd_fused_dc"))
+            else:
+                timed("pair", lambda: L.check(lib.wae_glu_bwd_fused(*args, st), "glu_bwd_fused"))
         else:
             k_x(l, g_next, g_cur)
             if l > 0:
@@ -801,7 +815,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
             eng._grads_done = (seg_lo, seg_hi)
             grad_sync.ready_range(seg_lo, seg_hi)
     # ---- local-conditioning gradient over all layers at once ---------------------------------------------------------
-    if g.Ccp:
+    if g.Ccp and not fold_dc:
         _tm(eng, B, T, g.Ccp, 0, 1.0, [(ws["dz"].data_ptr(), dzs, dzs, 0)], eng.w_bc.data_ptr(), ws["dc"].data_ptr(), g.Ccp)
     # ---- first conv: dW[r][class] = sum_t dx0[t][r] onehot(id[t])[class];  dx0 = dxhat_0 / sqrt(.5) -----------------------
     ctab, fb = eng.cview["ctab"], eng.cview["fb"]

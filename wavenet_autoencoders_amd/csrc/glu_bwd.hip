@@ -27,6 +27,13 @@ struct GbArgs {
   float alpha;
   int B, T, Sp, ktaps, dilation;
   unsigned long long* stamps;   // diagnostic builds (-DWAE_GBP_STAMPS) only, else null
+  // 16-bit pair kernel, dc folded in (Ccp = 64, 3 taps): dc += Wc_l^T dz_l rides on the chunks of the shift-0 tap, whose operand
+  // fragments ARE dz_l[t]; the running sum over the layers lives in an fp32 (B,T,64) array, the last launch writes the 16-bit dc
+  const char* w_c;      // this layer's chunks of the dc weight stream (first_gemm_map(Ccp, 2Hp): 8 KiB per column block), or null
+  float* dc_acc;        // (B,T,64) fp32
+  char* dc_out;         // (B,T,64) in the storage dtype: written instead of dc_acc when dc_mode & 2
+  int dc_mode;          // bit 0: add the previous sum (dc_acc); bit 1: write dc_out (the last layer of the sweep)
+  int last;             // 1: layer 0 -- phase A + epilogue A only (there is no layer below to gate)
 };
 
 template <typename E, int NTX, int NTU>
@@ -232,7 +239,40 @@ extern "C" void wae_debug_set_gbp_stamps(unsigned long long* dev_buf) { g_gbp_st
 #define GBP_TICK(v) do { } while (0)
 #endif
 
-template <typename E, int NTX, int NTU>
+// one tile (32 rows x 32 channels, accumulator layout) into a row-major fp32 / 16-bit array through the wave's 4-KiB staging tile:
+// v = acc (+ old[row]) ; old is the fp32 running sum, the result goes to out32 (fp32) or out16 (storage dtype)
+// (the old values are fetched by the caller ahead of time: rmw_fetch; rows at or beyond rows_valid fetch the last valid row)
+__device__ __forceinline__ void rmw_fetch(f32x4 (&w)[4], const float* old32, int tile, int rows_valid, int lane) {
+  const int rr = lane >> 3, ck = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = *(const f32x4*)(old32 + (int64_t)min(i * 8 + rr, rows_valid - 1) * 64 + tile * 32 + ck * 4);
+}
+template <typename E>
+__device__ __forceinline__ void stage_rmw_tile(char* stg, const f32x16& y, const f32x4 (&w)[4], bool add, float* out32, char* out16,
+                                               int tile, int rows_valid, int lane) {
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v = {y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
+    *(f32x4*)(stg + n * 128 + (((2 * g + h) ^ (n & 7)) << 4)) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int rr = lane >> 3, ck = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 8 + rr;
+    f32x4 v = *(const f32x4*)(stg + row * 128 + ((ck ^ (row & 7)) << 4));
+    if (add) v = v + w[i];
+    if (row < rows_valid) {
+      const int64_t o = (int64_t)row * 64 + tile * 32 + ck * 4;
+      if (out16) *(typename ET<E>::vec4*)(out16 + o * (int64_t)sizeof(E)) = from_f32x4<E>(v);
+      else *(f32x4*)(out32 + o) = v;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <typename E, int NTX, int NTU, bool FOLD = false>
 __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   static_assert(sizeof(E) == 2 && NTX % 2 == 0 && NTU % 2 == 0, "16-bit storage, pairwise epilogues");
 #ifdef WAE_GBP_STAMPS
@@ -252,6 +292,8 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   constexpr int Z2 = 2 * NTU * 32;
   constexpr int STGB = 4096;                     // per-wave staging tile (row pitch 128 B)
   static_assert(4 * STGB <= CHX, "the staging tiles of the four waves fit one ring slot");
+  constexpr int CHC = 2 * 4 * 1024;              // FOLD: a column block of the dc weights (Ccp = 64: two tiles x four k-blocks)
+  constexpr int SLOT = CHX + (FOLD ? CHC : 0);   // ring slot: a phase-A chunk [+ the dc block that rides on shift-0 chunks]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -271,10 +313,13 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   const int nqb2 = p.Sp / T_::CK;
   const int nq_total = nqa + nqb1 + nqb2;
   auto dma = [&](int qi) {                       // chunk qi of the whole sequence -> ring slot qi & 1
-    char* dst = smem + (qi & 1) * CHX;
+    char* dst = smem + (qi & 1) * SLOT;
     qi = min(qi, nq_total - 1);                  // (past the end: the last chunk again, into the slot nobody reads -- constant counts)
     const char* src;
     int bytes;
+    if constexpr (FOLD) {                        // (three taps: chunk qi = column block qi / 3 of tap qi % 3; tap 2 has shift 0)
+      if (qi < nqa && qi % 3 == 2) dma_chunk(p.w_c + (int64_t)(qi / 3) * CHC, dst + CHX, CHC, wave, lane);
+    }
     if (qi < nqa) { bytes = CHX; src = p.w_x + (int64_t)qi * CHX; }
     else if (qi < nqa + nqb1) { bytes = CHB1; src = p.w_uo + (int64_t)(qi - nqa) * CHB1; }
     else { bytes = CHB2; src = p.w_us + (int64_t)(qi - nqa - nqb1) * CHB2; }
@@ -314,19 +359,28 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   dma(0);
   request(G0, a_addr(0, k0));
   request(G1, a_addr(1, k1));
-  auto step_a = [&](int q, frag (&Gc)[4], bool kc, frag (&Gl)[4], bool& kl) {
+  [[maybe_unused]] f32x16 accd[2];               // FOLD: this tile's Wc_l^T dz_l (64 conditioning channels)
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[m][r] = 0.f;
+  }
+  auto step_a = [&](auto shift0, int q, frag (&Gc)[4], bool kc, frag (&Gl)[4], bool& kl) {
     wait_vmcnt_frags<4>(Gc);
     __builtin_amdgcn_s_barrier();     // chunk q visible; every wave is past its reads of chunk q-1, whose slot is refilled now
     zero_unless(Gc, kc);
     dma(q + 1);                       // (q + 1 == nqa: the first chunk of phase B1)
     request(Gl, a_addr(q + 2, kl));
-    gemm_chunk<4 * NTX, NTX, 4>(smem + (q & 1) * CHX + lane * 16, Gc, accx);
+    gemm_chunk<4 * NTX, NTX, 4>(smem + (q & 1) * SLOT + lane * 16, Gc, accx);
+    if constexpr (FOLD && decltype(shift0)::value != 0)      // the shift-0 tap's fragments are dz_l[t]: the dc block rides on them
+      gemm_chunk<8, 2, 4>(smem + (q & 1) * SLOT + CHX + lane * 16, Gc, accd);
   };
   GBP_TICK(g1);
   for (int q = 0; q < nqa; q += 3) {
-    step_a(q, G0, k0, G2, k2);
-    if (q + 1 < nqa) step_a(q + 1, G1, k1, G0, k0);
-    if (q + 2 < nqa) step_a(q + 2, G2, k2, G1, k1);
+    step_a(IntC<0>{}, q, G0, k0, G2, k2);
+    if (q + 1 < nqa) step_a(IntC<0>{}, q + 1, G1, k1, G0, k0);
+    if (q + 2 < nqa) step_a(IntC<1>{}, q + 2, G2, k2, G1, k1);      // (FOLD: three taps, q + 2 is the shift-0 tap)
   }
   drain_groups(G0, G1, G2);                          // chunk nqa (B1's first) has landed; the redundant operand requests are retired
   __builtin_amdgcn_s_barrier();                      // every wave has left slot (nqa - 1) & 1: it is the staging area of epilogue A
@@ -347,15 +401,35 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
     asm volatile("" : "+v"(le));
     const int ne = le & 31, he = le >> 5;
     frag rs[2 * NTX];
-    {
-      // (rows at or behind the clip's end read its last row: never stored)
-      const char* rp = p.g_next + ((int64_t)b * p.T + min(t0w + ne, p.T - 1)) * (int64_t)(NTX * 32 * ES) + he * 16;
+    // (rows at or behind the clip's end read its last row: never stored)
+    const char* rp = p.g_next + ((int64_t)b * p.T + min(t0w + ne, p.T - 1)) * (int64_t)(NTX * 32 * ES) + he * 16;
+    char* stg = smem + ((nqa - 1) & 1) * SLOT + wave * STGB;
+    if constexpr (FOLD) {
+      // the first half of the residual fragments and the running dc sum travel together; the dc tiles leave first (their 32 registers
+      // are what the second half of the fragments lands in)
+      [[maybe_unused]] f32x4 w0[4], w1[4];
+      const bool add = (p.dc_mode & 1) != 0;
+      if (add && rows_valid > 0) {
+        rmw_fetch(w0, p.dc_acc + row0 * 64, 0, rows_valid, le);
+        rmw_fetch(w1, p.dc_acc + row0 * 64, 1, rows_valid, le);
+      }
+#pragma unroll
+      for (int f = 0; f < NTX; ++f) rs[f] = *(const frag*)(rp + f * 32);
+      __builtin_amdgcn_sched_barrier(0);
+      if (rows_valid > 0) {
+        char* o16 = (p.dc_mode & 2) ? p.dc_out + row0 * 64 * ES : nullptr;
+        stage_rmw_tile<E>(stg, accd[0], w0, add, p.dc_acc + row0 * 64, o16, 0, rows_valid, le);
+        stage_rmw_tile<E>(stg, accd[1], w1, add, p.dc_acc + row0 * 64, o16, 1, rows_valid, le);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = NTX; f < 2 * NTX; ++f) rs[f] = *(const frag*)(rp + f * 32);
+    } else {
 #pragma unroll
       for (int f = 0; f < 2 * NTX; ++f) rs[f] = *(const frag*)(rp + f * 32);
     }
     __builtin_amdgcn_sched_barrier(0);
     residual_to_acc_layout(rs);
-    char* stg = smem + ((nqa - 1) & 1) * CHX + wave * STGB;
     char* orow = p.g_out + row0 * NTX * 32 * ES;
 #pragma unroll
     for (int pr = 0; pr < NTX / 2; ++pr) {
@@ -375,6 +449,10 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
       }
       if (rows_valid > 0) stage_store_pass<E, 2, 128>(stg, &accx[2 * pr], orow + pr * 64 * ES, (int64_t)NTX * 32 * ES, rows_valid, le);
     }
+  }
+  if (p.last) {                                      // layer 0: nothing below to gate (the B1 chunk requested by the last step lands first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
   }
 
   GBP_TICK(g3);
@@ -400,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
       request(G0, s_addr(0));
       request(G1, s_addr(1));
     }
-    gemm_chunk<MTB * NKB, MTB, NKB, true>(smem + (qi & 1) * CHX + lane * 16, xf, *(f32x16(*)[MTB]) & accu[q1 * MTB]);
+    gemm_chunk<MTB * NKB, MTB, NKB, true>(smem + (qi & 1) * SLOT + lane * 16, xf, *(f32x16(*)[MTB]) & accu[q1 * MTB]);
   }
   // B2: VMEM order per step j: [DMA(next)][dS(j + 2)]; at the top of step j >= 1 only dS(j + 1) may be outstanding
   // (the first step is peeled at compile time: a run-time branch around an asm request or its counted wait is what lets hipcc park a
@@ -427,7 +505,7 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
       for (int i = 0; i < 4; ++i) Gl[i] = zf;
     }
     request(Gl, s_addr(j + 2));
-    gemm_chunk<4 * NTU, NTU, 4>(smem + (qi & 1) * CHX + lane * 16, Gc, accu);
+    gemm_chunk<4 * NTU, NTU, 4>(smem + (qi & 1) * SLOT + lane * 16, Gc, accu);
   };
   GBP_TICK(g4);
   step_s(IntC<1>{}, 0, G0, G2);
@@ -484,10 +562,17 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
 template <typename E, int NTX, int NTU>
 static int launch_gb_pair(const GbArgs& a, hipStream_t st) {
   constexpr int CHX = NTX * 4 * 1024;
+  const int tiles = (a.T + 127) / 128;
+  if (a.w_c) {                                       // dc folded in: 8 KiB more per ring slot
+    const size_t lds = 2 * (CHX + 8192);
+    static WaeLdsCache lds_cache_f;
+    if (int rc = wae_ensure_lds((const void*)glu_bwd_pair_kernel<E, NTX, NTU, true>, lds_cache_f, lds, "glu_bwd_pair"); rc != WAE_OK) return rc;
+    hipLaunchKernelGGL((glu_bwd_pair_kernel<E, NTX, NTU, true>), dim3(a.B * tiles), dim3(256), lds, st, a);
+    return wae_check_launch("glu_bwd_pair");
+  }
   const size_t lds = 2 * CHX;
   static WaeLdsCache lds_cache;
   if (int rc = wae_ensure_lds((const void*)glu_bwd_pair_kernel<E, NTX, NTU>, lds_cache, lds, "glu_bwd_pair"); rc != WAE_OK) return rc;
-  const int tiles = (a.T + 127) / 128;
   hipLaunchKernelGGL((glu_bwd_pair_kernel<E, NTX, NTU>), dim3(a.B * tiles), dim3(256), lds, st, a);
   return wae_check_launch("glu_bwd_pair");
 }
@@ -536,20 +621,24 @@ extern "C" int wae_glu_bwd_fused_supported16(int32_t Rp, int32_t Hp) {
   return (x == 8 && (u == 6 || u == 4)) || (x == 4 && (u == 2 || u == 4));
 }
 
-extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
-                                 const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
-                                 const void* w_us, void* stream) {
+static int glu_bwd_fused_impl(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
+                              const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
+                              const void* w_us, const void* w_c, float* dc_acc, void* dc_out, int dc_mode, int last, void* stream) {
   WAE_REQUIRE(d && dz && g_next && g_out && dskip && z_prev && dz_prev && w_x && w_uo && w_us, "glu_bwd_fused: null pointer argument");
   WAE_REQUIRE(wae_dtype_ok(d->dtype), "glu_bwd_fused: bad dtype");
   const int ck = wae_is16(d->dtype) ? 64 : 32;
   WAE_REQUIRE(d->B > 0 && d->T > 0 && d->Rp % 128 == 0 && d->Hp % 32 == 0 && d->Sp % ck == 0 && d->Sp > 0 && d->ktaps >= 1 &&
                   d->dilation >= 1 && (2 * d->Hp) % ck == 0,
               "glu_bwd_fused: bad sizes");
+  WAE_REQUIRE(!w_c || (wae_is16(d->dtype) && d->ktaps == 3 && dc_acc && (!(dc_mode & 2) || dc_out)),
+              "glu_bwd_fused_dc: the folded dc needs 16-bit storage, three taps, dc_acc (and dc_out with mode bit 1)");
+  WAE_REQUIRE(!last || w_c, "glu_bwd_fused_dc: last = 1 (layer 0) exists for the folded-dc form only");
   GbArgs a;
   a.dz = (const char*)dz; a.g_next = (const char*)g_next; a.g_out = (char*)g_out; a.dskip = (const char*)dskip;
   a.z_prev = (const char*)z_prev; a.dz_prev = (char*)dz_prev; a.w_x = (const char*)w_x; a.w_uo = (const char*)w_uo;
   a.w_us = (const char*)w_us; a.dz_stride = dz_stride; a.alpha = d->alpha; a.B = d->B; a.T = d->T; a.Sp = d->Sp;
   a.ktaps = d->ktaps; a.dilation = d->dilation;
+  a.w_c = (const char*)w_c; a.dc_acc = dc_acc; a.dc_out = (char*)dc_out; a.dc_mode = dc_mode; a.last = last;
   a.stamps = nullptr;
 #ifdef WAE_GBP_STAMPS
   a.stamps = g_gbp_stamps;
@@ -558,4 +647,18 @@ extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int6
   if (d->dtype == WAE_BF16) return dispatch_gb<__bf16>(d->Rp / 32, d->Hp / 32, a, st);
   if (d->dtype == WAE_F16) return dispatch_gb<f16>(d->Rp / 32, d->Hp / 32, a, st);
   return dispatch_gb<float>(d->Rp / 32, d->Hp / 32, a, st);
+}
+
+extern "C" int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
+                                 const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
+                                 const void* w_us, void* stream) {
+  return glu_bwd_fused_impl(d, dz, dz_stride, g_next, g_out, dskip, z_prev, dz_prev, w_x, w_uo, w_us, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int wae_glu_bwd_fused_dc(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
+                                    const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
+                                    const void* w_us, const void* w_c, float* dc_acc, void* dc_out, int32_t dc_mode, int32_t last,
+                                    void* stream) {
+  WAE_REQUIRE(w_c, "glu_bwd_fused_dc: w_c is null (use wae_glu_bwd_fused)");
+  return glu_bwd_fused_impl(d, dz, dz_stride, g_next, g_out, dskip, z_prev, dz_prev, w_x, w_uo, w_us, w_c, dc_acc, dc_out, dc_mode, last, stream);
 }
