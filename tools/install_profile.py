@@ -37,6 +37,8 @@ out = ["# rocprofv3 --kernel-trace --pmc <set> (six separate passes, tools/pmc_r
        "# derived: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)  (SQ_BUSY_CYCLES counts per shader array: 32 arrays x 32 SIMDs);",
        "#          L2 hit = TCC_HIT / TCC_REQ;  LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024", ""]
 for k, lines in blocks.items():
+    if not lines:          # (a kernel that does not run in this configuration any more, e.g. the stand-alone residual launch)
+        continue
     v = {l.split()[0]: float(l.split()[2]) for l in lines}
     out.append("== " + NAMES.get(k, k))
     out.append("   derived: MFMA busy %.1f %%, L2 hit rate %.0f %%, LDS bank-conflict share %.1f %%, waves waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) %.0f %%, "
@@ -54,10 +56,11 @@ import bench
 d = json.loads(open(f"gpurun_out/{tag}/bench_train.json").read().strip().splitlines()[-1])
 fi = d["forward_inference"]
 print("csrc hash", bench.csrc_hash(), "profile", json.load(open(f"profiles/{tag}_pmc_traffic.json"))["csrc_hash"])
-print("train %.3f ms %.2f M/s | forward %.3f ms, layer %.1f us frac %.3f, whole %.3f | wgrad %.3f ms | glu_z %.1f us | gate %.1f res %.1f us | AR %.2f kHz | cpu %.0f" % (
+ms = lambda k: d[k]["avg_launch_ms"] * 1e3 if k in d else float("nan")      # (a family that did not run in this build: nan)
+print("train %.3f ms %.2f M/s | forward %.3f ms, layer %.1f us frac %.3f, whole %.3f | wgrad %.3f ms | glu_z %.1f us | gate %.1f res %.1f pair %.1f us | AR %.2f kHz | cpu %.0f" % (
     d["ms_per_step"], d["value"] / 1e6, fi["ms_per_step"], fi["roofline"]["avg_launch_ms"] * 1e3, fi["roofline"]["frac"], fi["roofline_whole"]["frac"],
-    d["roofline_wgrad"]["avg_launch_ms"], d["roofline_glu_fwd_z"]["avg_launch_ms"] * 1e3, d["roofline_gate_bwd"]["avg_launch_ms"] * 1e3,
-    d["roofline_residual_bwd"]["avg_launch_ms"] * 1e3, d["autoregressive"]["value"], d["cpu_baseline"]["value"]))
+    d["roofline_wgrad"]["avg_launch_ms"], ms("roofline_glu_fwd_z"), ms("roofline_gate_bwd"), ms("roofline_residual_bwd"), ms("roofline_bwd_pair"),
+    d["autoregressive"]["value"], d["cpu_baseline"]["value"]))
 for fn in ("bench_forward.json", "bench_fp16.json"):
     print(fn, json.loads(open(f"gpurun_out/{tag}/{fn}").read().strip().splitlines()[-1])["ms_per_step"])
 for fn in ("bench_c3.json", "bench_c5.json"):
