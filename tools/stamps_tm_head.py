@@ -39,3 +39,14 @@ for name, flags in (("two workgroups per CU", 0), ("one workgroup per CU", L.TM_
     print(f"{name}: {len(s)} workgroups; life {med(s[:, 1]) / 100:.1f} us = {med(s[:, 0]):.0f} clocks ({med(s[:, 0] / s[:, 1]) * 100:.0f} MHz); "
           f"chunk loop {med(s[:, 2]):.0f} ({med(s[:, 2] / s[:, 6]):.0f} per chunk x {int(med(s[:, 6]))}), epilogue {med(s[:, 3]):.0f}; "
           f"wave 0 per chunk: counted wait {med(s[:, 4] / s[:, 6]):.0f}, barrier {med(s[:, 5] / s[:, 6]):.0f}")
+    st0 = s[:, 7] - s[:, 7].min()
+    late = st0 > 0.25 * med(s[:, 1])
+    print(f"    launch span (first start .. last end) {(st0 + s[:, 1]).max() / 100:.1f} us; life p10 / p90 {np.percentile(s[:, 1], 10) / 100:.1f} / "
+          f"{np.percentile(s[:, 1], 90) / 100:.1f} us; {int(late.sum())} workgroups start more than a quarter life after the first "
+          f"(median start of those {np.median(st0[late]) / 100 if late.any() else 0:.1f} us)")
+    full = buf.cpu().numpy().reshape(nwg, 8).astype(np.float64)
+    ids = np.nonzero(full[:, 6] > 0)[0]
+    print("    median life by XCD (flat workgroup id mod 8): " + " ".join(f"{np.median(full[ids[ids % 8 == k], 1]) / 100:.0f}" for k in range(8)))
+    order = np.argsort(full[ids, 1])
+    print("    slowest ten workgroups (flat id: life us): " + ", ".join(f"{ids[i]}: {full[ids[i], 1] / 100:.0f}" for i in order[-10:]))
+    print("    fastest ten: " + ", ".join(f"{ids[i]}: {full[ids[i], 1] / 100:.0f}" for i in order[:10]))

@@ -65,7 +65,7 @@ struct TmArgs {
 
 #ifdef WAE_TM_STAMPS
 // diagnostic build (tools/stamps_tm.py): per workgroup 8 x u64: [0] life (s_memtime), [1] life (s_memrealtime, 100 MHz), [2] chunk loop,
-// [3] epilogue, [4] sum of counted waits of wave 0, [5] sum of its barrier waits, [6] chunks
+// [3] epilogue, [4] sum of counted waits of wave 0, [5] sum of its barrier waits, [6] chunks, [7] start (s_memrealtime)
 static unsigned long long* g_tm_stamps = nullptr;
 extern "C" void wae_debug_set_tm_stamps(unsigned long long* dev_buf) { g_tm_stamps = dev_buf; }
 #define TM_TICK() (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime())
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) gemm_tm_kernel(TmArgs p) {
   struct TmStampOut {
     unsigned long long *o, t0, w0, l0, l1, wt, br, n; int on;
     __device__ ~TmStampOut() {
-      if (on) { o[0] = TM_TICK() - t0; o[1] = __builtin_amdgcn_s_memrealtime() - w0; o[2] = l1 - l0; o[3] = TM_TICK() - l1; o[4] = wt; o[5] = br; o[6] = n; }
+      if (on) { o[0] = TM_TICK() - t0; o[1] = __builtin_amdgcn_s_memrealtime() - w0; o[2] = l1 - l0; o[3] = TM_TICK() - l1; o[4] = wt; o[5] = br; o[6] = n; o[7] = w0; }
     }
   } stamp_out{p.stamps ? p.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr, k_t0, k_w0, k_loop0, k_loop1, k_wait, k_bar, k_n,
               p.stamps != nullptr && threadIdx.x == 0};
