@@ -243,3 +243,33 @@ def test_synthesis_postprocessing_closed_form():
     assert np.allclose(imp, 0.85 ** np.arange(5), atol=1e-12)
     assert np.allclose(S.postprocess_indices(idx, 256, "none", 0.0), x, atol=1e-6)
     assert np.allclose(S.postprocess_indices(idx, 256, None, 1.0), x, atol=1e-6)
+
+
+def test_engine_options_are_read_once_and_checked(monkeypatch):
+    """wavenet_autoencoders_amd/options.py: the launch-path switches -- defaults, every documented variable reaches its field, and a
+    value outside a switch's vocabulary raises instead of silently selecting something."""
+    import re
+    from wavenet_autoencoders_amd.options import EngineOptions
+    import wavenet_autoencoders_amd.options as opts
+    for k in list(os.environ):
+        if k.startswith("WAE_"):
+            monkeypatch.delenv(k, raising=False)
+    d = EngineOptions.from_env()
+    assert d == EngineOptions() and d.bwd_fused == "auto" and d.bwd_fold_dc and d.dp_wire == "fp32" and d.glu_pair == "inference"
+    flips = dict(WAE_TN_STREAM=("0", "tn_stream", False), WAE_TN_STATIC=("0", "tn_static", False), WAE_HEAD_SPLIT=("0", "head_split", False),
+                 WAE_HEAD_WIDE=("1", "head_wide", True), WAE_GLU_PAIR=("1", "glu_pair", "1"), WAE_DP_SPLIT=("0", "dp_split", False),
+                 WAE_DP_WIRE=("bf16", "dp_wire", "bf16"), WAE_AR_COOP=("0", "ar_coop", False), WAE_AR_COOP_C=("16", "ar_coop_c", 16),
+                 WAE_BWD_FUSED=("0", "bwd_fused", "0"), WAE_BWD_FOLD_DC=("0", "bwd_fold_dc", False), WAE_AR_FUSED=("1", "ar_fused", True),
+                 WAE_TN_STATIC_HEAD=("0", "tn_static_head", False))
+    documented = set(re.findall(r"^    (WAE_[A-Z0-9_]+) ", opts.__doc__, re.M))
+    assert documented == set(flips), documented ^ set(flips)
+    for var, (val, field, want) in flips.items():
+        monkeypatch.setenv(var, val)
+        assert getattr(EngineOptions.from_env(), field) == want, var
+        monkeypatch.delenv(var)
+    for var, bad in (("WAE_BWD_FUSED", "yes"), ("WAE_DP_WIRE", "fp16"), ("WAE_GLU_PAIR", "2")):
+        monkeypatch.setenv(var, bad)
+        with pytest.raises(ValueError):
+            EngineOptions.from_env()
+        monkeypatch.delenv(var)
+
