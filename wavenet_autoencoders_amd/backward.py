@@ -319,13 +319,29 @@ class StaticStreamTable:
         self.nteams = max(1, ncu // gs)
         self.nwg = ncu if ncu % 8 == 0 and ncu >= self.nteams * gs else self.nteams * gs
         total = len(self.groups) * B * spc
+        # The members of a team walk the same slabs, but a slab costs the out + skip member 704 operand columns (96 tiles), a tap member
+        # 640 and the conditioning member 448 (36 tiles): by workgroup lives (tools/tq_member_lives.py, C2) 1 274 / 1 150-1 176 / 954 us,
+        # and the launch ends with the slowest.  A member's job kind is a field of the job record, so the second half of every team's
+        # share runs on a copy of the groups in which the last two slots have changed places: the two members each do half of both.
+        # (One more segment per team = one more prologue + flush per member; the partial sums are added atomically either way.)
+        ng = len(self.groups)
+        swap = eng.opt.tn_swap and gs >= 2
+        if swap:
+            def swapped(grp):
+                k = [j.kind if j.m_valid > 0 else -1 for j in grp]
+                if k[-2:] == [L.TQ_COND, L.TQ_OUTSKIP]:
+                    return grp[:-2] + [grp[-1], grp[-2]]
+                return grp
+            self.groups = self.groups + [swapped(grp) for grp in self.groups]
         for t in range(self.nteams):
             lo, hi = total * t // self.nteams, total * (t + 1) // self.nteams
-            while lo < hi:
-                grp = lo // (B * spc)
-                end = min(hi, (grp + 1) * B * spc)
-                segs.append(L.TsSeg(grp * gs, lo - grp * B * spc, end - grp * B * spc))
-                lo = end
+            mid = (lo + hi) // 2 if swap else hi
+            for a, b_, var in ((lo, mid, 0), (mid, hi, 1)):
+                while a < b_:
+                    grp = a // (B * spc)
+                    end = min(b_, (grp + 1) * B * spc)
+                    segs.append(L.TsSeg((var * ng + grp) * gs, a - grp * B * spc, end - grp * B * spc))
+                    a = end
             team_seg.append(len(segs))
         jobs = [j for g in self.groups for j in g]
         dev = eng.device

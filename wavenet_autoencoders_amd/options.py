@@ -9,6 +9,8 @@ arguments (include/wae.h) from tools/.
     variable               default   alternative
     WAE_TN_STREAM          1         0: weight gradients as one 128 x 128 tile launch per layer (what fp32 always runs)
     WAE_TN_STATIC          1         0: the any-shape stream-K launch (csrc/gemm_tn_stream.hip) instead of the static-schedule one
+    WAE_TN_SWAP            1         0: static weight-gradient launch: the conditioning and the out + skip member of a team keep their job
+                                     kind for the whole launch (1: they change places halfway through the team's share)
     WAE_TN_STATIC_HEAD     1         0: head + first-conv weight gradients on the tile launches, not as a group of the static launch
     WAE_HEAD_SPLIT         1         0: the one-kernel head (16-bit engines run GEMM 0 as its own wae_gemm_tm launch by default)
     WAE_HEAD_WIDE          0         1: the separate-launch head of skip widths > 256, forced onto narrow models (tests)
@@ -31,6 +33,7 @@ class EngineOptions:
     tn_stream: bool = True
     tn_static: bool = True
     tn_static_head: bool = True
+    tn_swap: bool = True
     head_split: bool = True
     head_wide: bool = False
     glu_pair: str = "inference"
@@ -55,7 +58,7 @@ class EngineOptions:
         if wire not in ("fp32", "bf16"):
             raise ValueError(f"WAE_DP_WIRE={wire!r}: 'fp32' or 'bf16'")
         return EngineOptions(dp_wire=wire, tn_stream=e("WAE_TN_STREAM", "1") != "0", tn_static=e("WAE_TN_STATIC", "1") != "0",
-                             tn_static_head=e("WAE_TN_STATIC_HEAD", "1") != "0", head_split=e("WAE_HEAD_SPLIT", "1") != "0",
+                             tn_static_head=e("WAE_TN_STATIC_HEAD", "1") != "0", tn_swap=e("WAE_TN_SWAP", "1") != "0", head_split=e("WAE_HEAD_SPLIT", "1") != "0",
                              head_wide=e("WAE_HEAD_WIDE", "0") == "1", glu_pair=pair, dp_split=e("WAE_DP_SPLIT", "1") != "0",
                              ar_coop=e("WAE_AR_COOP", "1") != "0", ar_coop_c=int(e("WAE_AR_COOP_C", "32")),
                              bwd_fused=fused, bwd_fold_dc=e("WAE_BWD_FOLD_DC", "1") != "0", ar_fused=e("WAE_AR_FUSED", "0") == "1")
