@@ -668,6 +668,13 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         tm_ev.setdefault(kind, []).append((e0, e1))
 
     def k_u(l, gn):                            # du -> dz of layer l
+        if gn.data_ptr() == ws["gzero"].data_ptr():
+            # the top layer: dx-hat above it is zero (its x' is dead), so W_out^T . 0 is left out -- the skip half of the weight stream
+            # on dS alone: the same sums (+ 0 exactly), half the chunks, 32 MB of zeros not read
+            timed("gate", lambda: _tm(eng, B, T, g.Hp, 2, 1.0, [(ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
+                                      eng.w_bu.data_ptr() + l * eng.n_bu * es + us_off, ws["dz"].data_ptr() + l * Z2 * es, dzs,
+                                      fw["z"][l].data_ptr(), Z2, flags=0))
+            return
         timed("gate", lambda: _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
                                   eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2,
                                   flags=0))
