@@ -191,16 +191,16 @@ __global__ void __launch_bounds__(64) conv_bwd_w_kernel(const float* __restrict_
 // clip, thread = (channel, slice of the co reduction); dpre windows of 256 output channels are staged in LDS.  ti0 is a multiple
 // of 32, so which (ti, j) pairs hit a whole output step, and where it sits in the staged window, is known at compile time.
 template <int K, int S, int PAD, int ET>
-__global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               const float* __restrict__ y, const float* __restrict__ dy,
-                                                               float* __restrict__ dx, int Cin, int Tin, int Cout, int Tout, int relu,
-                                                               int residual) {
+__device__ __forceinline__ void conv_bwd_x_tiled_body(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, int Cin, int Tin, int Cout, int Tout, int relu,
+                                                      int residual, int bx, int by, int bz) {
   extern __shared__ float sm[];
   constexpr int R0 = (((PAD - K + 1) % S) + S) % S;        // (ti0 + PAD - K + 1) mod S for ti0 = 0 mod S
   constexpr int BASE = K - 1 + R0;                         // ti_l - j + BASE = S * (to - tb) when that is a whole step
   constexpr int TWIN = (ET - 1 + BASE) / S + 1;
   constexpr int TP = (TWIN + 3) & ~3;
-  const int b = blockIdx.z, ci0 = blockIdx.y * ECB_T, ti0 = blockIdx.x * ET;
+  const int b = bz, ci0 = by * ECB_T, ti0 = bx * ET;
   const int tb = (ti0 + PAD - (K - 1) - R0) / S;           // exact: the numerator is a multiple of S (may be negative)
   const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int ci = ci0 + col;
@@ -283,15 +283,15 @@ __global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __re
 // dw[co][ci][j] += sum_{b, to} dpre[b][co][to] * x[b][ci][to*S + j - pad] (+ dbias[co] += sum dpre): block = 32 output x 32 input
 // channels over every clip and step (the unique owner of its outputs: plain read-modify-write), thread = (co, 4 input channels).
 template <int K, int S, int ET>
-__global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                               const float* __restrict__ dy, float* __restrict__ dw,
-                                                               float* __restrict__ dbias, int B, int Cin, int Tin, int Cout, int Tout,
-                                                               int pad, int relu, int residual) {
+__device__ __forceinline__ void conv_bwd_w_tiled_body(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ dy, float* __restrict__ dw,
+                                                      float* __restrict__ dbias, int B, int Cin, int Tin, int Cout, int Tout,
+                                                      int pad, int relu, int residual, int bx, int by) {
   constexpr int WIN = (ET - 1) * S + K;
   constexpr int WP = (WIN + 3) & ~3, GP = ET + 4;   // row pitches: whole 16-byte reads
   constexpr int GSZ = ECB_T * GP, XSZ = ECB_T * WP;
   extern __shared__ float sm[];     // ECB_RT x (dpre tile [32 co][GP] + x window [32 ci][WP]): one round of (clip, step tile) pairs
-  const int co0 = blockIdx.x * ECB_T, ci0 = blockIdx.y * ECB_T;
+  const int co0 = bx * ECB_T, ci0 = by * ECB_T;
   const int col = threadIdx.x & 31, cg = threadIdx.x >> 5;
   float acc[4][K];
 #pragma unroll
@@ -380,11 +380,44 @@ __global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < K; ++j) dw[((int64_t)co * Cin + ci) * K + j] += acc[c][j];
     }
-    if (dbias && cg == 0 && blockIdx.y == 0) dbias[co] += accb;
+    if (dbias && cg == 0 && by == 0) dbias[co] += accb;
   }
 }
 // ET: the time tile of both kernels (32, or 16 / 8 for the short sequences behind the encoder's strided blocks: at the reference's
 // 8 x 5120-sample shard eight of the ten blocks see 8 frames, and a 32-step tile there is 75 % padding)
+template <int K, int S, int PAD, int ET>
+__global__ void __launch_bounds__(256) conv_bwd_x_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ y, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int Cin, int Tin, int Cout, int Tout, int relu,
+                                                               int residual) {
+  conv_bwd_x_tiled_body<K, S, PAD, ET>(x, w, y, dy, dx, Cin, Tin, Cout, Tout, relu, residual, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template <int K, int S, int ET>
+__global__ void __launch_bounds__(256) conv_bwd_w_tiled_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ dy, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int B, int Cin, int Tin, int Cout, int Tout,
+                                                               int pad, int relu, int residual) {
+  conv_bwd_w_tiled_body<K, S, ET>(x, y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, pad, relu, residual, blockIdx.x, blockIdx.y);
+}
+// Input and weight gradient of one block in ONE launch: the two read the same dy / x / w and depend on nothing of each other, but as two
+// launches on one stream they ran one after the other -- each on 64 of the 256 CUs at the reference preset's shard (8 clips x 8-32
+// frames).  The first nxx * nxy * nxz workgroups of a flat grid run the input-gradient body, the rest the weight-gradient body (the
+// same arithmetic in the same order as the two kernels above).
+template <int K, int S, int PAD, int ET>
+__global__ void __launch_bounds__(256) conv_bwd_xw_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ y, const float* __restrict__ dy,
+                                                                float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias,
+                                                                int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual,
+                                                                int nxx, int nxy, int nxz, int nwx) {
+  const int id = blockIdx.x, nx = nxx * nxy * nxz;
+  if (id < nx) {
+    conv_bwd_x_tiled_body<K, S, PAD, ET>(x, w, y, dy, dx, Cin, Tin, Cout, Tout, relu, residual, id % nxx, (id / nxx) % nxy, id / (nxx * nxy));
+  } else {
+    const int iw = id - nx;
+    conv_bwd_w_tiled_body<K, S, ET>(x, y, dy, dw, dbias, B, Cin, Tin, Cout, Tout, PAD, relu, residual, iw % nwx, iw / nwx);
+  }
+}
+
 template <int K, int S, int PAD, int ET>
 static int launch_conv_bwd_tiled_et(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* dbias,
                                     int B, int Cin, int Tin, int Cout, int Tout, int relu, int residual, hipStream_t st) {
@@ -393,11 +426,17 @@ static int launch_conv_bwd_tiled_et(const float* x, const float* w, const float*
     constexpr int TWIN = (ET - 1 + K - 1 + R0) / S + 1;
     constexpr int TP = (TWIN + 3) & ~3;
     const size_t a = (size_t)(Cout < ECB_CH ? Cout : ECB_CH) * TP, r = (size_t)ECB_NS * ET * 33;
-    const size_t lds = (a > r ? a : r) * sizeof(float);
+    const size_t lds_x = (a > r ? a : r) * sizeof(float);
+    constexpr int WIN = (ET - 1) * S + K;
+    constexpr int WP = (WIN + 3) & ~3;
+    const size_t lds_w = (size_t)ECB_RT * (ECB_T * (ET + 4) + ECB_T * WP) * sizeof(float);
+    const size_t lds = lds_x > lds_w ? lds_x : lds_w;
+    const int nxx = (Tin + ET - 1) / ET, nxy = (Cin + ECB_T - 1) / ECB_T, nwx = (Cout + ECB_T - 1) / ECB_T, nwy = (Cin + ECB_T - 1) / ECB_T;
     static WaeLdsCache cache;
-    if (int rc = wae_ensure_lds((const void*)conv_bwd_x_tiled_kernel<K, S, PAD, ET>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
-    hipLaunchKernelGGL((conv_bwd_x_tiled_kernel<K, S, PAD, ET>), dim3((Tin + ET - 1) / ET, (Cin + ECB_T - 1) / ECB_T, B), dim3(256), lds,
-                       st, x, w, y, dy, dx, Cin, Tin, Cout, Tout, relu, residual);
+    if (int rc = wae_ensure_lds((const void*)conv_bwd_xw_tiled_kernel<K, S, PAD, ET>, cache, lds, "enc_conv_bwd"); rc != WAE_OK) return rc;
+    hipLaunchKernelGGL((conv_bwd_xw_tiled_kernel<K, S, PAD, ET>), dim3(nxx * nxy * B + nwx * nwy), dim3(256), lds, st, x, w, y, dy, dx, dw,
+                       dbias, B, Cin, Tin, Cout, Tout, relu, residual, nxx, nxy, B, nwx);
+    return WAE_OK;
   }
   {
     constexpr int WIN = (ET - 1) * S + K;
