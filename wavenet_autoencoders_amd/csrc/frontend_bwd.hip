@@ -16,8 +16,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // sum of the taps that reach it, coef[d + s] = sum_{j = max(0, s-d)}^{min(2s, 2s-1-d)} w[j] (formed once per block):
 // 3s loads per frame instead of s(2s+1).
 #define UPW_MAXTAPS 33
-__global__ void __launch_bounds__(256) upsample_stage_bwd_in_kernel(const float* __restrict__ dout, const float* __restrict__ w,
-                                                                   float* __restrict__ din, int C, int Tin, int s) {
+__device__ __forceinline__ void upsample_stage_bwd_in_body(const float* __restrict__ dout, const float* __restrict__ w,
+                                                           float* __restrict__ din, int C, int Tin, int s, int bx, int by, int bz) {
   __shared__ float coef[3 * (UPW_MAXTAPS / 2)];
   if (threadIdx.x < 3 * s) {
     const int d = (int)threadIdx.x - s;
@@ -26,8 +26,8 @@ __global__ void __launch_bounds__(256) upsample_stage_bwd_in_kernel(const float*
     coef[threadIdx.x] = a;
   }
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int c = blockIdx.y, b = blockIdx.z;
+  const int i = bx * 256 + threadIdx.x;
+  const int c = by, b = bz;
   if (i >= Tin) return;
   const int Tout = Tin * s;
   const float* dr = dout + ((int64_t)b * C + c) * Tout;
@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) upsample_stage_bwd_in_kernel(const float*
 // three in loads, 3s FMAs (the tap-by-tap form needed s(2s+1) selects + FMAs and took 0.1 ms per step).  A block walks
 // whole (clip, channel) rows; at most 256 blocks leave their 2s+1 sums as atomics.  S = 0: any s <= 16, tap-by-tap.
 template <int S>
-__global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* __restrict__ dout, const float* __restrict__ in,
-                                                                  float* __restrict__ dw, int BC, int Tin, int s_rt) {
+__device__ __forceinline__ void upsample_stage_bwd_w_body(const float* __restrict__ dout, const float* __restrict__ in,
+                                                          float* __restrict__ dw, int BC, int Tin, int s_rt, int bx, int nbx) {
   const int s = S > 0 ? S : s_rt;
   constexpr int NTAP = S > 0 ? 2 * S + 1 : UPW_MAXTAPS;
   const int Tout = Tin * s, ntap = 2 * s + 1;
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* 
     float A[S][3];
 #pragma unroll
     for (int r = 0; r < S; ++r) A[r][0] = A[r][1] = A[r][2] = 0.f;
-    for (int row = blockIdx.x; row < BC; row += gridDim.x) {
+    for (int row = bx; row < BC; row += nbx) {
       const float* drow = dout + (int64_t)row * Tout;
       const float* irow = in + (int64_t)row * Tin;
       for (int q = threadIdx.x; q < Tin; q += 256) {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* 
 #pragma unroll
       for (int r = 0; r < S; ++r) acc[j] += A[r][(r + j) / S];
   } else {
-    for (int row = blockIdx.x; row < BC; row += gridDim.x) {
+    for (int row = bx; row < BC; row += nbx) {
       const float* drow = dout + (int64_t)row * Tout;
       const float* irow = in + (int64_t)row * Tin;
       for (int t = threadIdx.x; t < Tout; t += 256) {
@@ -107,17 +107,28 @@ __global__ void __launch_bounds__(256) upsample_stage_bwd_w_kernel(const float* 
   __syncthreads();
   if (threadIdx.x < ntap) atomicAdd(dw + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
+// the input gradient and the FIR's weight gradient of a stage read the same dout and depend on nothing of each other: ONE launch, the first
+// nxx * C * B workgroups of a flat grid on the input gradient, the rest on the weight gradient (as two launches on one stream they ran one
+// after the other, 6-15 us each)
+template <int S>
+__global__ void __launch_bounds__(256) upsample_stage_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ in,
+                                                                const float* __restrict__ w, float* __restrict__ din,
+                                                                float* __restrict__ dw, int B, int C, int Tin, int s, int nxx, int nbw) {
+  const int id = blockIdx.x, nx = nxx * C * B;
+  if (id < nx) upsample_stage_bwd_in_body(dout, w, din, C, Tin, s, id % nxx, (id / nxx) % C, id / (nxx * C));
+  else upsample_stage_bwd_w_body<S>(dout, in, dw, B * C, Tin, s, id - nx, nbw);
+}
 extern "C" int wae_upsample_stage_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, int32_t B,
                                       int32_t C, int32_t Tin, int32_t s, void* stream) {
   WAE_REQUIRE(dout && in && w && din && dw && B > 0 && C > 0 && Tin > 0 && s > 0, "upsample_stage_bwd: bad arguments");
   WAE_REQUIRE(2 * s + 1 <= UPW_MAXTAPS, "upsample_stage_bwd: scale %d > %d is not supported", s, (UPW_MAXTAPS - 1) / 2);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(upsample_stage_bwd_in_kernel, dim3((Tin + 255) / 256, C, B), dim3(256), 0, st, dout, w, din, C, Tin, s);
-  const int rows = B * C, nb = rows < 256 ? rows : 256;
-  if (s == 4) hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<4>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
-  else if (s == 5) hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<5>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
-  else if (s == 8) hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<8>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
-  else hipLaunchKernelGGL(upsample_stage_bwd_w_kernel<0>, dim3(nb), dim3(256), 0, st, dout, in, dw, rows, Tin, s);
+  const int rows = B * C, nbw = rows < 256 ? rows : 256, nxx = (Tin + 255) / 256;
+  const dim3 grid(nxx * C * B + nbw);
+  if (s == 4) hipLaunchKernelGGL(upsample_stage_bwd_kernel<4>, grid, dim3(256), 0, st, dout, in, w, din, dw, B, C, Tin, s, nxx, nbw);
+  else if (s == 5) hipLaunchKernelGGL(upsample_stage_bwd_kernel<5>, grid, dim3(256), 0, st, dout, in, w, din, dw, B, C, Tin, s, nxx, nbw);
+  else if (s == 8) hipLaunchKernelGGL(upsample_stage_bwd_kernel<8>, grid, dim3(256), 0, st, dout, in, w, din, dw, B, C, Tin, s, nxx, nbw);
+  else hipLaunchKernelGGL(upsample_stage_bwd_kernel<0>, grid, dim3(256), 0, st, dout, in, w, din, dw, B, C, Tin, s, nxx, nbw);
   return wae_check_launch("upsample_stage_bwd");
 }
 
