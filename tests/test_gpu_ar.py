@@ -315,3 +315,31 @@ def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch
     for tag in ("default", "lds3", "lds2+bank5", "lds6+bank11", "lds1+bank13"):
         assert torch.equal(got["stream"][0], got[tag][0]), tag
         assert torch.equal(got["stream"][1], got[tag][1]), tag
+
+
+@pytest.mark.parametrize("layers,stacks", [(30, 3), (24, 2), (6, 2), (2, 1)])
+def test_resident_weights_at_other_depths(layers, stacks, monkeypatch):
+    """The residency of the fast cooperative kernel is sized for the reference's 20 layers (6 in LDS + 11 + 3 in registers); deeper stacks
+    stream the layers that do not fit, shallower ones leave bank slots empty: a sampled decode stays bitwise the streaming form's."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=layers, stacks=stacks, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5],
+               cin_pad=0)
+    sd = O.make_state_dict(dict(cfg), salt=7, with_encoder=False)
+    T = 1280
+    gen = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 64, T // 640, generator=gen).cuda()
+    gid = torch.tensor([3, 77]).cuda()
+    uni = torch.rand(2, T, generator=gen).cuda()
+    got = {}
+    for tag, env in (("stream", {"WAE_AR_LDS_LAYERS": "0"}), ("default", {})):
+        for k in ("WAE_AR_LDS_LAYERS", "WAE_AR_BANK_LAYERS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+        eng.load_state_dict(sd)
+        got[tag] = eng.incremental_forward(lat, gid, T, mode="sample", uniforms=uni)["idx"].clone()
+        torch.cuda.synchronize()
+    assert torch.equal(got["stream"], got["default"]) and int(torch.unique(got["default"]).numel()) > 50
+
