@@ -341,6 +341,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ar", action="store_true", help="skip the autoregressive leg (BASELINE config C4, rank 0 only)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the short fp32 (parity-grade mode) leg of the default line")
+    ap.add_argument("--lr", type=float, default=4e-4, help="Adam learning rate of the timed steps (0: the weights never change -- same-data "
+                    "A/B runs of timing-only kernel variants, tools/bench_fields.py)")
     args = ap.parse_args()
     conf = CONFIGS[args.config]
     args.dtype = args.dtype or conf["dtype"]
@@ -401,7 +403,7 @@ def main():
         eng._layer_events = ev if record is True else None
         eng._tn_events = ev_tn if record is True else None
         eng._tm_events = ev_tm if record == "tm" else None      # (only in the untimed extra steps below: 96 event records per step)
-        return eng.train_step(xi, lat, g, lengths=None, grad_sync=gsync)["loss"]
+        return eng.train_step(xi, lat, g, lengths=None, lr=args.lr, grad_sync=gsync)["loss"]
 
     def sync():
         if dist is not None:

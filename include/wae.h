@@ -179,6 +179,12 @@ int wae_onehot_rows(const int32_t* ids, void* out, int64_t n, int32_t width, int
 #define WAE_ERR_SPEAKER_ID 2
 #define WAE_ERR_TARGET_ID 4
 int wae_check_ids(const int32_t* ids, int64_t n, int32_t lo, int32_t hi, int32_t* err, int32_t code, void* stream);
+/* One-hot (B, C, T) fp32 input -> class ids (B, T).  wavenet.py:203 applies first_conv to any (B, C, T) float tensor; the kernels
+ * gather weight rows by class id, the same arithmetic for one-hot columns only.  A column that is not exactly one 1.0 among zeros
+ * ORs `code` (WAE_ERR_NOT_ONEHOT) into `err`: the host refuses dense inputs instead of arg-maxing them.  Strides in elements. */
+#define WAE_ERR_NOT_ONEHOT 8
+int wae_onehot_to_ids(const float* x, int32_t B, int32_t C, int32_t T, int64_t stride_b, int64_t stride_c, int64_t stride_t,
+                      int32_t* ids, int32_t* err, int32_t code, void* stream);
 
 /* ---- a6 ResidualConv1dGLU._forward (modules.py:115-163) -------------------------------------------------
  * One fused layer: dilated causal conv + 1x1(c) + hoisted 1x1(g) + gate + 1x1 out + residual.  The skip 1x1

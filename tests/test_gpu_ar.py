@@ -343,3 +343,32 @@ def test_resident_weights_at_other_depths(layers, stacks, monkeypatch):
         torch.cuda.synchronize()
     assert torch.equal(got["stream"], got["default"]) and int(torch.unique(got["default"]).numel()) > 50
 
+
+
+@pytest.mark.parametrize("kernel", ["coop", "one_cu"])
+def test_start_class_per_utterance_against_oracle(kernel, monkeypatch):
+    """wavenet.py:283-297: every batch item starts from ITS row of initial_input.  Two utterances with different start classes,
+    greedy roll-out (fp32: bit-exact against the oracle, which restates the reference loop with the same initial_input), on the
+    cooperative and on the one-CU kernel; a single start class still broadcasts (an int, or one row)."""
+    monkeypatch.setenv("WAE_AR_COOP", "1" if kernel == "coop" else "0")
+    cfg, sd, ins, zm, ocfg = golden_model("A")
+    z = load_npz("ar_A")
+    eng = _engine(cfg, sd, "fp32")
+    T = 24
+    c_up = torch.from_numpy(z["c_up"])[:, :, :T].contiguous()
+    starts = [3, cfg["O"] - 2]
+    init = torch.zeros(2, cfg["O"], 1)
+    for b, s in enumerate(starts):
+        init[b, s, 0] = 1
+    ref = O.incremental_forward(sd, ocfg, c_up, ins["g"], T, initial_input=init, mode="argmax").argmax(1).numpy()
+    out = eng.incremental_forward(c_up.cuda(), ins["g"].cuda(), T, mode="argmax", init_idx=torch.tensor(starts), c_is_upsampled=True)
+    torch.cuda.synchronize()
+    got = out["idx"].cpu().numpy()
+    assert np.array_equal(got, ref)
+    # the two utterances really started differently: the same start class for both gives another roll-out for at least one of them
+    same = eng.incremental_forward(c_up.cuda(), ins["g"].cuda(), T, mode="argmax", init_idx=starts[0], c_is_upsampled=True)["idx"].cpu().numpy()
+    assert np.array_equal(same[0], got[0])
+    with pytest.raises(IndexError):
+        eng.incremental_forward(c_up.cuda(), ins["g"].cuda(), T, mode="argmax", init_idx=torch.tensor([0, cfg["O"]]), c_is_upsampled=True)
+    with pytest.raises(ValueError):
+        eng.incremental_forward(c_up.cuda(), ins["g"].cuda(), T, mode="argmax", init_idx=torch.tensor([0, 1, 2]), c_is_upsampled=True)

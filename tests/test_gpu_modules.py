@@ -386,6 +386,52 @@ def test_out_of_range_ids_raise_index_error():
     eng.check_errors()
 
 
+def test_dense_decoder_input_is_refused_and_start_classes_are_per_utterance():
+    """wavenet.py:203 applies first_conv as a dense 1x1 to any (B, C, T) float tensor; the teacher-forced kernels gather weight rows by
+    class id, the same arithmetic for ONE-HOT columns only.  Soft labels are refused (NotImplementedError at the end of the call),
+    never arg-maxed (round-5 finding); one-hot columns in either layout give the logits of the id path.  incremental_forward starts
+    every utterance from its own row of initial_input (wavenet.py:283-297)."""
+    cfg, sd, ins, z, ocfg = golden_model("A")
+    model, wn = _build(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    xin = ins["xin"].cuda()
+    with torch.no_grad():
+        y_ref, _, _ = model(xin, ins["c"].cuda(), ins["g"].cuda(), False)
+        y_ids, _, _ = model(ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda(), False)         # (B, T) class ids
+        assert torch.equal(y_ref, y_ids)
+        soft = xin * 0.9 + 0.1 / cfg["O"]                        # label smoothing: columns still sum to one, argmax unchanged
+        with pytest.raises(NotImplementedError, match="not one-hot"):
+            model(soft, ins["c"].cuda(), ins["g"].cuda(), False)
+        two = xin.clone()
+        two[0, 5, 3] = 1.0                                        # a second one in one column
+        if float(xin[0, 5, 3]) == 1.0:
+            two[0, 6, 3] = 1.0
+        with pytest.raises(NotImplementedError, match="not one-hot"):
+            model(two, ins["c"].cuda(), ins["g"].cuda(), False)
+        y_again, _, _ = model(xin, ins["c"].cuda(), ins["g"].cuda(), False)                   # the flag is cleared
+        assert torch.equal(y_again, y_ref)
+    # per-utterance start classes through the module API, against the oracle's restatement of the reference loop (greedy, fp32)
+    za = load_npz("ar_A")
+    T = 16
+    c_up = torch.from_numpy(za["c_up"])[:, :, :T].contiguous()
+    starts = [1, cfg["O"] - 3]
+    init = torch.zeros(2, cfg["O"], 1)
+    for b, s_ in enumerate(starts):
+        init[b, s_, 0] = 1
+    ref = O.incremental_forward(sd, ocfg, c_up, ins["g"], T, initial_input=init, mode="logits")    # logits fed back (quantize=False)
+    _, wn3 = _build(cfg)
+    wn3.load_state_dict({k[len("wavenet."):]: v for k, v in sd.items() if k.startswith("wavenet.")})
+    wn3 = wn3.cuda().eval()
+    got = wn3.incremental_forward(init.cuda(), c=c_up.cuda(), g=ins["g"].cuda(), T=T, softmax=False, quantize=False)
+    assert rel_err(got.cpu(), ref) < 1e-3
+    got_t = wn3.incremental_forward(init.transpose(1, 2).contiguous().cuda(), c=c_up.cuda(), g=ins["g"].cuda(), T=T, softmax=False,
+                                    quantize=False)                                                  # (B, 1, C) start rows
+    assert torch.equal(got_t, got)
+    with pytest.raises(NotImplementedError, match="not one-hot"):
+        wn3.incremental_forward(init.cuda() * 0.5, c=c_up.cuda(), g=ins["g"].cuda(), T=T, softmax=False, quantize=False)
+
+
 @pytest.mark.parametrize("name,d,with_c", [("A", 2, True), ("B", 4, True), ("A", 1, False)])
 def test_standalone_layer_with_time_varying_global_features(name, d, with_c):
     """modules.py:148-152 convolves whatever (B, gin_channels, T) tensor it is given; the reference's WaveNet hands it one speaker vector

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("WAE_LIB_PATH") or os.path.join(_HERE, "libwae_hip.so"
 WAE_F32, WAE_BF16, WAE_F16 = 0, 1, 2
 GLU_SAVE_Z, GLU_NO_OUT, GLU_WAVES4, GLU_CG2, GLU_PAIR, GLU_GENERIC = 2, 4, 8, 16, 32, 64
 TM_INTERLEAVE, TM_ONE_WG = 1, 2
-ERR_CLASS_ID, ERR_SPEAKER_ID, ERR_TARGET_ID = 1, 2, 4
+ERR_CLASS_ID, ERR_SPEAKER_ID, ERR_TARGET_ID, ERR_NOT_ONEHOT = 1, 2, 4, 8
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "wae_gproj_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 6 + [c_vp, c_vp]),
     "wae_gproj_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64] + [c_i32] * 7 + [c_vp]),
     "wae_check_ids": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "wae_onehot_to_ids": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "wae_upsample_stage_bwd": (c_i32, [c_vp] * 5 + [c_i32] * 4 + [c_vp]),
     "wae_enc_conv_bwd": (c_i32, [c_vp] * 7 + [c_i32] * 9 + [c_vp]),
     "wae_vq_bwd": (c_i32, [c_vp] * 6 + [c_i32] * 3 + [c_f32, c_f32, c_vp]),

@@ -9,7 +9,7 @@
 // Same decomposition as the forward kernels: 128 time steps per workgroup, one wave per 32 time columns owning all
 // M rows (NT 32x32 accumulator tiles), weights in A-fragment order through a double-buffered LDS ring, operands as
 // 16-byte fragments straight from L2/HBM with the clip boundary as a zero-fill predicate.
-#include "wae_common.hpp"
+#include "gemm_tm.hpp"
 
 // timing-only ablation (tools/ablate_tm.sh): -DWAE_TM_ABLATE=bits; 1 no operand loads, 2 no weight DMA, 4 no MFMA, 8 no epilogue
 #ifndef WAE_TM_ABLATE
@@ -22,46 +22,6 @@
 #ifndef TM_ASM_B
 #define TM_ASM_B 1     // bf16: inline-asm operand requests two chunks ahead (0: the plain-load loop, one chunk ahead)
 #endif
-
-#define TM_MAX_SRC 4
-#define TM_PLAIN 0
-#define TM_RESIDUAL 1  // out = alpha * (acc + res[t])
-#define TM_GATE_BWD 2  // acc = du (NT = Hp/32 tiles); out (t, 2Hp) = [da | db] from z (t, 2Hp)
-// The wide decoder head (skip / head widths above 256: the fused csrc/head_fwd.hip / head_bwd.hip keep every tile of a time
-// column in one wave) runs as separate launches of this kernel, intermediate activations through HBM:
-#define TM_BIAS_RELU 3  // out = relu(alpha * (bias[m] + acc)), aux = fp32 bias (M)             (wavenet.py:208-213)
-#define TM_RELU_BWD 4   // out = aux[t][m] > 0 ? alpha * acc : 0, aux = the saved activation      (autograd of the ReLUs)
-#define TM_CE 5         // acc = bias + logits (M = Op): optional (B,O,T) store, nll / lse of the shifted targets
-#define TM_CE_BWD 6     // out = (softmax(bias + acc) - onehot(target[t+1])) * w[t]  from the saved lse
-
-struct TmCe {           // modes 5 / 6 (vqwae_train.py:363-379 with the shift of :764)
-  float* logits;
-  const int32_t* target;
-  float* nll;
-  float* lse;
-  const int32_t* lengths;
-  float inv_count;
-  int O;
-};
-
-struct TmArgs {
-  unsigned long long* stamps;   // diagnostic builds only, else null
-  const char* src[TM_MAX_SRC];
-  int64_t src_stride[TM_MAX_SRC];  // elements per row
-  int src_cols[TM_MAX_SRC];        // multiple of CK
-  int src_shift[TM_MAX_SRC];       // operand row = t + shift (zero outside [0,T))
-  int nsrc;
-  const char* w;
-  char* out;
-  int64_t out_stride;
-  const char* aux;  // RESIDUAL: res (t, M) ; GATE_BWD: z (t, 2Hp)
-  int64_t aux_stride;
-  float alpha;
-  int B, T, mode;
-  int interleave;  // chunk q -> source q % nsrc, column block q / nsrc (all sources equally wide)
-  int flags;       // wae_tm_desc.flags
-  TmCe ce;
-};
 
 #ifdef WAE_TM_STAMPS
 // diagnostic build (tools/stamps_tm.py): per workgroup 8 x u64: [0] life (s_memtime), [1] life (s_memrealtime, 100 MHz), [2] chunk loop,
@@ -556,6 +516,11 @@ static int tm_run(const wae_tm_desc* d, const void* const* src, const int64_t* s
   }
   hipStream_t st = as_stream(stream);
   const int nt = d->M / 32;
+  {   // the long-K, one-source contractions (the head's skip GEMM) on the static 8-wave schedule: csrc/gemm_tm8.hip
+    bool handled = false;
+    const int rc = wae_gemm_tm8_launch(a, d->dtype, d->M, st, &handled);
+    if (rc != WAE_OK || handled) return rc;
+  }
   if (d->dtype == WAE_BF16) return dispatch_mode<__bf16>(d->mode, nt, a, st);
   if (d->dtype == WAE_F16) return dispatch_mode<f16>(d->mode, nt, a, st);
   return dispatch_mode<float>(d->mode, nt, a, st);

@@ -313,6 +313,9 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   const int nqb2 = p.Sp / T_::CK;
   const int nq_total = nqa + nqb1 + nqb2;
   auto dma = [&](int qi) {                       // chunk qi of the whole sequence -> ring slot qi & 1
+#ifdef WAE_GBP_NOW
+    return;                                      // timing-only: no weight DMA at all
+#endif
     char* dst = smem + (qi & 1) * SLOT;
     qi = min(qi, nq_total - 1);                  // (past the end: the last chunk again, into the slot nobody reads -- constant counts)
     const char* src;
@@ -323,6 +326,9 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
     if (qi < nqa) { bytes = CHX; src = p.w_x + (int64_t)qi * CHX; }
     else if (qi < nqa + nqb1) { bytes = CHB1; src = p.w_uo + (int64_t)(qi - nqa) * CHB1; }
     else { bytes = CHB2; src = p.w_us + (int64_t)(qi - nqa - nqb1) * CHB2; }
+#ifdef WAE_GBP_HALFW
+    bytes /= 2;                                  // timing-only: half the weight bytes per chunk (what a 256-column workgroup would pull)
+#endif
     dma_chunk(src, dst, bytes, wave, lane);
   };
 

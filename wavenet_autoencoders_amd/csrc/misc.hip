@@ -950,6 +950,37 @@ extern "C" int wae_check_ids(const int32_t* ids, int64_t n, int32_t lo, int32_t 
   return wae_check_launch("check_ids");
 }
 
+// One-hot (B, C, T) fp32 inputs -> class ids (wavenet.py:203 applies first_conv to whatever (B, C, T) tensor it is handed; the
+// teacher-forced kernels gather rows of its weight by class id, which is the same arithmetic for ONE-HOT columns only).  A column
+// that is not exactly one 1.0 among zeros sets `code` in the sticky error word: the host refuses the call instead of silently
+// taking an argmax of soft labels.  Strides in elements, so (B, T, C) views need no copy.
+__global__ void __launch_bounds__(256) onehot_to_ids_kernel(const float* __restrict__ x, int64_t n, int C, int T, int64_t sb, int64_t sc,
+                                                            int64_t st, int32_t* __restrict__ ids, int32_t* __restrict__ err, int code) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / T, t = i - b * T;
+    const float* col = x + b * sb + t * st;
+    int ones = 0, best = 0;
+    bool other = false;
+    for (int c = 0; c < C; ++c) {
+      const float v = col[(int64_t)c * sc];
+      if (v == 1.0f) { ++ones; best = c; }
+      else other |= v != 0.0f;
+    }
+    ids[i] = best;
+    bad |= ones != 1 || other;
+  }
+  if (__any(bad) && err && (threadIdx.x & 63) == 0) atomicOr(err, code);
+}
+extern "C" int wae_onehot_to_ids(const float* x, int32_t B, int32_t C, int32_t T, int64_t stride_b, int64_t stride_c, int64_t stride_t,
+                                 int32_t* ids, int32_t* err, int32_t code, void* stream) {
+  WAE_REQUIRE(x && ids && B > 0 && C > 0 && T > 0, "onehot_to_ids: bad arguments");
+  const int64_t n = (int64_t)B * T;
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(onehot_to_ids_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, n, C, T, stride_b, stride_c, stride_t, ids, err, code);
+  return wae_check_launch("onehot_to_ids");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // zb[b][l][:] = conv bias + conv1x1g(g_b) (modules.py:148-152 hoisted out of the time loop).  Block = (layer, clip, 32 gate rows);
 // eight lanes share a row and walk its Cg weights 32 bytes at a time (one thread per row walked Cg dependent strided loads: 21 us).

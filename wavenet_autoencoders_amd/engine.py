@@ -127,10 +127,26 @@ class WaeEngine:
         bits = int(self.err.item())
         if bits:
             self.err.zero_()
+            if bits & L.ERR_NOT_ONEHOT:
+                # wavenet.py:203 runs first_conv as a dense 1x1 on ANY (B, C, T) float tensor; the kernels gather rows of its weight by
+                # class id -- identical for one-hot columns only.  Soft labels / probabilities are refused, not arg-maxed.
+                raise NotImplementedError("decoder input (B, C, T) is not one-hot (every column exactly one 1.0 among zeros): dense inputs "
+                                          "to first_conv are not implemented on the teacher-forced path; pass one-hot columns or (B, T) class ids")
             what = [n for b, n in ((L.ERR_CLASS_ID, f"input class id outside [0, {self.g.O})"),
                                    (L.ERR_SPEAKER_ID, f"speaker id outside [0, {self.g.n_speakers})"),
                                    (L.ERR_TARGET_ID, f"target class id outside [0, {self.g.O})")) if bits & b]
             raise IndexError("index out of range in self: " + "; ".join(what) + " (ids were clamped; results of that call are invalid)")
+
+    def ids_from_onehot(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, C, T) one-hot floats (any strides: a transposed (B, T, C) view needs no copy) -> (B, T) int32 class ids.  A column that is
+        not one-hot sets WAE_ERR_NOT_ONEHOT in the sticky error word; check_errors() raises (wae_onehot_to_ids, include/wae.h)."""
+        x = x.to(self.device, torch.float32)
+        B, C, T = x.shape
+        ids = torch.empty(B, T, dtype=torch.int32, device=self.device)
+        L.check(self.lib.wae_onehot_to_ids(L.ptr(x), B, C, T, x.stride(0), x.stride(1), x.stride(2), L.ptr(ids), L.ptr(self.err),
+                                           L.ERR_NOT_ONEHOT, self.stream()), "onehot_to_ids")
+        self._onehot_keep = x
+        return ids
 
     # ------------------------------------------------------------------ parameters
     def stream(self):
@@ -520,7 +536,9 @@ class WaeEngine:
         "probs" / "raw" (quantize=False, wavenet.py:335-338 skipped): the softmax probabilities / raw logits of a step are the
         dense input of the next; they come back as `logits` (B,O,T).
         n_forced: test_inputs covers only the first n_forced steps (default: its length), later steps run free in `mode`
-        (wavenet.py:300-305).  Returns dict(idx (B,T) int32, logits (B,O,T) | None).
+        (wavenet.py:300-305).  init_idx: the class fed to step 0 when nothing is forced -- an int for every utterance (wavenet.py:288:
+        127) or one id per utterance (wavenet.py:283-297 starts each batch item from its own row of initial_input); ids per utterance
+        run as a forced first step.  Returns dict(idx (B,T) int32, logits (B,O,T) | None).
         Scalar-input decoders: test_inputs (B,T) fp32 teacher-forces the inputs (mode "logits" -> the mixture parameters
         (B,3M,T) as `logits`); mode "sample" draws every step from the mixture of logistics on the uniforms u_mix (B,T,M),
         u_log (B,T) (torch.rand in (1e-5, 1-1e-5) if None) -> dict(x (B,T) fp32, logits | None)."""
@@ -531,6 +549,18 @@ class WaeEngine:
         B = c.shape[0] if c is not None else (test_inputs.shape[0] if test_inputs is not None else 1)
         m = {"logits": 0, "argmax": 1, "sample": 2, "probs": 3, "raw": 4}[mode]
         dev = self.device
+        if not isinstance(init_idx, int) and not g.scalar_input:
+            ii = torch.as_tensor(init_idx).reshape(-1).to("cpu", torch.int64)
+            if ii.numel() == 1:
+                init_idx = int(ii[0])
+            else:
+                if ii.numel() != B:
+                    raise ValueError(f"init_idx: {ii.numel()} start classes for {B} utterances")
+                if int(ii.min()) < 0 or int(ii.max()) >= g.O:
+                    raise IndexError(f"index {int(ii.max() if ii.max() >= g.O else ii.min())} is out of bounds for dimension 2 with size {g.O}")
+                if test_inputs is None:     # (forced steps override the start class anyway: wavenet.py:300-302)
+                    test_inputs, n_forced = ii.to(dev, torch.int32).reshape(B, 1), 1
+                init_idx = int(ii[0])
         if test_inputs is not None:
             nf = int(test_inputs.shape[1]) if n_forced is None else int(n_forced)
             nf = max(0, min(nf, int(test_inputs.shape[1]), T))
@@ -568,7 +598,9 @@ class WaeEngine:
         coop = (B <= 8 and g.R <= 256 and g.S <= 256 and g.O <= 256 and not g.scalar_input and m <= 2
                 and self.opt.ar_coop)
         C = max(1, min(self.opt.ar_coop_c, 32, g.H, g.S)) if coop else 1
-        ring = torch.empty(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
+        # zeros: the rows read as history before their first write (t - d, t - 2d of the first samples) are the causal pad; the
+        # cooperative kernel zero-fills its ring itself, but only when its members share an XCD (round-5 advisor finding)
+        ring = torch.zeros(B * C * self.ar_ring_total, dtype=torch.float32, device=dev)
         if g.scalar_input:
             es = self.ar_w.element_size()
             M = g.O // 3

@@ -69,7 +69,7 @@ class VQVAE(ArenaModel):
         return [params[r] for r in self._pnames]
 
     def forward(self, x, c, g, softmax=False):
-        ids = _ids_from_input(x, self.out_channels, self.scalar_input)
+        ids = _ids_from_input(x, self.out_channels, self.scalar_input, self.engine())
         gid = g.reshape(-1) if g is not None else None
         params = self._params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (inside Function.forward grad mode is off)
@@ -87,9 +87,8 @@ class VQVAE(ArenaModel):
                 eng.prepare_weights()
             lat = eng.encoder_forward(c.float())
             quant, idx, stats = eng.vq_forward(lat)
-            init = 127
-            if initial_input is not None:
-                init = int(initial_input.reshape(initial_input.shape[0], -1)[0].argmax())
+            from .wavenet_vocoder.wavenet import _start_classes
+            init = 127 if self.scalar_input else _start_classes(initial_input, self.out_channels, eng)     # one start class per utterance
             gid = g.reshape(-1) if g is not None else None
             if self.scalar_input:
                 M = self.out_channels // 3

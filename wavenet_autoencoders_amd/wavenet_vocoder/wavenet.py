@@ -25,15 +25,31 @@ def receptive_field_size(total_layers, num_cycles, kernel_size, dilation=lambda 
     return (kernel_size - 1) * sum(dilation(i % per) for i in range(total_layers)) + 1
 
 
-def _ids_from_input(x, out_channels, scalar_input):
-    """Reference inputs are one-hot (B, C, T) floats (or (B, 1, T) scalars); the kernels take class ids."""
+def _ids_from_input(x, out_channels, scalar_input, eng=None):
+    """Reference inputs are one-hot (B, C, T) floats (or (B, 1, T) scalars); the kernels take class ids.  wavenet.py:203 would run
+    first_conv densely on soft labels too: a (B, C, T) input that is not one-hot is REFUSED (WaeEngine.check_errors raises at the end
+    of the call), never arg-maxed."""
     if scalar_input:
         return x.reshape(x.shape[0], -1).float()
     if x.dim() == 3:
         if x.shape[1] != out_channels and x.shape[2] == out_channels:
             x = x.transpose(1, 2)
-        return x.argmax(dim=1).to(torch.int32)
+        if eng is None:
+            raise RuntimeError("one-hot inputs are converted on the GPU: pass the engine")
+        return eng.ids_from_onehot(x)
     return x.to(torch.int32)
+
+
+def _start_classes(initial_input, out_channels, eng):
+    """initial_input (B, C, 1) / (B, 1, C) one-hot rows -> one start class per utterance (wavenet.py:283-297); None -> 127 (:288)."""
+    if initial_input is None:
+        return 127
+    ii = initial_input
+    if ii.dim() == 3:
+        ii = ii.reshape(ii.shape[0], -1)
+    ids = eng.ids_from_onehot(ii.reshape(ii.shape[0], out_channels, 1)).reshape(-1)
+    eng.check_errors()
+    return ids
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -160,7 +176,7 @@ class WaveNet(ArenaModel):
     def forward(self, x, c=None, g=None, softmax=False):
         """x (B, C, T) one-hot / (B, 1, T) scalar / (B, T) ids; c (B, Cc, Tc); g (B,) ids or (B, Cg, 1) features.
         Returns (B, out_channels, T) logits (probabilities if softmax)  -- wavenet.py:164-216."""
-        ids = _ids_from_input(x, self.out_channels, self.scalar_input)
+        ids = _ids_from_input(x, self.out_channels, self.scalar_input, self.engine())
         if g is not None and g.dtype in (torch.int32, torch.int64):
             g = g.reshape(-1)
         c_is_up = not bool(self.geom.upsample_scales)
@@ -203,16 +219,12 @@ class WaveNet(ArenaModel):
             return out["x"].unsqueeze(1)
         tf = None
         if test_inputs is not None:
-            tf = _ids_from_input(test_inputs, self.out_channels, False)
+            tf = _ids_from_input(test_inputs, self.out_channels, False, eng)
+            eng.check_errors()                                                           # (rows that are not one-hot are refused)
             T = max(int(T or 0), tf.shape[1])                                            # wavenet.py:259-262
         T = int(T)
         nf = tf.shape[1] if tf is not None else 0
-        init = 127                                                                      # wavenet.py:288
-        if initial_input is not None:
-            ii = initial_input
-            if ii.dim() == 3:
-                ii = ii.reshape(ii.shape[0], -1)
-            init = int(ii[0].argmax())
+        init = _start_classes(initial_input, self.out_channels, eng)                    # wavenet.py:283-297 (None: class 127, :288)
         gid = g.reshape(-1) if (g is not None and g.dtype in (torch.int32, torch.int64)) else None
         gvec = None if (g is None or gid is not None) else g.reshape(g.shape[0], -1).float().contiguous()
         c_is_up = c is not None and (not self.geom.upsample_scales or c.shape[-1] == T)
