@@ -388,23 +388,31 @@ def test_dropout_train_step_bf16_learns():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("case", ["B", "s44", "c2", "c3dec"])
+@pytest.mark.parametrize("case", ["B", "s44", "c2", "c3dec", "cc80", "nocond", "k2", "k4", "nofold"])
 def test_fused_residual_gate_launch_16bit(case, dtype, monkeypatch):
     """Round 5: K_X of layer l + K_U of layer l-1 as ONE launch in 16-bit storage (csrc/glu_bwd.hip: glu_bwd_pair_kernel; two workgroups
     per CU, the residual launch's weight stream and chunk order; opt-in WAE_BWD_FUSED=1) against the two wae_gemm_tm launches on the
     same operands: the top layer's dx-hat BITWISE equal (same weights, same MFMA order), dz and the dx-hat below to 2e-2 of their range
     (the W_out^T contraction sums the same products in accumulator-row order; dz is rounded to 16 bits once in both paths, and every
     layer below inherits that rounding), dc and every parameter gradient to 2e-2 of each tensor's range.  Golden model B (Rp 128, Hp 64: instance <4, 2>), a 128 x 128 geometry (<4, 4>), C2 at full size (<8, 6>), the
-    hps/vqwae.json decoder (<8, 4>); ragged lengths."""
+    hps/vqwae.json decoder (<8, 4>); ragged lengths.
+    The launch is the 16-bit DEFAULT (WAE_BWD_FUSED=auto) for every supported (Rp, Hp), also where the conditioning gradient cannot ride
+    in it -- the FOLD = false instantiation (round-5 advisor finding: never exercised in 16 bits): Cc = 80 (the reference's default
+    cin_channels: Ccp = 128), no local conditioning, 2 and 4 taps, and WAE_BWD_FOLD_DC=0 on a geometry that folds by default."""
     from wavenet_autoencoders_amd import Geometry
     from wavenet_autoencoders_amd import backward as BW
     from wavenet_autoencoders_amd.engine import WaeEngine
-    if case == "s44":
-        cfg = dict(layers=4, stacks=2, R=96, G=256, S=96, O=64, Cc=64, Cg=16, k=3, n_speakers=5, upsample_scales=None)
+    if case == "nofold":
+        monkeypatch.setenv("WAE_BWD_FOLD_DC", "0")
+        case = "B"
+    if case in ("s44", "cc80", "nocond", "k2", "k4"):
+        cc = {"cc80": 80, "nocond": -1}.get(case, 64)
+        cfg = dict(layers=4, stacks=2, R=96, G=256, S=96, O=64, Cc=cc, Cg=16, k={"k2": 2, "k4": 4}.get(case, 3), n_speakers=5,
+                   upsample_scales=None)
         sd = O.make_state_dict(dict(cfg), salt=9, with_encoder=False)
         B, T = 3, 700
         x = ((O.hash_fill((B, T), 31) * 0.5 + 0.5) * 64).long().clamp(0, 63).cuda()
-        c = O.hash_fill((B, 64, T), 32, 1.2).cuda()
+        c = O.hash_fill((B, cc, T), 32, 1.2).cuda() if cc > 0 else None
         g = (torch.arange(B) % 5).cuda()
         up = True
     elif case == "B":
@@ -440,13 +448,15 @@ def test_fused_residual_gate_launch_16bit(case, dtype, monkeypatch):
         dc = BW.decoder_backward(eng, x, x, lengths, g)
         assert eng.fused_bwd == (fused == "1")
         ws = eng._ws[("bwd", B, T)]
+        if dc is None:
+            dc = torch.zeros(1, device="cuda")
         got[fused] = (ws["dz"].clone(), [t_.clone() for t_ in ws["gx"]], dc.clone(), BW.finish_grads(eng).clone())
         torch.cuda.synchronize()
         lay = eng.lay
         del eng
         torch.cuda.empty_cache()
-    a, b_ = got["0"][1][-1].float(), got["1"][1][-1].float()          # dx-hat of the top layer: same weights, same chunk order
-    assert float((a - b_).abs().max()) <= 4e-3 * float(a.abs().max()), ("top dx-hat", float((a - b_).abs().max()), float(a.abs().max()))
+    a, b_ = got["0"][1][-1], got["1"][1][-1]          # dx-hat of the top layer: same dz, same weights, same chunk and MFMA order
+    assert torch.equal(a.view(torch.int16), b_.view(torch.int16)), ("top dx-hat", float((a.float() - b_.float()).abs().max()))
     for a, b_ in zip(got["0"][1], got["1"][1]):
         err, ref = float((a.float() - b_.float()).abs().max()), float(a.float().abs().max())
         assert err < 2e-2 * ref + 1e-9, ("dx-hat", err, ref)

@@ -273,3 +273,15 @@ def test_engine_options_are_read_once_and_checked(monkeypatch):
             EngineOptions.from_env()
         monkeypatch.delenv(var)
 
+
+
+def test_negative_leaky_relu_slope_is_refused():
+    """round-5 advisor finding: wae_act_bwd derives the derivative from the sign of the activation's OUTPUT, which a negative
+    negative_slope flips -- Geometry refuses it (torch accepts it), for the module constructor and the training script alike."""
+    import pytest
+    from wavenet_autoencoders_amd import Geometry
+    cfg = dict(layers=4, stacks=2, R=64, G=128, S=64, O=64, Cc=16, Cg=8, upsample_scales=[4], up_act="LeakyReLU")
+    assert Geometry.from_cfg(dict(cfg, up_act_slope=0.2)).up_act_slope == 0.2
+    assert Geometry.from_cfg(dict(cfg, up_act_slope=0.0)).up_act_slope == 0.0
+    with pytest.raises(NotImplementedError, match="negative"):
+        Geometry.from_cfg(dict(cfg, up_act_slope=-0.1))

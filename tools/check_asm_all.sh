@@ -7,8 +7,10 @@ TMP=$(mktemp -d)
 {
 echo "# tools/check_asm_all.sh: no compiler-generated instruction may touch a register between its inline-asm request and the"
 echo "# counted wait that retires it (csrc/wae_common.hpp: gload_async).  hipcc $(/opt/rocm/bin/hipcc --version | grep -o 'HIP version.*')"
-for f in glu_fwd glu_fwd_static head_fwd gemm_tm glu_bwd; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only $ROOT/wavenet_autoencoders_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
+# (the ISA is a by-product of the product build: csrc/obj/<name>.s, csrc/Makefile)
+make -C $ROOT/wavenet_autoencoders_amd/csrc -j8 > /dev/null
+for f in glu_fwd glu_fwd_static head_fwd gemm_tm gemm_tm8 glu_bwd; do
+  cp $ROOT/wavenet_autoencoders_amd/csrc/obj/$f.s $TMP/$f.s
   # lookahead: glu_fwd requests two chunks ahead; glu_fwd_static mixes two-chunks-ahead fragments with residual rows that are retired
   # by the very next counted wait (text-order scanning cannot tell them apart): the always-valid lookahead 1
   la=1; [ $f = glu_fwd ] && la=3
@@ -26,13 +28,13 @@ echo "# tools/check_asm_drains.py over every 16-bit kernel with asynchronous req
 echo "# s_waitcnt vmcnt(0) inside the innermost loops that issue LDS-DMA pieces / inline-asm loads (fp32 instantiations use plain"
 echo "# loads and are expected to wait; they are not listed)"
 for f in gemm_tn_stream glu_fwd head_fwd gemm_tm head_bwd gemm_tn glu_bwd; do
-  [ -f $TMP/$f.s ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only $ROOT/wavenet_autoencoders_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
+  [ -f $TMP/$f.s ] || cp $ROOT/wavenet_autoencoders_amd/csrc/obj/$f.s $TMP/$f.s
   python3 $ROOT/tools/check_asm_drains.py $TMP/$f.s IDF16 | grep -v "^_Z.*: 0 loop"
 done
 } > $DR
 rm -rf $TMP
 # third check: the hand-allocated register banks of the autoregressive kernels (tools/check_ar_banks.py)
-python3 $ROOT/tools/check_ar_banks.py > ${OUT%_load_check.txt}_ar_banks.txt || echo "AR register bank check FAILED"
+python3 $ROOT/tools/check_ar_banks.py $ROOT/wavenet_autoencoders_amd/csrc/obj/ar_coop.s > ${OUT%_load_check.txt}_ar_banks.txt || echo "AR register bank check FAILED"
 grep -c " 0 violation" $OUT | sed 's/$/ kernels clean/'
 grep -c ", 0 scratch" $DR | sed 's/$/ kernels without drains in their asynchronous loops/'
 grep "^_Z" $DR | grep -v ", 0 scratch" | sed 's/: .*loop(s) with asynchronous requests,/:/' | head -20

@@ -67,11 +67,17 @@ class GradBucketer:
         assert grads.dim() == 1 and grads.dtype == torch.float32
         if wire_dtype not in ("fp32", "bf16"):
             raise ValueError(f"wire_dtype={wire_dtype!r}: 'fp32' (exact: the rank mean of fp32 gradients) or 'bf16'")
-        # wire_dtype "bf16": every collective carries a bf16 copy of its slice (half the bytes per xGMI link; the ranks' gradients
-        # are rounded to 8 bits of mantissa and summed in bf16) and the sum is widened back into the fp32 arena -- opt-in, for
-        # 16-bit engines whose gradients carry bf16 rounding already; the default keeps the all-reduce in fp32
+        # wire_dtype "bf16": every collective carries a bf16 copy of its slice (half the bytes per xGMI link) and the result is widened
+        # back into the fp32 arena -- opt-in, for 16-bit engines whose gradients carry bf16 rounding already; the default keeps the
+        # all-reduce in fp32.  Each rank's slice is scaled by 1 / world BEFORE the cast (exact for a power-of-two world), so the wire
+        # carries the addends of the MEAN: the running sum never leaves the gradients' own range (a small tail of the arena cannot be
+        # swamped by a sum W times its size, nothing overflows) and no scale follows the collective.  Error: the collective adds W
+        # bf16 addends in bf16 -- at most (W - 1) roundings of 2^-9 relative to the running partial sum on top of the cast's 2^-9, i.e.
+        # <= W * 2^-9 of the mean's range (world 8: 1.6e-2; measured 4e-3 at world 2, tests/test_distributed_cpu.py).  The copies live in
+        # ONE persistent bf16 staging arena (round 5 allocated a fresh copy per collective and step).
         self.wire_bf16 = wire_dtype == "bf16"
         self._wires = []
+        self._wire_arena = None
         self.grads = grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -108,18 +114,22 @@ class GradBucketer:
                     e = torch.cuda.Event(enable_timing=True)
                     e.record(self.comm_stream)
                     self._ev.append(e)
-                self.handles.append(dist.all_reduce(self._wire(view), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.handles.append(dist.all_reduce(self._wire(view, lo, hi), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             if self.timing_host and self._t0 is None:
                 import time
                 self._t0 = time.perf_counter()
-            self.handles.append(dist.all_reduce(self._wire(view), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.handles.append(dist.all_reduce(self._wire(view, lo, hi), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _wire(self, view: torch.Tensor) -> torch.Tensor:
-        """what the collective carries for this slice of the arena (called under the stream the collective is issued on)"""
+    def _wire(self, view: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+        """what the collective carries for slice [lo, hi) of the arena (called under the stream the collective is issued on)"""
         if not self.wire_bf16:
             return view
-        w = view.to(torch.bfloat16)
+        if self._wire_arena is None:
+            self._wire_arena = torch.empty(self.grads.numel(), dtype=torch.bfloat16, device=self.grads.device)
+        w = self._wire_arena[lo:hi]
+        torch.mul(view, 1.0 / self.world, out=view)      # the addend of the mean, in place (the arena slice is overwritten by the result)
+        w.copy_(view)
         self._wires.append((w, view))
         return w
 
@@ -175,7 +185,8 @@ class GradBucketer:
                 self.last_comm_ms, self.last_wait_ms = (t1 - self._t0) * 1e3, (t1 - tw0) * 1e3
             self._t0 = None
         if self.world > 1:
-            self.grads.mul_(1.0 / self.world)
+            if not self.wire_bf16:                       # (the bf16 wire carried the addends of the mean already)
+                self.grads.mul_(1.0 / self.world)
             if self.timing:
                 w1.record(torch.cuda.current_stream(dev))
                 self._pending = (self._ev, (w0, w1))

@@ -96,6 +96,10 @@ class Geometry:
             self.dilations = [int(d) for d in self.dilations_override]
         self.receptive_field = (self.k - 1) * sum(self.dilations) + 1   # wavenet.py:42-60
         self.has_encoder = self.c_in is not None
+        if self.up_act == "LeakyReLU" and not self.up_act_slope >= 0.0:
+            # wae_act_bwd forms act'(x) from the sign of the stored OUTPUT (csrc/misc.hip: act_bwd_kernel); with a negative slope the
+            # output's sign no longer is the input's (torch accepts such slopes): refused, not differentiated wrongly
+            raise NotImplementedError(f"upsample_activation LeakyReLU(negative_slope={self.up_act_slope}): negative slopes are not implemented")
 
     @staticmethod
     def from_cfg(cfg: dict) -> "Geometry":
