@@ -124,14 +124,26 @@ def ar_leg(device, T_ar=4000, cpu=True, full_clip=True):
                         "short prefix run"}
     us = 1e3 / out[best]
     wbytes = n_w * (2 if best == "bf16" else 4)
-    bound_us = wbytes / (HBM_PEAK_GBS * 1e9) * 1e6
+    stream_us = wbytes / (HBM_PEAK_GBS * 1e9) * 1e6
+    # The floor of this kernel is the chain of cross-CU hand-overs, not bytes: a sample is 20 strictly sequential layers, each of which
+    # exchanges the members' shares of x' twice (reduce-scatter + all-gather over {sequence number, fp32} granules inside one XCD).
+    # Measured inside the kernel with every request removed (timing-only ablation, profiles/r03_ar_stamps.txt, EXPERIMENT_LOG "Round 3:
+    # ar_coop"): the two hand-overs of a layer take 1.76 k clocks at the 2.09 GHz this kernel holds (68 k clocks per 32.6-us sample);
+    # tools/handover_probe.hip prices one store -> L2 -> poll hand-over at ~0.9 k clocks on an idle XCD.
+    HANDOVER_CLOCKS_PER_LAYER, AR_CLOCK_GHZ = 1760.0, 2.09
+    floor_us = cfg["layers"] * HANDOVER_CLOCKS_PER_LAYER / (AR_CLOCK_GHZ * 1e3)
     res = {"metric": "autoregressive kHz (synthesis.py incremental_forward, 1 utterance, 1 GPU)", "value": out[best],
            "unit": "kHz", "fp32_khz": out["fp32"], "bf16_khz": out["bf16"], "samples": Tg, "us_per_sample": us,
            "realtime_factor": out[best] / 16.0,
-           "roofline": {"bound": "latency (weight streaming as the stated floor)", "achieved": us, "peak": bound_us, "unit": "us/sample",
-                        "frac": bound_us / us, "weight_bytes_per_sample": wbytes,
-                        "note": "SURVEY 8(d): every effective weight once per sample (%d x %d B) / 8 TB/s; 20 strictly sequential "
-                                "layers + head per sample" % (n_w, 2 if best == "bf16" else 4)},
+           "roofline": {"bound": "latency (the chain of cross-CU hand-overs: 2 per layer, %d layers per sample)" % cfg["layers"],
+                        "achieved": us, "peak": floor_us, "unit": "us/sample", "frac": floor_us / us,
+                        "handover_clocks_per_layer": HANDOVER_CLOCKS_PER_LAYER, "kernel_clock_ghz": AR_CLOCK_GHZ,
+                        "note": "exchange-latency floor = layers x 1.76 k clocks of hand-over at 2.09 GHz (measured in-kernel with every "
+                                "request ablated); the rest of a sample is the per-layer GEMV + gate + barriers between the hand-overs",
+                        "weight_streaming_us": stream_us, "weight_bytes_per_sample": wbytes,
+                        "weight_streaming_note": "SURVEY 8(d)'s stated bound -- every effective weight once per sample (%d x %d B) / 8 TB/s "
+                                                 "-- no longer describes the 16-bit kernel: every layer's weights stay on chip for the whole clip "
+                                                 "(LDS + registers), nothing is streamed per sample" % (n_w, 2 if best == "bf16" else 4)},
            "config": "C4: hps/vqwae.json decoder (20 layers, R=G=S=256), categorical sampling, one persistent launch"}
     if full is not None:
         res["full_clip"] = full
@@ -277,6 +289,33 @@ def fp32_leg(conf, sd, device, steps=4):
     return out
 
 
+def sub_config_line(name, steps=5, warmup=2, cpu=True):
+    """`bench.py --config <name>` as a child process, its line cut down to what the default line embeds."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", str(warmup), "--no-ar",
+           "--no-fp32", "--no-sub"] + ([] if cpu else ["--no-cpu"])
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": "rc %d: %s" % (p.returncode, p.stderr[-400:])}
+        d = json.loads(line[-1])
+    except (subprocess.TimeoutExpired, ValueError) as e:
+        return {"error": repr(e)}
+    keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "loss", "roofline_step", "cpu_baseline")
+            if k in d}
+    keep["workload"] = d["config"]["workload"]
+    r = d["roofline"]
+    keep["roofline"] = {k: r[k] for k in ("bound", "kernel", "family", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                          "ms_per_step", "algorithmic_bytes_per_launch", "mfma_frac", "family_ms_per_step") if k in r}
+    fi = d.get("forward_inference")
+    if fi:
+        keep["forward_inference"] = {"ms_per_step": fi["ms_per_step"], "value": fi["value"], "roofline_whole_frac": fi["roofline_whole"]["frac"],
+                                     "layer_launch_frac": fi["roofline"]["frac"], "layer_launch_ms": fi["roofline"]["avg_launch_ms"]}
+    keep["wall_s"] = time.perf_counter() - t0
+    return keep
+
+
 def csrc_hash():
     """sha256 over the kernel sources: profiles/*_pmc_traffic.json carries the hash of the build it was measured on"""
     import glob
@@ -341,6 +380,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ar", action="store_true", help="skip the autoregressive leg (BASELINE config C4, rank 0 only)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the short fp32 (parity-grade mode) leg of the default line")
+    ap.add_argument("--no-sub", action="store_true", help="skip the c3 / c5 sub-lines of the default line (BASELINE configs[2] and [4], 5 steps each)")
     ap.add_argument("--lr", type=float, default=4e-4, help="Adam learning rate of the timed steps (0: the weights never change -- same-data "
                     "A/B runs of timing-only kernel variants, tools/bench_fields.py)")
     args = ap.parse_args()
@@ -632,6 +672,14 @@ def main():
             ncl = 2 if args.config == "c5" else B_PER_GPU
             cb, cpu_loss = cpu_baseline_train(sd, ncl, conf) if args.mode == "train" else cpu_baseline(sd, ncl, conf)
             res["cpu_baseline"] = cb
+        if args.config == "c2" and args.mode == "train" and world == 1 and not args.no_sub and args.dtype == conf["dtype"]:
+            # BASELINE configs[2] and [4] -- the two 8-GPU configurations -- as their per-GPU shard on this GPU: a few steps each, run as
+            # CHILD processes of this one (never an exec from a process that holds the GPU) after everything above has been timed.  The
+            # driver's line then carries all three trainable configurations; the full lines are `bench.py --config c3|c5`.
+            del eng
+            torch.cuda.empty_cache()
+            for sub in ("c3", "c5"):
+                res[sub] = sub_config_line(sub, cpu=not args.no_cpu)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

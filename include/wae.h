@@ -320,6 +320,11 @@ typedef struct wae_ar_desc {
   float scale;          /* sqrt(1/L) */
   int32_t n_forced;     /* with inputs: steps t < n_forced consume inputs[t], later steps the fed-back output
                            (test_inputs shorter than T, wavenet.py:300-305); <= 0 or >= T: every step is forced */
+  /* wae_ar_generate_coop only (the library reads no environment variable; rounds 4-5 had three): */
+  int32_t coop_generic;  /* 1: the any-shape cooperative kernel also where the reference's geometry has one with its sizes as constants */
+  int32_t resident_lds;  /* layers whose weight packets the fast kernel keeps in LDS: 0 = as many as fit, n > 0 = n, < 0 = none */
+  int32_t resident_regs; /* ... and in registers (accumulation registers, then hand-allocated arch VGPRs): 0 = all that fit, n > 0 = n,
+                            < 0 = none.  Where the packets wait is not arithmetic: results are bitwise the same for every split. */
 } wae_ar_desc;
 int wae_ar_generate(const wae_ar_desc* d, const int32_t* dilations, const int64_t* ring_off, float* ring,
                     int64_t ring_total, const void* w_layers, int64_t layer_stride_bytes, int64_t w2_off_bytes,
@@ -346,12 +351,13 @@ int wae_ar_generate_scalar(const wae_ar_desc* d, const int32_t* dilations, const
  * the launch; error[0] != 0 afterwards means a wait timed out (the output is then invalid).  No atomics: every share is one
  * stored {sequence number, fp32} granule and the members add them in a fixed order -- results are bitwise reproducible.  The
  * reference's geometry (R = G = S = O = 256, 3 taps, Cc <= 256) on C = 32 runs a kernel with those sizes as constants
- * (WAE_AR_COOP_GENERIC=1 in the environment keeps the any-shape kernel); both zero-fill / overwrite `ring` themselves.  That kernel's
+ * (wae_ar_desc.coop_generic = 1 keeps the any-shape kernel); both zero-fill / overwrite `ring` themselves (the caller should still hand
+ * over a zeroed ring: the fast kernel's members zero-fill their shares only when they sit on one XCD).  That kernel's
  * 32 members share ONE history ring per utterance (member 0's region of the (B, C, ring_total) allocation: every member writes every
  * row, the same bits) and, in 16-bit storage, keep every layer's weight packets on chip for the whole clip -- 6 layers in LDS, 11 in
  * the accumulation registers, 3 in hand-allocated arch VGPRs at the reference's 20 layers; deeper stacks stream the rest from L2.
- * Debugging aids read by the library itself: WAE_AR_LDS_LAYERS=n / WAE_AR_BANK_LAYERS=n override the number of layers kept in LDS /
- * in registers (0 0: the streaming form; results are bitwise the same for every split, tests/test_gpu_ar.py). */
+ * wae_ar_desc.resident_lds / resident_regs override the number of layers kept in LDS / in registers (-1 -1: the streaming form;
+ * results are bitwise the same for every split, tests/test_gpu_ar.py). */
 int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d);
 int wae_ar_coop_msg_values(const wae_ar_desc* d, int32_t C);
 int wae_ar_generate_coop(const wae_ar_desc* d, int32_t C, const int32_t* dilations, const int64_t* ring_off, float* ring,

@@ -136,8 +136,8 @@ def test_constant_size_cooperative_kernel_every_packet_count(cc, dtype, tol, mon
 
     def run(coop, fused):
         monkeypatch.setenv("WAE_AR_COOP", coop)
-        monkeypatch.setenv("WAE_AR_FUSED", fused)
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.ar_path(one_handover=fused == "1")
         eng.load_state_dict(sd)
         out = eng.incremental_forward(c, gid, T, mode="logits", test_inputs=x, c_is_upsampled=True)
         torch.cuda.synchronize()
@@ -284,8 +284,9 @@ def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch
     of the last 3 in hand-allocated arch VGPRs (ar_coop_fast_vb_kernel: bank slots 11-13), and its 32 members share one history ring
     (csrc/ar_coop.hip: LDSW).  Where a layer's packets live is not arithmetic: a sampled
     decode at the C4 geometry (20 layers, dilations to 512, T = 1500: the rings of the wide layers wrap) must be BITWISE the decode of the
-    streaming form (WAE_AR_LDS_LAYERS=0: no resident layer, private rings), for every split of the layers between LDS, registers and
-    memory; teacher-forced logits likewise."""
+    streaming form (ar_path(lds_layers=0): no resident layer, private rings), for every split of the layers between LDS, registers and
+    memory; teacher-forced logits likewise.  (Round 6: the split is a field of wae_ar_desc; rounds 4-5 read it from the environment
+    inside the library.)"""
     from wavenet_autoencoders_amd import Geometry
     from wavenet_autoencoders_amd.engine import WaeEngine
     cfg = dict(layers=20, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5], cin_pad=0)
@@ -297,15 +298,12 @@ def test_resident_weights_and_shared_ring_do_not_change_a_bit(dtype, monkeypatch
     uni = torch.rand(2, T, generator=gen).cuda()
     forced = torch.randint(0, 256, (2, T), generator=gen).cuda()
     got = {}
-    for tag, env in (("stream", {"WAE_AR_LDS_LAYERS": "0"}), ("default", {}), ("lds3", {"WAE_AR_LDS_LAYERS": "3", "WAE_AR_BANK_LAYERS": "0"}),
-                     ("lds2+bank5", {"WAE_AR_LDS_LAYERS": "2", "WAE_AR_BANK_LAYERS": "5"}),
-                     ("lds6+bank11", {"WAE_AR_BANK_LAYERS": "11"}),            # the instantiation without the arch-VGPR bank
-                     ("lds1+bank13", {"WAE_AR_LDS_LAYERS": "1", "WAE_AR_BANK_LAYERS": "13"})):
-        for k in ("WAE_AR_LDS_LAYERS", "WAE_AR_BANK_LAYERS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for tag, split in (("stream", dict(lds_layers=0)), ("default", {}), ("lds3", dict(lds_layers=3, reg_layers=0)),
+                       ("lds2+bank5", dict(lds_layers=2, reg_layers=5)),
+                       ("lds6+bank11", dict(reg_layers=11)),            # the instantiation without the arch-VGPR bank
+                       ("lds1+bank13", dict(lds_layers=1, reg_layers=13))):
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.ar_path(**split)
         eng.load_state_dict(sd)
         a = eng.incremental_forward(lat, gid, T, mode="sample", uniforms=uni)["idx"].clone()
         b_ = eng.incremental_forward(lat, gid, T, mode="logits", test_inputs=forced, want_logits=True)["logits"].clone()
@@ -332,12 +330,9 @@ def test_resident_weights_at_other_depths(layers, stacks, monkeypatch):
     gid = torch.tensor([3, 77]).cuda()
     uni = torch.rand(2, T, generator=gen).cuda()
     got = {}
-    for tag, env in (("stream", {"WAE_AR_LDS_LAYERS": "0"}), ("default", {})):
-        for k in ("WAE_AR_LDS_LAYERS", "WAE_AR_BANK_LAYERS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for tag, split in (("stream", dict(lds_layers=0)), ("default", {})):
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype="bf16")
+        eng.ar_path(**split)
         eng.load_state_dict(sd)
         got[tag] = eng.incremental_forward(lat, gid, T, mode="sample", uniforms=uni)["idx"].clone()
         torch.cuda.synchronize()

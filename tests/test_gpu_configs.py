@@ -41,8 +41,7 @@ def _set_ar_path(monkeypatch, coop):
     (wae_ar_generate_coop_fused with the host-formed W1_cur . W_out products), 'generic': the any-shape cooperative kernel on the same
     geometry, '0': one CU per utterance"""
     monkeypatch.setenv("WAE_AR_COOP", "0" if coop == "0" else "1")
-    monkeypatch.setenv("WAE_AR_COOP_GENERIC", "1" if coop == "generic" else "0")
-    monkeypatch.setenv("WAE_AR_FUSED", "1" if coop == "fused" else "0")
+    return dict(generic=coop == "generic", one_handover=coop == "fused")      # WaeEngine.ar_path(**...)
 
 
 @pytest.mark.parametrize("coop", ["1", "fused", "generic", "0"])
@@ -51,8 +50,8 @@ def test_c4_teacher_forced_logits(c4, dtype, tol, coop, monkeypatch):
     """Teacher-forced incremental decode over 2560 samples == the reference's incremental_forward(test_inputs) at the probe
     steps (every 13th + the steps around both wraps of the d = 512 rings), and the log-sum-exp of EVERY step."""
     cfg, sd, z = c4
-    _set_ar_path(monkeypatch, coop)
-    eng = _engine(cfg, sd, dtype)
+    path = _set_ar_path(monkeypatch, coop)          # (WAE_AR_COOP is read when the engine is built)
+    eng = _engine(cfg, sd, dtype).ar_path(**path)
     T = z["x"].shape[1]
     x = torch.from_numpy(z["x"].astype(np.int64)).cuda()
     out = eng.incremental_forward(torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda(), T, mode="logits",
@@ -88,8 +87,8 @@ def test_c4_cooperative_decode_is_bitwise_reproducible(c4, dtype, coop, monkeypa
     """The members' shares are added in a fixed order (csrc/ar_coop.hip: arc_allsum / arc_allsum2), not by atomics in arrival order:
     two runs give the same bits, logits and drawn samples alike."""
     cfg, sd, z = c4
-    _set_ar_path(monkeypatch, coop)
-    eng = _engine(cfg, sd, dtype)
+    path = _set_ar_path(monkeypatch, coop)          # (WAE_AR_COOP is read when the engine is built)
+    eng = _engine(cfg, sd, dtype).ar_path(**path)
     T = z["x"].shape[1]
     lat, g = torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda()
     uni = torch.rand(1, T, generator=torch.Generator().manual_seed(5)).cuda()
@@ -105,8 +104,8 @@ def test_c4_cooperative_decode_is_bitwise_reproducible(c4, dtype, coop, monkeypa
 @pytest.mark.parametrize("coop", ["1", "fused", "generic", "0"])
 def test_c4_greedy_rollout_fp32(c4, coop, monkeypatch):
     cfg, sd, z = c4
-    _set_ar_path(monkeypatch, coop)
-    eng = _engine(cfg, sd, "fp32")
+    path = _set_ar_path(monkeypatch, coop)          # (WAE_AR_COOP is read when the engine is built)
+    eng = _engine(cfg, sd, "fp32").ar_path(**path)
     T = z["x"].shape[1]
     lat, g = torch.from_numpy(z["lat"]).cuda(), torch.from_numpy(z["g"]).cuda()
     out = eng.incremental_forward(lat, g, T, mode="argmax", init_idx=127)

@@ -23,7 +23,8 @@ class GluDesc(ctypes.Structure):
 
 class ArDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "B", "T", "L", "R", "Rp", "G", "Hp", "S", "O", "Cc", "Ccp", "ktaps", "mode",
-                                     "init_idx", "scalar_input")] + [("scale", c_f32), ("n_forced", c_i32)]
+                                     "init_idx", "scalar_input")] + [("scale", c_f32), ("n_forced", c_i32), ("coop_generic", c_i32),
+                                                                       ("resident_lds", c_i32), ("resident_regs", c_i32)]
 
 
 class TmDesc(ctypes.Structure):

@@ -1581,18 +1581,10 @@ static void launch_arc_fast(const ArcArgs& a, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((ar_coop_fast_kernel<E, NU, false>), dim3(8 * 32), dim3(ARC_THREADS), lds, st, a);
 }
 
-static int flags_env() {
-  const char* e = getenv("WAE_AR_COOP_GENERIC");
-  return e && e[0] == '1' ? 1 : 0;
-}
-static int nlds_env(int dflt) {     // debugging aid: WAE_AR_LDS_LAYERS=n overrides the number of LDS-resident layers (0: none)
-  const char* e = getenv("WAE_AR_LDS_LAYERS");
-  return e ? atoi(e) : dflt;
-}
-static int nbank_env(int dflt) {    // ... WAE_AR_BANK_LAYERS=n the number of layers kept in registers (0 .. ARC_NBANK in the accumulation
-  const char* e = getenv("WAE_AR_BANK_LAYERS");   // registers; up to ARC_NVB more select the instantiation with the arch-VGPR bank)
-  const int v = e ? atoi(e) : dflt;
-  return v < 0 ? 0 : (v > ARC_NBANK + ARC_NVB ? ARC_NBANK + ARC_NVB : v);
+// how many layers stay resident (wae_ar_desc.resident_lds / resident_regs): 0 = the default, n > 0 = n, < 0 = none
+static int resident_count(int field, int dflt, int cap) {
+  const int v = field == 0 ? dflt : (field < 0 ? 0 : field);
+  return v > cap ? cap : v;
 }
 
 extern "C" int64_t wae_ar_coop_acc_floats(const wae_ar_desc* d) {
@@ -1653,7 +1645,7 @@ static int ar_generate_coop_impl(const wae_ar_desc* d, int32_t C, const int32_t*
   // the reference's own geometry on 32 members: the kernel with the sizes as constants (NU = W1 packets per GEMV thread)
   const int nu = ((3 * d->R + (d->Cc > 0 ? d->Cc : 0) + epl - 1) / epl + 31) / 32;
   const bool fast_shape = C == 32 && d->R == 256 && d->S == 256 && d->O == 256 && d->G == 256 && d->ktaps == 3 && d->Cc <= 256 &&
-                          ring_total % 4 == 0 && !(flags_env() & 1);
+                          ring_total % 4 == 0 && !d->coop_generic;
   if (fast_shape) {
     a.w_fused = d->L >= 2 ? (const char*)w_fused : nullptr;     // the one-hand-over-per-layer kernel (else: ar_coop_fast_kernel's two)
     size_t lds_f = sizeof(float) * (size_t)(32 + 4 * nu * 32 * epl / 4 + 4 * 256 + 8 + 4 * (d->L + 1) + 3 * d->L + epl);
@@ -1662,12 +1654,12 @@ static int ar_generate_coop_impl(const wae_ar_desc* d, int32_t C, const int32_t*
     if (wae_is16(d->dtype)) {
       const size_t per = (size_t)(nu + 2) * 16 * ARC_THREADS;
       int fit = (int)((160 * 1024 - lds_f - 64) / per);
-      a.nlds = nlds_env(fit);
+      a.nlds = resident_count(d->resident_lds, fit, fit);
       if (a.nlds > fit) a.nlds = fit;
       if (a.nlds > d->L) a.nlds = d->L;
       if (a.nlds < 0) a.nlds = 0;
       lds_f += 64 + per * a.nlds;
-      a.nbank = a.nlds > 0 ? nbank_env(ARC_NBANK + ARC_NVB) : 0;      // (the register banks belong to the LDS-resident instantiations)
+      a.nbank = a.nlds > 0 ? resident_count(d->resident_regs, ARC_NBANK + ARC_NVB, ARC_NBANK + ARC_NVB) : 0;      // (the register banks belong to the LDS-resident instantiations)
       if (a.w_fused && a.nbank > ARC_NBANK) a.nbank = ARC_NBANK;      // (the one-hand-over form has the accumulation registers only)
       if (a.nbank > d->L - a.nlds) a.nbank = d->L - a.nlds > 0 ? d->L - a.nlds : 0;
     }

@@ -93,6 +93,8 @@ class WaeEngine:
         self.w_head = torch.zeros(self.m_hw.numel(), dtype=self.tdtype, device=dev)
         self.b_head = torch.zeros(2 * g.Sp + g.Op, dtype=torch.float32, device=dev)   # [sum skip bias | b1 | b3]
         self._ws: Dict[tuple, dict] = {}
+        # which form of the cooperative decode kernel runs (ar_path(); arguments of the C ABI, not environment variables)
+        self.ar_generic, self.ar_one_handover, self.ar_resident = False, False, (0, 0)
         self._param_gen, self._prep_gen, self._ar_gen = 1, 0, -1
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)      # sticky WAE_ERR_* bits set by the kernels (include/wae.h)
 
@@ -497,15 +499,28 @@ class WaeEngine:
         self.ar_wm = self._pack_ar_fused()
         self._ar_packed = True
 
+    def ar_path(self, generic: bool = False, one_handover: bool = False, lds_layers: Optional[int] = None,
+                reg_layers: Optional[int] = None):
+        """Selects the form of the cooperative decode kernel (csrc/ar_coop.hip) for this engine's next incremental_forward calls -- the
+        A/B and test handles that rounds 4-5 read from the environment inside the library: `generic` = the any-shape kernel on the
+        reference's geometry too; `one_handover` = one exchange per layer on host-formed W1_cur . W_out products (measured slower:
+        23.9 against 31.4 kHz; wae_ar_generate_coop_fused); lds_layers / reg_layers = how many layers' weight packets stay in LDS / in
+        registers (None: as many as fit, 0: none -- (0, 0) is the streaming form; results are bitwise the same for every split)."""
+        enc = lambda v: 0 if v is None else (-1 if int(v) == 0 else int(v))  # noqa: E731  (wae_ar_desc: 0 = default, < 0 = none)
+        if bool(one_handover) != self.ar_one_handover:
+            self._ar_packed = False                    # the products are formed by pack_ar_weights
+        self.ar_generic, self.ar_one_handover, self.ar_resident = bool(generic), bool(one_handover), (enc(lds_layers), enc(reg_layers))
+        return self
+
     def _pack_ar_fused(self):
         """include/wae.h: wae_ar_generate_coop_fused.  M_l = sqrt(.5) W1_cur[l] W_out[l-1] for the reference's own geometry (the one the
         cooperative kernel has with its sizes as constants), from the packed decode weights: one small matrix product per layer, once per
-        weight update -- like make_generation_fast_ (wavenet.py:358-364) it is preparation, not the decode path.  Opt-in (WAE_AR_FUSED=1):
+        weight update -- like make_generation_fast_ (wavenet.py:358-364) it is preparation, not the decode path.  Opt-in (ar_path(one_handover=True)):
         with the exchange's stores no longer waiting for their acknowledgement a hand-over costs ~1.3 k clocks, and the fused layer's
         longer window (its requests miss L2: 11.7 MB of weights cycle through a 4-MB L2 every sample) measures 19 kHz against 22.7."""
         g = self.g
         if not (g.R == 256 and g.S == 256 and g.O == 256 and g.G == 256 and g.k == 3 and g.layers >= 2 and not g.scalar_input
-                and self.opt.ar_fused):
+                and self.ar_one_handover):
             return None
         epl = 4 if self.dt == L.WAE_F32 else 8
         K1 = 3 * g.R + max(g.Cc, 0)
@@ -637,7 +652,7 @@ class WaeEngine:
         logits = torch.empty(B, g.O, T, dtype=torch.float32, device=dev) if (want_logits or m == 0 or m >= 3) else None
         es = self.ar_w.element_size()
         d = L.ArDesc(self.dt, B, T, g.layers, g.R, g.Rp, g.G, g.Hp, g.S, g.O, max(g.Cc, 0), g.Ccp, g.k, m, int(init_idx), 0,
-                     math.sqrt(1.0 / g.layers), nf)
+                     math.sqrt(1.0 / g.layers), nf, int(self.ar_generic), self.ar_resident[0], self.ar_resident[1])
         if coop:
             nv = lib.wae_ar_coop_msg_values(ctypes.byref(d), C)
             msg = torch.zeros(B * 2 * C * nv, dtype=torch.int64, device=dev)
@@ -648,7 +663,7 @@ class WaeEngine:
                                                    L.ptr(self.ar_b2), L.ptr(zb), L.ptr(self.first_tab), L.ptr(self.first_bias),
                                                    L.ptr(self.ar_wh), L.ptr(self.ar_hb), L.ptr(c_up), self.dt, L.ptr(inputs),
                                                    L.ptr(uni), L.ptr(out_idx), L.ptr(logits), L.ptr(msg), L.ptr(acc), L.ptr(err),
-                                                   L.ptr(getattr(self, "ar_wm", None)), st),
+                                                   L.ptr(getattr(self, "ar_wm", None) if self.ar_one_handover else None), st),
                     "ar_generate_coop")
             self._ar_profile = err
             if int(err[0].item()) != 0:  # synchronises: generation is a blocking call for its callers anyway

@@ -1,7 +1,7 @@
 """The engine's launch-path switches: ONE place, read ONCE per engine (WaeEngine.__init__ -> eng.opt).
 
 Every entry selects between two implementations that are both kept correct and both tested -- the alternative is the yardstick of
-the default (or, for the last group, an opt-in that has not earned the default).  Nothing else in the host code reads the
+the default (or an opt-in that has not earned the default).  Nothing else in the host code reads the
 environment: the experiment switches of rounds 1-4 (request schedules, pacing, launch shapes that measured equal or slower;
 profiles/EXPERIMENT_LOG.md) are gone from the product; what remains of them in the kernels is reachable through the C ABI's own
 arguments (include/wae.h) from tools/.
@@ -22,7 +22,6 @@ arguments (include/wae.h) from tools/.
     WAE_BWD_FUSED          auto      residual(l) + gate(l-1) of the backward sweep as one launch (csrc/glu_bwd.hip): auto = 16-bit engines
                                      where the kernel has an instantiation; 0: always the two wae_gemm_tm launches; 1: fp32 too
     WAE_BWD_FOLD_DC        1         0: dc = sum_l Wc_l^T dz_l as its own K = L * 2Hp launch instead of riding in the fused backward launches
-    WAE_AR_FUSED           0         1: one hand-over per layer in the cooperative decode kernel (measured slower)
 """
 import os
 from dataclasses import dataclass
@@ -43,7 +42,6 @@ class EngineOptions:
     ar_coop_c: int = 32
     bwd_fused: str = "auto"
     bwd_fold_dc: bool = True
-    ar_fused: bool = False
 
     @staticmethod
     def from_env() -> "EngineOptions":
@@ -61,4 +59,4 @@ class EngineOptions:
                              tn_static_head=e("WAE_TN_STATIC_HEAD", "1") != "0", tn_swap=e("WAE_TN_SWAP", "1") != "0", head_split=e("WAE_HEAD_SPLIT", "1") != "0",
                              head_wide=e("WAE_HEAD_WIDE", "0") == "1", glu_pair=pair, dp_split=e("WAE_DP_SPLIT", "1") != "0",
                              ar_coop=e("WAE_AR_COOP", "1") != "0", ar_coop_c=int(e("WAE_AR_COOP_C", "32")),
-                             bwd_fused=fused, bwd_fold_dc=e("WAE_BWD_FOLD_DC", "1") != "0", ar_fused=e("WAE_AR_FUSED", "0") == "1")
+                             bwd_fused=fused, bwd_fold_dc=e("WAE_BWD_FOLD_DC", "1") != "0")
