@@ -46,8 +46,8 @@ def _kernels16(path):
     return sorted(set(re.findall(r"^(_Z[0-9]*[a-z_0-9]*kernelIDF16[b_][A-Za-z0-9_]*):", open(path).read(), re.M)))
 
 
-@pytest.mark.parametrize("name,lookahead", [("glu_fwd", 3), ("glu_fwd_static", 1), ("head_fwd", 1), ("gemm_tm", 1), ("gemm_tm8", 1),
-                                            ("glu_bwd", 1)])
+# (csrc/gemm_tm8.hip requests everything by LDS-DMA: it has no register with a load in flight; its loops are in the drain test below)
+@pytest.mark.parametrize("name,lookahead", [("glu_fwd", 3), ("glu_fwd_static", 1), ("head_fwd", 1), ("gemm_tm", 1), ("glu_bwd", 1)])
 def test_no_instruction_touches_a_register_with_a_load_in_flight(isa, name, lookahead):
     kernels = _kernels16(isa[name])
     assert kernels, name

@@ -1,6 +1,7 @@
-"""The static 8-wave form of the time-major GEMM (csrc/gemm_tm8.hip: the head's skip contraction, wavenet.py:204-209) against the
-generic kernel it replaces (csrc/gemm_tm.hip, forced by WAE_TM_ONE_WG): same packed weight stream, same accumulation order, so the
-outputs are compared BITWISE; the generic kernel is the one the oracle comparisons of tests/test_gpu_parity.py / test_gpu_wide.py pin."""
+"""The wave-specialised form of the time-major GEMM (csrc/gemm_tm8.hip: 8 consumer + 4 loader waves; the head's skip contraction,
+wavenet.py:204-209) against the generic kernel it replaces (csrc/gemm_tm.hip, forced by WAE_TM_ONE_WG): same packed weight stream, same
+accumulation order, so the outputs are compared BITWISE; the generic kernel is the one the oracle comparisons of
+tests/test_gpu_parity.py / test_gpu_wide.py pin.  (K = 192: an odd chunk count, which the new kernel leaves to the generic one.)"""
 import ctypes
 
 import pytest
@@ -22,7 +23,7 @@ def _run(lib, L, dt, B, T, K, M, u, w, bias, alpha, flags):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,T,K", [(1, 1000, 256), (3, 777, 2560), (2, 8000, 4608), (1, 33, 512)])
+@pytest.mark.parametrize("B,T,K", [(1, 1000, 256), (3, 777, 2560), (2, 8000, 4608), (1, 33, 512), (2, 300, 384), (1, 257, 192)])
 def test_skip_contraction_static_schedule_is_bitwise_the_generic_kernel(dtype, B, T, K):
     from wavenet_autoencoders_amd import _lib as L
     lib = L.lib()
@@ -33,8 +34,11 @@ def test_skip_contraction_static_schedule_is_bitwise_the_generic_kernel(dtype, B
     u = (torch.randn(B, T, K, generator=gen) * 0.5).to(td).to(dev)
     w = (torch.randn((K // 64) * (M // 32) * 4 * 64 * 8, generator=gen) * (1.0 / K ** 0.5)).to(td).to(dev)   # packed fragment stream
     bias = torch.randn(M, generator=gen).to(dev)
-    new = _run(lib, L, dt, B, T, K, M, u, w, bias, 0.25, 0)
     old = _run(lib, L, dt, B, T, K, M, u, w, bias, 0.25, L.TM_ONE_WG)
-    assert not torch.isnan(new.float()).any()
-    assert torch.equal(new.view(torch.int16), old.view(torch.int16))
-    assert new.float().abs().max() > 0
+    assert old.float().abs().max() > 0
+    # (repeated: the kernel's loader and consumer waves meet only at barriers -- a missing one shows as an occasional stale tile, which is
+    #  what the first build of the wave-specialised form had at its very first operand tile)
+    for _ in range(12):
+        new = _run(lib, L, dt, B, T, K, M, u, w, bias, 0.25, 0)
+        assert not torch.isnan(new.float()).any()
+        assert torch.equal(new.view(torch.int16), old.view(torch.int16))
