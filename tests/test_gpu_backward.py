@@ -471,3 +471,49 @@ def test_fused_residual_gate_launch_16bit(case, dtype, monkeypatch):
         if err > 2e-2 * max(ref, 1e-6) + 1e-7:
             bad[k] = (err, ref)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["c2", "c2small", "c3small"])
+def test_pair8_launch_is_bitwise_the_pair_launch(case, dtype):
+    """Round 6: the backward pair launch on 8 waves x 256 columns with both operand streams through LDS (csrc/glu_bwd8.hip) against the
+    round-5 kernel (4 waves x 128 columns, csrc/glu_bwd.hip; forced by dc_mode bit 2): same packed streams, same MFMA order per
+    accumulator -- dz of every layer, every dx-hat and dc are compared BITWISE.  C2 at full size (Hp 192: 36 + 6 + 8 half-chunks), the
+    same geometry on short ragged clips whose last tile is mostly past the end, and the hps/vqwae.json decoder (Hp 128)."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    if case == "c2":
+        cfg = dict(layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153, upsample_scales=[4, 4, 4, 5], cin_pad=0)
+        B, T, hop = 8, 8000, 320
+    elif case == "c2small":
+        cfg = dict(layers=6, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153, upsample_scales=[4, 4, 4, 5], cin_pad=0)
+        B, T, hop = 3, 960, 320
+    else:
+        cfg = dict(layers=6, stacks=3, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5], cin_pad=0)
+        B, T, hop = 2, 1280, 640
+    sd = O.make_state_dict(dict(cfg), salt=5, with_encoder=False)
+    gen = torch.Generator().manual_seed(177)
+    x = torch.randint(0, 256, (B, T), generator=gen).cuda()
+    c = torch.randn(B, 64, T // hop, generator=gen).cuda()
+    g = torch.randint(0, cfg["n_speakers"], (B,), generator=gen).cuda()
+    lengths = torch.tensor([T - 61 * i for i in range(B)])
+    got = {}
+    for four in (True, False):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.bwd_pair4 = four
+        eng.load_state_dict(sd, strict=False)
+        eng.decoder_forward(x, c, g, targets=x, lengths=lengths.cuda(), train=True, want_logits=False)
+        dc = BW.decoder_backward(eng, x, x, lengths, g)
+        assert eng.fused_bwd
+        ws = eng._ws[("bwd", B, T)]
+        got[four] = (ws["dz"].clone(), [t_.clone() for t_ in ws["gx"]], dc.clone(), BW.finish_grads(eng).clone())
+        torch.cuda.synchronize()
+        del eng
+        torch.cuda.empty_cache()
+    i16 = lambda t_: t_.view(torch.int16)  # noqa: E731
+    assert float(got[True][0].float().abs().max()) > 0
+    assert torch.equal(i16(got[True][0]), i16(got[False][0])), "dz"
+    for i, (a, b_) in enumerate(zip(got[True][1], got[False][1])):
+        assert torch.equal(i16(a), i16(b_)), ("dx-hat", i)
+    assert torch.equal(i16(got[True][2]), i16(got[False][2])), "dc"

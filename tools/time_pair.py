@@ -35,7 +35,7 @@ for path in sys.argv[1:]:
     lib = ctypes.CDLL(os.path.abspath(path))
     fn = lib.wae_glu_bwd_fused_dc
     fn.argtypes, fn.restype = sig, ctypes.c_int32
-    for l in [int(a) for a in os.environ.get("PAIR_LAYERS", "13,4").split(",")]:
+    for l, four in [(int(a), f) for a in os.environ.get("PAIR_LAYERS", "13,4").split(",") for f in (0, 4)]:
         d = L.GluBwdDesc(eng.dt, B, T, g.Rp, g.Hp, g.Sp, g.k, g.dilations[l], math.sqrt(0.5))
         lp = l - 1
         args = [ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(ws["gx"][(l + 1) % ngx]),
@@ -43,16 +43,17 @@ for path in sys.argv[1:]:
                 ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
                 ctypes.c_void_p(eng.w_buo.data_ptr() + lp * eng.n_buo * es),
                 ctypes.c_void_p(eng.w_bu.data_ptr() + lp * eng.n_bu * es + us_off),
-                ctypes.c_void_p(eng.w_bc.data_ptr() + l * cbytes), L.ptr(ws["dc32"]), L.ptr(ws["dc"]), 1, 0, None]
+                ctypes.c_void_p(eng.w_bc.data_ptr() + l * cbytes), L.ptr(ws["dc32"]), L.ptr(ws["dc"]), 1 | four, 0, None]
         dz_keep = ws["dz"].clone()
         for _ in range(3):
             assert fn(*args) == 0
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
+        for _ in range(100):
             fn(*args)
         e1.record()
         torch.cuda.synchronize()
         ws["dz"].copy_(dz_keep)          # (a timing-only variant writes garbage into dz_{l-1}: the next library starts from the same data)
-        print(f"{os.path.basename(path):28s} layer {l:2d} (dilation {g.dilations[l]:4d}): {e0.elapsed_time(e1) / 20 * 1e3:6.1f} us", flush=True)
+        print(f"{os.path.basename(path):28s} layer {l:2d} (dilation {g.dilations[l]:4d}) {'4 waves x 2 workgroups' if four else '8 waves, operands via LDS':26s}: "
+              f"{e0.elapsed_time(e1) / 100 * 1e3:6.1f} us", flush=True)

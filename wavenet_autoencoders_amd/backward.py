@@ -800,7 +800,8 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
                     ctypes.c_void_p(eng.w_buo.data_ptr() + lp * eng.n_buo * es),
                     ctypes.c_void_p(eng.w_bu.data_ptr() + lp * eng.n_bu * es + us_off)]
             if fold_dc:
-                mode = (0 if l == g.layers - 1 else 1) | (2 if l == 0 else 0)
+                mode = (0 if l == g.layers - 1 else 1) | (2 if l == 0 else 0) | (4 if getattr(eng, "bwd_pair4", False) else 0)
+                # (bit 2: keep the 4-wave kernel where the 8-wave one, csrc/glu_bwd8.hip, has an instantiation -- tests and tools)
                 args += [ctypes.c_void_p(eng.w_bc.data_ptr() + l * cbytes), L.ptr(ws["dc32"]), L.ptr(ws["dc"]), mode, int(l == 0)]
                 timed("pair", lambda: L.check(lib.wae_glu_bwd_fused_dc(*args, st), "glu_bwd_fused_dc"))
             else:

@@ -11,30 +11,7 @@
 // (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand") -- the same chaining as
 // csrc/glu_fwd.hip, run backwards.  Decomposition as in csrc/gemm_tm.hip: 128 time steps per workgroup, one wave per
 // 32 time columns owning all rows, weights in A-fragment order through a double-buffered LDS ring.
-#include "wae_common.hpp"
-
-struct GbArgs {
-  const char* dz;       // (B,T,dz_stride): dz_l columns (2Hp) of layer l
-  const char* g_next;   // (B,T,Rp): dx_{l+1}-hat
-  char* g_out;          // (B,T,Rp): dx_l-hat
-  const char* dskip;    // (B,T,Sp)
-  const char* z_prev;   // (B,T,2Hp): pre-activations of layer l-1
-  char* dz_prev;        // (B,T,dz_stride): dz_{l-1} columns
-  const char* w_x;      // first_gemm_map(Rp, k*2Hp): chunks [q][blk][m]
-  const char* w_uo;     // second_gemm_map(Hp, Rp): [mt][kb] in accumulator-row k order
-  const char* w_us;     // first_gemm_map(Hp, Sp)
-  int64_t dz_stride;
-  float alpha;
-  int B, T, Sp, ktaps, dilation;
-  unsigned long long* stamps;   // diagnostic builds (-DWAE_GBP_STAMPS) only, else null
-  // 16-bit pair kernel, dc folded in (Ccp = 64, 3 taps): dc += Wc_l^T dz_l rides on the chunks of the shift-0 tap, whose operand
-  // fragments ARE dz_l[t]; the running sum over the layers lives in an fp32 (B,T,64) array, the last launch writes the 16-bit dc
-  const char* w_c;      // this layer's chunks of the dc weight stream (first_gemm_map(Ccp, 2Hp): 8 KiB per column block), or null
-  float* dc_acc;        // (B,T,64) fp32
-  char* dc_out;         // (B,T,64) in the storage dtype: written instead of dc_acc when dc_mode & 2
-  int dc_mode;          // bit 0: add the previous sum (dc_acc); bit 1: write dc_out (the last layer of the sweep)
-  int last;             // 1: layer 0 -- phase A + epilogue A only (there is no layer below to gate)
-};
+#include "glu_bwd.hpp"
 
 template <typename E, int NTX, int NTU>
 __global__ void __launch_bounds__(256, 1) glu_bwd_fused_kernel(GbArgs p) {
@@ -239,39 +216,6 @@ extern "C" void wae_debug_set_gbp_stamps(unsigned long long* dev_buf) { g_gbp_st
 #define GBP_TICK(v) do { } while (0)
 #endif
 
-// one tile (32 rows x 32 channels, accumulator layout) into a row-major fp32 / 16-bit array through the wave's 4-KiB staging tile:
-// v = acc (+ old[row]) ; old is the fp32 running sum, the result goes to out32 (fp32) or out16 (storage dtype)
-// (the old values are fetched by the caller ahead of time: rmw_fetch; rows at or beyond rows_valid fetch the last valid row)
-__device__ __forceinline__ void rmw_fetch(f32x4 (&w)[4], const float* old32, int tile, int rows_valid, int lane) {
-  const int rr = lane >> 3, ck = lane & 7;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = *(const f32x4*)(old32 + (int64_t)min(i * 8 + rr, rows_valid - 1) * 64 + tile * 32 + ck * 4);
-}
-template <typename E>
-__device__ __forceinline__ void stage_rmw_tile(char* stg, const f32x16& y, const f32x4 (&w)[4], bool add, float* out32, char* out16,
-                                               int tile, int rows_valid, int lane) {
-  const int n = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 v = {y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
-    *(f32x4*)(stg + n * 128 + (((2 * g + h) ^ (n & 7)) << 4)) = v;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int rr = lane >> 3, ck = lane & 7;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 8 + rr;
-    f32x4 v = *(const f32x4*)(stg + row * 128 + ((ck ^ (row & 7)) << 4));
-    if (add) v = v + w[i];
-    if (row < rows_valid) {
-      const int64_t o = (int64_t)row * 64 + tile * 32 + ck * 4;
-      if (out16) *(typename ET<E>::vec4*)(out16 + o * (int64_t)sizeof(E)) = from_f32x4<E>(v);
-      else *(f32x4*)(out32 + o) = v;
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 template <typename E, int NTX, int NTU, bool FOLD = false>
 __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
   static_assert(sizeof(E) == 2 && NTX % 2 == 0 && NTU % 2 == 0, "16-bit storage, pairwise epilogues");
@@ -345,6 +289,16 @@ __global__ void __launch_bounds__(256, 2) glu_bwd_pair_kernel(GbArgs p) {
     return p.dskip + (((int64_t)b * p.T + (tvalid ? t : 0)) * p.Sp) * ES + q * 128 + h * 16;
   };
   auto request = [&](frag (&G)[4], const char* src) {
+#ifdef WAE_GBP_NOB
+    return;                                      // timing-only: no operand requests (dz taps, dS)
+#endif
+#ifdef WAE_GBP_LINEB
+    // timing-only: the same bytes as whole 128-byte lines (8 rows per request) -- what LDS-staged pieces would ask the memory system for
+    src += ((lane >> 3) - (lane & 31)) * (int64_t)(p.dz_stride * ES) + ((lane & 7) - (lane >> 5)) * 16;
+    gload_async<0>(G[0], src); gload_async<0>(G[1], src + 8 * p.dz_stride * ES); gload_async<0>(G[2], src + 16 * p.dz_stride * ES);
+    gload_async<0>(G[3], src + 24 * p.dz_stride * ES);
+    return;
+#endif
     gload_async<0>(G[0], src); gload_async<32>(G[1], src); gload_async<64>(G[2], src); gload_async<96>(G[3], src);
   };
   auto zero_unless = [&](frag (&G)[4], bool ok) {
@@ -650,6 +604,12 @@ static int glu_bwd_fused_impl(const wae_glu_bwd_desc* d, const void* dz, int64_t
   a.stamps = g_gbp_stamps;
 #endif
   hipStream_t st = as_stream(stream);
+  if (!(dc_mode & 4)) {     // (dc_mode bit 2: keep the 4-wave kernel -- the A/B and parity handle of tests/ and tools/)
+    bool handled = false;
+    const int rc = wae_glu_bwd8_launch(a, d->dtype, d->Rp / 32, d->Hp / 32, st, &handled);
+    if (rc != WAE_OK || handled) return rc;
+  }
+  a.dc_mode &= 3;
   if (d->dtype == WAE_BF16) return dispatch_gb<__bf16>(d->Rp / 32, d->Hp / 32, a, st);
   if (d->dtype == WAE_F16) return dispatch_gb<f16>(d->Rp / 32, d->Hp / 32, a, st);
   return dispatch_gb<float>(d->Rp / 32, d->Hp / 32, a, st);

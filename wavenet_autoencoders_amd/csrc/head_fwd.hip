@@ -28,8 +28,12 @@ struct HeadArgs {
 
 // FROM_H0: GEMM 0 ran as its own launch (wae_gemm_tm, mode BIAS_RELU: two workgroups per CU hide the long K loop's memory trips
 // behind each other, which this kernel's one workgroup per CU cannot); p.u then is h0 (B,T,Sp) and p.w starts at GEMM 1's chunks.
-template <typename E, int NT, bool FROM_H0 = false>
-__global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
+// NW waves per workgroup (32 time columns each), NSL ring slots for the chunks behind GEMM 0.  The FROM_H0 launches of 16-bit engines
+// run 8 waves x 256 columns on a three-slot ring, weights two chunks ahead under a counted wait (round 6): the 4-wave form waited
+// for every chunk's DMA in full right after requesting it (one chunk ahead, vmcnt(0)) on two rounds of workgroups per CU -- 47 us at C2
+// for 9 us of MFMAs and 5 us of HBM.
+template <typename E, int NT, bool FROM_H0 = false, int NW = 4, int NSL = 2>
+__global__ void __launch_bounds__(NW * 64, 1) head_fwd_kernel(HeadArgs p) {
   using T_ = ET<E>;
   using frag = typename T_::frag;
   constexpr int CHB = NT * 4 * 1024;
@@ -43,10 +47,14 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 31, h = lane >> 5;
-  const int tiles_per_b = (p.T + 127) >> 7;
+  static_assert(NW == 4 || (FROM_H0 && NW == 8), "the 8-wave shape exists for the FROM_H0 launches");
+  static_assert(NSL == 2 || FROM_H0, "deeper rings behind GEMM 0: FROM_H0 only");
+  constexpr int TW = NW * 32;
+  constexpr int PPW = CHB / NW / 1024;         // LDS-DMA pieces per wave and chunk
+  const int tiles_per_b = (p.T + TW - 1) / TW;
   const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int b = tile_id / tiles_per_b;
-  const int t0w = (tile_id % tiles_per_b) * 128 + wave * 32;
+  const int t0w = (tile_id % tiles_per_b) * TW + wave * 32;
   const int t = t0w + n;
   const bool tvalid = t < p.T;
   const int rows_valid = min(max(p.T - t0w, 0), 32);
@@ -55,11 +63,22 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   const int nq2 = (p.Op >> 5) / MT2;
   const int nq_total = nq0 + NQ1 + nq2;
   const char* urow = p.u + ((int64_t)b * p.T + (tvalid ? t : 0)) * p.Ku * ES + h * 16;
-  char* stg = smem + 3 * CHB + wave * STG_BYTES;
-  float* bias_lds = (float*)(smem + 3 * CHB + 4 * STG_BYTES);
+  constexpr int RSL = FROM_H0 ? NSL : 3;       // ring slots allocated (GEMM 0 runs a three-slot ring)
+  constexpr int STGW = NW == 8 ? 4096 : STG_BYTES, SPITCH = STGW / 32;      // staging tile per wave (8 waves: row pitch 128 B)
+  char* stg = smem + RSL * CHB + wave * STGW;
+  float* bias_lds = (float*)(smem + RSL * CHB + NW * STGW);
 
   // biases -> LDS once (accumulator inits then never touch vmcnt)
-  for (int i = threadIdx.x * 4; i < 2 * p.Sp + p.Op; i += 1024) *(f32x4*)(bias_lds + i) = *(const f32x4*)(p.bias + i);
+  for (int i = threadIdx.x * 4; i < 2 * p.Sp + p.Op; i += NW * 256) *(f32x4*)(bias_lds + i) = *(const f32x4*)(p.bias + i);
+  // chunk qi (counted from GEMM 1's first) -> slot qi % NSL, requested NSL - 1 chunks ahead; the wait in front of chunk qi leaves the
+  // NSL - 2 younger chunks' pieces in flight (stores issued in between only make it stricter)
+  [[maybe_unused]] auto dma_tail = [&](int qt) {
+    if (nq0 + qt < nq_total) dma_chunk<NW>(p.w + (int64_t)(nq0 + qt) * CHB, smem + (qt % NSL) * CHB, CHB, wave, lane);
+  };
+  [[maybe_unused]] auto wait_tail = [&]() {
+    if constexpr (NSL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSL - 2) * PPW) : "memory");
+  };
 
   // ---- GEMM 0: skip contraction over all layers' u --------------------------------------------------------
   // K = Ku is long (72 chunks at C2) and its operand comes from HBM: with the operand one chunk ahead and one workgroup
@@ -70,13 +89,14 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   f32x16 acc[NT];
   frag uf[NKB];
   if constexpr (FROM_H0) {
-    dma_chunk(p.w, smem, CHB, wave, lane);
+#pragma unroll
+    for (int qt = 0; qt < NSL - 1; ++qt) dma_tail(qt);
     // h0 rows of this wave's 32 time columns -> accumulator layout (coalesced rows through the staging tile) -> operand fragments
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    if (rows_valid > 0) stage_load_tiles<E, NT>(stg, acc, p.u + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
+    if (rows_valid > 0) stage_load_tiles<E, NT, SPITCH>(stg, acc, p.u + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
       frag tmp[KBU];
@@ -148,18 +168,24 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
     for (int s = 0; s < KBU; ++s) uf[m * KBU + s] = tmp[s];
   }
   if (p.h0_save && rows_valid > 0)
-    stage_store_tiles<E, NT>(stg, acc, p.h0_save + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
+    stage_store_tiles<E, NT, SPITCH>(stg, acc, p.h0_save + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
   }
 
   // ---- GEMM 1: h1 = relu(b1 + W1 . h0); all NT output tiles stay in registers --------------------------------
 #pragma unroll
   for (int q1 = 0; q1 < NQ1; ++q1) {
     const int qi = nq0 + q1;
-    if (q1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi - nq0 + 1) & 1) * CHB, CHB, wave, lane);
-    const char* buf = smem + ((qi - nq0) & 1) * CHB + lane * 16;
+    if constexpr (FROM_H0) {
+      if (q1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the h0 rows: plain loads hipcc waits for itself)
+      else wait_tail();
+      __builtin_amdgcn_s_barrier();
+      dma_tail(q1 + NSL - 1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi - nq0 + 1) & 1) * CHB, CHB, wave, lane);
+    }
+    const char* buf = smem + (FROM_H0 ? ((qi - nq0) % NSL) : ((qi - nq0) & 1)) * CHB + lane * 16;
     f32x16(&y)[MT2] = *reinterpret_cast<f32x16(*)[MT2]>(&acc[q1 * MT2]);
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], bias_lds + p.Sp + 32 * (q1 * MT2 + mt), h);
@@ -175,7 +201,7 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
     for (int s = 0; s < KBU; ++s) uf[m * KBU + s] = tmp[s];
   }
   if (p.h1_save && rows_valid > 0)
-    stage_store_tiles<E, NT>(stg, acc, p.h1_save + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
+    stage_store_tiles<E, NT, SPITCH>(stg, acc, p.h1_save + ((int64_t)b * p.T + t0w) * p.Sp * ES, (int64_t)p.Sp * ES, rows_valid, lane);
 
   // ---- GEMM 2 + logits store + online log-sum-exp ------------------------------------------------------------
   const bool want_ce = p.target != nullptr && p.nll != nullptr;
@@ -185,10 +211,16 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
   const float* b3 = bias_lds + 2 * p.Sp;
   for (int q2 = 0; q2 < nq2; ++q2) {
     const int qi = nq0 + NQ1 + q2;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi - nq0 + 1) & 1) * CHB, CHB, wave, lane);
-    const char* buf = smem + ((qi - nq0) & 1) * CHB + lane * 16;
+    if constexpr (FROM_H0) {
+      wait_tail();
+      __builtin_amdgcn_s_barrier();
+      dma_tail(NQ1 + q2 + NSL - 1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (qi + 1 < nq_total) dma_chunk(p.w + (int64_t)(qi + 1) * CHB, smem + ((qi - nq0 + 1) & 1) * CHB, CHB, wave, lane);
+    }
+    const char* buf = smem + (FROM_H0 ? ((qi - nq0) % NSL) : ((qi - nq0) & 1)) * CHB + lane * 16;
     f32x16 y[MT2];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) init_rows(y[mt], b3 + 32 * (q2 * MT2 + mt), h);
@@ -240,11 +272,15 @@ __global__ void __launch_bounds__(256, 1) head_fwd_kernel(HeadArgs p) {
 template <typename E, int NT, bool FROM_H0 = false>
 static int launch_head(const HeadArgs& a, hipStream_t st) {
   constexpr int CHB = NT * 4 * 1024;
-  const size_t lds = 3 * CHB + 4 * STG_BYTES + (size_t)(2 * a.Sp + a.Op) * 4;
+  // FROM_H0 in 16-bit storage: 8 waves x 256 columns on a three-slot ring, 4-KiB staging tiles (3 x 32 + 8 x 4 + 3 KiB at Sp = 256)
+  constexpr bool WIDE8 = FROM_H0 && sizeof(E) == 2;
+  constexpr int NW = WIDE8 ? 8 : 4, NSL = WIDE8 ? 3 : 2;
+  const size_t lds = (size_t)(FROM_H0 ? NSL : 3) * CHB + NW * (WIDE8 ? 4096 : STG_BYTES) + (size_t)(2 * a.Sp + a.Op) * 4;
   static WaeLdsCache lds_cache;
-  if (int rc = wae_ensure_lds((const void*)head_fwd_kernel<E, NT, FROM_H0>, lds_cache, lds, "head_fwd"); rc != WAE_OK) return rc;
-  const int tiles = (a.T + 127) / 128;
-  hipLaunchKernelGGL((head_fwd_kernel<E, NT, FROM_H0>), dim3(a.B * tiles), dim3(256), lds, st, a);
+  auto kern = head_fwd_kernel<E, NT, FROM_H0, NW, NSL>;
+  if (int rc = wae_ensure_lds((const void*)kern, lds_cache, lds, "head_fwd"); rc != WAE_OK) return rc;
+  const int tiles = (a.T + NW * 32 - 1) / (NW * 32);
+  hipLaunchKernelGGL(kern, dim3(a.B * tiles), dim3(NW * 64), lds, st, a);
   return wae_check_launch("head_fwd");
 }
 

@@ -387,13 +387,14 @@ __device__ __forceinline__ void stage_store_tiles(char* stg, const f32x16* y, ch
 // stage_load_tiles: the inverse -- NT tiles (32 rows x 32 channels) of a time-major (rows, channels) array into the
 // accumulator layout (lane = time column, register group g = channels 8g+4h..+3): coalesced 16-B row loads -> LDS ->
 // per-lane column pieces.  Rows at or beyond rows_valid read row rows_valid-1 (callers never use them).
-template <typename EO, int NTP>
+template <typename EO, int NTP, int PITCH = 256>
 __device__ __forceinline__ void stage_load_pass(char* stg, f32x16* y, const char* gin, int64_t row_stride, int rows_valid,
                                                 int lane) {
   using vec4 = typename ET<EO>::vec4;
   constexpr int SEG = NTP * 32 * sizeof(EO);
-  static_assert(SEG <= 256 && SEG >= 64, "a staging pass covers 64..256 bytes per row");
+  static_assert(SEG <= PITCH && SEG >= 64, "a staging pass covers 64..PITCH bytes per row");
   constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 32 / RPI;
+  constexpr int KEY = PITCH / 16 - 1;
   const int n = lane & 31, h = lane >> 5;
   const int rr = lane / LPR, ck = lane % LPR;
   f32x4 tmp[NI];
@@ -405,7 +406,7 @@ __device__ __forceinline__ void stage_load_pass(char* stg, f32x16* y, const char
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int row = i * RPI + rr;
-    *(f32x4*)(stg + row * 256 + ((ck ^ (row & 15)) << 4)) = tmp[i];
+    *(f32x4*)(stg + row * PITCH + ((ck ^ (row & KEY)) << 4)) = tmp[i];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -414,23 +415,23 @@ __device__ __forceinline__ void stage_load_pass(char* stg, f32x16* y, const char
     for (int g = 0; g < 4; ++g) {
       int c16, sub;
       if constexpr (sizeof(EO) == 2) { c16 = 4 * mt + g; sub = 8 * h; } else { c16 = 8 * mt + 2 * g + h; sub = 0; }
-      const f32x4 v = to_f32x4(*(const vec4*)(stg + n * 256 + ((c16 ^ (n & 15)) << 4) + sub));
+      const f32x4 v = to_f32x4(*(const vec4*)(stg + n * PITCH + ((c16 ^ (n & KEY)) << 4) + sub));
       y[mt][4 * g] = v.x; y[mt][4 * g + 1] = v.y; y[mt][4 * g + 2] = v.z; y[mt][4 * g + 3] = v.w;
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
-template <typename EO, int NT>
+template <typename EO, int NT, int PITCH = 256>
 __device__ __forceinline__ void stage_load_tiles(char* stg, f32x16* y, const char* gin, int64_t row_stride, int rows_valid,
                                                  int lane) {
-  constexpr int PT = 256 / (32 * (int)sizeof(EO));
+  constexpr int PT = PITCH / (32 * (int)sizeof(EO));
   if constexpr (NT >= PT) {
-    stage_load_pass<EO, PT>(stg, y, gin, row_stride, rows_valid, lane);
-    if constexpr (NT > PT) stage_load_tiles<EO, NT - PT>(stg, y + PT, gin + 256, row_stride, rows_valid, lane);
+    stage_load_pass<EO, PT, PITCH>(stg, y, gin, row_stride, rows_valid, lane);
+    if constexpr (NT > PT) stage_load_tiles<EO, NT - PT, PITCH>(stg, y + PT, gin + PITCH, row_stride, rows_valid, lane);
   } else if constexpr (NT >= 2) {
-    stage_load_pass<EO, 2>(stg, y, gin, row_stride, rows_valid, lane);
-    if constexpr (NT > 2) stage_load_tiles<EO, NT - 2>(stg, y + 2, gin + 64 * sizeof(EO), row_stride, rows_valid, lane);
+    stage_load_pass<EO, 2, PITCH>(stg, y, gin, row_stride, rows_valid, lane);
+    if constexpr (NT > 2) stage_load_tiles<EO, NT - 2, PITCH>(stg, y + 2, gin + 64 * sizeof(EO), row_stride, rows_valid, lane);
   } else {
-    stage_load_pass<EO, 1>(stg, y, gin, row_stride, rows_valid, lane);
+    stage_load_pass<EO, 1, PITCH>(stg, y, gin, row_stride, rows_valid, lane);
   }
 }
 
