@@ -86,7 +86,9 @@ int wae_unpack_scatter_add(const float* src, const int32_t* map, float* dst, int
 
 /* Several of either in ONE launch (a train step packs / scatters eleven families; the reference holds weights in one layout and
  * needs neither).  jobs_host: HOST array of at most WAE_MULTI_MAX jobs, copied into the kernel arguments; the fields mean what
- * the arguments of the single-job entries mean.  The scatter jobs of one call must write disjoint slots when unique != 0. */
+ * the arguments of the single-job entries mean.  The scatter jobs of one call must write disjoint slots when unique != 0.
+ * A gather job with map == NULL is a FILL: n fp32 zeros at dst (16-byte aligned; src / strides / nbatch unused) -- the backward's two
+ * gradient accumulators are cleared by the launch that packs its weights (round 6). */
 #define WAE_MULTI_MAX 16
 typedef struct wae_gather_job {
   const float* src;
@@ -401,7 +403,11 @@ typedef struct wae_tm_desc {
 } wae_tm_desc;
 #define WAE_TM_INTERLEAVE 1
 #define WAE_TM_ONE_WG 2   /* bf16 gate-backward / residual / ReLU-backward launches: one 4-wave workgroup per CU with the 8 KiB
-                             staging tiles instead of two per CU (same results; an A/B switch per launch) */
+                             staging tiles instead of two per CU (same results; an A/B switch per launch).  It also keeps a mode-3
+                             launch on this generic kernel where the wave-specialised one (below) has an instantiation. */
+/* Mode 3 with ONE source, no shift, 16-bit storage, M a multiple of 256 and an even chunk count (the head's skip contraction, the
+ * wide head's h0 / h1 launches) runs on csrc/gemm_tm8.hip since round 6: 8 consumer + 4 loader waves per workgroup, 256 time columns,
+ * both operands by LDS-DMA -- same packed stream, same accumulation order, bit-identical outputs (170 against 196 us at C2). */
 /* (flag value 4 was WAE_TM_BLDS, the 8-wave LDS-staged-operand shape of rounds 3-4: measured not faster, removed in round 5) */
 int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
                 const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,
@@ -476,7 +482,10 @@ int wae_glu_bwd_fused(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stri
  * fragments are dz_l[t]: w_c = layer l's 2Hp / 64 chunks (8 KiB each) of that launch's weight stream (packing.py: bwd_c_map), dc_acc =
  * the fp32 (B,T,64) running sum over the layers, dc_mode bit 0: add dc_acc's previous content (clear: the first launch of a sweep),
  * bit 1: write the sum in the storage dtype to dc_out (B,T,64) instead (the last launch of the sweep).  last = 1: layer 0 -- phase A +
- * its epilogue only (z_prev / dz_prev / w_uo / w_us are not used but must be valid pointers). */
+ * its epilogue only (z_prev / dz_prev / w_uo / w_us are not used but must be valid pointers).
+ * Rp = 256, Sp = 256, Hp in {128, 192} (BASELINE C2, hps/vqwae.json) run csrc/glu_bwd8.hip since round 6 -- 8 waves x 256 columns, one
+ * workgroup per CU, weights AND activation operands through LDS (77.6 against 84 us per launch at C2), bitwise the 4-wave kernel's
+ * results; dc_mode bit 2 keeps the 4-wave kernel (the A/B and parity handle of tests/ and tools/time_pair.py). */
 int wae_glu_bwd_fused_dc(const wae_glu_bwd_desc* d, const void* dz, int64_t dz_stride, const void* g_next, void* g_out,
                          const void* dskip, const void* z_prev, void* dz_prev, const void* w_x, const void* w_uo,
                          const void* w_us, const void* w_c, float* dc_acc, void* dc_out, int32_t dc_mode, int32_t last,

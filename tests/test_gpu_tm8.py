@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(lib, L, dt, B, T, K, M, u, w, bias, alpha, flags):
+    """wae_gemm_tm mode 3: out (B, T, M) = relu(alpha * (bias + W u)); M > 256 runs in slices of 256 rows (the wide head of config C5)"""
     out = torch.full((B, T, M), float("nan"), dtype=u.dtype, device=u.device)
     d = L.TmDesc(dt, B, T, M, 1, 3, alpha, flags)
     ptrs = (ctypes.c_void_p * 1)(u.data_ptr())
@@ -23,13 +24,13 @@ def _run(lib, L, dt, B, T, K, M, u, w, bias, alpha, flags):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,T,K", [(1, 1000, 256), (3, 777, 2560), (2, 8000, 4608), (1, 33, 512), (2, 300, 384), (1, 257, 192)])
-def test_skip_contraction_static_schedule_is_bitwise_the_generic_kernel(dtype, B, T, K):
+@pytest.mark.parametrize("B,T,K,M", [(1, 1000, 256, 256), (3, 777, 2560, 256), (2, 8000, 4608, 256), (1, 33, 512, 256), (2, 300, 384, 256),
+                                     (1, 257, 192, 256), (2, 900, 1024, 512)])
+def test_skip_contraction_static_schedule_is_bitwise_the_generic_kernel(dtype, B, T, K, M):
     from wavenet_autoencoders_amd import _lib as L
     lib = L.lib()
     dev = torch.device("cuda:0")
     td, dt = (torch.bfloat16, L.WAE_BF16) if dtype == "bf16" else (torch.float16, L.WAE_F16)
-    M = 256
     gen = torch.Generator(device="cpu").manual_seed(B * 100003 + T * 17 + K)
     u = (torch.randn(B, T, K, generator=gen) * 0.5).to(td).to(dev)
     w = (torch.randn((K // 64) * (M // 32) * 4 * 64 * 8, generator=gen) * (1.0 / K ** 0.5)).to(td).to(dev)   # packed fragment stream

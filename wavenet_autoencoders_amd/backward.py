@@ -100,8 +100,11 @@ def pack_bwd_weights(eng):
             lst += [J(eng.m_hwide[k], eng.w_hwide[k], eng.m_hwide[k].numel(), 1, 0, 0) for k in ("w3t", "w1t")]
         else:
             lst.append(J(eng.m_hb_w, eng.w_hb, eng.m_hb_w.numel(), 1, 0, 0))
+        # ... and the step's two gradient accumulators cleared by the same launch (fill jobs: no map; round 5 cleared them with two
+        # torch fills of 43 + 50 MB between launches, 19 us that this launch's idle store bandwidth absorbs)
+        lst += [L.GatherJob(None, None, t_.data_ptr(), t_.numel(), 0, 0, 1, L.WAE_F32) for t_ in (eng.d_eff, eng.cbuf)]
         jobs = eng._pack_bwd_jobs = (L.GatherJob * len(lst))(*lst)
-    L.check(lib.wae_pack_gather_multi(jobs, len(jobs), st), "pack backward weights")
+    L.check(lib.wae_pack_gather_multi(jobs, len(jobs), st), "pack backward weights + clear the gradient accumulators")
 
 
 def _arr(ctype, vals):
@@ -607,9 +610,7 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     ws = bwd_workspace(eng, B, T)
     es = eng.w_glu.element_size()
     sm = eng.sm
-    pack_bwd_weights(eng)
-    eng.d_eff.zero_()
-    eng.cbuf.zero_()
+    pack_bwd_weights(eng)          # (also clears eng.d_eff and eng.cbuf)
     if lengths is None:
         count = B * (T - 1)
     else:
@@ -911,9 +912,7 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None, lead=0):
         eng._ws[key] = ws
     ws["gn"].copy_(gx_hat)
     ws["dskip"].copy_(ds)
-    pack_bwd_weights(eng)
-    eng.d_eff.zero_()
-    eng.cbuf.zero_()
+    pack_bwd_weights(eng)          # (also clears eng.d_eff and eng.cbuf)
     _tm(eng, B, T, g.Hp, 2, 1.0, [(ws["gn"].data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)], eng.w_bu.data_ptr(),
         ws["dz"].data_ptr(), Z2, fw["z"][0].data_ptr(), Z2)
     ws["tt"].launch(B, T)

@@ -85,13 +85,18 @@ __global__ void __launch_bounds__(768, 1) gemm_tm8s_kernel(TmArgs p) {
   const unsigned clip_bytes = (unsigned)p.T * row_bytes;
   const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
   float* bias_lds = (float*)(smem + RING + TILES);
+  // outputs wider than 256 rows (the wide head, BASELINE config C5): blockIdx.y picks a slice of 8 tiles; the weight stream is
+  // [slice][chunk] (packing.py: first_gemm_map), bias and output columns follow
+  const int slice = blockIdx.y;
+  const char* wslice = p.w + (int64_t)slice * nh * HCB;
+  const int64_t col0 = (int64_t)slice * NT * 32;
 
   if (wave >= NW) {
     // ================= loader waves: 8, 9 the weights (KiB 8 lq .. +8 of every half-chunk), 10, 11 the operand (consumer waves 4 lq .. +4)
     const int lw = wave - NW, lq = lw & 1;
     const bool wl = lw < 2;
     const i32x4 srd_b = make_srd8(p.src[0] + (int64_t)b * clip_bytes, clip_bytes);
-    const i32x4 srd_w = make_srd8(p.w, (unsigned)min((int64_t)nh * HCB, (int64_t)0x7fffffff));
+    const i32x4 srd_w = make_srd8(wslice, (unsigned)min((int64_t)nh * HCB, (int64_t)0x7fffffff));
     i32x4 srd;
     srd.x = wl ? srd_w.x : srd_b.x; srd.y = wl ? srd_w.y : srd_b.y; srd.z = wl ? srd_w.z : srd_b.z; srd.w = srd_w.w;
     unsigned voff[8], lds_piece[8];
@@ -117,7 +122,8 @@ __global__ void __launch_bounds__(768, 1) gemm_tm8s_kernel(TmArgs p) {
     };
     f32x4 tb = {};
     const unsigned tb_off = lane * 16;
-    if (lw == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(tb) : "v"(tb_off), "s"(p.aux));
+    const char* bias_g = p.aux + col0 * 4;
+    if (lw == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(tb) : "v"(tb_off), "s"(bias_g));
     static_for8<0, DB>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       if (c < role_d) static_for8<0, 8>([&](auto kc) { piece(c, IntC<c % NSW>{}, IntC<c % NTB>{}, kc); });
@@ -220,20 +226,20 @@ __global__ void __launch_bounds__(768, 1) gemm_tm8s_kernel(TmArgs p) {
   for (int m = 0; m < NM; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = fmaxf(acc[m][r] * p.alpha, 0.f);
-  char* orow = p.out + ((int64_t)b * p.T + t0w) * p.out_stride * ES;
+  char* orow = p.out + (((int64_t)b * p.T + t0w) * p.out_stride + col0) * ES;
   stage_store_tiles<E, NT>(stg, acc, orow, p.out_stride * ES, rows_valid, lane);
 }
 
 namespace {
 
 template <typename E, int NT, int MODE>
-int launch_tm8s(const TmArgs& a, hipStream_t st) {
+int launch_tm8s(const TmArgs& a, int nslices, hipStream_t st) {
   auto kern = gemm_tm8s_kernel<E, NT, MODE, 4>;
   const size_t lds = (size_t)4 * NT * 2048 + (size_t)4 * 8 * 2048 + 1024;
   static WaeLdsCache lds_cache;
   if (int rc = wae_ensure_lds((const void*)kern, lds_cache, lds, "gemm_tm8s"); rc != WAE_OK) return rc;
   const int tiles = (a.T + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(a.B * tiles), dim3(768), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.B * tiles, nslices), dim3(768), lds, st, a);
   return wae_check_launch("gemm_tm8s");
 }
 
@@ -241,12 +247,12 @@ int launch_tm8s(const TmArgs& a, hipStream_t st) {
 
 int wae_gemm_tm8_launch(const TmArgs& a, int dtype, int M, hipStream_t st, bool* handled) {
   *handled = false;
-  if (!wae_is16(dtype) || a.nsrc != 1 || a.src_shift[0] != 0 || a.mode != TM_BIAS_RELU || M != 256) return WAE_OK;
+  if (!wae_is16(dtype) || a.nsrc != 1 || a.src_shift[0] != 0 || a.mode != TM_BIAS_RELU || M <= 0 || M % 256 != 0) return WAE_OK;
   if ((a.flags & WAE_TM_ONE_WG) || a.stamps) return WAE_OK;               // A/B switch and diagnostic builds: the generic kernel
   const int nq = a.src_cols[0] / 64;
   if (nq < 4 || nq % 2 != 0) return WAE_OK;                                // bodies of 4 half-chunks
   if ((int64_t)a.T * a.src_stride[0] * 2 >= (int64_t)1 << 31) return WAE_OK;   // 32-bit offsets inside a clip's descriptor
   *handled = true;
-  if (dtype == WAE_BF16) return launch_tm8s<__bf16, 8, TM_BIAS_RELU>(a, st);
-  return launch_tm8s<f16, 8, TM_BIAS_RELU>(a, st);
+  if (dtype == WAE_BF16) return launch_tm8s<__bf16, 8, TM_BIAS_RELU>(a, M / 256, st);
+  return launch_tm8s<f16, 8, TM_BIAS_RELU>(a, M / 256, st);
 }

@@ -383,9 +383,24 @@ __device__ __forceinline__ void gather_job_pairs(const wae_gather_job& jb, int64
     }
   }
 }
+// a job without a map is a FILL: n fp32 zeros at dst (the gradient arenas of a step are cleared by the launch that packs the backward
+// weights, beside its gathers -- round 5 cleared them with two torch fills of 43 + 50 MB between launches)
+#define MG_FILL 8192        // floats per block of a fill job
 __global__ void __launch_bounds__(256) gather_multi_kernel(MultiGather p) {
   const int k = multi_find(p, blockIdx.x);
   const wae_gather_job& jb = p.j[k];
+  if (jb.map == nullptr) {
+    float* dst = (float*)jb.dst;
+    const int64_t base = (int64_t)(blockIdx.x - p.first[k]) * MG_FILL;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < MG_FILL / 1024; ++u) {
+      const int64_t o = base + u * 1024 + threadIdx.x * 4;
+      if (o + 3 < jb.n) *(f32x4*)(dst + o) = z;
+      else for (int64_t q = o; q < jb.n; ++q) dst[q] = 0.f;
+    }
+    return;
+  }
   const int64_t i = ((int64_t)(blockIdx.x - p.first[k]) * 256 + threadIdx.x) * MG_PAIR;
   if (i >= jb.n) return;
   if (jb.dtype == WAE_BF16) gather_job_pairs<__bf16>(jb, i);
@@ -431,9 +446,11 @@ extern "C" int wae_pack_gather_multi(const wae_gather_job* jobs_host, int32_t nj
   int total = 0;
   for (int k = 0; k < njobs; ++k) {
     const wae_gather_job& j = jobs_host[k];
-    WAE_REQUIRE(j.src && j.map && j.dst && j.n > 0 && j.nbatch > 0 && wae_dtype_ok(j.dtype), "pack_gather_multi: bad job");
+    WAE_REQUIRE(j.dst && j.n > 0 && (j.map ? (j.src && j.nbatch > 0 && wae_dtype_ok(j.dtype)) : ((((uintptr_t)j.dst) & 15) == 0)),
+                "pack_gather_multi: bad job (a fill job -- map null -- needs a 16-byte aligned fp32 dst)");
     a.j[k] = j;
-    a.bx[k] = (int)((j.n + 256 * MG_PAIR - 1) / (256 * MG_PAIR));   // every batch entry of a block's elements is walked by that block
+    a.bx[k] = j.map ? (int)((j.n + 256 * MG_PAIR - 1) / (256 * MG_PAIR))    // every batch entry of a block's elements is walked by that block
+                    : (int)((j.n + MG_FILL - 1) / MG_FILL);
     a.first[k] = total;
     total += a.bx[k];
   }

