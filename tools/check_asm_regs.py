@@ -51,6 +51,8 @@ def main():
     for i, l in enumerate(body):
         if kinds[i] != "asm" or not ("global_load_dwordx4" in l or "buffer_load_dwordx4" in l):   # (buffer form: csrc/glu_fwd_static.hip)
             continue
+        if l.split(";")[0].rstrip().endswith(" lds"):     # an LDS-DMA piece has no destination register (its first operand is the address)
+            continue
         nload += 1
         dst = regs_of(l.split(",")[0])
         later = [w for w in waits if w > i]
