@@ -51,9 +51,6 @@ extern "C" {
                                (same results bit for bit; an A/B switch per launch, not process state) */
 #define WAE_GLU_GENERIC 64   /* 16-bit dtypes: run the run-time-scheduled kernel (csrc/glu_fwd.hip) even where a static-schedule
                                instantiation (csrc/glu_fwd_static.hip) exists for the geometry; same results bit for bit */
-#define WAE_GLU_STATIC_REG 128 /* 16-bit dtypes, Rp = 256: run the static-schedule kernel that requests the activation operand straight into
-                               registers (csrc/glu_fwd_static.hip, round 3) instead of the one that streams it through LDS
-                               (csrc/glu_fwd8.hip, round 6); same results bit for bit */
 
 const char* wae_version(void);
 const char* wae_last_error(void);

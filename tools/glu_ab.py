@@ -55,8 +55,7 @@ def child(lib, geom, dtype):
     print(f"{name}: bitwise vs generic over 5 dilations: {'EQUAL' if bad == 0 else f'{bad} MISMATCHES'}", flush=True)
     xo, u, z = torch.zeros_like(x), torch.zeros(B, T, g.Hp, device="cuda").to(eng.tdtype), torch.zeros(B, T, 2 * g.Hp, device="cuda").to(eng.tdtype)
     res = []
-    kinds = (0, L.GLU_GENERIC | L.GLU_PAIR) if os.environ.get("AB_GENERIC") else ((0, L.GLU_STATIC_REG) if os.environ.get("AB_STATIC_REG") else (0,))
-    for gen in kinds:
+    for gen in ((0, L.GLU_GENERIC | L.GLU_PAIR) if os.environ.get("AB_GENERIC") else (0,)):
         for flags in (0, L.GLU_SAVE_Z):
             for d in (1, 64):
                 for _ in range(5):
@@ -67,7 +66,7 @@ def child(lib, geom, dtype):
                     run(xo, u, z, flags | gen, d)
                 e1.record()
                 torch.cuda.synchronize()
-                res.append(f"{'reg ' if gen == L.GLU_STATIC_REG else 'gen ' if gen else ''}{'z' if flags else 'inf'} d={d}: {e0.elapsed_time(e1) / 30 * 1e3:6.1f}")
+                res.append(f"{'gen ' if gen else ''}{'z' if flags else 'inf'} d={d}: {e0.elapsed_time(e1) / 30 * 1e3:6.1f}")
     print(f"{name:34s} us/launch  " + "  ".join(res), flush=True)
 
 

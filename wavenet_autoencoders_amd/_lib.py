@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAE_LIB_PATH") or os.path.join(_HERE, "libwae_hip.so")   # WAE_LIB_PATH: A/B of two builds (tools/)
 
 WAE_F32, WAE_BF16, WAE_F16 = 0, 1, 2
-GLU_SAVE_Z, GLU_NO_OUT, GLU_WAVES4, GLU_CG2, GLU_PAIR, GLU_GENERIC, GLU_STATIC_REG = 2, 4, 8, 16, 32, 64, 128
+GLU_SAVE_Z, GLU_NO_OUT, GLU_WAVES4, GLU_CG2, GLU_PAIR, GLU_GENERIC = 2, 4, 8, 16, 32, 64
 TM_INTERLEAVE, TM_ONE_WG = 1, 2
 ERR_CLASS_ID, ERR_SPEAKER_ID, ERR_TARGET_ID, ERR_NOT_ONEHOT = 1, 2, 4, 8
 

@@ -654,10 +654,6 @@ extern "C" int wae_glu_layer_fwd_drop(const wae_glu_desc* d, const void* x_in, c
   // the shape flags and WAE_GLU_GENERIC select this file's kernel
   if (!(d->flags & (WAE_GLU_GENERIC | WAE_GLU_CG2 | WAE_GLU_WAVES4))) {
     bool handled = false;
-    if (!(d->flags & WAE_GLU_STATIC_REG)) {
-      rc = wae_glu_fwd8_launch(a, d->dtype, st, &handled);
-      if (handled || rc != WAE_OK) return rc;
-    }
     rc = wae_glu_static_launch(a, d->dtype, st, &handled);
     if (handled || rc != WAE_OK) return rc;
   }

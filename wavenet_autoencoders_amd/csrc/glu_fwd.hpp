@@ -22,5 +22,3 @@ struct GluArgs {
 // glu_fwd_static.hip: 16-bit instantiations whose whole chunk schedule (ring slots, request counts, tap offsets) is a compile-time
 // constant.  Returns WAE_OK and sets *handled when it launched; leaves *handled false for every geometry it has no instantiation of.
 int wae_glu_static_launch(const GluArgs& a, int dtype, hipStream_t st, bool* handled);
-// glu_fwd8.hip (round 6): Rp = 256 / Ccp = 64 / three taps with both operand streams of GEMM 1 through LDS; bitwise the static kernel.
-int wae_glu_fwd8_launch(const GluArgs& a, int dtype, hipStream_t st, bool* handled);
