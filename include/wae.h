@@ -188,6 +188,14 @@ int wae_check_ids(const int32_t* ids, int64_t n, int32_t lo, int32_t hi, int32_t
 int wae_onehot_to_ids(const float* x, int32_t B, int32_t C, int32_t T, int64_t stride_b, int64_t stride_c, int64_t stride_t,
                       int32_t* ids, int32_t* err, int32_t code, void* stream);
 
+/* ---- two chains of layer launches (round 6) ------------------------------------------------------------------
+ * Every workgroup of a layer launch stores its outputs at the same time (forward: z, u, x' -- 106 MB at BASELINE C2, ~20 us of a 55-us
+ * launch in which nothing computes).  One launch cannot be de-phased against itself, two CHAINS of launches can: the host runs the
+ * gated stack (and the backward sweep) as two half-batch chains on two streams -- the same entry points with B / 2 clips and offset
+ * pointers; every array of this ABI is clip-major -- and starts the second chain `us` microseconds late with this call: one wave that
+ * sleeps on the wall clock.  Results are bit for bit those of one chain (no clip reads another clip's rows). */
+int wae_stream_delay(double us, void* stream);
+
 /* ---- a6 ResidualConv1dGLU._forward (modules.py:115-163) -------------------------------------------------
  * One fused layer: dilated causal conv + 1x1(c) + hoisted 1x1(g) + gate + 1x1 out + residual.  The skip 1x1
  * (modules.py:157) and `skips += h` (wavenet.py:204-207) are deferred: the layer stores its gated activation

@@ -279,13 +279,14 @@ def test_c2_full_size_backward_properties(monkeypatch):
     assert rel < 1e-5, rel
 
 
-@pytest.mark.parametrize("dtype,name", [("fp32", "A"), ("bf16", "A"), ("bf16", "B")])
-def test_grad_sync_path_equals_plain_backward(dtype, name):
+@pytest.mark.parametrize("dtype,name,chains", [("fp32", "A", "auto"), ("bf16", "A", "auto"), ("bf16", "B", "auto"), ("bf16", "B", "2")])
+def test_grad_sync_path_equals_plain_backward(dtype, name, chains):
     """Data-parallel step order: with a GradSync the arena is handed to the all-reduce in THREE pieces -- the upper half
     of the gated layers + the head in the middle of the backward sweep (the stream-K weight-gradient launch is cut into two layer
     halves for that), the lower half at its end, the rest in finish_grads; fp32 (per-layer tile launches) hands the layers + head
     over in one piece.  Single process (no collective runs): the hand-over order is checked, and the gradients and the updated
-    weights must equal those of the plain order."""
+    weights must equal those of the plain order.  chains = "2": the sweep as two half-batch chains of launches (engine.chain_plan),
+    joined for the hand-over in its middle and forked again behind it."""
     from wavenet_autoencoders_amd import Geometry
     from wavenet_autoencoders_amd import backward as BW
     from wavenet_autoencoders_amd.distributed import GradSync
@@ -297,8 +298,10 @@ def test_grad_sync_path_equals_plain_backward(dtype, name):
     handed = []
     for tag in ("plain", "sync"):
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.opt.chains = chains
         eng.load_state_dict(sd)
         eng.init_optimizer()
+        assert (eng.chain_plan(*x.shape) is not None) == (chains == "2")
         seen = {}
         sync = GradSync(eng) if tag == "sync" else None
         if sync is not None:
@@ -517,3 +520,71 @@ def test_pair8_launch_is_bitwise_the_pair_launch(case, dtype):
     for i, (a, b_) in enumerate(zip(got[True][1], got[False][1])):
         assert torch.equal(i16(a), i16(b_)), ("dx-hat", i)
     assert torch.equal(i16(got[True][2]), i16(got[False][2])), "dc"
+
+
+@pytest.mark.parametrize("case", ["c2", "c2small", "c3small", "wide"])
+def test_two_chains_are_bitwise_one_chain(case):
+    """Round 6: the gated stack and the backward sweep as two half-batch chains of launches on two streams, the second started half a
+    launch late (engine.chain_plan, include/wae.h: wae_stream_delay) against one chain of full-batch launches.  Same kernels, same
+    arithmetic per clip: every saved activation of the forward, the loss terms, dz of every layer, every dx-hat and dc are compared
+    BITWISE; the weight gradients (one launch downstream of both chains, fp32 atomics) to the tolerance of two runs of that launch.
+    C2 at full size (auto: 250 workgroups per launch), an odd batch of short ragged clips (forced: 2 + 1 clips), the hps/vqwae.json
+    decoder, and a 512-wide fp16 model whose sweep runs the two launches per layer (forced)."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd import backward as BW
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    dtype = "bf16"
+    if case == "c2":
+        cfg = dict(layers=24, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153, upsample_scales=[4, 4, 4, 5], cin_pad=0)
+        B, T, hop, force = 8, 8000, 320, "auto"
+    elif case == "c2small":
+        cfg = dict(layers=6, stacks=2, R=256, G=368, S=256, O=256, Cc=64, Cg=64, k=3, n_speakers=153, upsample_scales=[4, 4, 4, 5], cin_pad=0)
+        B, T, hop, force = 3, 960, 320, "2"
+    elif case == "c3small":
+        cfg = dict(layers=6, stacks=3, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=153, upsample_scales=[4, 4, 8, 5], cin_pad=0)
+        B, T, hop, force = 2, 1280, 640, "2"
+    else:
+        cfg = dict(layers=4, stacks=2, R=512, G=512, S=512, O=256, Cc=64, Cg=32, k=3, n_speakers=7, upsample_scales=[4, 4, 4, 5], cin_pad=0)
+        B, T, hop, force, dtype = 4, 1600, 320, "2", "fp16"
+    sd = O.make_state_dict(dict(cfg), salt=6, with_encoder=False)
+    gen = torch.Generator().manual_seed(277)
+    x = torch.randint(0, 256, (B, T), generator=gen).cuda()
+    c = torch.randn(B, 64, T // hop, generator=gen).cuda()
+    g = torch.randint(0, cfg["n_speakers"], (B,), generator=gen).cuda()
+    lengths = torch.tensor([T - 61 * i for i in range(B)])
+    got = {}
+    for chains in ("1", force):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.opt.chains = chains
+        eng.load_state_dict(sd, strict=False)
+        assert (eng.chain_plan(B, T) is not None) == (chains != "1")
+        out = eng.decoder_forward(x, c, g, targets=x, lengths=lengths.cuda(), train=True, want_logits=False)
+        fw = eng._ws[(B, T, True)]
+        dc = BW.decoder_backward(eng, x, x, lengths, g)
+        ws = eng._ws[("bwd", B, T)]
+        torch.cuda.synchronize()
+        got[chains] = dict(x=[t_.clone() for t_ in fw["x"]], z=[t_.clone() for t_ in fw["z"]], u=fw["u"].clone(), nll=fw["nll"].clone(),
+                           loss=out["loss"].detach().clone(), dz=ws["dz"].clone(), gx=[t_.clone() for t_ in ws["gx"]], dc=dc.clone(),
+                           grads=BW.finish_grads(eng).clone())
+        torch.cuda.synchronize()
+        lay = eng.lay
+        del eng
+        torch.cuda.empty_cache()
+    one, two = got["1"], got[force]
+    bits = lambda t_: t_.contiguous().view(torch.int16 if t_.element_size() == 2 else torch.int32)  # noqa: E731
+    assert float(one["dz"].float().abs().max()) > 0 and float(one["u"].float().abs().max()) > 0
+    for k in ("u", "nll", "loss", "dz", "dc"):
+        assert torch.equal(bits(one[k]), bits(two[k])), k
+    for k in ("x", "z", "gx"):
+        for i, (a, b_) in enumerate(zip(one[k], two[k])):
+            if k == "x" and i == len(one[k]) - 1:
+                continue                                   # (the last layer's x' is dead: never written)
+            assert torch.equal(bits(a), bits(b_)), (k, i)
+    bad = {}
+    for k in lay.offsets:
+        a = one["grads"][lay.off(k):lay.off(k) + lay.numel(k)]
+        b_ = two["grads"][lay.off(k):lay.off(k) + lay.numel(k)]
+        err, ref = float((a - b_).abs().max()), float(a.abs().max())
+        if err > 1e-4 * max(ref, 1e-6) + 1e-7:
+            bad[k] = (err, ref)
+    assert not bad, bad

@@ -98,6 +98,7 @@ SIGNATURES = {
     "wae_gproj_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64] + [c_i32] * 7 + [c_vp]),
     "wae_check_ids": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "wae_onehot_to_ids": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp]),
+    "wae_stream_delay": (c_i32, [ctypes.c_double, c_vp]),
     "wae_upsample_stage_bwd": (c_i32, [c_vp] * 5 + [c_i32] * 4 + [c_vp]),
     "wae_enc_conv_bwd": (c_i32, [c_vp] * 7 + [c_i32] * 9 + [c_vp]),
     "wae_vq_bwd": (c_i32, [c_vp] * 6 + [c_i32] * 3 + [c_f32, c_f32, c_vp]),

@@ -111,7 +111,7 @@ def _arr(ctype, vals):
     return (ctype * len(vals))(*vals)
 
 
-def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=None, aux_stride=0, flags=0):
+def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=None, aux_stride=0, flags=0, st=None):
     """srcs: list of (device ptr int, row stride elems, cols, shift)"""
     d = L.TmDesc(eng.dt, B, T, M, len(srcs), mode, alpha, flags)
     ptrs = _arr(ctypes.c_void_p, [s[0] for s in srcs])
@@ -119,7 +119,7 @@ def _tm(eng, B, T, M, mode, alpha, srcs, w_ptr, out_ptr, out_stride, aux_ptr=Non
     cols = _arr(ctypes.c_int32, [s[2] for s in srcs])
     shifts = _arr(ctypes.c_int32, [s[3] for s in srcs])
     L.check(eng.lib.wae_gemm_tm(ctypes.byref(d), ptrs, strides, cols, shifts, ctypes.c_void_p(w_ptr), ctypes.c_void_p(out_ptr),
-                                out_stride, ctypes.c_void_p(aux_ptr) if aux_ptr else None, aux_stride, eng.stream()), "gemm_tm")
+                                out_stride, ctypes.c_void_p(aux_ptr) if aux_ptr else None, aux_stride, st if st is not None else eng.stream()), "gemm_tm")
 
 
 def _tm_ce(eng, B, T, M, mode, srcs, w_ptr, out_ptr, out_stride, bias_ptr, ce):
@@ -659,8 +659,8 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
 
     tm_ev = getattr(eng, "_tm_events", None)   # bench.py: {"gate": [(e0, e1), ...], "res": [...], "pair": [...]} -- HIP events around every launch
 
-    def timed(kind, fn):
-        if tm_ev is None:
+    def timed(kind, fn, stc=None):
+        if tm_ev is None or stc is not None:   # (HIP events bracket the current stream's launches only)
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(eng.device))
@@ -668,25 +668,34 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         e1.record(torch.cuda.current_stream(eng.device))
         tm_ev.setdefault(kind, []).append((e0, e1))
 
-    def k_u(l, gn):                            # du -> dz of layer l
+    # (b0, nb, stc): the clips of a chain and its stream -- every array of the sweep is clip-major, so a chain is the same call on its
+    #  clips (engine.chain_plan); (0, B, None) = the whole batch on the current stream
+    WHOLE = (0, B, None)
+
+    def k_u(l, gn, part=WHOLE):                # du -> dz of layer l
+        b0, nb, stc = part
+        r = b0 * T * es
         if gn.data_ptr() == ws["gzero"].data_ptr():
             # the top layer: dx-hat above it is zero (its x' is dead), so W_out^T . 0 is left out -- the skip half of the weight stream
             # on dS alone: the same sums (+ 0 exactly), half the chunks, 32 MB of zeros not read
-            timed("gate", lambda: _tm(eng, B, T, g.Hp, 2, 1.0, [(ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
-                                      eng.w_bu.data_ptr() + l * eng.n_bu * es + us_off, ws["dz"].data_ptr() + l * Z2 * es, dzs,
-                                      fw["z"][l].data_ptr(), Z2, flags=0))
+            timed("gate", lambda: _tm(eng, nb, T, g.Hp, 2, 1.0, [(ws["dskip"].data_ptr() + r * g.Sp, g.Sp, g.Sp, 0)],
+                                      eng.w_bu.data_ptr() + l * eng.n_bu * es + us_off, ws["dz"].data_ptr() + l * Z2 * es + r * dzs, dzs,
+                                      fw["z"][l].data_ptr() + r * Z2, Z2, flags=0, st=stc), stc)
             return
-        timed("gate", lambda: _tm(eng, B, T, g.Hp, 2, 1.0, [(gn.data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)],
-                                  eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es, dzs, fw["z"][l].data_ptr(), Z2,
-                                  flags=0))
+        timed("gate", lambda: _tm(eng, nb, T, g.Hp, 2, 1.0, [(gn.data_ptr() + r * g.Rp, g.Rp, g.Rp, 0),
+                                                            (ws["dskip"].data_ptr() + r * g.Sp, g.Sp, g.Sp, 0)],
+                                  eng.w_bu.data_ptr() + l * eng.n_bu * es, ws["dz"].data_ptr() + l * Z2 * es + r * dzs, dzs,
+                                  fw["z"][l].data_ptr() + r * Z2, Z2, flags=0, st=stc), stc)
 
     seeds = getattr(eng, "_drop_seeds", None)   # set by the train-mode forward when dropout is active
 
-    def k_x(l, gn, gc):                        # dx-hat of layer l
-        srcs = [(ws["dz"].data_ptr() + l * Z2 * es, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
+    def k_x(l, gn, gc, part=WHOLE):            # dx-hat of layer l
+        b0, nb, stc = part
+        r = b0 * T * es
+        srcs = [(ws["dz"].data_ptr() + l * Z2 * es + r * dzs, dzs, Z2, (g.k - 1 - tap) * g.dilations[l]) for tap in range(g.k)]
         if seeds is None:
-            timed("res", lambda: _tm(eng, B, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr(), g.Rp,
-                                     gn.data_ptr(), g.Rp, flags=P.TM_INTERLEAVE))
+            timed("res", lambda: _tm(eng, nb, T, g.Rp, 1, RS, srcs, eng.w_bx.data_ptr() + l * eng.n_bx * es, gc.data_ptr() + r * g.Rp, g.Rp,
+                                     gn.data_ptr() + r * g.Rp, g.Rp, flags=P.TM_INTERLEAVE, st=stc), stc)
         else:
             # dropout: the tap contraction alone (mode 0), then out = sqrt(.5) * (g_next + keep * acc / (1 - p)) with the mask
             # the forward applied to this layer's convolution operand
@@ -786,40 +795,68 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         ws["dc32"] = torch.empty(B, T, 64, dtype=torch.float32, device=eng.device)
     cbytes = (Z2 // 64) * 8192                # bytes of one layer's chunks in the dc weight stream (packing.bwd_c_map)
     k_u(g.layers - 1, g_next)
+    # two half-batch chains of the sweep's launches (engine.chain_plan), the second half a launch late; not with dropout (its mask
+    # generator counts elements of the full batch) and not with per-layer weight-gradient launches (they read both chains' rows)
+    plan = eng.chain_plan(B, T, backward=True) if (seeds is None and ws["stream"] is not None) else None
+
+    def fork():
+        if plan is None:
+            return [WHOLE]
+        side = eng.chain_fork(plan[1])
+        return [(0, plan[0], None), (plan[0], B - plan[0], ctypes.c_void_p(side.cuda_stream))]
+
+    if tm_ev is not None:                      # bench.py: HIP events around the whole sweep (both chains)
+        sweep_e0, sweep_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sweep_e0.record(torch.cuda.current_stream(eng.device))
+    parts = fork()
     for l in range(g.layers - 1, -1, -1):
         assert l == g.layers - 1 or g_next.data_ptr() == ws["gx"][(l + 1) % ngx].data_ptr()
         tn_layer(l)                            # needs dz_l and dx_{l+1}-hat
         g_cur = ws["gx"][l % ngx]
         if (l > 0 or fold_dc) and eng.fused_bwd and seeds is None:
             # K_X of layer l and K_U of layer l-1 in one launch (csrc/glu_bwd.hip); layer 0 (fold_dc): K_X + the last dc term only
-            d = L.GluBwdDesc(eng.dt, B, T, g.Rp, g.Hp, g.Sp, g.k, g.dilations[l], RS)
             lp = max(l - 1, 0)
-            args = [ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es), dzs, L.ptr(g_next),
-                    L.ptr(g_cur), L.ptr(ws["dskip"]), L.ptr(fw["z"][lp]),
-                    ctypes.c_void_p(ws["dz"].data_ptr() + lp * Z2 * es),
-                    ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
-                    ctypes.c_void_p(eng.w_buo.data_ptr() + lp * eng.n_buo * es),
-                    ctypes.c_void_p(eng.w_bu.data_ptr() + lp * eng.n_bu * es + us_off)]
-            if fold_dc:
-                mode = (0 if l == g.layers - 1 else 1) | (2 if l == 0 else 0) | (4 if getattr(eng, "bwd_pair4", False) else 0)
-                # (bit 2: keep the 4-wave kernel where the 8-wave one, csrc/glu_bwd8.hip, has an instantiation -- tests and tools)
-                args += [ctypes.c_void_p(eng.w_bc.data_ptr() + l * cbytes), L.ptr(ws["dc32"]), L.ptr(ws["dc"]), mode, int(l == 0)]
-                timed("pair", lambda: L.check(lib.wae_glu_bwd_fused_dc(*args, st), "glu_bwd_fused_dc"))
-            else:
-                timed("pair", lambda: L.check(lib.wae_glu_bwd_fused(*args, st), "glu_bwd_fused"))
+            for b0, nb, stc in parts:
+                d = L.GluBwdDesc(eng.dt, nb, T, g.Rp, g.Hp, g.Sp, g.k, g.dilations[l], RS)
+                r = b0 * T * es
+                args = [ctypes.byref(d), ctypes.c_void_p(ws["dz"].data_ptr() + l * Z2 * es + r * dzs), dzs,
+                        ctypes.c_void_p(g_next.data_ptr() + r * g.Rp), ctypes.c_void_p(g_cur.data_ptr() + r * g.Rp),
+                        ctypes.c_void_p(ws["dskip"].data_ptr() + r * g.Sp), ctypes.c_void_p(fw["z"][lp].data_ptr() + r * Z2),
+                        ctypes.c_void_p(ws["dz"].data_ptr() + lp * Z2 * es + r * dzs),
+                        ctypes.c_void_p((eng.w_bxf if hasattr(eng, "w_bxf") else eng.w_bx).data_ptr() + l * eng.n_bx * es),
+                        ctypes.c_void_p(eng.w_buo.data_ptr() + lp * eng.n_buo * es),
+                        ctypes.c_void_p(eng.w_bu.data_ptr() + lp * eng.n_bu * es + us_off)]
+                sq = stc if stc is not None else st
+                if fold_dc:
+                    mode = (0 if l == g.layers - 1 else 1) | (2 if l == 0 else 0) | (4 if getattr(eng, "bwd_pair4", False) else 0)
+                    # (bit 2: keep the 4-wave kernel where the 8-wave one, csrc/glu_bwd8.hip, has an instantiation -- tests and tools)
+                    args += [ctypes.c_void_p(eng.w_bc.data_ptr() + l * cbytes), ctypes.c_void_p(ws["dc32"].data_ptr() + b0 * T * 64 * 4),
+                             ctypes.c_void_p(ws["dc"].data_ptr() + r * ws["dc"].shape[-1]), mode, int(l == 0)]
+                    timed("pair", lambda: L.check(lib.wae_glu_bwd_fused_dc(*args, sq), "glu_bwd_fused_dc"), stc)
+                else:
+                    timed("pair", lambda: L.check(lib.wae_glu_bwd_fused(*args, sq), "glu_bwd_fused"), stc)
         else:
-            k_x(l, g_next, g_cur)
-            if l > 0:
-                k_u(l - 1, g_cur)
+            for part in parts:
+                k_x(l, g_next, g_cur, part)
+                if l > 0:
+                    k_u(l - 1, g_cur, part)
         g_next = g_cur
         if split is not None and l == split:
             # data parallel: dz, dx-hat and the saved activations of layers [split, L) are complete -> their weight gradients now
             # (one stream-K launch over the upper half), the head's and theirs into the arena, weight-norm backward of that slice,
             # and the all-reduce of ~half the arena starts while the lower half of the sweep still runs
+            if plan is not None:
+                eng.chain_join()
             launch_stream(ws["stream_hi"])
             finish_layers(split, g.layers, with_head=True)
             _wn_bwd_range(eng, seg_mid, seg_hi)
             grad_sync.ready_range(seg_mid, seg_hi)
+            parts = fork()
+    if plan is not None:
+        eng.chain_join()
+    if tm_ev is not None:
+        sweep_e1.record(torch.cuda.current_stream(eng.device))
+        tm_ev.setdefault("sweep", []).append((sweep_e0, sweep_e1))
     if split is not None:
         launch_stream(ws["stream_lo"])
     elif ws["stream"] is not None:        # every layer's dW1 taps, dWc + zb sums, dW_out + bias: one launch

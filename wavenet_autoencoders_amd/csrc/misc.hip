@@ -999,6 +999,32 @@ extern "C" int wae_onehot_to_ids(const float* x, int32_t B, int32_t C, int32_t T
 }
 
 // ---------------------------------------------------------------------------------------------------
+// A stream that starts `us` microseconds late: the second of two half-batch chains of layer launches (engine.py: chain_plan) is
+// started half a launch behind the first, so that the store bursts of one chain's launches meet the GEMM phases of the other's.
+// One wave that sleeps on the constant-rate wall clock (s_memrealtime); no memory traffic.
+__global__ void __launch_bounds__(64) stream_delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+extern "C" int wae_stream_delay(double us, void* stream) {
+  WAE_REQUIRE(us >= 0 && us <= 1e6, "stream_delay: %g us is out of range [0, 1 s]", us);
+  static int khz = 0;
+  if (khz == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+      khz = 0;
+      wae_set_error("stream_delay: cannot read the wall clock rate");
+      return WAE_EHIP;
+    }
+  }
+  const unsigned long long ticks = (unsigned long long)(us * khz / 1000.0);
+  if (ticks == 0) return WAE_OK;
+  hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, as_stream(stream), ticks);
+  return wae_check_launch("stream_delay");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // zb[b][l][:] = conv bias + conv1x1g(g_b) (modules.py:148-152 hoisted out of the time loop).  Block = (layer, clip, 32 gate rows);
 // eight lanes share a row and walk its Cg weights 32 bytes at a time (one thread per row walked Cg dependent strided loads: 21 us).
 __global__ void __launch_bounds__(256) gproj_fwd_kernel(const float* __restrict__ eff, int64_t wg_off, int64_t bias_off,

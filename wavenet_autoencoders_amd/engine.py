@@ -154,6 +154,51 @@ class WaeEngine:
     def stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    # ------------------------------------------------------------------ two chains of layer launches (include/wae.h: wae_stream_delay)
+    def chain_plan(self, B: int, T: int, backward: bool = False):
+        """None (one chain of full-batch launches), or (b_cut, delay_us): clips [0, b_cut) stay on the current stream, clips
+        [b_cut, B) run as a second chain of the same launches on the engine's side stream, started delay_us late.
+        Every workgroup of a layer launch stores its outputs at the same time -- at BASELINE C2 ~20 us of a 55-us forward launch and
+        ~30 of a 77-us backward launch in which nothing computes -- and a launch with more workgroups than CUs (C5: 320) ends with a
+        quarter-full second round.  One launch cannot be de-phased against itself (it ends with its late half: profiles/
+        r06_pair8_experiments.txt); two chains of launches can, and two 160-workgroup launches side by side fill C5's machine.
+        Measured on whole train steps (profiles/r06_chains.txt): C5 37.5 -> 33.4 ms, C2 5.26 -> 5.19 ms; hps/vqwae.json's 160-workgroup
+        launches gain nothing, so `auto` leaves them alone.  Same kernels, same arithmetic per clip: results are bit for bit those of
+        one chain (tests/test_gpu_backward.py::test_two_chains_are_bitwise_one_chain)."""
+        mode = self.opt.chains
+        if mode == "1" or B < 2 or self.dt not in (L.WAE_BF16, L.WAE_F16):
+            return None
+        if mode == "auto" and B * ((T + 255) // 256) < 200:
+            return None
+        g = self.g
+        delay = getattr(self, "chain_delay_us", None)        # (tools)
+        if delay is None:
+            # The forward chains start together and stay in step (started half a launch apart they ran 64 us per layer at C2 until they
+            # fell into step, 53 in step, 55.5 as one chain).  The backward sweep's second chain starts half a launch late: 35 us at
+            # C2, scaled by the MFMA work of a workgroup.  Its launches then run 70-72 us per layer against 77 in step -- for about 14
+            # layers, until the trailing chain (~3 us per launch faster) has caught up; holding it back with events on a third stream
+            # costs more than it keeps (profiles/r06_chains.txt).
+            work = (g.k * g.Rp + g.Ccp) * 2 * g.Hp + g.Hp * g.Rp
+            delay = 35.0 * work / 368640.0 if backward else 0.0
+        return (B + 1) // 2, float(delay)
+
+    def chain_fork(self, delay_us: float):
+        """The side stream waits for everything enqueued on the current stream so far, then for delay_us; returns it."""
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        side, cur = self._side_stream, torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        side.wait_event(ev)
+        L.check(self.lib.wae_stream_delay(delay_us, ctypes.c_void_p(side.cuda_stream)), "stream_delay")
+        return side
+
+    def chain_join(self):
+        """The current stream waits for the side stream's chain."""
+        ev = torch.cuda.Event()
+        ev.record(self._side_stream)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+
     def view(self, name: str) -> torch.Tensor:
         off = self.lay.off(name)
         return self.params[off:off + self.lay.numel(name)].view(self.lay.shapes[name])
@@ -372,7 +417,6 @@ class WaeEngine:
                                            B * T, g.Rp, g.O, self.dt, L.ptr(self.err), st), "first_conv")
         # gated residual stack
         es = self.w_glu.element_size()
-        d = L.GluDesc(self.dt, B, T, g.Rp, g.Ccp, g.Hp, g.k, 1, 0)
         # dropout (modules.py:127-128) only in a train-mode forward of a model in training mode; eval is the identity
         if train:
             self.fwd_gen = getattr(self, "fwd_gen", 0) + 1       # the saved activations now belong to THIS forward
@@ -384,12 +428,17 @@ class WaeEngine:
         if layer_events is not None:   # HIP events on the launch stream around the whole gated stack (bench.py)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
+        # two half-batch chains of the same launches (chain_plan): not with dropout (its mask generator counts elements of the full batch)
+        plan = self.chain_plan(B, T) if (drop == 0 and not (train and "xd" in ws)) else None
+        parts = [(0, B, st)]
+        if plan is not None:
+            side = self.chain_fork(plan[1])
+            parts = [(0, plan[0], st), (plan[0], B - plan[0], ctypes.c_void_p(side.cuda_stream))]
         for i, dil in enumerate(g.dilations):
-            d.dilation = dil
             last = i == g.layers - 1
-            d.flags = (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0) | self.glu_flags
+            flags = (L.GLU_SAVE_Z if train else 0) | (L.GLU_NO_OUT if last else 0) | self.glu_flags
             if not train and self.glu_pair == "inference":
-                d.flags |= L.GLU_PAIR
+                flags |= L.GLU_PAIR
             xin = ws["x"][i if train else i % 2]
             xout = ws["x"][(i + 1) if train else (i + 1) % 2]
             xconv = xin
@@ -400,12 +449,20 @@ class WaeEngine:
                 # an engine built with dropout > 0 running a train-mode forward of a model in eval mode: the weight-gradient
                 # tables of this (B, T) point at xd, so it must hold the (undropped) operand
                 L.check(lib.wae_dropout_fwd(L.ptr(xin), L.ptr(ws["xd"][i]), B * T * g.Rp, 0, 0.0, self.dt, st), "dropout (identity)")
-            L.check(lib.wae_glu_layer_fwd_drop(ctypes.byref(d), L.ptr(xin), L.ptr(xconv), None if last else L.ptr(xout), L.ptr(ws["c_up"]),
-                                          ctypes.c_void_p(ws["u"].data_ptr() + i * g.Hp * es), g.Ku,
-                                          ctypes.c_void_p(ws["zb"].data_ptr() + i * 2 * g.Hp * 4),
-                                          g.layers * 2 * g.Hp, L.ptr(ws["z"][i]) if train else None,
-                                          ctypes.c_void_p(self.w_glu.data_ptr() + i * self.glu_elems * es),
-                                          ctypes.c_void_p(self.b_glu.data_ptr() + i * g.Rp * 4), st), f"glu layer {i}")
+            for b0, nb, stc in parts:      # every array is clip-major: a chain is the same call on its clips
+                dd = L.GluDesc(self.dt, nb, T, g.Rp, g.Ccp, g.Hp, g.k, dil, flags)
+                rx = b0 * T * g.Rp * es
+                L.check(lib.wae_glu_layer_fwd_drop(ctypes.byref(dd), ctypes.c_void_p(xin.data_ptr() + rx), ctypes.c_void_p(xconv.data_ptr() + rx),
+                                                   None if last else ctypes.c_void_p(xout.data_ptr() + rx),
+                                                   ctypes.c_void_p(ws["c_up"].data_ptr() + b0 * T * g.Ccp * es) if ws["c_up"] is not None else None,
+                                                   ctypes.c_void_p(ws["u"].data_ptr() + (b0 * T * g.Ku + i * g.Hp) * es), g.Ku,
+                                                   ctypes.c_void_p(ws["zb"].data_ptr() + (b0 * g.layers + i) * 2 * g.Hp * 4),
+                                                   g.layers * 2 * g.Hp,
+                                                   ctypes.c_void_p(ws["z"][i].data_ptr() + b0 * T * 2 * g.Hp * es) if train else None,
+                                                   ctypes.c_void_p(self.w_glu.data_ptr() + i * self.glu_elems * es),
+                                                   ctypes.c_void_p(self.b_glu.data_ptr() + i * g.Rp * 4), stc), f"glu layer {i}")
+        if plan is not None:
+            self.chain_join()
         if layer_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
             layer_events.append((e0, e1))
