@@ -588,3 +588,37 @@ def test_two_chains_are_bitwise_one_chain(case):
         if err > 1e-4 * max(ref, 1e-6) + 1e-7:
             bad[k] = (err, ref)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,name", [("fp32", "A"), ("bf16", "A"), ("bf16", "B")])
+def test_side_streams_change_nothing(dtype, name):
+    """Round 6 (options.py: WAE_SIDE): the step's independent side work on side streams -- the upsampling network + hoisted global
+    conditioning and the backward's weight packing (with the clearing of the gradient accumulators) beside the forward weight packing,
+    the front end's backward beside the scatter of the layers' weight gradients -- against every launch on one stream.  Three train
+    steps each (a hazard between a step's early packing and the previous step's optimizer would show in the second): losses bitwise,
+    gradients and parameters to the tolerance of two runs of the atomically accumulated weight gradients."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg, sd, ins, z, ocfg = golden_model(name)
+    x, c, g = ins["x"].cuda(), ins["c"].cuda(), ins["g"].cuda()
+    lengths = torch.tensor([x.shape[1], x.shape[1] - 217])
+    got = {}
+    for side in (False, True):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.opt.side = side
+        eng.load_state_dict(sd)
+        eng.init_optimizer()
+        losses, seen = [], {}
+        for _ in range(3):
+            r = eng.train_step(x, c, g, lengths=lengths, lr=1e-3, grad_hook=lambda gr: seen.__setitem__("g", gr.clone()))
+            losses.append(r["loss"].detach().clone())
+        torch.cuda.synchronize()
+        assert (eng._ev_wn is not None) == side
+        got[side] = (torch.stack(losses).cpu(), seen["g"].cpu(), eng.params.cpu().clone())
+        del eng
+        torch.cuda.empty_cache()
+    (l0, g0, p0), (l1, g1, p1) = got[False], got[True]
+    assert torch.equal(l0[:1], l1[:1]), (l0, l1)                       # the first step sees the same weights: the same loss bit for bit
+    assert float((l0 - l1).abs().max()) < (1e-5 if dtype == "fp32" else 2e-3), (l0, l1)
+    assert float((g0 - g1).abs().max()) <= (2e-5 if dtype == "fp32" else 2e-3) * float(g0.abs().max())
+    assert float((p0 - p1).abs().max()) < (1e-5 if dtype == "fp32" else 2e-3)

@@ -260,7 +260,7 @@ def test_engine_options_are_read_once_and_checked(monkeypatch):
                  WAE_HEAD_WIDE=("1", "head_wide", True), WAE_GLU_PAIR=("1", "glu_pair", "1"), WAE_DP_SPLIT=("0", "dp_split", False),
                  WAE_DP_WIRE=("bf16", "dp_wire", "bf16"), WAE_AR_COOP=("0", "ar_coop", False), WAE_AR_COOP_C=("16", "ar_coop_c", 16),
                  WAE_BWD_FUSED=("0", "bwd_fused", "0"), WAE_BWD_FOLD_DC=("0", "bwd_fold_dc", False),
-                 WAE_TN_STATIC_HEAD=("0", "tn_static_head", False), WAE_TN_SWAP=("0", "tn_swap", False), WAE_CHAINS=("2", "chains", "2"))
+                 WAE_TN_STATIC_HEAD=("0", "tn_static_head", False), WAE_TN_SWAP=("0", "tn_swap", False), WAE_CHAINS=("2", "chains", "2"), WAE_SIDE=("0", "side", False))
     documented = set(re.findall(r"^    (WAE_[A-Z0-9_]+) ", opts.__doc__, re.M))
     assert documented == set(flips), documented ^ set(flips)
     for var, (val, field, want) in flips.items():

@@ -610,7 +610,11 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     ws = bwd_workspace(eng, B, T)
     es = eng.w_glu.element_size()
     sm = eng.sm
-    pack_bwd_weights(eng)          # (also clears eng.d_eff and eng.cbuf)
+    early = eng.__dict__.pop("_early_pack", None)
+    if early is not None:          # train_step queued it on a side stream right behind weight norm
+        eng.join(early[0])
+    else:
+        pack_bwd_weights(eng)      # (also clears eng.d_eff and eng.cbuf)
     if lengths is None:
         count = B * (T - 1)
     else:
@@ -857,6 +861,13 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     if tm_ev is not None:
         sweep_e1.record(torch.cuda.current_stream(eng.device))
         tm_ev.setdefault("sweep", []).append((sweep_e0, sweep_e1))
+    if fold_dc and eng.opt.side:
+        # dc is complete: the front end's backward may start (engine.backward: a side stream).  Its launches then sit behind the
+        # weight-gradient launch below, which fills every SIMD's registers, and run in that launch's ragged end (its workgroups finish
+        # 60-90 us apart) and beside the scatters.  (Started behind the weight-gradient launch instead they ran beside the scatters
+        # only, and both took longer: 54 us per step gained instead of 90.)
+        eng._ev_dc = torch.cuda.Event()
+        eng._ev_dc.record(torch.cuda.current_stream(eng.device))
     if split is not None:
         launch_stream(ws["stream_lo"])
     elif ws["stream"] is not None:        # every layer's dW1 taps, dWc + zb sums, dW_out + bias: one launch
@@ -949,7 +960,11 @@ def layer_backward(eng, B, T, gx_hat, ds, gvec, drop_seed=None, lead=0):
         eng._ws[key] = ws
     ws["gn"].copy_(gx_hat)
     ws["dskip"].copy_(ds)
-    pack_bwd_weights(eng)          # (also clears eng.d_eff and eng.cbuf)
+    early = eng.__dict__.pop("_early_pack", None)
+    if early is not None:          # train_step queued it on a side stream right behind weight norm
+        eng.join(early[0])
+    else:
+        pack_bwd_weights(eng)      # (also clears eng.d_eff and eng.cbuf)
     _tm(eng, B, T, g.Hp, 2, 1.0, [(ws["gn"].data_ptr(), g.Rp, g.Rp, 0), (ws["dskip"].data_ptr(), g.Sp, g.Sp, 0)], eng.w_bu.data_ptr(),
         ws["dz"].data_ptr(), Z2, fw["z"][0].data_ptr(), Z2)
     ws["tt"].launch(B, T)

@@ -8,6 +8,7 @@ VectorQuantize.forward (vector_quantization.py:21-49), WaveNet.forward (wavenet.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 
@@ -182,10 +183,37 @@ class WaeEngine:
             delay = 35.0 * work / 368640.0 if backward else 0.0
         return (B + 1) // 2, float(delay)
 
+    def side_stream(self, k: int = 0):
+        ss = self.__dict__.setdefault("_side_streams", {})
+        if k not in ss:
+            ss[k] = torch.cuda.Stream(self.device)
+        return ss[k]
+
+    @contextlib.contextmanager
+    def branch(self, k: int, after=None):
+        """Independent side work of a step: the body's launches go to side stream k, which first waits for `after` (an event of the
+        main stream; default: everything enqueued on the current stream so far).  Yields a one-element list that holds the branch's
+        completion event afterwards: `self.join(box[0])` where the main stream needs the results.  (The step's small launches --
+        weight packing, the upsampling network, the front end's backward, scatters -- fill a fraction of the machine each and run
+        one after the other on one stream: DESIGN 3.4.)"""
+        side, cur = self.side_stream(k), torch.cuda.current_stream(self.device)
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(cur)
+        side.wait_event(after)
+        box = [None]
+        with torch.cuda.stream(side):
+            yield box
+        box[0] = torch.cuda.Event()
+        box[0].record(side)
+
+    def join(self, ev):
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
     def chain_fork(self, delay_us: float):
         """The side stream waits for everything enqueued on the current stream so far, then for delay_us; returns it."""
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(self.device)
+        self._side_stream = self.side_stream(0)
         side, cur = self._side_stream, torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
         ev.record(cur)
@@ -226,6 +254,10 @@ class WaeEngine:
         lib, st, g, lay = self.lib, self.stream(), self.g, self.lay
         L.check(lib.wae_weight_norm_fwd(L.ptr(self.params), L.ptr(self.eff), lay.total, L.ptr(self.wn_v), L.ptr(self.wn_g),
                                         L.ptr(self.wn_c), len(lay.wn_cols), st), "weight_norm_fwd")
+        self._ev_wn = None
+        if self.opt.side and self.device.type == "cuda":      # the effective weights exist: what only needs them may start (train_step)
+            self._ev_wn = torch.cuda.Event()
+            self._ev_wn.record(torch.cuda.current_stream(self.device))
         jobs = getattr(self, "_pack_jobs", None)
         if jobs is None:       # the pointers never change: one host array, one launch for every family
             es = self.w_glu.element_size()
@@ -369,7 +401,8 @@ class WaeEngine:
     def decoder_forward(self, x: torch.Tensor, c: Optional[torch.Tensor], gid: Optional[torch.Tensor],
                         targets: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
                         want_logits: bool = True, train: bool = False, c_is_upsampled: bool = False,
-                        gvec: Optional[torch.Tensor] = None, layer_events: Optional[list] = None, dropout_on: bool = True):
+                        gvec: Optional[torch.Tensor] = None, layer_events: Optional[list] = None, dropout_on: bool = True,
+                        front_event=None):
         """WaveNet.forward (wavenet.py:164-216) on class ids.
 
         x: (B,T) int32 class ids (mulaw-quantize) or (B,T) fp32 scalars (scalar_input).
@@ -382,30 +415,35 @@ class WaeEngine:
         g, lib, st = self.g, self.lib, self.stream()
         B, T = x.shape
         ws = self.workspace(B, T, train)
-        # local conditioning
-        if g.Ccp:
-            if c is None:
-                raise ValueError("model has local conditioning but c is None")
-            if c_is_upsampled or not g.upsample_scales:
-                if c.shape[-1] != T:
-                    raise Exception(f"c {tuple(c.shape)} x T={T}")           # wavenet.py:198-200
-                L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(ws["c_up"]), B, g.Cc, T, g.Ccp, self.dt, st), "to_btc")
-            else:
-                Tup = (c.shape[-1] - 2 * g.cin_pad) * int(np.prod(g.upsample_scales))
-                if Tup != T:
-                    raise Exception(f"c {tuple(c.shape)} upsamples to {Tup} != T={T}")  # wavenet.py:198-200
-                self.upsample_forward(c.float(), ws["c_up"])
-        # global conditioning folded with the conv bias
-        wg_off = self.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
-        emb_off = self.lay.offsets.get("wavenet.embed_speakers.weight", 0)
-        use_gid = gid is not None and "wavenet.embed_speakers.weight" in self.lay.offsets
-        if gid is not None:
-            gid = gid.to(torch.int32).contiguous()
-        L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
-                                  self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
-                                  L.ptr(gid) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
-                                  L.ptr(ws["zb"]), B, g.layers, g.G, g.Hp, max(g.Cg, 0), int(g.n_speakers or 0), L.ptr(self.err), st),
-                "gproj")
+        # (front_event, train_step: c is an input of the step and `front_event` fired when weight norm had produced the effective
+        #  weights -- the upsampling network and the hoisted global conditioning then run on a side stream beside the weight packing
+        #  that prepare_weights() queued behind it, and meet the main stream in front of the gated stack)
+        front = self.branch(0, after=front_event) if (front_event is not None and self.opt.side) else contextlib.nullcontext([None])
+        with front as front_done:
+            # local conditioning
+            if g.Ccp:
+                if c is None:
+                    raise ValueError("model has local conditioning but c is None")
+                if c_is_upsampled or not g.upsample_scales:
+                    if c.shape[-1] != T:
+                        raise Exception(f"c {tuple(c.shape)} x T={T}")           # wavenet.py:198-200
+                    L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(ws["c_up"]), B, g.Cc, T, g.Ccp, self.dt, self.stream()), "to_btc")
+                else:
+                    Tup = (c.shape[-1] - 2 * g.cin_pad) * int(np.prod(g.upsample_scales))
+                    if Tup != T:
+                        raise Exception(f"c {tuple(c.shape)} upsamples to {Tup} != T={T}")  # wavenet.py:198-200
+                    self.upsample_forward(c.float(), ws["c_up"])
+            # global conditioning folded with the conv bias
+            wg_off = self.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
+            emb_off = self.lay.offsets.get("wavenet.embed_speakers.weight", 0)
+            use_gid = gid is not None and "wavenet.embed_speakers.weight" in self.lay.offsets
+            if gid is not None:
+                gid = gid.to(torch.int32).contiguous()
+            L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
+                                      self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
+                                      L.ptr(gid) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
+                                      L.ptr(ws["zb"]), B, g.layers, g.G, g.Hp, max(g.Cg, 0), int(g.n_speakers or 0), L.ptr(self.err), self.stream()),
+                    "gproj")
         # first conv
         if g.scalar_input:
             xs = x.contiguous().float()
@@ -415,6 +453,7 @@ class WaeEngine:
             xi = x.to(torch.int32).contiguous()
             L.check(lib.wae_first_conv_fwd(L.ptr(xi), None, L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(ws["x"][0]),
                                            B * T, g.Rp, g.O, self.dt, L.ptr(self.err), st), "first_conv")
+        self.join(front_done[0])
         # gated residual stack
         es = self.w_glu.element_size()
         # dropout (modules.py:127-128) only in a train-mode forward of a model in training mode; eval is the identity
@@ -495,7 +534,13 @@ class WaeEngine:
         out = dict(logits=logits, nll=None, loss=None)
         if tg is not None:
             ln = lengths.to(self.device, torch.int32).contiguous() if lengths is not None else None
-            L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, st), "masked_mean")
+            if front_event is not None and self.opt.side:
+                # train_step: nothing on the device waits for the loss value -- its reduction leaves the main stream (train_step joins)
+                with self.branch(1) as self._loss_done:
+                    L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, self.stream()), "masked_mean")
+                self._ln_keep = ln
+            else:
+                L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, st), "masked_mean")
             out["nll"] = ws["nll"]
             out["loss"] = ws["loss"][0]
         return out
@@ -762,9 +807,17 @@ class WaeEngine:
         train-mode forward -> self.grads (flat arena).  loss_scale multiplies the CE term, vq_scale (default: loss_scale) the
         vq_loss term; grad_sync: see backward.decoder_backward."""
         from . import backward as BW
+        self._ev_dc = None
         dc = BW.decoder_backward(self, x, targets, lengths, gid, gvec, ext_dy=ext_dy, loss_scale=loss_scale, grad_sync=grad_sync)
         if self.g.Ccp and self.g.upsample_scales:
-            BW.frontend_backward(self, dc, loss_scale if vq_scale is None else vq_scale)
+            if self._ev_dc is not None:
+                # dc was complete when the sweep ended (the event): the front end's backward runs on a side stream beside the scatter of
+                # the layers' weight gradients that decoder_backward queued behind the sweep (disjoint slices of the gradient arena)
+                with self.branch(0, after=self._ev_dc) as tail:
+                    BW.frontend_backward(self, dc, loss_scale if vq_scale is None else vq_scale)
+                self.join(tail[0])
+            else:
+                BW.frontend_backward(self, dc, loss_scale if vq_scale is None else vq_scale)
         return BW.finish_grads(self)
 
     def dmol_loss_and_grad(self, y_hat: torch.Tensor, y: torch.Tensor, lengths, num_classes: int = 65536,
@@ -816,23 +869,34 @@ class WaeEngine:
                 self._gid32_key, self._gid32 = key, gid.to(self.device, torch.int32).contiguous()
             gid = self._gid32
         from . import backward as BW
-        if self.g.scalar_input:
-            fwd = self.forward if self.g.has_encoder else self.decoder_forward
-            out = fwd(x, c, gid, targets=None, lengths=None, want_logits=True, train=True)
-            if not self.g.has_encoder:
+        if self._ev_wn is not None:
+            # the backward's weight packing (+ the clearing of the step's gradient accumulators) needs the effective weights only: on a
+            # side stream of its own, now, instead of between the head's forward and backward; decoder_backward waits for it
+            with self.branch(1, after=self._ev_wn) as early:
+                BW.pack_bwd_weights(self)
+            self._early_pack = early
+        try:
+            if self.g.scalar_input:
+                fwd = self.forward if self.g.has_encoder else self.decoder_forward
+                out = fwd(x, c, gid, targets=None, lengths=None, want_logits=True, train=True)
+                if not self.g.has_encoder:
+                    self._fe = None
+                loss, dyt = self.dmol_loss_and_grad(out["logits"], x, lengths, quantize_channels, log_scale_min, scale=ce_scale)
+                out["loss"] = loss
+                grads = self.backward(x, gid, None, lengths, ext_dy=dyt, vq_scale=1.0, grad_sync=grad_sync)
+            elif self.g.has_encoder:
+                out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
+                                   layer_events=getattr(self, "_layer_events", None))
+            else:
+                out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
+                                           layer_events=getattr(self, "_layer_events", None), front_event=self._ev_wn)
                 self._fe = None
-            loss, dyt = self.dmol_loss_and_grad(out["logits"], x, lengths, quantize_channels, log_scale_min, scale=ce_scale)
-            out["loss"] = loss
-            grads = self.backward(x, gid, None, lengths, ext_dy=dyt, vq_scale=1.0, grad_sync=grad_sync)
-        elif self.g.has_encoder:
-            out = self.forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
-                               layer_events=getattr(self, "_layer_events", None))
-        else:
-            out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
-                                       layer_events=getattr(self, "_layer_events", None))
-            self._fe = None
-        if not self.g.scalar_input:
-            grads = self.backward(x, gid, x, lengths, loss_scale=ce_scale, vq_scale=1.0, grad_sync=grad_sync)
+            if not self.g.scalar_input:
+                grads = self.backward(x, gid, x, lengths, loss_scale=ce_scale, vq_scale=1.0, grad_sync=grad_sync)
+        except BaseException:
+            self.__dict__.pop("_early_pack", None)      # (a refused input: nothing of this step may be taken for the next call's)
+            self.__dict__.pop("_loss_done", None)
+            raise
         if grad_sync is not None:
             grad_sync.finish()
         if grad_hook is not None:
@@ -843,6 +907,9 @@ class WaeEngine:
                                            self.opt_step, lr, betas[0], betas[1], eps, weight_decay, clip_thresh, ema_decay,
                                            self.stream()), "clip_adam_ema")
         self.weights_dirty = True
+        ld = self.__dict__.pop("_loss_done", None)
+        if ld is not None:
+            self.join(ld[0])
         res = dict(ce=out["loss"], grad_norm=self.grad_norm[0])
         if self.g.has_encoder:
             res.update(vq_loss=out["vq_loss"], perp=out["perp"], loss=out["loss"] + out["vq_loss"])

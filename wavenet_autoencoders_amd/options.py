@@ -22,6 +22,9 @@ arguments (include/wae.h) from tools/.
     WAE_BWD_FUSED          auto      residual(l) + gate(l-1) of the backward sweep as one launch (csrc/glu_bwd.hip): auto = 16-bit engines
                                      where the kernel has an instantiation; 0: always the two wae_gemm_tm launches; 1: fp32 too
     WAE_BWD_FOLD_DC        1         0: dc = sum_l Wc_l^T dz_l as its own K = L * 2Hp launch instead of riding in the fused backward launches
+    WAE_SIDE               1         0: every launch of a train step on one stream (1: the step's independent side work -- the upsampling network
+                                     and the backward weight packing beside the forward weight packing, the front end's backward beside
+                                     the scatter of the weight gradients -- runs on side streams; engine.py: branch)
     WAE_CHAINS             auto      the gated stack and the backward sweep as two half-batch chains of launches on two streams, the second
                                      started half a launch late (engine.py: chain_plan): auto = 16-bit engines whose layer launch has >= 200
                                      workgroups; 1: always one chain of full-batch launches; 2: two chains whenever the batch has two clips
@@ -46,6 +49,7 @@ class EngineOptions:
     bwd_fused: str = "auto"
     bwd_fold_dc: bool = True
     chains: str = "auto"
+    side: bool = True
 
     @staticmethod
     def from_env() -> "EngineOptions":
@@ -62,7 +66,7 @@ class EngineOptions:
         chains = e("WAE_CHAINS", "auto")
         if chains not in ("auto", "1", "2"):
             raise ValueError(f"WAE_CHAINS={chains!r}: 'auto', '1' or '2'")
-        return EngineOptions(chains=chains, dp_wire=wire, tn_stream=e("WAE_TN_STREAM", "1") != "0", tn_static=e("WAE_TN_STATIC", "1") != "0",
+        return EngineOptions(chains=chains, side=e("WAE_SIDE", "1") != "0", dp_wire=wire, tn_stream=e("WAE_TN_STREAM", "1") != "0", tn_static=e("WAE_TN_STATIC", "1") != "0",
                              tn_static_head=e("WAE_TN_STATIC_HEAD", "1") != "0", tn_swap=e("WAE_TN_SWAP", "1") != "0", head_split=e("WAE_HEAD_SPLIT", "1") != "0",
                              head_wide=e("WAE_HEAD_WIDE", "0") == "1", glu_pair=pair, dp_split=e("WAE_DP_SPLIT", "1") != "0",
                              ar_coop=e("WAE_AR_COOP", "1") != "0", ar_coop_c=int(e("WAE_AR_COOP_C", "32")),
