@@ -249,15 +249,24 @@ class WaeEngine:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: self.view(k).detach().clone() for k in self.lay.offsets}
 
-    def prepare_weights(self):
-        """K14 weight norm + fragment packing; call after every parameter update."""
+    def prepare_weights(self, side: bool = False):
+        """K14 weight norm + fragment packing; call after every parameter update.  side (train_step): the packing runs on a side stream
+        behind weight norm -- what needs the effective weights only (an encoder, the upsampling network, the hoisted global
+        conditioning) goes ahead on the main stream beside it; decoder_forward joins in front of the first launch that reads a packed
+        array."""
         lib, st, g, lay = self.lib, self.stream(), self.g, self.lay
         L.check(lib.wae_weight_norm_fwd(L.ptr(self.params), L.ptr(self.eff), lay.total, L.ptr(self.wn_v), L.ptr(self.wn_g),
                                         L.ptr(self.wn_c), len(lay.wn_cols), st), "weight_norm_fwd")
         self._ev_wn = None
-        if self.opt.side and self.device.type == "cuda":      # the effective weights exist: what only needs them may start (train_step)
+        if side and self.opt.side and self.device.type == "cuda":      # the effective weights exist: what only needs them may start
             self._ev_wn = torch.cuda.Event()
             self._ev_wn.record(torch.cuda.current_stream(self.device))
+        with (self.branch(1, after=self._ev_wn) if self._ev_wn is not None else contextlib.nullcontext([None])) as self._pack_done:
+            self._pack_weights()
+        self.weights_dirty = False
+
+    def _pack_weights(self):
+        lib, st, g, lay = self.lib, self.stream(), self.g, self.lay
         jobs = getattr(self, "_pack_jobs", None)
         if jobs is None:       # the pointers never change: one host array, one launch for every family
             es = self.w_glu.element_size()
@@ -278,7 +287,6 @@ class WaeEngine:
         L.check(lib.wae_pack_gather_multi(jobs, len(jobs), st), "pack weights")
         L.check(lib.wae_sum_rows(L.ptr(self.eff), lay.off("wavenet.conv_layers.0.conv1x1_skip.bias"), lay.layer_stride,
                                  g.layers, g.S, g.Sp, L.ptr(self.b_head), st), "sum skip bias")
-        self.weights_dirty = False
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, B: int, T: int, train: bool = False) -> dict:
@@ -401,8 +409,7 @@ class WaeEngine:
     def decoder_forward(self, x: torch.Tensor, c: Optional[torch.Tensor], gid: Optional[torch.Tensor],
                         targets: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
                         want_logits: bool = True, train: bool = False, c_is_upsampled: bool = False,
-                        gvec: Optional[torch.Tensor] = None, layer_events: Optional[list] = None, dropout_on: bool = True,
-                        front_event=None):
+                        gvec: Optional[torch.Tensor] = None, layer_events: Optional[list] = None, dropout_on: bool = True):
         """WaveNet.forward (wavenet.py:164-216) on class ids.
 
         x: (B,T) int32 class ids (mulaw-quantize) or (B,T) fp32 scalars (scalar_input).
@@ -415,35 +422,32 @@ class WaeEngine:
         g, lib, st = self.g, self.lib, self.stream()
         B, T = x.shape
         ws = self.workspace(B, T, train)
-        # (front_event, train_step: c is an input of the step and `front_event` fired when weight norm had produced the effective
-        #  weights -- the upsampling network and the hoisted global conditioning then run on a side stream beside the weight packing
-        #  that prepare_weights() queued behind it, and meet the main stream in front of the gated stack)
-        front = self.branch(0, after=front_event) if (front_event is not None and self.opt.side) else contextlib.nullcontext([None])
-        with front as front_done:
-            # local conditioning
-            if g.Ccp:
-                if c is None:
-                    raise ValueError("model has local conditioning but c is None")
-                if c_is_upsampled or not g.upsample_scales:
-                    if c.shape[-1] != T:
-                        raise Exception(f"c {tuple(c.shape)} x T={T}")           # wavenet.py:198-200
-                    L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(ws["c_up"]), B, g.Cc, T, g.Ccp, self.dt, self.stream()), "to_btc")
-                else:
-                    Tup = (c.shape[-1] - 2 * g.cin_pad) * int(np.prod(g.upsample_scales))
-                    if Tup != T:
-                        raise Exception(f"c {tuple(c.shape)} upsamples to {Tup} != T={T}")  # wavenet.py:198-200
-                    self.upsample_forward(c.float(), ws["c_up"])
-            # global conditioning folded with the conv bias
-            wg_off = self.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
-            emb_off = self.lay.offsets.get("wavenet.embed_speakers.weight", 0)
-            use_gid = gid is not None and "wavenet.embed_speakers.weight" in self.lay.offsets
-            if gid is not None:
-                gid = gid.to(torch.int32).contiguous()
-            L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
-                                      self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
-                                      L.ptr(gid) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
-                                      L.ptr(ws["zb"]), B, g.layers, g.G, g.Hp, max(g.Cg, 0), int(g.n_speakers or 0), L.ptr(self.err), self.stream()),
-                    "gproj")
+        # global conditioning folded with the conv bias (first: in a train step the launches below run beside the weight packing)
+        wg_off = self.lay.off("wavenet.conv_layers.0.conv1x1g.weight_v") if g.Cg > 0 else -1
+        emb_off = self.lay.offsets.get("wavenet.embed_speakers.weight", 0)
+        use_gid = gid is not None and "wavenet.embed_speakers.weight" in self.lay.offsets
+        if gid is not None:
+            gid = gid.to(torch.int32).contiguous()
+        L.check(lib.wae_gproj_fwd(L.ptr(self.eff), wg_off if (gid is not None or gvec is not None) else -1,
+                                  self.lay.off("wavenet.conv_layers.0.conv.bias"), self.lay.layer_stride,
+                                  L.ptr(gid) if use_gid else None, emb_off, L.ptr(gvec) if gvec is not None else None,
+                                  L.ptr(ws["zb"]), B, g.layers, g.G, g.Hp, max(g.Cg, 0), int(g.n_speakers or 0), L.ptr(self.err), self.stream()),
+                "gproj")
+        # local conditioning
+        if g.Ccp:
+            if c is None:
+                raise ValueError("model has local conditioning but c is None")
+            if c_is_upsampled or not g.upsample_scales:
+                if c.shape[-1] != T:
+                    raise Exception(f"c {tuple(c.shape)} x T={T}")           # wavenet.py:198-200
+                L.check(lib.wae_to_btc(L.ptr(c.contiguous().float()), L.ptr(ws["c_up"]), B, g.Cc, T, g.Ccp, self.dt, self.stream()), "to_btc")
+            else:
+                Tup = (c.shape[-1] - 2 * g.cin_pad) * int(np.prod(g.upsample_scales))
+                if Tup != T:
+                    raise Exception(f"c {tuple(c.shape)} upsamples to {Tup} != T={T}")  # wavenet.py:198-200
+                self.upsample_forward(c.float(), ws["c_up"])
+        # (train_step: the packing of the weights runs on a side stream beside the launches above -- prepare_weights(side=True))
+        self.join(self.__dict__.pop("_pack_done", [None])[0])
         # first conv
         if g.scalar_input:
             xs = x.contiguous().float()
@@ -453,7 +457,6 @@ class WaeEngine:
             xi = x.to(torch.int32).contiguous()
             L.check(lib.wae_first_conv_fwd(L.ptr(xi), None, L.ptr(self.first_tab), L.ptr(self.first_bias), L.ptr(ws["x"][0]),
                                            B * T, g.Rp, g.O, self.dt, L.ptr(self.err), st), "first_conv")
-        self.join(front_done[0])
         # gated residual stack
         es = self.w_glu.element_size()
         # dropout (modules.py:127-128) only in a train-mode forward of a model in training mode; eval is the identity
@@ -534,13 +537,7 @@ class WaeEngine:
         out = dict(logits=logits, nll=None, loss=None)
         if tg is not None:
             ln = lengths.to(self.device, torch.int32).contiguous() if lengths is not None else None
-            if front_event is not None and self.opt.side:
-                # train_step: nothing on the device waits for the loss value -- its reduction leaves the main stream (train_step joins)
-                with self.branch(1) as self._loss_done:
-                    L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, self.stream()), "masked_mean")
-                self._ln_keep = ln
-            else:
-                L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, st), "masked_mean")
+            L.check(lib.wae_masked_mean(L.ptr(ws["nll"]), L.ptr(ln), L.ptr(ws["loss"]), B, T, st), "masked_mean")
             out["nll"] = ws["nll"]
             out["loss"] = ws["loss"][0]
         return out
@@ -858,7 +855,7 @@ class WaeEngine:
         Class-id input: masked cross-entropy; scalar input (hparams input_type "raw"): discretized mixture of logistics."""
         if not hasattr(self, "exp_avg"):
             self.init_optimizer()
-        self.prepare_weights()
+        self.prepare_weights(side=True)
         # one int32 copy of the ids for forward, targets and backward (each of them converts what it is handed: four 5-us launches)
         if not self.g.scalar_input and x.dtype != torch.int32:
             x = x.to(self.device, torch.int32).contiguous()
@@ -870,11 +867,13 @@ class WaeEngine:
             gid = self._gid32
         from . import backward as BW
         if self._ev_wn is not None:
-            # the backward's weight packing (+ the clearing of the step's gradient accumulators) needs the effective weights only: on a
-            # side stream of its own, now, instead of between the head's forward and backward; decoder_backward waits for it
-            with self.branch(1, after=self._ev_wn) as early:
+            # the backward's weight packing (+ the clearing of the step's gradient accumulators) needs the effective weights only:
+            # behind the forward's packing on the same side stream, instead of between the head's forward and backward;
+            # decoder_backward waits for it.  (Queued when the first conv is enqueued instead -- beside the first layer -- it made that
+            # layer's launch 45 us longer: 20 us per step worse.  Two side streams carry everything: a process has few hardware
+            # queues, and streams that share one run one after the other -- four chains of layer launches ran at half the speed of two.)
+            with self.branch(1, after=self._ev_wn) as self._early_pack:
                 BW.pack_bwd_weights(self)
-            self._early_pack = early
         try:
             if self.g.scalar_input:
                 fwd = self.forward if self.g.has_encoder else self.decoder_forward
@@ -889,13 +888,13 @@ class WaeEngine:
                                    layer_events=getattr(self, "_layer_events", None))
             else:
                 out = self.decoder_forward(x, c, gid, targets=x, lengths=lengths, want_logits=False, train=True,
-                                           layer_events=getattr(self, "_layer_events", None), front_event=self._ev_wn)
+                                           layer_events=getattr(self, "_layer_events", None))
                 self._fe = None
             if not self.g.scalar_input:
                 grads = self.backward(x, gid, x, lengths, loss_scale=ce_scale, vq_scale=1.0, grad_sync=grad_sync)
         except BaseException:
             self.__dict__.pop("_early_pack", None)      # (a refused input: nothing of this step may be taken for the next call's)
-            self.__dict__.pop("_loss_done", None)
+            self.join(self.__dict__.pop("_pack_done", [None])[0])
             raise
         if grad_sync is not None:
             grad_sync.finish()
@@ -907,9 +906,6 @@ class WaeEngine:
                                            self.opt_step, lr, betas[0], betas[1], eps, weight_decay, clip_thresh, ema_decay,
                                            self.stream()), "clip_adam_ema")
         self.weights_dirty = True
-        ld = self.__dict__.pop("_loss_done", None)
-        if ld is not None:
-            self.join(ld[0])
         res = dict(ce=out["loss"], grad_norm=self.grad_norm[0])
         if self.g.has_encoder:
             res.update(vq_loss=out["vq_loss"], perp=out["perp"], loss=out["loss"] + out["vq_loss"])
