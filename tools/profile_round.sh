@@ -4,17 +4,20 @@ TAG=${1:-rXX}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
+# (PROFILE_ONLY=1: only the rocprofv3 passes -- the bench lines of a tag already exist)
+if [ -z "$PROFILE_ONLY" ]; then
 python3 bench.py > $OUT/bench_train.json 2> $OUT/bench_train.err
 python3 bench.py --mode forward --no-cpu --no-ar > $OUT/bench_forward.json 2> $OUT/bench_forward.err
 python3 bench.py --dtype fp16 --no-cpu --no-ar --no-fp32 > $OUT/bench_fp16.json 2> $OUT/bench_fp16.err
 # BASELINE configs 3 and 5 (the two 8-GPU configurations), the per-GPU shard of each: the full line (roofline family, roofline_step, cpu_baseline)
 python3 bench.py --config c3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 python3 bench.py --config c5 --steps 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+fi
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-ar --no-fp32 > $OUT/profiled_line.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-ar --no-fp32 --no-sub > $OUT/profiled_line.json 2> $OUT/stats.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fwd -- python3 $ROOT/bench.py --mode forward --steps 10 --warmup 3 --no-cpu --no-ar > $OUT/profiled_forward_line.json 2> $OUT/stats_fwd.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-ar --no-fp32 > $OUT/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-ar --no-fp32 --no-sub > $OUT/pmc_$c.log 2>&1
 done
 cd $ROOT
 python3 - <<PY
@@ -39,7 +42,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             res.setdefault(k, {})[c] = sum(v) / len(v)
 out = {k: {"fetch_kb_raw": v.get("FETCH_SIZE", 0.0), "write_kb": v.get("WRITE_SIZE", 0.0),
            "hbm_bytes_per_launch": (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024} for k, v in res.items()}
-json.dump({"csrc_hash": bench.csrc_hash(), "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-ar (two separate passes)",
+json.dump({"csrc_hash": bench.csrc_hash(), "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-ar --no-fp32 --no-sub (two separate passes)",
            "correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 1/2 of the bytes of 16-B/lane streaming reads on gfx950 -> doubled; WRITE_SIZE exact; unit KB -> x1024",
            "kernels": out}, open("$OUT/pmc_traffic.json", "w"), indent=1)
 PY
