@@ -567,13 +567,16 @@ def test_two_chains_are_bitwise_one_chain(case):
                            loss=out["loss"].detach().clone(), dz=ws["dz"].clone(), gx=[t_.clone() for t_ in ws["gx"]], dc=dc.clone(),
                            grads=BW.finish_grads(eng).clone())
         torch.cuda.synchronize()
+        # ... and the inference forward (two ping-pong buffers instead of one per layer, no z)
+        got[chains]["logits"] = eng.decoder_forward(x, c, g, train=False, want_logits=True)["logits"].clone()
+        torch.cuda.synchronize()
         lay = eng.lay
         del eng
         torch.cuda.empty_cache()
     one, two = got["1"], got[force]
     bits = lambda t_: t_.contiguous().view(torch.int16 if t_.element_size() == 2 else torch.int32)  # noqa: E731
     assert float(one["dz"].float().abs().max()) > 0 and float(one["u"].float().abs().max()) > 0
-    for k in ("u", "nll", "loss", "dz", "dc"):
+    for k in ("u", "nll", "loss", "dz", "dc", "logits"):
         assert torch.equal(bits(one[k]), bits(two[k])), k
     for k in ("x", "z", "gx"):
         for i, (a, b_) in enumerate(zip(one[k], two[k])):
