@@ -528,7 +528,7 @@ def test_two_chains_are_bitwise_one_chain(case):
     launch late (engine.chain_plan, include/wae.h: wae_stream_delay) against one chain of full-batch launches.  Same kernels, same
     arithmetic per clip: every saved activation of the forward, the loss terms, dz of every layer, every dx-hat and dc are compared
     BITWISE; the weight gradients (one launch downstream of both chains, fp32 atomics) to the tolerance of two runs of that launch.
-    C2 at full size (auto: 250 workgroups per launch), an odd batch of short ragged clips (forced: 2 + 1 clips), the hps/vqwae.json
+    C2 at full size (auto: 250 workgroups per launch -- the backward sweep; its forward stack stays on one chain), an odd batch of short ragged clips (forced: 2 + 1 clips), the hps/vqwae.json
     decoder, and a 512-wide fp16 model whose sweep runs the two launches per layer (forced)."""
     from wavenet_autoencoders_amd import Geometry
     from wavenet_autoencoders_amd import backward as BW
@@ -557,7 +557,7 @@ def test_two_chains_are_bitwise_one_chain(case):
         eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
         eng.opt.chains = chains
         eng.load_state_dict(sd, strict=False)
-        assert (eng.chain_plan(B, T) is not None) == (chains != "1")
+        assert (eng.chain_plan(B, T, backward=True) is not None) == (chains != "1")
         out = eng.decoder_forward(x, c, g, targets=x, lengths=lengths.cuda(), train=True, want_logits=False)
         fw = eng._ws[(B, T, True)]
         dc = BW.decoder_backward(eng, x, x, lengths, g)

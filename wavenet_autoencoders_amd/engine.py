@@ -163,13 +163,18 @@ class WaeEngine:
         ~30 of a 77-us backward launch in which nothing computes -- and a launch with more workgroups than CUs (C5: 320) ends with a
         quarter-full second round.  One launch cannot be de-phased against itself (it ends with its late half: profiles/
         r06_pair8_experiments.txt); two chains of launches can, and two 160-workgroup launches side by side fill C5's machine.
-        Measured on whole train steps (profiles/r06_chains.txt): C5 37.5 -> 33.4 ms, C2 5.26 -> 5.19 ms; hps/vqwae.json's 160-workgroup
-        launches gain nothing, so `auto` leaves them alone.  Same kernels, same arithmetic per clip: results are bit for bit those of
-        one chain (tests/test_gpu_backward.py::test_two_chains_are_bitwise_one_chain)."""
+        Measured on whole train steps (profiles/r06_chains.txt): C5 37.5 -> 33.4 ms (both directions), C2 5.26 -> 5.19 ms (the backward
+        sweep only: `auto` leaves a forward stack of one round of workgroups on one chain); hps/vqwae.json's 160-workgroup launches gain
+        nothing, so `auto` leaves them alone.  Same kernels, same arithmetic per clip: results are bit for bit those of one chain
+        (tests/test_gpu_backward.py::test_two_chains_are_bitwise_one_chain)."""
         mode = self.opt.chains
         if mode == "1" or B < 2 or self.dt not in (L.WAE_BF16, L.WAE_F16):
             return None
-        if mode == "auto" and B * ((T + 255) // 256) < 200:
+        tiles = B * ((T + 255) // 256)
+        if mode == "auto" and (tiles < 200 or (not backward and tiles <= 256)):
+            # (the FORWARD stack within one round of the machine gains nothing from two chains: C2 training 5.166-5.189 ms per step with,
+            #  5.148-5.159 without, layer 56.7 against 55.8 us; inference 1.475-1.482 against 1.457-1.463 ms.  Beyond one round -- C5 -- two
+            #  chains win in either direction.)
             return None
         g = self.g
         delay = getattr(self, "chain_delay_us", None)        # (tools)
@@ -472,6 +477,7 @@ class WaeEngine:
             e0.record(torch.cuda.current_stream(self.device))
         # two half-batch chains of the same launches (chain_plan): not with dropout (its mask generator counts elements of the full batch)
         plan = self.chain_plan(B, T) if (drop == 0 and not (train and "xd" in ws)) else None
+
         parts = [(0, B, st)]
         if plan is not None:
             side = self.chain_fork(plan[1])

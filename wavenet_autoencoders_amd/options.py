@@ -25,9 +25,10 @@ arguments (include/wae.h) from tools/.
     WAE_SIDE               1         0: every launch of a train step on one stream (1: the step's independent side work -- the upsampling network
                                      and the backward weight packing beside the forward weight packing, the front end's backward beside
                                      the scatter of the weight gradients -- runs on side streams; engine.py: branch)
-    WAE_CHAINS             auto      the gated stack and the backward sweep as two half-batch chains of launches on two streams, the second
-                                     started half a launch late (engine.py: chain_plan): auto = 16-bit engines whose layer launch has >= 200
-                                     workgroups; 1: always one chain of full-batch launches; 2: two chains whenever the batch has two clips
+    WAE_CHAINS             auto      the backward sweep (and, beyond one round of workgroups, the gated stack) as two half-batch chains of launches
+                                     on two streams (engine.py: chain_plan): auto = 16-bit engines whose layer launch has >= 200 workgroups
+                                     (forward: > 256); 1: always one chain of full-batch launches; 2: two chains in both directions whenever
+                                     the batch has two clips
 """
 import os
 from dataclasses import dataclass
