@@ -411,11 +411,14 @@ typedef struct wae_tm_desc {
 } wae_tm_desc;
 #define WAE_TM_INTERLEAVE 1
 #define WAE_TM_ONE_WG 2   /* bf16 gate-backward / residual / ReLU-backward launches: one 4-wave workgroup per CU with the 8 KiB
-                             staging tiles instead of two per CU (same results; an A/B switch per launch).  It also keeps a mode-3
-                             launch on this generic kernel where the wave-specialised one (below) has an instantiation. */
+                             staging tiles instead of two per CU (same results; an A/B switch per launch).  It also keeps a mode-1 / -2 / -3
+                             launch on this generic kernel where csrc/gemm_tm8.hip (below) has an instantiation. */
 /* Mode 3 with ONE source, no shift, 16-bit storage, M a multiple of 256 and an even chunk count (the head's skip contraction, the
  * wide head's h0 / h1 launches) runs on csrc/gemm_tm8.hip since round 6: 8 consumer + 4 loader waves per workgroup, 256 time columns,
  * both operands by LDS-DMA -- same packed stream, same accumulation order, bit-identical outputs (170 against 196 us at C2). */
+/* Modes 1 (interleaved taps of ONE array, M a multiple of 256) and 2 (M = Hp in {256, 192, 128}) in 16-bit storage with an even chunk
+ * count run on gemm_tm8x_kernel of the same file since round 6: 256 columns per workgroup, both operand streams by LDS-DMA, the
+ * eight waves sharing the requests (csrc/glu_bwd8.hip's schedule); bit for bit the generic kernel's results. */
 /* (flag value 4 was WAE_TM_BLDS, the 8-wave LDS-staged-operand shape of rounds 3-4: measured not faster, removed in round 5) */
 int wae_gemm_tm(const wae_tm_desc* d, const void* const* src_host, const int64_t* src_stride_host,
                 const int32_t* src_cols_host, const int32_t* src_shift_host, const void* w_packed, void* out,

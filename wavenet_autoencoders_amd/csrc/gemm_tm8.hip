@@ -232,6 +232,253 @@ __global__ void __launch_bounds__(768, 1) gemm_tm8s_kernel(TmArgs p) {
 
 namespace {
 
+// what a loader wave of gemm_tm8x_kernel needs to place piece k of X(cbase + J) (by value: a capturing lambda of this size ended up
+// with its captures in scratch memory in one instantiation, and a reload with s_waitcnt vmcnt(0) in front of every request)
+struct Tm8xLoader {
+  unsigned lds0, rb0, rb1, swz, lane16;
+  int rowl, wq, nsrc, nq0, nh;
+  bool wl;
+  const char* wslice;
+  i32x4 srd0, srd1;
+};
+
+// piece K of X(c), c = cbase + J0 with cbase a multiple of 4 and J0 a compile-time constant: ring slot, tile and k-block half of c follow
+// from J0 (the bodies are 4 half-chunks long)
+template <int NT, int MODE, int J0, int K>
+__device__ __forceinline__ void tm8x_issue(const Tm8xLoader& L, int cbase, int sh0, int sh1, int sh2) {
+  constexpr int J = J0;
+  // (the row shifts by value: as fields of L the select below becomes an indexed load, and the whole of L stays in scratch memory)
+  constexpr int NM = NT, HCB = NM * 2 * 1024, NSW = 4, NTB = 4, TILEB = 8 * 2048, RING = NSW * HCB, PPW = NM / 2;
+  constexpr int slot = J % NSW, tile = J % NTB, hk = J % 2;
+  const int c = cbase + J;
+  if (c >= L.nh) return;
+  if (L.wl) {
+    if constexpr (K < PPW) {
+      const char* src = L.wslice + ((int64_t)c * HCB + (L.wq * PPW + K) * 1024) + L.lane16;
+      const unsigned dst = L.lds0 + slot * HCB + (L.wq * PPW + K) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
+    }
+  } else {
+    // (wave-uniform values that hipcc may keep in vector registers: the asm's scalar operands are made scalar explicitly)
+    auto sgpr = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    const unsigned m0v = sgpr(L.lds0 + RING + tile * TILEB + (2 * L.wq + (K >> 1)) * 2048 + (K & 1) * 1024);
+    const int q = c >> 1;
+    bool second = false;
+    int cb, shift;
+    if constexpr (MODE == TM_RESIDUAL) {     // chunk q: tap q % nsrc of column block q / nsrc (TM_INTERLEAVE), every tap the same array
+      cb = q / L.nsrc;
+      const int tap = q - cb * L.nsrc;
+      shift = tap == 0 ? sh0 : (tap == 1 ? sh1 : sh2);
+    } else {                                 // the sources one after the other
+      second = q >= L.nq0;
+      cb = second ? q - L.nq0 : q;
+      shift = second ? sh1 : sh0;
+    }
+    const unsigned vo = (unsigned)(L.rowl + 16 * K + shift) * (second ? L.rb1 : L.rb0) + L.swz;
+    const unsigned so = sgpr((unsigned)(cb * 128 + hk * 64));
+    i32x4 sr;
+    sr.x = (int)sgpr((unsigned)(second ? L.srd1.x : L.srd0.x)); sr.y = (int)sgpr((unsigned)(second ? L.srd1.y : L.srd0.y));
+    sr.z = (int)sgpr((unsigned)(second ? L.srd1.z : L.srd0.z)); sr.w = (int)sgpr((unsigned)L.srd0.w);
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(vo), "s"(sr), "s"(so) : "m0");
+  }
+}
+
+}  // namespace
+
+// ---- the backward sweep's two launches on the same machinery (round 6) --------------------------------------------------------------------
+// TM_RESIDUAL with interleaved taps (dx-hat of a layer: K = taps x 2Hp over shifted rows of dz, output rows in slices of 256) and
+// TM_GATE_BWD (du -> dz of a layer: K = Rp + Sp over dx-hat and dskip, Hp <= 256 output rows, gate derivative from the saved z): what the
+// 16-bit sweep runs where csrc/glu_bwd8.hip has no instantiation (Rp = 512: BASELINE C5), on its top and bottom layer, and with
+// WAE_BWD_FUSED=0.  The registers do not allow loader waves of their own here (eight accumulator tiles + the epilogue's rows), so the
+// eight waves share the requests as in glu_bwd_pair8_kernel: waves 0-3 the weight pieces (4-slot ring of K = 32 half-chunks, three
+// ahead), waves 4-7 the operand pieces (16 rows x 64 bytes through per-clip descriptors into four swizzled tiles, four ahead), issued
+// between their MFMAs; one workgroup barrier per half-chunk.  Same packed weight streams, fragment layouts, accumulation order and
+// epilogue arithmetic as gemm_tm_kernel: bit-identical results (tests/test_gpu_tm8.py).
+template <typename E, int NT, int MODE>
+__global__ void __launch_bounds__(512, 1) gemm_tm8x_kernel(TmArgs p) {
+  using T_ = ET<E>;
+  using frag = typename T_::frag;
+  static_assert(sizeof(E) == 2 && T_::CK == 64 && (MODE == TM_RESIDUAL || MODE == TM_GATE_BWD) && NT % 2 == 0 && NT <= 8, "16-bit storage");
+  constexpr int NW = 8, NM = NT, ES = 2, PD = 4;
+  constexpr int HCB = NM * 2 * 1024;
+  constexpr int NSW = 4, DW = 3, NTB = 4, DB = 4;
+  constexpr int TILEB = NW * 2048, RING = NSW * HCB, TILES = NTB * TILEB;
+  constexpr int BODY = 4, NSTEP = 2 * NM, NG = BODY * NSTEP, PPW = NM / 2, SP = NSTEP / 4;
+  constexpr int STGB = 4096;
+  static_assert(RING + TILES <= 160 * 1024 && NW * STGB <= TILES && PPW <= 4 && 4 * SP <= NSTEP && 2 + PD < NSTEP, "LDS budget; four issue points per half-chunk");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  constexpr int TW = NW * 32;
+  const int tiles_per_b = (p.T + TW - 1) / TW;
+  const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int b = tile_id / tiles_per_b;
+  const int t0 = (tile_id % tiles_per_b) * TW;
+  const int t0w = t0 + wave * 32;
+  const int rows_valid = min(max(p.T - t0w, 0), 32);
+  const int slice = blockIdx.y, col0 = slice * NT * 32;
+  const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+  const int nsrc = p.nsrc;
+  const int nq0 = p.src_cols[0] / 64;
+  const int nq = MODE == TM_RESIDUAL ? nsrc * nq0 : nq0 + (nsrc > 1 ? p.src_cols[1] : 0) / 64;
+  const int nh = 2 * nq, nit = nh / BODY;
+  const char* wslice = p.w + (int64_t)slice * nh * HCB;
+
+  // ---- loader roles ------------------------------------------------------------------------------------------------------------------
+  const bool wl = wave < 4;
+  const int wq = wave & 3;
+  const unsigned lane16 = lane * 16;
+  // operand: this loader's piece k = rows 16 (k & 1) .. +16 of consumer wave 2 wq + (k >> 1); lane -> row (lane >> 2), 16-byte column
+  // (lane & 3) ^ ((lane >> 4) & 3)   [= col ^ ((row >> 2) & 3): the tile's swizzle, applied on the global side]
+  const int rowl = t0 + 64 * wq + (lane >> 2);
+  const unsigned swz = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+  // (no run-time index into the kernel argument: that would put a copy of it into scratch memory)
+  const bool two = MODE == TM_GATE_BWD && nsrc > 1;
+  const char* src1 = two ? p.src[1] : p.src[0];
+  const int64_t stride1 = two ? p.src_stride[1] : p.src_stride[0];
+  const int cols1 = two ? p.src_cols[1] : p.src_cols[0];
+  const unsigned rb0 = (unsigned)(p.src_stride[0] * ES), rb1 = (unsigned)(stride1 * ES);
+  // (a source may be a column slice of a wider array: the clip's descriptor ends with the last row's own columns)
+  const i32x4 srd0 = make_srd8(p.src[0] + (int64_t)b * p.T * rb0, (unsigned)p.T * rb0 - (unsigned)(p.src_stride[0] - p.src_cols[0]) * ES);
+  const i32x4 srd1 = make_srd8(src1 + (int64_t)b * p.T * rb1, (unsigned)p.T * rb1 - (unsigned)(stride1 - cols1) * ES);
+  const int sh0 = p.src_shift[0], sh1 = p.src_shift[1], sh2 = p.src_shift[2];
+  const Tm8xLoader ld{lds0, rb0, rb1, swz, lane16, rowl, wq, nsrc, nq0, nh, wl, wslice, srd0, srd1};
+  auto issue = [&](int cbase, auto jc, auto kc) __attribute__((always_inline)) {      // cbase: a multiple of 4
+    tm8x_issue<NT, MODE, decltype(jc)::value, decltype(kc)::value>(ld, cbase, sh0, sh1, sh2);
+  };
+  auto issue_all = [&](int cbase, auto jc) __attribute__((always_inline)) { static_for8<0, 4>([&](auto kc) { issue(cbase, jc, kc); }); };
+  // a loader's counted wait at the top of half-chunk c: everything through X(c + 1) has landed, X(c + 2) .. X(c + D - 1) may be in flight.
+  // At the end of the stream issue() drops X(>= nh): the same count would then leave pieces of X(c + 1) in flight -- the last D - 1
+  // half-chunks drain instead (tail).
+  auto top = [&](bool tail) __attribute__((always_inline)) {
+    if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wl) wait_vm8<(DW - 2) * PPW>();
+    else wait_vm8<(DB - 2) * 4>();
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- consumer side -----------------------------------------------------------------------------------------------------------------
+  unsigned a_base = lds0 + lane16;
+  auto a_read = [&](auto jc, auto ic, frag& dst) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value, I = decltype(ic)::value;
+    lds_read_off<(j % NSW) * HCB + I * 1024>(dst, a_base);
+  };
+  unsigned b_addr[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) b_addr[f] = lds0 + RING + wave * 2048 + n * 64 + (((2 * f + h) ^ ((n >> 2) & 3)) << 4);
+  auto b_read = [&](auto tlc, frag (&dst)[2]) __attribute__((always_inline)) {
+    constexpr int tl = decltype(tlc)::value;
+    lds_read_off<tl * TILEB>(dst[0], b_addr[0]);
+    lds_read_off<tl * TILEB>(dst[1], b_addr[1]);
+  };
+
+  // ---- prologue: X(0) .. X(D - 1); half-chunk "-1": X(0) visible, the first operand fragments into registers --------------------------
+  static_for8<0, DB>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < DW) { if (wl) issue_all(0, jc); }
+    if (!wl) issue_all(0, jc);
+  });
+  if (wl) wait_vm8<(DW - 1) * PPW>(); else wait_vm8<(DB - 1) * 4>();
+  __builtin_amdgcn_s_barrier();
+  frag Bf[2][2];
+  b_read(IntC<0>{}, Bf[0]);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bf[0][0]), "+v"(Bf[0][1]));
+
+  f32x16 acc[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  for (int it = 0; it < nit; ++it) {
+    const int c0 = it * BODY;
+    frag a[PD];
+    static_for8<0, BODY>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      top(c0 + j + DB > nh);
+      asm volatile("" : "+v"(Bf[j % 2][0]), "+v"(Bf[j % 2][1]));
+      if constexpr (j == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for8<0, PD>([&](auto ic) { a_read(IntC<0>{}, ic, a[decltype(ic)::value]); });
+      }
+      static_for8<0, NSTEP>([&](auto ic) {
+        constexpr int I = decltype(ic)::value, G = j * NSTEP + I, AI = G % PD;
+        constexpr int remaining = NG - 1 - G;
+        constexpr int younger_a = remaining < PD - 1 ? remaining : PD - 1;
+        constexpr int extra = (I >= 2 && I <= 1 + PD) ? 2 : 0;          // the operand-fragment reads of step 1
+        lds_wait<younger_a + extra>(a[AI]);
+        mma32(acc[I % NM], a[AI], Bf[j % 2][I / NM]);
+        if constexpr (remaining >= PD) {
+          constexpr int G2 = G + PD;
+          a_read(IntC<G2 / NSTEP>{}, IntC<G2 % NSTEP>{}, a[AI]);
+        }
+        if constexpr (I == 1) b_read(IntC<(j + 1) % NTB>{}, Bf[(j + 1) % 2]);
+        if constexpr (I % SP == 0 && I / SP < 4) {
+          if (wl) issue(c0, IntC<j + DW>{}, IntC<I / SP>{}); else issue(c0, IntC<j + DB>{}, IntC<I / SP>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();      // every wave is done with ring and tiles: the ring becomes the staging area
+  if (rows_valid <= 0) return;
+  int le = lane;
+  asm volatile("" : "+v"(le));
+  char* stg = smem + wave * STGB;
+  f32x4 fa[8], fb[8];
+  if constexpr (MODE == TM_RESIDUAL) {
+    // out = alpha * (acc + res[t])   (csrc/gemm_tm.hip: the paired residual epilogue)
+    const char* arow = p.aux + (((int64_t)b * p.T + t0w) * p.aux_stride + col0) * ES;
+    char* orow = p.out + (((int64_t)b * p.T + t0w) * p.out_stride + col0) * ES;
+    stage_fetch_pass<E, 2>(fa, arow, p.aux_stride * ES, rows_valid, le);
+#pragma unroll
+    for (int pr = 0; pr < NT / 2; ++pr) {
+      f32x16 res[2];
+      stage_unpack_pass<E, 2, 128>(stg, res, fa, le);
+      if (pr + 1 < NT / 2) stage_fetch_pass<E, 2>(fa, arow + (pr + 1) * 64 * ES, p.aux_stride * ES, rows_valid, le);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[2 * pr + i][r] = p.alpha * (acc[2 * pr + i][r] + res[i][r]);
+      stage_store_pass<E, 2, 128>(stg, &acc[2 * pr], orow + pr * 64 * ES, p.out_stride * ES, rows_valid, le);
+    }
+  } else {
+    // gate backward (modules.py:154: u = tanh(a) * sigmoid(b)):  da = du * s * (1 - th^2),  db = du * th * s * (1 - s)
+    const char* zrow = p.aux + ((int64_t)b * p.T + t0w) * p.aux_stride * ES;
+    char* orow = p.out + ((int64_t)b * p.T + t0w) * p.out_stride * ES;
+    stage_fetch_pass<E, 2>(fa, zrow, p.aux_stride * ES, rows_valid, le);
+    stage_fetch_pass<E, 2>(fb, zrow + (int64_t)NT * 32 * ES, p.aux_stride * ES, rows_valid, le);
+#pragma unroll
+    for (int pr = 0; pr < NT / 2; ++pr) {
+      f32x16 za[2], zg[2];
+      stage_unpack_pass<E, 2, 128>(stg, za, fa, le);
+      stage_unpack_pass<E, 2, 128>(stg, zg, fb, le);
+      if (pr + 1 < NT / 2) {
+        stage_fetch_pass<E, 2>(fa, zrow + (pr + 1) * 64 * ES, p.aux_stride * ES, rows_valid, le);
+        stage_fetch_pass<E, 2>(fb, zrow + ((int64_t)NT * 32 + (pr + 1) * 64) * ES, p.aux_stride * ES, rows_valid, le);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ea = __builtin_amdgcn_exp2f(fmaxf(za[i][r], -15.0f) * -2.885390081777927f);
+          const float th = (1.0f - ea) * fast_rcp(1.0f + ea);
+          const float sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(zg[i][r] * -1.4426950408889634f));
+          const float du = acc[2 * pr + i][r];
+          za[i][r] = du * sg * (1.0f - th * th);
+          zg[i][r] = du * th * sg * (1.0f - sg);
+        }
+      stage_store_pass<E, 2, 128>(stg, za, orow + pr * 64 * ES, p.out_stride * ES, rows_valid, le);
+      stage_store_pass<E, 2, 128>(stg, zg, orow + ((int64_t)NT * 32 + pr * 64) * ES, p.out_stride * ES, rows_valid, le);
+    }
+  }
+}
+
+namespace {
+
 template <typename E, int NT, int MODE>
 int launch_tm8s(const TmArgs& a, int nslices, hipStream_t st) {
   auto kern = gemm_tm8s_kernel<E, NT, MODE, 4>;
@@ -245,10 +492,61 @@ int launch_tm8s(const TmArgs& a, int nslices, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+
+template <typename E, int NT, int MODE>
+int launch_tm8x(const TmArgs& a, int nslices, hipStream_t st) {
+  auto kern = gemm_tm8x_kernel<E, NT, MODE>;
+  const size_t lds = (size_t)4 * NT * 2048 + (size_t)4 * 8 * 2048;
+  static WaeLdsCache lds_cache;
+  if (int rc = wae_ensure_lds((const void*)kern, lds_cache, lds, "gemm_tm8x"); rc != WAE_OK) return rc;
+  const int tiles = (a.T + 255) / 256;
+  hipLaunchKernelGGL(kern, dim3(a.B * tiles, nslices), dim3(512), lds, st, a);
+  return wae_check_launch("gemm_tm8x");
+}
+
+template <typename E>
+int dispatch_tm8x(const TmArgs& a, int M, hipStream_t st, bool* handled) {
+  *handled = true;
+  if (a.mode == TM_RESIDUAL) return launch_tm8x<E, 8, TM_RESIDUAL>(a, M / 256, st);
+  switch (M) {
+    case 256: return launch_tm8x<E, 8, TM_GATE_BWD>(a, 1, st);
+    case 192: return launch_tm8x<E, 6, TM_GATE_BWD>(a, 1, st);
+    case 128: return launch_tm8x<E, 4, TM_GATE_BWD>(a, 1, st);
+  }
+  *handled = false;
+  return WAE_OK;
+}
+
+// the backward sweep's residual (interleaved taps of ONE array) and gate launches: shapes gemm_tm8x_kernel covers
+bool tm8x_covers(const TmArgs& a, int M) {
+  if (!a.aux || a.nsrc < 1) return false;
+  int nq = 0;
+  if (a.mode == TM_RESIDUAL) {
+    if (!a.interleave || a.nsrc > 3 || M % 256 != 0) return false;
+    for (int s = 1; s < a.nsrc; ++s)
+      if (a.src[s] != a.src[0] || a.src_stride[s] != a.src_stride[0] || a.src_cols[s] != a.src_cols[0]) return false;
+    nq = a.nsrc * (a.src_cols[0] / 64);
+  } else if (a.mode == TM_GATE_BWD) {
+    if (a.interleave || a.nsrc > 2 || (M != 256 && M != 192 && M != 128)) return false;
+    for (int s = 0; s < a.nsrc; ++s) nq += a.src_cols[s] / 64;
+  } else {
+    return false;
+  }
+  if (nq < 4 || nq % 2 != 0) return false;                                  // bodies of 4 half-chunks
+  for (int s = 0; s < a.nsrc; ++s)
+    if ((int64_t)a.T * a.src_stride[s] * 2 >= (int64_t)1 << 31) return false;   // 32-bit offsets inside a clip's descriptor
+  return true;
+}
+
+}  // namespace
+
 int wae_gemm_tm8_launch(const TmArgs& a, int dtype, int M, hipStream_t st, bool* handled) {
   *handled = false;
-  if (!wae_is16(dtype) || a.nsrc != 1 || a.src_shift[0] != 0 || a.mode != TM_BIAS_RELU || M <= 0 || M % 256 != 0) return WAE_OK;
+  if (!wae_is16(dtype) || M <= 0) return WAE_OK;
   if ((a.flags & WAE_TM_ONE_WG) || a.stamps) return WAE_OK;               // A/B switch and diagnostic builds: the generic kernel
+  if (tm8x_covers(a, M)) return dtype == WAE_BF16 ? dispatch_tm8x<__bf16>(a, M, st, handled) : dispatch_tm8x<f16>(a, M, st, handled);
+  if (a.nsrc != 1 || a.src_shift[0] != 0 || a.mode != TM_BIAS_RELU || M % 256 != 0) return WAE_OK;
   const int nq = a.src_cols[0] / 64;
   if (nq < 4 || nq % 2 != 0) return WAE_OK;                                // bodies of 4 half-chunks
   if ((int64_t)a.T * a.src_stride[0] * 2 >= (int64_t)1 << 31) return WAE_OK;   // 32-bit offsets inside a clip's descriptor

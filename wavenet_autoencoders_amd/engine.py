@@ -171,11 +171,13 @@ class WaeEngine:
         if mode == "1" or B < 2 or self.dt not in (L.WAE_BF16, L.WAE_F16):
             return None
         tiles = B * ((T + 255) // 256)
-        if mode == "auto" and (tiles < 200 or (not backward and tiles <= 256)):
-            # (the FORWARD stack within one round of the machine gains nothing from two chains: C2 training 5.166-5.189 ms per step with,
-            #  5.148-5.159 without, layer 56.7 against 55.8 us; inference 1.475-1.482 against 1.457-1.463 ms.  Beyond one round -- C5 -- two
-            #  chains win in either direction.)
-            return None
+        if mode == "auto":
+            # BACKWARD: from 200 workgroups per launch (C2: 5.26 -> 5.19 ms per step; C5's two-launch sweep: 13.0 -> 10.9 ms).
+            # FORWARD: only beyond one round of the machine (C5: 320 workgroups, 10.5 -> 8.4 ms).  Within one round two chains gain
+            # nothing -- C2 training 5.166-5.189 ms per step with, 5.148-5.159 without (layer 56.7 against 55.8 us); inference
+            # 1.475-1.482 against 1.457-1.463 ms.
+            if tiles < 200 or (not backward and tiles <= 256):
+                return None
         g = self.g
         delay = getattr(self, "chain_delay_us", None)        # (tools)
         if delay is None:
