@@ -535,7 +535,8 @@ def main():
                 "mfma_frac": tn_flops / (tn_ms * 1e-3) / 1e12 / peak_tf,
                 "note": "weight gradients of %d layer(s) per launch (dW1 taps, dWc, dW_out%s); operands read once = (G+2R+Cc+H)*e per "
                         "sample and layer%s" % (nl, ", dW_skip" if static else "", " + S*e per sample" if static else "")}
-        # (csrc/glu_bwd8.hip has the instantiations of the 256-wide 16-bit shapes; csrc/glu_bwd.hip the rest)
+        # (csrc/glu_bwd8.hip has the instantiations of the 256-wide 16-bit shapes; csrc/glu_bwd.hip the rest.  The two-launch sweep's
+        #  residual (mode 1) and gate (mode 2) launches run on csrc/gemm_tm8.hip's gemm_tm8x_kernel in 16-bit storage at the bench shapes.)
         pair_kernel = "glu_bwd_pair8_kernel" if (es == 2 and C2["R"] == 256 and C2["S"] == 256 and H in (192, 128, 184) and C2["k"] == 3) else "glu_bwd_pair_kernel"
         for kind, mode_id, kb, kf, what in (
                 ("gate", 2, (C2["R"] + C2["S"] + 2 * C2["G"]) * es, 2 * H * (C2["R"] + C2["S"]),
@@ -557,7 +558,7 @@ def main():
                 ls = samples * part
                 gbs = kb * ls / (k_ms * 1e-3) / 1e9
                 fam = {
-                    "bound": "hbm", "kernel": ("gemm_tm_kernel:%d" % mode_id) if mode_id else pair_kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "bound": "hbm", "kernel": (("gemm_tm8x_kernel:%d" if es == 2 else "gemm_tm_kernel:%d") % mode_id) if mode_id else pair_kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k_ms, "ms_per_step": k_ms * per_step,
                     "algorithmic_bytes_per_launch": kb * ls, "mfma_achieved_tflops": kf * ls / (k_ms * 1e-3) / 1e12,
                     "mfma_frac": kf * ls / (k_ms * 1e-3) / 1e12 / peak_tf,
