@@ -285,3 +285,16 @@ def test_negative_leaky_relu_slope_is_refused():
     assert Geometry.from_cfg(dict(cfg, up_act_slope=0.0)).up_act_slope == 0.0
     with pytest.raises(NotImplementedError, match="negative"):
         Geometry.from_cfg(dict(cfg, up_act_slope=-0.1))
+
+
+def test_two_chains_rule():
+    """options.two_chains (WaeEngine.chain_plan): which sweeps of layer launches run as two half-batch chains."""
+    from wavenet_autoencoders_amd.options import two_chains
+    c2, c3, c5 = (8, 8000), (8, 5120), (16, 5120)            # BASELINE configs[1], [2], [4]: 250 / 160 / 320 workgroups per layer launch
+    assert two_chains("auto", True, *c2, backward=True) and not two_chains("auto", True, *c2, backward=False)
+    assert not two_chains("auto", True, *c3, backward=True) and not two_chains("auto", True, *c3, backward=False)
+    assert two_chains("auto", True, *c5, backward=True) and two_chains("auto", True, *c5, backward=False)
+    assert not two_chains("auto", False, *c5, backward=True)                       # fp32 engines: one chain
+    assert not two_chains("auto", True, 1, 64000, backward=True)                   # one clip cannot be cut
+    assert not two_chains("1", True, *c5, backward=True) and two_chains("2", True, 2, 256, backward=False)
+    assert not two_chains("2", True, 1, 256, backward=False) and not two_chains("2", False, 2, 256, backward=True)

@@ -19,6 +19,7 @@ import torch
 
 from . import _lib as L
 from . import packing as P
+from .options import two_chains
 
 
 def _dt(dtype) -> int:
@@ -167,17 +168,8 @@ class WaeEngine:
         sweep only: `auto` leaves a forward stack of one round of workgroups on one chain); hps/vqwae.json's 160-workgroup launches gain
         nothing, so `auto` leaves them alone.  Same kernels, same arithmetic per clip: results are bit for bit those of one chain
         (tests/test_gpu_backward.py::test_two_chains_are_bitwise_one_chain)."""
-        mode = self.opt.chains
-        if mode == "1" or B < 2 or self.dt not in (L.WAE_BF16, L.WAE_F16):
+        if not two_chains(self.opt.chains, self.dt in (L.WAE_BF16, L.WAE_F16), B, T, backward):      # (options.py: the rule and its numbers)
             return None
-        tiles = B * ((T + 255) // 256)
-        if mode == "auto":
-            # BACKWARD: from 200 workgroups per launch (C2: 5.26 -> 5.19 ms per step; C5's two-launch sweep: 13.0 -> 10.9 ms).
-            # FORWARD: only beyond one round of the machine (C5: 320 workgroups, 10.5 -> 8.4 ms).  Within one round two chains gain
-            # nothing -- C2 training 5.166-5.189 ms per step with, 5.148-5.159 without (layer 56.7 against 55.8 us); inference
-            # 1.475-1.482 against 1.457-1.463 ms.
-            if tiles < 200 or (not backward and tiles <= 256):
-                return None
         g = self.g
         delay = getattr(self, "chain_delay_us", None)        # (tools)
         if delay is None:

@@ -72,3 +72,18 @@ class EngineOptions:
                              head_wide=e("WAE_HEAD_WIDE", "0") == "1", glu_pair=pair, dp_split=e("WAE_DP_SPLIT", "1") != "0",
                              ar_coop=e("WAE_AR_COOP", "1") != "0", ar_coop_c=int(e("WAE_AR_COOP_C", "32")),
                              bwd_fused=fused, bwd_fold_dc=e("WAE_BWD_FOLD_DC", "1") != "0")
+
+
+def two_chains(mode: str, is16: bool, B: int, T: int, backward: bool) -> bool:
+    """The rule behind WaeEngine.chain_plan: does a sweep of layer launches over a (B, T) batch run as two half-batch chains?
+    mode: EngineOptions.chains.  A layer launch has B * ceil(T / 256) workgroups on 256 CUs.
+      BACKWARD: from 200 workgroups per launch (C2: 5.26 -> 5.19 ms per step; C5's two-launch sweep: 13.0 -> 10.9 ms);
+      FORWARD: only beyond one round of the machine (C5: 320 workgroups, 10.5 -> 8.4 ms).  Within one round two chains gain nothing
+      (C2 training 5.166-5.189 ms per step with, 5.148-5.159 without; inference 1.475-1.482 against 1.457-1.463 ms);
+      hps/vqwae.json's 160-workgroup launches: nothing in either direction."""
+    if mode == "1" or B < 2 or not is16:
+        return False
+    if mode == "2":
+        return True
+    tiles = B * ((T + 255) // 256)
+    return tiles >= 200 and (backward or tiles > 256)
