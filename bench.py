@@ -523,7 +523,18 @@ def main():
             nl = geom.layers if per_step <= 2 else 1
             tn_ms = sum(a.elapsed_time(b) for a, b in ev_tn) / len(ev_tn) * (per_step if nl > 1 else 1)
             from wavenet_autoencoders_amd import backward as BW
-            static = nl > 1 and isinstance(eng._ws[("bwd", B_PER_GPU, T)]["stream"], BW.StaticStreamTable)
+            bws = eng._ws[("bwd", B_PER_GPU, T)]
+            static = nl > 1 and isinstance(bws["stream"], BW.StaticStreamTable)
+            beside = None
+            if "stream_beside" in bws and per_step == 2 and dist is None:
+                # an under-filled sweep (backward.decoder_backward: `beside`): two launches per step, the upper layers' on the idle CUs BESIDE
+                # the sweep (its duration is mostly hidden, and long: a third of the machine), the lower layers' behind the sweep
+                t_b = sum(a.elapsed_time(b) for a, b in ev_tn[0::2]) / len(ev_tn[0::2])
+                t_l = sum(a.elapsed_time(b) for a, b in ev_tn[1::2]) / len(ev_tn[1::2])
+                beside = {"beside_sweep_launch_ms": t_b, "behind_sweep_launch_ms": t_l, "sum_ms": tn_ms,
+                          "note": "two launches of the same kernel: the upper layers' + the head's sized for the CUs the sweep leaves idle, on a side "
+                                  "stream beside the sweep's lower part; the lower layers' behind the sweep.  avg_launch_ms = their sum "
+                                  "(the work), of which only ~behind_sweep_launch_ms extends the step"}
             tn_bytes = (nl * (C2["G"] + 2 * C2["R"] + C2["Cc"] + H) + (C2["S"] if static else 0)) * es * samples
             tn_flops = nl * 2 * (C2["G"] * (C2["R"] * C2["k"] + C2["Cc"]) + C2["R"] * H + (C2["S"] * H if static else 0)) * samples
             tn_gbs = tn_bytes / (tn_ms * 1e-3) / 1e9
@@ -535,6 +546,9 @@ def main():
                 "mfma_frac": tn_flops / (tn_ms * 1e-3) / 1e12 / peak_tf,
                 "note": "weight gradients of %d layer(s) per launch (dW1 taps, dWc, dW_out%s); operands read once = (G+2R+Cc+H)*e per "
                         "sample and layer%s" % (nl, ", dW_skip" if static else "", " + S*e per sample" if static else "")}
+            if beside is not None:
+                families["wgrad"]["beside_sweep"] = beside
+                families["wgrad"]["ms_per_step"] = beside["behind_sweep_launch_ms"]      # (what extends the step: the family ranking uses it)
         # (csrc/glu_bwd8.hip has the instantiations of the 256-wide 16-bit shapes; csrc/glu_bwd.hip the rest.  The two-launch sweep's
         #  residual (mode 1) and gate (mode 2) launches run on csrc/gemm_tm8.hip's gemm_tm8x_kernel in 16-bit storage at the bench shapes.)
         pair_kernel = "glu_bwd_pair8_kernel" if (es == 2 and C2["R"] == 256 and C2["S"] == 256 and H in (192, 128, 184) and C2["k"] == 3) else "glu_bwd_pair_kernel"

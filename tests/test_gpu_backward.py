@@ -625,3 +625,49 @@ def test_side_streams_change_nothing(dtype, name):
     assert float((l0 - l1).abs().max()) < (1e-5 if dtype == "fp32" else 2e-3), (l0, l1)
     assert float((g0 - g1).abs().max()) <= (2e-5 if dtype == "fp32" else 2e-3) * float(g0.abs().max())
     assert float((p0 - p1).abs().max()) < (1e-5 if dtype == "fp32" else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_weight_gradients_beside_an_underfilled_sweep(dtype):
+    """Round 6: when the sweep's launches leave a quarter of the CUs or more idle (hps/vqwae.json's shard: 160 workgroups on 256 CUs), the
+    weight gradients of the upper layers and the head run BESIDE the lower part of the sweep -- a launch of the same static kernel
+    sized for the idle CUs, on a side stream -- and the lower layers' follow the sweep (backward.decoder_backward: `beside`).  Same jobs,
+    same regions of the dense gradient tiles: every parameter gradient against the one-launch order (WAE_SIDE=0) to the tolerance of
+    two runs of that launch (fp32 atomics arrive in another order), over two consecutive steps."""
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    cfg = dict(layers=10, stacks=2, R=256, G=256, S=256, O=256, Cc=64, Cg=32, k=3, n_speakers=11, upsample_scales=[4, 4, 8, 5], cin_pad=0)
+    B, T, hop = 3, 1920, 640
+    sd = O.make_state_dict(dict(cfg), salt=9, with_encoder=False)
+    gen = torch.Generator().manual_seed(377)
+    x = torch.randint(0, 256, (B, T), generator=gen).cuda()
+    c = torch.randn(B, 64, T // hop, generator=gen).cuda()
+    g = torch.randint(0, cfg["n_speakers"], (B,), generator=gen).cuda()
+    lengths = torch.tensor([T - 97 * i for i in range(B)])
+    got = {}
+    for side in (False, True):
+        eng = WaeEngine(Geometry.from_cfg(cfg), dtype=dtype)
+        eng.opt.side = side
+        eng.load_state_dict(sd, strict=False)
+        eng.init_optimizer()
+        seen = []
+        for _ in range(2):
+            eng.train_step(x, c, g, lengths=lengths, lr=1e-3, grad_hook=lambda gr: seen.append(gr.clone()))
+        torch.cuda.synchronize()
+        assert ("stream_beside" in eng._ws[("bwd", B, T)]) == side
+        got[side] = ([s_.cpu() for s_ in seen], eng.params.cpu().clone())
+        lay = eng.lay
+        del eng
+        torch.cuda.empty_cache()
+    for step in range(2):
+        a, b_ = got[False][0][step], got[True][0][step]
+        bad = {}
+        for k in lay.offsets:
+            ga, gb = a[lay.off(k):lay.off(k) + lay.numel(k)], b_[lay.off(k):lay.off(k) + lay.numel(k)]
+            err, ref = float((ga - gb).abs().max()), float(ga.abs().max())
+            if step == 0 and err > 1e-4 * max(ref, 1e-6) + 1e-7:
+                bad[k] = (err, ref)
+        assert not bad, (step, bad)
+        # (the second step starts from weights that differ in their last bits, and 16-bit activations amplify that: norm-wise only)
+        assert float((a - b_).norm()) < 5e-2 * float(a.norm()), step
+    assert float((got[False][1] - got[True][1]).abs().max()) < 2e-3

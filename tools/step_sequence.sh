@@ -3,7 +3,12 @@
 # tools/step_sequence.sh <tag> [bench_train.py args]  -> gpurun_out/<tag>/step_sequence.txt
 TAG=${1:-seq}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/trs
-rocprofv3 --kernel-trace --output-format csv -d /tmp/trs -- python3 $ROOT/tools/bench_train.py ${2:-bf16} 6 > $OUT/run.log 2>&1
+# (STEP_CONFIG=c3|c5: the same for another bench configuration, through bench.py)
+if [ -n "$STEP_CONFIG" ]; then
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/trs -- python3 $ROOT/bench.py --config $STEP_CONFIG --steps 6 --warmup 2 --no-sub --no-ar --no-fp32 --no-cpu > $OUT/run.log 2>&1
+else
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/trs -- python3 $ROOT/tools/bench_train.py ${2:-bf16} 6 > $OUT/run.log 2>&1
+fi
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, sys

@@ -311,11 +311,12 @@ class StaticStreamTable:
         assert f["shift"] <= 0 and f["m_valid"] % 8 == 0 and f["n0_valid"] % 8 == 0 and f["n1_valid"] % 8 == 0
         self.groups[-1].append(L.TqJob(*[f[n] for n, _ in L.TqJob._fields_]))
 
-    def finalize(self):
+    def finalize(self, ncu=None):
+        """ncu: the CUs this launch may count on (default: all) -- a launch that runs BESIDE an under-filled sweep takes the idle ones"""
         eng, B, T = self.eng, self.B, self.T
         gs = len(self.groups[0])
         assert all(len(g) == gs for g in self.groups), "every layer must contribute the same list of jobs"
-        ncu = torch.cuda.get_device_properties(eng.device).multi_processor_count
+        ncu = ncu or torch.cuda.get_device_properties(eng.device).multi_processor_count
         spc = (T + self.KT - 1) // self.KT
         segs, team_seg = [], [0]
         self.team_size = gs
@@ -397,7 +398,7 @@ def bwd_workspace(eng, B, T):
     return ws
 
 
-def _build_stream_table(eng, ws, fw, B, T, l0, l1):
+def _build_stream_table(eng, ws, fw, B, T, l0, l1, ncu=None):
     """The stream-K launch (csrc/gemm_tn_stream.hip) over the weight gradients of layers [l0, l1): dW1 taps, dWc + zb sums, dW_out +
     bias of every layer of the range.  The whole stack is one launch; data-parallel steps cut it into an upper and a lower half so
     that the upper half's slice of the gradient arena reaches the all-reduce in the middle of backward (decoder_backward)."""
@@ -497,7 +498,8 @@ def _build_stream_table(eng, ws, fw, B, T, l0, l1):
                 stt.begin_group()
                 for j in grp:
                     stt.add(**j)
-        return stt.finalize()
+        return stt.finalize(ncu)
+    assert ncu is None, "a CU budget is a feature of the static launch"
     stt = StreamTable(eng, B, T)
     for l in range(l0, l1):
         d = g.dilations[l]
@@ -798,6 +800,25 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
     if fold_dc and "dc32" not in ws:
         ws["dc32"] = torch.empty(B, T, 64, dtype=torch.float32, device=eng.device)
     cbytes = (Z2 // 64) * 8192                # bytes of one layer's chunks in the dc weight stream (packing.bwd_c_map)
+    # ---- an UNDER-FILLED sweep (hps/vqwae.json's shard: 160 workgroups per launch on 256 CUs): the weight gradients of the upper layers
+    #      (+ the head's) run BESIDE the lower part of the sweep, as a launch sized for the idle CUs on a side stream; the lower layers'
+    #      follow the sweep as before.  `beside` = the first layer of the upper part.  Measured at that shard (20 layers, 96 idle CUs;
+    #      ms per train step, one box): 6 / 8 / 10 / 12 / 14 layers beside the sweep 3.247 / 3.226-3.239 / 3.223-3.230 / 3.230 / 3.287
+    #      against 3.37-3.39 without.  The side launch runs a layer's share in ~114 us on 96 CUs (all 256: 31 -- its teams no longer sit
+    #      on one XCD each, and the sweep's launches share L2 and HBM with it) and slows the sweep's launches by ~5 %; what it has not
+    #      finished when the sweep ends runs beside the lower layers' launch, so the split is not critical: L / (1 + ncu / (2 idle)).
+    beside = None
+    if (grad_sync is None and eng.opt.side and isinstance(ws["stream"], StaticStreamTable) and seeds is None and g.layers >= 8):
+        ncu_all = torch.cuda.get_device_properties(eng.device).multi_processor_count
+        idle = (ncu_all - B * ((T + 255) // 256)) // 8 * 8
+        if idle >= 64:
+            nup = int(g.layers / (1.0 + 0.5 * ncu_all / idle))
+            if nup >= 2:
+                beside = g.layers - nup
+                if "stream_beside" not in ws:
+                    ws["stream_beside"] = _build_stream_table(eng, ws, fw, B, T, beside, g.layers, ncu=idle)
+                    ws["stream_below"] = _build_stream_table(eng, ws, fw, B, T, 0, beside)
+    beside_done = [None]
     k_u(g.layers - 1, g_next)
     # two half-batch chains of the sweep's launches (engine.chain_plan), the second half a launch late; not with dropout (its mask
     # generator counts elements of the full batch) and not with per-layer weight-gradient launches (they read both chains' rows)
@@ -845,6 +866,10 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
                 if l > 0:
                     k_u(l - 1, g_cur, part)
         g_next = g_cur
+        if beside is not None and l == beside:
+            # dz, dx-hat and the saved activations of layers [beside, L) are complete: their weight gradients start on the idle CUs
+            with eng.branch(1) as beside_done:
+                launch_stream(ws["stream_beside"])
         if split is not None and l == split:
             # data parallel: dz, dx-hat and the saved activations of layers [split, L) are complete -> their weight gradients now
             # (one stream-K launch over the upper half), the head's and theirs into the arena, weight-norm backward of that slice,
@@ -870,6 +895,9 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
         eng._ev_dc.record(torch.cuda.current_stream(eng.device))
     if split is not None:
         launch_stream(ws["stream_lo"])
+    elif beside is not None:              # the lower layers' (the upper ones' launch has been running beside the sweep)
+        launch_stream(ws["stream_below"])
+        eng.join(beside_done[0])
     elif ws["stream"] is not None:        # every layer's dW1 taps, dWc + zb sums, dW_out + bias: one launch
         launch_stream(ws["stream"])
     if split is not None:
