@@ -817,7 +817,11 @@ def decoder_backward(eng, x_ids: torch.Tensor, targets: torch.Tensor, lengths: O
                 beside = g.layers - nup
                 if "stream_beside" not in ws:
                     ws["stream_beside"] = _build_stream_table(eng, ws, fw, B, T, beside, g.layers, ncu=idle)
-                    ws["stream_below"] = _build_stream_table(eng, ws, fw, B, T, 0, beside)
+                    # with an encoder in front, the front end's backward is a chain of ~20 small launches (~0.3 ms) that starts at the end of
+                    # the sweep on its own side stream (engine.backward): the lower layers' launch leaves it 32 CUs instead of taking
+                    # every SIMD's registers (0 / 32 / 48 / 64 CUs left: 3.20-3.21 / 3.08-3.14 / 3.10 / 3.11 ms per step at hps/vqwae.json)
+                    reserve = 32 if g.has_encoder else 0
+                    ws["stream_below"] = _build_stream_table(eng, ws, fw, B, T, 0, beside, ncu=(ncu_all - reserve) if reserve else None)
     beside_done = [None]
     k_u(g.layers - 1, g_next)
     # two half-batch chains of the sweep's launches (engine.chain_plan), the second half a launch late; not with dropout (its mask
