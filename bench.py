@@ -617,7 +617,8 @@ def main():
             if doc.get("csrc_hash") == csrc_hash():
                 traffic_src = os.path.basename(fpath)
                 traffic_doc = doc
-                if args.dtype in ("bf16", "fp16") and args.mode == "train":
+                # (the passes profile the DEFAULT command: the C2 shard in bf16 -- another configuration's launches move other bytes)
+                if args.dtype == "bf16" and args.mode == "train" and args.config == "c2":
                     for rf in [roof] + [v for v in extra.values() if "kernel" in v]:
                         for k, v in doc["kernels"].items():
                             if kernel_matches(rf["kernel"], k):
@@ -626,6 +627,8 @@ def main():
                 break
     except (OSError, KeyError, ValueError):
         pass
+    if traffic_src is not None and roof.get("traffic") is None:
+        roof["traffic_note"] = "%s profiles the default command (config c2, bf16, train): no PMC pass of this configuration" % traffic_src
     if traffic_src is None:
         roof["traffic_note"] = "no profiles/*_pmc_traffic.json matches this build's csrc hash %s: traffic not reported" % csrc_hash()
 
