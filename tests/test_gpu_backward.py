@@ -671,3 +671,41 @@ def test_weight_gradients_beside_an_underfilled_sweep(dtype):
         # (the second step starts from weights that differ in their last bits, and 16-bit activations amplify that: norm-wise only)
         assert float((a - b_).norm()) < 5e-2 * float(a.norm()), step
     assert float((got[False][1] - got[True][1]).abs().max()) < 2e-3
+
+
+def test_weight_gradients_beside_the_sweep_with_the_encoder_in_front():
+    """The same on the reference's own preset (hps/vqwae.json in full: encoder, VQ, upsampling network, 20-layer decoder; a short
+    batch): there the lower layers' launch also leaves 32 CUs to the front end's backward, which runs on its own side stream from the
+    end of the sweep.  Losses, VQ statistics and every parameter gradient of the first step against the one-stream order."""
+    import bench
+    from wavenet_autoencoders_amd import Geometry
+    from wavenet_autoencoders_amd.engine import WaeEngine
+    conf = dict(bench.CONFIGS["c3"], B=2, T=2560)
+    sd = O.make_state_dict(dict(conf["cfg"]), salt=conf["salt"], with_encoder=True)
+    x, lat, g = bench.synth_inputs(0, torch.device("cuda:0"), conf)
+    got = {}
+    for side in (False, True):
+        eng = WaeEngine(Geometry.from_cfg(conf["cfg"]), dtype="bf16")
+        eng.opt.side = side
+        eng.load_state_dict(sd)
+        eng.init_optimizer()
+        seen = []
+        r = eng.train_step(x, lat, g, lr=1e-3, grad_hook=lambda gr: seen.append(gr.clone()))
+        torch.cuda.synchronize()
+        ws = eng._ws[("bwd", 2, 2560)]
+        assert ("stream_beside" in ws) == side
+        if side:
+            assert ws["stream_below"].nwg < ws["stream"].nwg            # 32 CUs left to the front end's backward
+        got[side] = (seen[0].cpu(), float(r["loss"]), float(r["vq_loss"]), float(r["perp"]))
+        lay = eng.lay
+        del eng
+        torch.cuda.empty_cache()
+    assert got[False][1:] == got[True][1:]                          # the forward is the same launches in the same order per stream
+    a, b_ = got[False][0], got[True][0]
+    bad = {}
+    for k in lay.offsets:
+        ga, gb = a[lay.off(k):lay.off(k) + lay.numel(k)], b_[lay.off(k):lay.off(k) + lay.numel(k)]
+        err, ref = float((ga - gb).abs().max()), float(ga.abs().max())
+        if err > 1e-4 * max(ref, 1e-6) + 1e-7:
+            bad[k] = (err, ref)
+    assert not bad, bad
