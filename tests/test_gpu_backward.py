@@ -621,7 +621,8 @@ def test_side_streams_change_nothing(dtype, name):
         del eng
         torch.cuda.empty_cache()
     (l0, g0, p0), (l1, g1, p1) = got[False], got[True]
-    assert torch.equal(l0[:1], l1[:1]), (l0, l1)                       # the first step sees the same weights: the same loss bit for bit
+    # the first step sees the same weights: the same loss (bit for bit but for the VQ term's atomically summed statistics)
+    assert float((l0[:1] - l1[:1]).abs().max()) <= 1e-6 * float(l0[:1].abs().max()), (l0, l1)
     assert float((l0 - l1).abs().max()) < (1e-5 if dtype == "fp32" else 2e-3), (l0, l1)
     assert float((g0 - g1).abs().max()) <= (2e-5 if dtype == "fp32" else 2e-3) * float(g0.abs().max())
     assert float((p0 - p1).abs().max()) < (1e-5 if dtype == "fp32" else 2e-3)
@@ -700,7 +701,9 @@ def test_weight_gradients_beside_the_sweep_with_the_encoder_in_front():
         lay = eng.lay
         del eng
         torch.cuda.empty_cache()
-    assert got[False][1:] == got[True][1:]                          # the forward is the same launches in the same order per stream
+    # the forward is the same launches in the same order per stream: the CE bit for bit; the VQ statistics are atomic sums
+    assert got[False][1] == got[True][1]
+    assert abs(got[False][2] - got[True][2]) < 1e-5 * abs(got[False][2]) + 1e-9 and abs(got[False][3] - got[True][3]) < 1e-4 * got[False][3]
     a, b_ = got[False][0], got[True][0]
     bad = {}
     for k in lay.offsets:
