@@ -598,7 +598,7 @@ def test_side_streams_change_nothing(dtype, name):
     """Round 6 (options.py: WAE_SIDE): the step's independent side work on side streams -- the upsampling network + hoisted global
     conditioning and the backward's weight packing (with the clearing of the gradient accumulators) beside the forward weight packing,
     the front end's backward beside the scatter of the layers' weight gradients -- against every launch on one stream.  Three train
-    steps each (a hazard between a step's early packing and the previous step's optimizer would show in the second): losses bitwise,
+    steps each (a hazard between a step's early packing and the previous step's optimizer would show in the second): losses,
     gradients and parameters to the tolerance of two runs of the atomically accumulated weight gradients."""
     from wavenet_autoencoders_amd import Geometry
     from wavenet_autoencoders_amd.engine import WaeEngine
