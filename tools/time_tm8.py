@@ -10,10 +10,9 @@ if len(sys.argv) > 1:
     L.LIB_PATH = os.path.abspath(sys.argv[1])
 lib = L.lib()
 dev = torch.device("cuda:0")
-for name, B, T, K in (("C2", 8, 8000, 4608), ("C3", 8, 5120, 2560)):
-    M = 256
+for name, B, T, K, M in (("C2", 8, 8000, 4608, 256), ("C3", 8, 5120, 2560, 256), ("C5 (two output slices)", 16, 5120, 12288, 512)):
     u = (torch.randn(B, T, K, device=dev) * 0.5).to(torch.bfloat16)
-    w = (torch.randn((K // 64) * 8 * 4 * 64 * 8, device=dev) / K ** 0.5).to(torch.bfloat16)
+    w = (torch.randn((K // 64) * (M // 32) * 4 * 64 * 8, device=dev) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(M, device=dev)
     out = torch.empty(B, T, M, dtype=torch.bfloat16, device=dev)
     ptrs = (ctypes.c_void_p * 1)(u.data_ptr()); strides = (ctypes.c_int64 * 1)(K)

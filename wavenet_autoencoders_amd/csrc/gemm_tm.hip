@@ -505,6 +505,7 @@ static int tm_run(const wae_tm_desc* d, const void* const* src, const int64_t* s
   a.aux_stride = aux_stride; a.alpha = d->alpha; a.B = d->B; a.T = d->T; a.mode = d->mode;
   a.interleave = (d->flags & WAE_TM_INTERLEAVE) ? 1 : 0;
   a.flags = d->flags;
+  a.nslices = 0;
   if (a.interleave)
     for (int s = 1; s < d->nsrc; ++s) WAE_REQUIRE(src_cols[s] == src_cols[0], "gemm_tm: interleaved sources must be equally wide");
   a.ce = TmCe{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};

@@ -40,6 +40,7 @@ struct TmArgs {
   int interleave;  // chunk q -> source q % nsrc, column block q / nsrc (all sources equally wide)
   int flags;       // wae_tm_desc.flags
   TmCe ce;
+  int nslices;     // gemm_tm8s_kernel: output slices of 256 rows, adjacent in the launch order (else 0)
 };
 
 

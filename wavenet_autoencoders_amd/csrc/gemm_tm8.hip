@@ -76,7 +76,11 @@ __global__ void __launch_bounds__(768, 1) gemm_tm8s_kernel(TmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int TW = NW * 32;
   const int tiles_per_b = (p.T + TW - 1) / TW;
-  const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  // (the slices of one time tile sit next to each other in the XCD-contiguous launch order: they run on one XCD at the same time, and
+  //  the second one's operand requests are hits in that XCD's L2.  As blockIdx.y the slices ran a whole grid apart: C5's skip
+  //  contraction -- 2 GB of u, two slices -- 1 112 us; adjacent 943 us, tools/time_tm8.py)
+  const int lin_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int tile_id = lin_id / p.nslices;
   const int b = tile_id / tiles_per_b;
   const int t0 = (tile_id % tiles_per_b) * TW;
   const int nh = 2 * (p.src_cols[0] / T_::CK);
@@ -85,9 +89,9 @@ __global__ void __launch_bounds__(768, 1) gemm_tm8s_kernel(TmArgs p) {
   const unsigned clip_bytes = (unsigned)p.T * row_bytes;
   const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
   float* bias_lds = (float*)(smem + RING + TILES);
-  // outputs wider than 256 rows (the wide head, BASELINE config C5): blockIdx.y picks a slice of 8 tiles; the weight stream is
+  // outputs wider than 256 rows (the wide head, BASELINE config C5): a slice of 8 tiles per workgroup; the weight stream is
   // [slice][chunk] (packing.py: first_gemm_map), bias and output columns follow
-  const int slice = blockIdx.y;
+  const int slice = lin_id % p.nslices;
   const char* wslice = p.w + (int64_t)slice * nh * HCB;
   const int64_t col0 = (int64_t)slice * NT * 32;
 
@@ -486,7 +490,9 @@ int launch_tm8s(const TmArgs& a, int nslices, hipStream_t st) {
   static WaeLdsCache lds_cache;
   if (int rc = wae_ensure_lds((const void*)kern, lds_cache, lds, "gemm_tm8s"); rc != WAE_OK) return rc;
   const int tiles = (a.T + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(a.B * tiles, nslices), dim3(768), lds, st, a);
+  TmArgs as = a;
+  as.nslices = nslices;
+  hipLaunchKernelGGL(kern, dim3(a.B * tiles * nslices), dim3(768), lds, st, as);
   return wae_check_launch("gemm_tm8s");
 }
 
