@@ -577,6 +577,9 @@ def main():
                     "algorithmic_bytes_per_launch": kb * ls, "mfma_achieved_tflops": kf * ls / (k_ms * 1e-3) / 1e12,
                     "mfma_frac": kf * ls / (k_ms * 1e-3) / 1e12 / peak_tf,
                     "note": what + " -- the bytes this launch itself has to move; HIP events around every launch"}
+                if part < 1.0:
+                    fam["note"] = ("TWO launches of this kernel run side by side, each over half of the batch (engine.chain_plan): achieved / frac "
+                                   "are ONE launch's bytes over its own duration; `both_chains` prices the pair.  ") + fam["note"]
                 if part < 1.0 and ev_tm.get("sweep"):
                     sw_ms = sum(a.elapsed_time(b) for a, b in ev_tm["sweep"]) / len(ev_tm["sweep"])
                     lay_ms = sw_ms / max(per_step, 1)
